@@ -1,0 +1,276 @@
+"""ctypes binding of libdotring_hip.so (include/dotring_hip.h) — the only door from Python to the GPU kernels.
+
+No CPU fallback exists: if the shared library is missing, or there is no gfx950 device, the calls raise.
+Error mapping follows the reference's exception types at these seams (ValueError / MemoryError).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_size_t, c_uint, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdotring_hip.so")
+
+DR_OK, DR_ERR_INVALID, DR_ERR_NOMEM, DR_ERR_DEVICE, DR_ERR_NOTSQUARE = 0, -1, -2, -3, -4
+
+
+class DotRingHipError(RuntimeError):
+    """HIP runtime failure, or no usable MI355X device."""
+
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/dotring_hip.h one to one
+_PROTOTYPES = {
+    "dr_version": (c_char_p, []),
+    "dr_last_error": (c_char_p, []),
+    "dr_device_count": (c_int, []),
+    "dr_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "dr_ctx_destroy": (None, [c_void_p]),
+    "dr_ctx_sync": (c_int, [c_void_p]),
+    "dr_dev_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    "dr_dev_free": (c_int, [c_void_p, c_void_p]),
+    "dr_dev_upload": (c_int, [c_void_p, c_void_p, c_char_p, c_size_t]),
+    "dr_dev_download": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "dr_prof_enable": (c_int, [c_void_p, c_int]),
+    "dr_prof_reset": (c_int, [c_void_p]),
+    "dr_prof_get": (c_int, [c_void_p, c_char_p, POINTER(c_double), POINTER(c_int)]),
+    "dr_bsn_scalar_mul_batch": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, c_void_p]),
+    "dr_bsn_scalar_mul_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dr_bsn_msm": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, c_void_p]),
+    "dr_bsn_msm_groups": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, c_size_t, c_void_p]),
+    "dr_fr_sqrt": (c_int, [c_char_p, c_void_p]),
+    "dr_srs_load": (c_int, [c_void_p, c_char_p, c_size_t, POINTER(c_void_p)]),
+    "dr_srs_destroy": (None, [c_void_p]),
+    "dr_srs_size": (c_size_t, [c_void_p]),
+    "dr_g1_msm": (c_int, [c_void_p, c_void_p, c_size_t, c_char_p, c_size_t, c_void_p, POINTER(c_int)]),
+    "dr_g1_msm_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, POINTER(c_int)]),
+    "dr_g1_msm_batch": (c_int, [c_void_p, c_void_p, c_char_p, c_size_t, c_size_t, c_void_p, POINTER(c_int)]),
+    "dr_g1_msm_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, POINTER(c_int)]),
+    "dr_g1_msm_points": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, c_void_p, POINTER(c_int)]),
+    "dr_g1_compress": (c_int, [c_char_p, c_int, c_void_p]),
+    "dr_g1_decompress": (c_int, [c_char_p, c_void_p, POINTER(c_int)]),
+    "dr_g1_serialize_check": (c_int, [c_char_p]),
+    "dr_ntt": (c_int, [c_void_p, c_void_p, c_uint, c_size_t, c_char_p, c_char_p]),
+    "dr_ntt_dev": (c_int, [c_void_p, c_void_p, c_uint, c_size_t, c_char_p, c_char_p]),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+
+def lib() -> ctypes.CDLL:
+    """Load libdotring_hip.so (built by __graft_entry__.build() / `make -C dot_ring_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C dot_ring_amd/csrc` (hipcc, gfx950). "
+                "dot_ring_amd has no CPU fallback."
+            )
+        cdll = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(cdll, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = cdll
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc == DR_OK:
+        return
+    msg = (lib().dr_last_error() or b"").decode("utf-8", "replace")
+    if rc in (DR_ERR_INVALID, DR_ERR_NOTSQUARE):
+        raise ValueError(msg)
+    if rc == DR_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise DotRingHipError(msg)
+
+
+def device_count() -> int:
+    return int(lib().dr_device_count())
+
+
+class DeviceBuffer:
+    """A block of HBM owned by a Context."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, nbytes
+        self.ptr = c_void_p()
+        _check(lib().dr_dev_alloc(ctx.handle, nbytes, byref(self.ptr)))
+
+    def upload(self, data: bytes) -> "DeviceBuffer":
+        if len(data) > self.nbytes:
+            raise ValueError("upload larger than the buffer")
+        _check(lib().dr_dev_upload(self.ctx.handle, self.ptr, data, len(data)))
+        return self
+
+    def download(self, nbytes: int | None = None) -> bytes:
+        nbytes = self.nbytes if nbytes is None else nbytes
+        out = ctypes.create_string_buffer(nbytes)
+        _check(lib().dr_dev_download(self.ctx.handle, out, self.ptr, nbytes))
+        return out.raw
+
+    def free(self) -> None:
+        if self.ptr:
+            lib().dr_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = c_void_p()
+
+
+class Srs:
+    """SRS bases resident in HBM (Montgomery-form affine)."""
+
+    def __init__(self, ctx: "Context", g1_be_xy: bytes):
+        if len(g1_be_xy) % 96:
+            raise ValueError("SRS bytes must be a multiple of 96")
+        self.ctx = ctx
+        self.handle = c_void_p()
+        self.count = len(g1_be_xy) // 96
+        _check(lib().dr_srs_load(ctx.handle, g1_be_xy, self.count, byref(self.handle)))
+
+    def close(self) -> None:
+        if self.handle:
+            lib().dr_srs_destroy(self.handle)
+            self.handle = c_void_p()
+
+
+class Context:
+    """One GPU + one HIP stream.  Not thread-safe; create one per thread / per rank."""
+
+    def __init__(self, device_id: int = 0):
+        self.handle = c_void_p()
+        _check(lib().dr_ctx_create(device_id, byref(self.handle)))
+        self.device_id = device_id
+
+    def close(self) -> None:
+        if self.handle:
+            lib().dr_ctx_destroy(self.handle)
+            self.handle = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self) -> None:
+        _check(lib().dr_ctx_sync(self.handle))
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    # ---- profiling
+    def prof_enable(self, on: bool = True) -> None:
+        _check(lib().dr_prof_enable(self.handle, 1 if on else 0))
+
+    def prof_reset(self) -> None:
+        _check(lib().dr_prof_reset(self.handle))
+
+    def prof_get(self, kernel: str) -> tuple[float, int]:
+        ms, cnt = c_double(0), c_int(0)
+        _check(lib().dr_prof_get(self.handle, kernel.encode(), byref(ms), byref(cnt)))
+        return ms.value, cnt.value
+
+    # ---- seam A
+    def bsn_scalar_mul_batch(self, pts_xy: bytes, scalars: bytes) -> bytes:
+        n = len(scalars) // 32
+        if len(scalars) != 32 * n or len(pts_xy) != 64 * n:
+            raise ValueError("Points and scalars must have same length")
+        out = ctypes.create_string_buffer(max(64 * n, 1))
+        _check(lib().dr_bsn_scalar_mul_batch(self.handle, pts_xy, scalars, n, out))
+        return out.raw[: 64 * n]
+
+    def bsn_scalar_mul_batch_dev(self, d_pts: DeviceBuffer, d_scalars: DeviceBuffer, n: int, d_out: DeviceBuffer) -> None:
+        _check(lib().dr_bsn_scalar_mul_batch_dev(self.handle, d_pts.ptr, d_scalars.ptr, n, d_out.ptr))
+
+    def bsn_msm(self, pts_xy: bytes, scalars: bytes) -> bytes:
+        n = len(scalars) // 32
+        if len(scalars) != 32 * n or len(pts_xy) != 64 * n:
+            raise ValueError("Points and scalars must have same length")
+        out = ctypes.create_string_buffer(64)
+        _check(lib().dr_bsn_msm(self.handle, pts_xy, scalars, n, out))
+        return out.raw
+
+    def bsn_msm_groups(self, pts_xy: bytes, scalars: bytes, m: int) -> bytes:
+        n = len(scalars) // 32
+        if m <= 0 or n % m or len(scalars) != 32 * n or len(pts_xy) != 64 * n:
+            raise ValueError("Points and scalars must have same length (a multiple of the group size)")
+        groups = n // m
+        out = ctypes.create_string_buffer(max(64 * groups, 1))
+        _check(lib().dr_bsn_msm_groups(self.handle, pts_xy, scalars, groups, m, out))
+        return out.raw[: 64 * groups]
+
+    # ---- seam B
+    def srs_load(self, g1_be_xy: bytes) -> Srs:
+        return Srs(self, g1_be_xy)
+
+    def g1_msm(self, srs: Srs, scalars: bytes, offset: int = 0) -> bytes | None:
+        """Affine BE x||y (96 bytes) or None for the point at infinity."""
+        n = len(scalars) // 32
+        if len(scalars) != 32 * n:
+            raise ValueError("scalars must be a multiple of 32 bytes")
+        out, inf = ctypes.create_string_buffer(96), c_int(0)
+        _check(lib().dr_g1_msm(self.handle, srs.handle, offset, scalars, n, out, byref(inf)))
+        return None if inf.value else out.raw
+
+    def g1_msm_dev(self, srs: Srs, d_scalars: DeviceBuffer, n: int, offset: int = 0) -> bytes | None:
+        out, inf = ctypes.create_string_buffer(96), c_int(0)
+        _check(lib().dr_g1_msm_dev(self.handle, srs.handle, offset, d_scalars.ptr, n, out, byref(inf)))
+        return None if inf.value else out.raw
+
+    def g1_msm_batch(self, srs: Srs, scalars: bytes, n: int) -> list[bytes | None]:
+        if n <= 0 or len(scalars) % (32 * n):
+            raise ValueError("scalars must be batch * n * 32 bytes")
+        batch = len(scalars) // (32 * n)
+        out, inf = ctypes.create_string_buffer(96 * batch), (c_int * batch)()
+        _check(lib().dr_g1_msm_batch(self.handle, srs.handle, scalars, n, batch, out, inf))
+        return [None if inf[b] else out.raw[96 * b : 96 * b + 96] for b in range(batch)]
+
+    def g1_msm_batch_dev(self, srs: Srs, d_scalars: DeviceBuffer, n: int, batch: int) -> list[bytes | None]:
+        out, inf = ctypes.create_string_buffer(96 * batch), (c_int * batch)()
+        _check(lib().dr_g1_msm_batch_dev(self.handle, srs.handle, d_scalars.ptr, n, batch, out, inf))
+        return [None if inf[b] else out.raw[96 * b : 96 * b + 96] for b in range(batch)]
+
+    def g1_msm_points(self, pts_be_xy: bytes, scalars: bytes) -> bytes | None:
+        n = len(scalars) // 32
+        if len(scalars) != 32 * n or len(pts_be_xy) != 96 * n:
+            raise ValueError("Points and scalars must have same length")
+        out, inf = ctypes.create_string_buffer(96), c_int(0)
+        _check(lib().dr_g1_msm_points(self.handle, pts_be_xy, scalars, n, out, byref(inf)))
+        return None if inf.value else out.raw
+
+    # ---- seam C
+    def ntt(self, data: bytes, log2n: int, omega: int, scale: int | None = None) -> bytes:
+        n = 1 << log2n
+        if len(data) % (32 * n):
+            raise ValueError(f"coefficient length does not match native NTT plan size {n}")
+        batch = len(data) // (32 * n)
+        buf = ctypes.create_string_buffer(data, len(data))
+        sc = scale.to_bytes(32, "little") if scale is not None else None
+        _check(lib().dr_ntt(self.handle, buf, log2n, batch, omega.to_bytes(32, "little"), sc))
+        return buf.raw
+
+    def ntt_dev(self, d_data: DeviceBuffer, log2n: int, batch: int, omega: int, scale: int | None = None) -> None:
+        sc = scale.to_bytes(32, "little") if scale is not None else None
+        _check(lib().dr_ntt_dev(self.handle, d_data.ptr, log2n, batch, omega.to_bytes(32, "little"), sc))
+
+
+# ---- host-only helpers (no GPU needed)
+def fr_sqrt(v: int) -> int:
+    out = ctypes.create_string_buffer(32)
+    _check(lib().dr_fr_sqrt(int(v).to_bytes(32, "little"), out))
+    return int.from_bytes(out.raw, "little")
+
+
+def g1_compress(xy: bytes | None) -> bytes:
+    out = ctypes.create_string_buffer(48)
+    _check(lib().dr_g1_compress(xy if xy is not None else bytes(96), 1 if xy is None else 0, out))
+    return out.raw
+
+
+def g1_decompress(data: bytes) -> bytes | None:
+    if len(data) != 48:
+        raise ValueError(f"invalid BLS12-381 G1 length: expected 48, got {len(data)}")
+    out, inf = ctypes.create_string_buffer(96), c_int(0)
+    _check(lib().dr_g1_decompress(data, out, byref(inf)))
+    return None if inf.value else out.raw

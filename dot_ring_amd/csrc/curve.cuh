@@ -1,0 +1,199 @@
+// Device-side group law for the two curves on the Ring-VRF hot path.
+//
+//  * Bandersnatch (twisted Edwards a=-5 over Fr), extended coordinates (X,Y,Z,T) — the formulas the
+//    reference runs in dot_ring/curve/native_field/bandersnatch_te.pyx:127-174 (dbl/add-2008-hwcd);
+//    a*A is computed as -(4A+A) instead of a Montgomery multiplication.
+//  * BLS12-381 G1 (y^2 = x^3 + 4 over Fq), XYZZ coordinates (X,Y,ZZ,ZZZ) for bucket sums:
+//    mixed add 8M+2S, full add 12M+2S, doubling 6M+4S (EFD "xyzz": madd-2008-s, add-2008-s, dbl-2008-s-1).
+//    The reference reaches this arithmetic through blst (dot_ring/ring_proof/pcs/kzg.py:147-175).
+#pragma once
+#include "field.cuh"
+
+namespace dr {
+
+// ================================================================= Bandersnatch
+struct TePoint {
+    Fr x, y, z, t;
+};
+
+DR_DEV TePoint te_identity() {
+    TePoint p;
+    p.x = Fr::zero();
+    p.y = Fr::one();
+    p.z = Fr::one();
+    p.t = Fr::zero();
+    return p;
+}
+
+// d = 0x6389C12633C267CBC66E3BF86BE3B6D8CB66677177E54F92B369F2F5188D58E7 in Montgomery form
+DR_DEV Fr te_d_mont() {
+    Fr d;
+    d.l[0] = 0x47a2c730u; d.l[1] = 0xa8dced1bu; d.l[2] = 0xad3cccc7u; d.l[3] = 0x381c065au;
+    d.l[4] = 0x188351f8u; d.l[5] = 0x53ff52e1u; d.l[6] = 0x990fe940u; d.l[7] = 0x362e8d63u;
+    return d;
+}
+
+// a*v for a = -5
+DR_DEV Fr te_mul_a(const Fr& v) {
+    Fr t = dbl(v);
+    t = dbl(t);
+    t = add(t, v);
+    return neg(t);
+}
+
+// dbl-2008-hwcd.  WITH_T=false skips T3 (valid when the result is only doubled again).
+template <bool WITH_T>
+DR_DEV TePoint te_dbl(const TePoint& p) {
+    Fr A = sqr(p.x), B = sqr(p.y);
+    Fr C = dbl(sqr(p.z));
+    Fr D = te_mul_a(A);
+    Fr E = sub(sub(sqr(add(p.x, p.y)), A), B);
+    Fr G = add(D, B), F = sub(G, C), H = sub(D, B);
+    TePoint r;
+    r.x = mul(E, F);
+    r.y = mul(G, H);
+    r.z = mul(F, G);
+    if (WITH_T) r.t = mul(E, H);
+    else r.t = Fr::zero();
+    return r;
+}
+
+// add-2008-hwcd, unified (also correct for doubling and for the identity).
+DR_DEV TePoint te_add(const TePoint& p, const TePoint& q) {
+    Fr A = mul(p.x, q.x), B = mul(p.y, q.y);
+    Fr C = mul(mul(te_d_mont(), p.t), q.t);
+    Fr D = mul(p.z, q.z);
+    Fr E = sub(sub(mul(add(p.x, p.y), add(q.x, q.y)), A), B);
+    Fr F = sub(D, C), G = add(D, C), H = sub(B, te_mul_a(A));
+    TePoint r;
+    r.x = mul(E, F);
+    r.y = mul(G, H);
+    r.t = mul(E, H);
+    r.z = mul(F, G);
+    return r;
+}
+
+DR_DEV TePoint te_cneg(const TePoint& p, bool negate) {
+    TePoint r = p;
+    Fr nx = neg(p.x), nt = neg(p.t);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        r.x.l[i] = negate ? nx.l[i] : p.x.l[i];
+        r.t.l[i] = negate ? nt.l[i] : p.t.l[i];
+    }
+    return r;
+}
+
+// ================================================================= BLS12-381 G1
+struct G1Affine {   // Montgomery form; (0,0) encodes the point at infinity (not on the curve: b = 4)
+    Fq x, y;
+    DR_DEV bool is_inf() const { return x.is_zero() && y.is_zero(); }
+};
+
+struct G1Xyzz {     // x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2 ; ZZ == 0 encodes infinity
+    Fq x, y, zz, zzz;
+    DR_DEV bool is_inf() const { return zz.is_zero(); }
+};
+
+DR_DEV G1Xyzz g1_inf() {
+    G1Xyzz r;
+    r.x = Fq::zero(); r.y = Fq::zero(); r.zz = Fq::zero(); r.zzz = Fq::zero();
+    return r;
+}
+
+DR_DEV G1Xyzz g1_from_affine(const G1Affine& p) {
+    G1Xyzz r;
+    if (p.is_inf()) return g1_inf();
+    r.x = p.x; r.y = p.y; r.zz = Fq::one(); r.zzz = Fq::one();
+    return r;
+}
+
+// 2*(affine P) -> XYZZ   (mdbl-2008-s-1, a = 0).  Out of line: only reached for duplicate bases.
+__device__ __noinline__ G1Xyzz g1_dbl_affine(const G1Affine& p) {
+    Fq U = dbl(p.y);
+    Fq V = sqr(U);
+    Fq W = mul(U, V);
+    Fq S = mul(p.x, V);
+    Fq X2 = sqr(p.x);
+    Fq M = add(dbl(X2), X2);
+    G1Xyzz r;
+    r.x = sub(sub(sqr(M), S), S);
+    r.y = sub(mul(M, sub(S, r.x)), mul(W, p.y));
+    r.zz = V;
+    r.zzz = W;
+    return r;
+}
+
+// 2*P in XYZZ (dbl-2008-s-1, a = 0).  Out of line (reduction kernels call it from several sites; keeps
+// their code inside the instruction cache).
+__device__ __noinline__ G1Xyzz g1_dbl(const G1Xyzz& p) {
+    if (p.is_inf()) return p;
+    Fq U = dbl(p.y);
+    Fq V = sqr(U);
+    Fq W = mul(U, V);
+    Fq S = mul(p.x, V);
+    Fq X2 = sqr(p.x);
+    Fq M = add(dbl(X2), X2);
+    G1Xyzz r;
+    r.x = sub(sub(sqr(M), S), S);
+    r.y = sub(mul(M, sub(S, r.x)), mul(W, p.y));
+    r.zz = mul(V, p.zz);
+    r.zzz = mul(W, p.zzz);
+    return r;
+}
+
+// acc + (affine q)   (madd-2008-s) with the exceptional cases made explicit
+DR_DEV G1Xyzz g1_madd(const G1Xyzz& acc, const G1Affine& q) {
+    if (q.is_inf()) return acc;
+    if (acc.is_inf()) return g1_from_affine(q);
+    Fq U2 = mul(q.x, acc.zz);
+    Fq S2 = mul(q.y, acc.zzz);
+    Fq P = sub(U2, acc.x);
+    Fq R = sub(S2, acc.y);
+    if (P.is_zero()) {
+        if (R.is_zero()) return g1_dbl_affine(q);
+        return g1_inf();
+    }
+    Fq PP = sqr(P);
+    Fq PPP = mul(P, PP);
+    Fq Q = mul(acc.x, PP);
+    G1Xyzz r;
+    r.x = sub(sub(sub(sqr(R), PPP), Q), Q);
+    r.y = sub(mul(R, sub(Q, r.x)), mul(acc.y, PPP));
+    r.zz = mul(acc.zz, PP);
+    r.zzz = mul(acc.zzz, PPP);
+    return r;
+}
+
+// p + q, both XYZZ (add-2008-s) with the exceptional cases made explicit.  Out of line, as g1_dbl.
+__device__ __noinline__ G1Xyzz g1_add(const G1Xyzz& p, const G1Xyzz& q) {
+    if (p.is_inf()) return q;
+    if (q.is_inf()) return p;
+    Fq U1 = mul(p.x, q.zz), U2 = mul(q.x, p.zz);
+    Fq S1 = mul(p.y, q.zzz), S2 = mul(q.y, p.zzz);
+    Fq P = sub(U2, U1);
+    Fq R = sub(S2, S1);
+    if (P.is_zero()) {
+        if (R.is_zero()) return g1_dbl(p);
+        return g1_inf();
+    }
+    Fq PP = sqr(P);
+    Fq PPP = mul(P, PP);
+    Fq Q = mul(U1, PP);
+    G1Xyzz r;
+    r.x = sub(sub(sub(sqr(R), PPP), Q), Q);
+    r.y = sub(mul(R, sub(Q, r.x)), mul(S1, PPP));
+    r.zz = mul(mul(p.zz, q.zz), PP);
+    r.zzz = mul(mul(p.zzz, q.zzz), PPP);
+    return r;
+}
+
+DR_DEV G1Affine g1_neg_affine(const G1Affine& p, bool negate) {
+    G1Affine r = p;
+    Fq ny = neg(p.y);
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.y.l[i] = negate ? ny.l[i] : p.y.l[i];
+    return r;
+}
+
+}  // namespace dr

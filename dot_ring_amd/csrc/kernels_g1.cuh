@@ -1,0 +1,268 @@
+// BLS12-381 G1 Pippenger MSM (seam B, kernel K5) — the KZG commit behind RingRoot / ring proofs.
+// Replaces blst.P1_Affines.mult_pippenger as called from dot_ring/ring_proof/pcs/kzg.py:152-175.
+//
+// Data layout in HBM
+//   bases    : G1Affine[n]            96 B AoS, Montgomery form, (0,0) = infinity. One gather of a base is
+//                                     six 16-B loads from one or two 128-B lines.
+//   scalars  : u32[batch][n][8]       little-endian limbs as uploaded (any value < 2^256)
+//   digits   : i32[batch*W][n]        signed window digits in (-2^(c-1), 2^(c-1)], coalesced along n
+//   counts / offsets : u32[batch*W*H (+1)]   H = 2^(c-1) buckets per window
+//   sorted   : u32[nnz]               base index | sign<<31, grouped by bucket (counting sort)
+//   buckets  : G1Xyzz[batch*W*H]      192 B AoS
+//   partial  : G1Xyzz[batch*W*T]      per-chunk running-sum results, T = H / L
+//   winsum   : G1Xyzz[batch*W]        sum_j (j+1)*bucket_j for each window
+// "batch" independent scalar vectors over the same bases are handled as extra windows (window id =
+// b*W + w): the bases are read once per window from L2/HBM and nothing else changes.
+//
+// Pipeline: k_g1_digits -> scan (3 small kernels) -> k_g1_scatter -> k_g1_accumulate (dominant)
+//           -> k_g1_reduce_chunks -> k_g1_reduce_windows -> [host or k_g1_horner] combine windows.
+#pragma once
+#include "curve.cuh"
+
+namespace dr {
+
+DR_DEV Fq load_fq(const uint32_t* p) {
+    Fq r;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1], c = q[2];
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
+    return r;
+}
+DR_DEV void store_fq(uint32_t* p, const Fq& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    q[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+}
+DR_DEV G1Affine load_affine(const uint32_t* bases, uint32_t idx) {
+    const uint32_t* p = bases + (size_t)idx * 24;
+    G1Affine a;
+    a.x = load_fq(p);
+    a.y = load_fq(p + 12);
+    return a;
+}
+DR_DEV G1Xyzz load_xyzz(const uint32_t* arr, size_t idx) {
+    const uint32_t* p = arr + idx * 48;
+    G1Xyzz r;
+    r.x = load_fq(p); r.y = load_fq(p + 12); r.zz = load_fq(p + 24); r.zzz = load_fq(p + 36);
+    return r;
+}
+DR_DEV void store_xyzz(uint32_t* arr, size_t idx, const G1Xyzz& v) {
+    uint32_t* p = arr + idx * 48;
+    store_fq(p, v.x); store_fq(p + 12, v.y); store_fq(p + 24, v.zz); store_fq(p + 36, v.zzz);
+}
+
+// standard-form little-endian limbs -> Montgomery, in place (SRS load). (0,0) stays (0,0).
+__global__ void k_g1_bases_to_mont(uint32_t* bases, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t* p = bases + (size_t)i * 24;
+    store_fq(p, to_mont(load_fq(p)));
+    store_fq(p + 12, to_mont(load_fq(p + 12)));
+}
+
+// ---- 1. signed window digits + bucket histogram.  One lane per scalar.
+__global__ void k_g1_digits(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t batch, int c, int W,
+                            int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n * batch) return;
+    uint32_t b = (uint32_t)(gid / n), i = (uint32_t)(gid % n);
+    uint32_t k[9];
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(scalars + gid * 8);
+        uint4 lo = q[0], hi = q[1];
+        k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+        k[8] = 0;
+    }
+    const uint32_t H = 1u << (c - 1), mask = (1u << c) - 1;
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+        int bit = w * c, li = bit >> 5, sh = bit & 31;
+        uint32_t raw = 0;
+        if (li < 8) {
+            uint64_t two = (uint64_t)k[li] | ((uint64_t)k[li + 1] << 32);
+            raw = (uint32_t)(two >> sh) & mask;
+        }
+        raw += carry;
+        int32_t d;
+        if (raw > H) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
+        else { d = (int32_t)raw; carry = 0; }
+        size_t win = (size_t)b * W + w;
+        digits[win * n + i] = d;
+        if (d != 0) {
+            uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+            atomicAdd(&counts[win * H + (mag - 1)], 1u);
+        }
+    }
+}
+
+// ---- 2. exclusive scan of the histogram (three passes; the array is at most a few million entries)
+constexpr int SCAN_BLOCK = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+DR_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t* smem, uint32_t& total) {
+    // wave scan with shuffles, then scan of the 4 wave totals through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        uint32_t y = __shfl_up(x, s, 64);
+        if (lane >= s) x += y;
+    }
+    if (lane == 63) smem[wave] = x;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int w = 0; w < SCAN_BLOCK / 64; w++) {
+        uint32_t t = smem[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                           uint32_t* __restrict__ tile_sums, size_t n) {
+    __shared__ uint32_t smem[SCAN_BLOCK / 64];
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        v[j] = base + j < n ? in[base + j] : 0;
+        sum += v[j];
+    }
+    uint32_t total;
+    uint32_t excl = block_exclusive_scan(sum, smem, total);
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        if (base + j < n) out[base + j] = excl;
+        excl += v[j];
+    }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+// single block: exclusive scan of the tile sums (serial over tiles of 256; tile count is small)
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_tile_sums(uint32_t* tile_sums, uint32_t ntiles, uint32_t* grand_total) {
+    __shared__ uint32_t smem[SCAN_BLOCK / 64];
+    uint32_t running = 0;
+    for (uint32_t base = 0; base < ntiles; base += SCAN_BLOCK) {
+        uint32_t idx = base + threadIdx.x;
+        uint32_t v = idx < ntiles ? tile_sums[idx] : 0;
+        uint32_t total;
+        uint32_t excl = block_exclusive_scan(v, smem, total);
+        if (idx < ntiles) tile_sums[idx] = running + excl;
+        running += total;
+    }
+    if (threadIdx.x == 0) *grand_total = running;
+}
+__global__ void k_scan_add(uint32_t* out, const uint32_t* tile_sums, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += tile_sums[i / SCAN_TILE];
+}
+
+// ---- 3. counting-sort scatter: group (index|sign) by bucket
+__global__ void k_g1_scatter(const int32_t* __restrict__ digits, uint32_t n, size_t windows, int c,
+                             const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                             uint32_t* __restrict__ sorted) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= windows * n) return;
+    int32_t d = digits[gid];
+    if (d == 0) return;
+    size_t win = gid / n;
+    uint32_t i = (uint32_t)(gid % n);
+    const uint32_t H = 1u << (c - 1);
+    uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+    size_t bucket = win * H + (mag - 1);
+    uint32_t pos = offsets[bucket] + atomicAdd(&cursor[bucket], 1u);
+    sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
+}
+
+// ---- 4. bucket accumulation: one lane per bucket walks its segment with mixed additions.  DOMINANT KERNEL.
+// Algorithmic traffic: 96 B base + 32 B scalar per (base,scalar) pair; the gather of bases is the
+// only large stream, the segment lists are 4 B per entry.
+__global__ __launch_bounds__(256) void k_g1_accumulate(const uint32_t* __restrict__ bases,
+                                                       const uint32_t* __restrict__ sorted,
+                                                       const uint32_t* __restrict__ offsets,
+                                                       const uint32_t* __restrict__ counts,
+                                                       uint32_t* __restrict__ buckets, size_t nbuckets) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    uint32_t beg = offsets[b], len = counts[b];
+    G1Xyzz acc = g1_inf();
+#pragma unroll 1
+    for (uint32_t p = 0; p < len; p++) {
+        uint32_t e = sorted[beg + p];
+        G1Affine q = load_affine(bases, e & 0x7fffffffu);
+        q = g1_neg_affine(q, (e >> 31) != 0);
+        acc = g1_madd(acc, q);
+    }
+    store_xyzz(buckets, b, acc);
+}
+
+// ---- 5. bucket reduction.  Window value = sum_j (j+1) * B_j.  Chunk [s, s+L): running sums give
+//        sum_j (j-s+1) B_j and A = sum_j B_j; the chunk contributes that plus s*A (double-and-add, s < H).
+__global__ __launch_bounds__(128) void k_g1_reduce_chunks(const uint32_t* __restrict__ buckets, size_t windows,
+                                                          uint32_t H, uint32_t L, uint32_t* __restrict__ partial) {
+    const uint32_t T = H / L;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= windows * T) return;
+    size_t win = gid / T;
+    uint32_t ch = (uint32_t)(gid % T), s = ch * L;
+    G1Xyzz run = g1_inf(), sum = g1_inf();
+#pragma unroll 1
+    for (int j = (int)L - 1; j >= 0; j--) {
+        G1Xyzz bk = load_xyzz(buckets, win * H + s + j);
+        run = g1_add(run, bk);
+        sum = g1_add(sum, run);
+    }
+    if (s != 0 && !run.is_inf()) {
+        G1Xyzz t = g1_inf();
+        int top = 31 - __clz(s);
+#pragma unroll 1
+        for (int bit = top; bit >= 0; bit--) {
+            t = g1_dbl(t);
+            if ((s >> bit) & 1) t = g1_add(t, run);
+        }
+        sum = g1_add(sum, t);
+    }
+    store_xyzz(partial, gid, sum);
+}
+
+// one workgroup per window: lanes stride over the T chunk results, then an LDS tree folds the workgroup.
+constexpr int RW_BLOCK = 128;
+__global__ __launch_bounds__(RW_BLOCK) void k_g1_reduce_windows(const uint32_t* __restrict__ partial, uint32_t T,
+                                                                uint32_t* __restrict__ winsum) {
+    __shared__ uint32_t sm[RW_BLOCK * 48];
+    size_t win = blockIdx.x;
+    G1Xyzz acc = g1_inf();
+#pragma unroll 1
+    for (uint32_t t = threadIdx.x; t < T; t += RW_BLOCK) acc = g1_add(acc, load_xyzz(partial, win * T + t));
+    store_xyzz(sm, threadIdx.x, acc);
+    __syncthreads();
+#pragma unroll 1
+    for (int s = RW_BLOCK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            acc = g1_add(acc, load_xyzz(sm, threadIdx.x + s));
+            store_xyzz(sm, threadIdx.x, acc);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) store_xyzz(winsum, win, acc);
+}
+
+// ---- 6. (batch > 1) combine the W window sums of each MSM on the device: Horner over windows, c doublings each.
+__global__ void k_g1_horner(const uint32_t* __restrict__ winsum, uint32_t batch, int W, int c, uint32_t* __restrict__ out) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    G1Xyzz acc = g1_inf();
+#pragma unroll 1
+    for (int w = W - 1; w >= 0; w--) {
+#pragma unroll 1
+        for (int j = 0; j < c; j++) acc = g1_dbl(acc);
+        acc = g1_add(acc, load_xyzz(winsum, (size_t)b * W + w));
+    }
+    store_xyzz(out, b, acc);
+}
+
+}  // namespace dr

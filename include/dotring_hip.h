@@ -1,0 +1,134 @@
+/*
+ * dotring_hip.h — C ABI of libdotring_hip.so: the MI355X (gfx950) replacement for the native arithmetic on
+ * dot-ring's Ring-VRF prove/verify hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative dr_status; dr_last_error() gives the text
+ *     (thread-local).  The Python shim maps DR_ERR_INVALID -> ValueError, DR_ERR_NOMEM -> MemoryError,
+ *     the same exception types the reference raises at these seams.
+ *   - the caller owns every buffer; the library keeps no caller pointer after return.  Handles made by
+ *     *_create / *_load are freed by *_destroy.  A dr_ctx is bound to one GPU and one HIP stream; calls on
+ *     one ctx are synchronous (results are on the host when the call returns) and must not be issued
+ *     concurrently from several threads; different ctx objects are independent.
+ *   - Bandersnatch field elements / scalars: 32 bytes little-endian, standard form (as the reference's
+ *     bls_scalar_from_bytes, dot_ring/curve/native_field/bls12_381_scalar.c:266).  A TE affine point is
+ *     x(32) || y(32).
+ *   - BLS12-381 G1 affine points: 96 bytes, big-endian x(48) || y(48) — the SRS file record
+ *     (dot_ring/ring_proof/pcs/srs.py:61-70) and blst's serialize() format; all-zero coordinates or the
+ *     0x40 flag in byte 0 denote infinity.  KZG scalars: 32 bytes little-endian, any value < 2^256.
+ *   - *_dev variants take pointers into GPU memory obtained from dr_dev_alloc (same layouts) so that a
+ *     pipeline — or a benchmark — can keep its operands resident in HBM.
+ */
+#ifndef DOTRING_HIP_H
+#define DOTRING_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define DR_API __attribute__((visibility("default")))
+#else
+#define DR_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dr_ctx dr_ctx;
+typedef struct dr_srs dr_srs;
+
+enum dr_status {
+    DR_OK = 0,
+    DR_ERR_INVALID = -1,   /* bad length / encoding / argument  (reference: ValueError) */
+    DR_ERR_NOMEM = -2,     /* host or device allocation failed  (reference: MemoryError) */
+    DR_ERR_DEVICE = -3,    /* HIP runtime failure, no usable gfx950 device */
+    DR_ERR_NOTSQUARE = -4  /* dr_fr_sqrt: input is a quadratic non-residue (reference: ValueError) */
+};
+
+/* ---- library / context ------------------------------------------------------------------------- */
+DR_API const char *dr_version(void);
+DR_API const char *dr_last_error(void);
+DR_API int dr_device_count(void);
+DR_API int dr_ctx_create(int device_id, dr_ctx **out);
+DR_API void dr_ctx_destroy(dr_ctx *ctx);
+DR_API int dr_ctx_sync(dr_ctx *ctx);
+
+/* HBM buffers for the *_dev entry points */
+DR_API int dr_dev_alloc(dr_ctx *ctx, size_t bytes, void **dptr);
+DR_API int dr_dev_free(dr_ctx *ctx, void *dptr);
+DR_API int dr_dev_upload(dr_ctx *ctx, void *dptr, const void *host, size_t bytes);
+DR_API int dr_dev_download(dr_ctx *ctx, void *host, const void *dptr, size_t bytes);
+
+/* Per-kernel timing with HIP events on the ctx stream (used by bench.py for the roofline line).
+ * dr_prof_get: accumulated milliseconds and launch count of the kernel called `name` since the last reset. */
+DR_API int dr_prof_enable(dr_ctx *ctx, int on);
+DR_API int dr_prof_reset(dr_ctx *ctx);
+DR_API int dr_prof_get(dr_ctx *ctx, const char *name, double *total_ms, int *launches);
+
+/* ---- seam A: Bandersnatch kernels ---------------------------------------------------------------
+ * Replaces dot_ring/curve/native_field/bandersnatch_te.pyx:
+ *   scalar_mult_windowed_native_w2_cy :480 (+ GLV callers dot_ring/curve/glv.py:191, specs/bandersnatch.py:177)
+ *   scalar_mult_4_native_w2_cy :557, scalar_mult_6_native_w2_cy :669, msm_pippenger_signed_native_cy :257
+ *   sqrt_mod_bls_scalar_cy :421, projective_to_affine_cy :244
+ * Outputs are canonical affine coordinates (the reference normalises its projective tuples immediately,
+ * glv.py:243-248), so any internal windowing gives identical bytes.
+ */
+
+/* out[i] = scalars[i] * pts[i]  for i < n.  Scalars are taken mod the group order. */
+DR_API int dr_bsn_scalar_mul_batch(dr_ctx *ctx, const uint8_t *pts_xy /* n*64 */, const uint8_t *scalars /* n*32 */,
+                            size_t n, uint8_t *out_xy /* n*64 */);
+DR_API int dr_bsn_scalar_mul_batch_dev(dr_ctx *ctx, const void *d_pts_xy, const void *d_scalars, size_t n, void *d_out_xy);
+
+/* out = sum_i scalars[i] * pts[i]   (n may be 0: identity (0,1)) */
+DR_API int dr_bsn_msm(dr_ctx *ctx, const uint8_t *pts_xy, const uint8_t *scalars, size_t n, uint8_t out_xy[64]);
+
+/* groups[g] = sum of `m` consecutive terms: out[g] = sum_{j<m} scalars[g*m+j] * pts[g*m+j], g < groups.
+ * One launch for the many small fixed-arity MSMs of the sigma protocols (m = 2, 3, 4). */
+DR_API int dr_bsn_msm_groups(dr_ctx *ctx, const uint8_t *pts_xy, const uint8_t *scalars, size_t groups, size_t m,
+                      uint8_t *out_xy /* groups*64 */);
+
+/* square root in the Bandersnatch base field; DR_ERR_NOTSQUARE if none exists. Host-side, no ctx. */
+DR_API int dr_fr_sqrt(const uint8_t in[32], uint8_t out[32]);
+
+/* ---- seam B: KZG / BLS12-381 G1 -----------------------------------------------------------------
+ * Replaces the blst calls behind dot_ring/ring_proof/pcs/kzg.py: commit :152-175 (mult_pippenger over
+ * srs.blst_g1_memory[:n]), msm_g1 :147, compress_g1 :129, serialize_g1_uncompressed :133, decompress_g1 :137,
+ * and the SRS memory built in dot_ring/ring_proof/pcs/srs.py:98-114.
+ */
+DR_API int dr_srs_load(dr_ctx *ctx, const uint8_t *g1_be_xy /* m*96 */, size_t m, dr_srs **out);
+DR_API void dr_srs_destroy(dr_srs *srs);
+DR_API size_t dr_srs_size(const dr_srs *srs);
+
+/* out = sum_{i<n} scalars[i] * SRS[offset+i] ; *is_inf = 1 and out = zeros when the sum is the identity */
+DR_API int dr_g1_msm(dr_ctx *ctx, const dr_srs *srs, size_t offset, const uint8_t *scalars /* n*32 */, size_t n,
+              uint8_t out_be_xy[96], int *is_inf);
+DR_API int dr_g1_msm_dev(dr_ctx *ctx, const dr_srs *srs, size_t offset, const void *d_scalars, size_t n,
+                  uint8_t out_be_xy[96], int *is_inf);
+/* `batch` independent MSMs over the same bases SRS[0..n): scalars is batch*n*32, out is batch*96, is_inf batch ints */
+DR_API int dr_g1_msm_batch(dr_ctx *ctx, const dr_srs *srs, const uint8_t *scalars, size_t n, size_t batch,
+                    uint8_t *out_be_xy, int *is_inf);
+DR_API int dr_g1_msm_batch_dev(dr_ctx *ctx, const dr_srs *srs, const void *d_scalars, size_t n, size_t batch,
+                        uint8_t *out_be_xy, int *is_inf);
+/* MSM over caller-supplied points (verifier folds, kzg.py:295-301,332-338) */
+DR_API int dr_g1_msm_points(dr_ctx *ctx, const uint8_t *pts_be_xy /* n*96 */, const uint8_t *scalars, size_t n,
+                     uint8_t out_be_xy[96], int *is_inf);
+
+/* zcash encodings, host-side */
+DR_API int dr_g1_compress(const uint8_t xy[96], int is_inf, uint8_t out[48]);
+DR_API int dr_g1_decompress(const uint8_t in[48], uint8_t out_xy[96], int *is_inf);   /* on-curve check, no subgroup check (as blst P1_Affine(bytes)) */
+DR_API int dr_g1_serialize_check(const uint8_t xy[96]);                              /* DR_OK iff on curve or infinity */
+
+/* ---- seam C: NTT over Fr ------------------------------------------------------------------------
+ * Replaces BlsScalarNTTPlan.transform / transform_scaled (dot_ring/ring_proof/polynomial/ntt.pyx:104-163,
+ * bls_scalar_ntt_round in bls12_381_scalar.c:333): `batch` in-place radix-2 transforms of size 2^log2n with
+ * the primitive root `omega`; when scale != NULL every output is multiplied by it (inverse transform: pass
+ * omega^-1 and n^-1).  data: batch * 2^log2n * 32 bytes, natural order in and out.
+ */
+DR_API int dr_ntt(dr_ctx *ctx, uint8_t *data, unsigned log2n, size_t batch, const uint8_t omega[32], const uint8_t *scale);
+DR_API int dr_ntt_dev(dr_ctx *ctx, void *d_data, unsigned log2n, size_t batch, const uint8_t omega[32], const uint8_t *scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOTRING_HIP_H */

@@ -1,0 +1,163 @@
+"""GPU parity: HIP kernels (through the C ABI) against the CPU oracle on the same seeded inputs. Bit-exact."""
+import hashlib
+import random
+
+import pytest
+
+from oracle import coracle
+from oracle.pyref import bandersnatch as bsn
+
+pytestmark = pytest.mark.gpu
+
+N = bsn.N
+P = bsn.P
+
+
+def _seeded_points(count, tag=b"bsn-pt"):
+    pts = []
+    for i in range(count):
+        k = int.from_bytes(hashlib.sha256(tag + i.to_bytes(8, "little")).digest(), "little") % N
+        pts.append(coracle.te_mul(bsn.G, k or 1))
+    return pts
+
+
+def _seeded_scalars(count, tag=b"bsn-k", mod=N):
+    return [int.from_bytes(hashlib.sha256(tag + i.to_bytes(8, "little")).digest(), "little") % mod for i in range(count)]
+
+
+# ------------------------------------------------------------------ seam A
+def test_bsn_scalar_mul_batch_matches_oracle(ctx):
+    n = 300
+    pts, ks = _seeded_points(n), _seeded_scalars(n)
+    # edge scalars: 0, 1, n-1, n (== 0), 2^256-1 (reduced inside), small values
+    ks[:8] = [0, 1, N - 1, N, (1 << 256) - 1, 2, 8, 16]
+    got = ctx.bsn_scalar_mul_batch(coracle.te_pack(pts), b"".join(k.to_bytes(32, "little") for k in ks))
+    want = coracle.te_mul_batch_raw(coracle.te_pack(pts), coracle.scalars_pack([k % N for k in ks]), n, glv=False)
+    assert got == want
+
+
+def test_bsn_scalar_mul_identity_and_kat(ctx):
+    # identity input, and the reference KAT pk = sk*G (tests/golden/ark-vrf/bandersnatch_sha-512_ell2_tiny.json #1)
+    sk = int.from_bytes(bytes.fromhex("c9922b7a9849b9928e15c655dd2f22ceef737cc355024f43d4b04bf4398c270d"), "little")
+    out = ctx.bsn_scalar_mul_batch(coracle.te_pack([bsn.IDENTITY, bsn.G]), (5).to_bytes(32, "little") + sk.to_bytes(32, "little"))
+    pts = coracle.te_unpack(out)
+    assert pts[0] == bsn.IDENTITY
+    assert bsn.enc_point(pts[1]).hex() == "5a538209ff1fc7b1c9c8e1da05b3e169acf10a8b1591b3af029fe4eede0bbc71"
+
+
+def test_bsn_scalar_mul_ragged_sizes(ctx):
+    for n in (1, 63, 64, 65, 129):
+        pts, ks = _seeded_points(n, b"rag"), _seeded_scalars(n, b"ragk")
+        got = ctx.bsn_scalar_mul_batch(coracle.te_pack(pts), coracle.scalars_pack(ks))
+        assert got == coracle.te_mul_batch_raw(coracle.te_pack(pts), coracle.scalars_pack(ks), n, glv=True)
+    assert ctx.bsn_scalar_mul_batch(b"", b"") == b""
+
+
+def test_bsn_rejects_non_canonical_coordinate(ctx):
+    bad = (P).to_bytes(32, "little") + (1).to_bytes(32, "little")
+    with pytest.raises(ValueError):
+        ctx.bsn_scalar_mul_batch(bad, (1).to_bytes(32, "little"))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 17, 64, 65, 200])
+def test_bsn_msm_matches_oracle(ctx, n):
+    pts, ks = _seeded_points(n, b"msm"), _seeded_scalars(n, b"msmk")
+    got = coracle.te_unpack(ctx.bsn_msm(coracle.te_pack(pts), coracle.scalars_pack(ks)))[0]
+    assert got == (coracle.te_msm(pts, ks) if n else bsn.IDENTITY)
+
+
+def test_bsn_msm_groups(ctx):
+    for m in (2, 3, 4):
+        groups = 37
+        pts, ks = _seeded_points(groups * m, b"grp"), _seeded_scalars(groups * m, b"grpk")
+        out = coracle.te_unpack(ctx.bsn_msm_groups(coracle.te_pack(pts), coracle.scalars_pack(ks), m))
+        for g in range(groups):
+            assert out[g] == coracle.te_msm(pts[g * m : (g + 1) * m], ks[g * m : (g + 1) * m], 2)
+
+
+# ------------------------------------------------------------------ seam B
+def _be_to_le(raw96: bytes) -> bytes:
+    return raw96[:48][::-1] + raw96[48:][::-1]
+
+
+def _le_pack_from_be(blob: bytes, n: int) -> bytes:
+    return b"".join(_be_to_le(blob[96 * i : 96 * i + 96]) for i in range(n))
+
+
+def _oracle_msm_be(blob_be: bytes, ks: bytes, n: int):
+    out = coracle.g1_msm_raw(_le_pack_from_be(blob_be, n), ks, n)
+    if out == bytes(96):
+        return None
+    return out[:48][::-1] + out[48:][::-1]
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 100, 1000, 2048, 6145])
+def test_g1_msm_matches_oracle(ctx, srs_bytes, n):
+    srs = ctx.srs_load(srs_bytes)
+    rng = random.Random(n)
+    ks = b"".join(rng.randrange(coracle.FR_P).to_bytes(32, "little") for _ in range(n))
+    assert ctx.g1_msm(srs, ks) == _oracle_msm_be(srs_bytes, ks, n)
+    srs.close()
+
+
+def test_g1_msm_edge_scalars(ctx, srs_bytes):
+    srs = ctx.srs_load(srs_bytes[: 96 * 64])
+    n = 64
+    assert ctx.g1_msm(srs, bytes(32 * n)) is None                      # all-zero -> infinity (kzg.py:167)
+    assert ctx.g1_msm(srs, b"") is None
+    # 0/1 column (the ring prover's bit column), tiny values, r-1, values >= r (unreduced quotient coefficients)
+    r = coracle.FR_P
+    vals = [1, 0] * 16 + [3, 5, 255, 256, 65535, 65536] + [r - 1, r, r + 1, (1 << 256) - 1] + [7] * 22
+    ks = b"".join(v.to_bytes(32, "little") for v in vals)
+    assert ctx.g1_msm(srs, ks) == _oracle_msm_be(srs_bytes, b"".join((v % r).to_bytes(32, "little") for v in vals), n)
+    # offset into the SRS
+    ks2 = b"".join((v % r).to_bytes(32, "little") for v in vals[:20])
+    assert ctx.g1_msm(srs, ks2, offset=11) == _oracle_msm_be(srs_bytes[96 * 11 :], ks2, 20)
+    with pytest.raises(ValueError):
+        ctx.g1_msm(srs, bytes(32 * 65))
+    srs.close()
+
+
+def test_g1_msm_points_duplicates_and_cancellation(ctx, srs_bytes):
+    g = srs_bytes[:96]
+    neg_y = (coracle.FP_P - int.from_bytes(g[48:], "big")).to_bytes(48, "big")
+    pts = g * 5 + g[:48] + neg_y + bytes(96)                 # 5 x G, -G, infinity
+    ks = b"".join(v.to_bytes(32, "little") for v in (1, 1, 2, 3, 9, 16, 12345))
+    assert ctx.g1_msm_points(pts, ks) is None                # 16 G - 16 G
+    ks = b"".join(v.to_bytes(32, "little") for v in (1, 1, 2, 3, 9, 15, 12345))
+    assert ctx.g1_msm_points(pts, ks) == g                   # = 1 * G
+    with pytest.raises(ValueError):
+        ctx.g1_msm_points(g[:48] + bytes(47) + b"\x01", (1).to_bytes(32, "little"))   # not on the curve
+
+
+@pytest.mark.parametrize("window", [0])
+def test_g1_msm_batch_matches_singles(ctx, srs_bytes, window):
+    srs = ctx.srs_load(srs_bytes[: 96 * 512])
+    n, batch = 512, 5
+    rng = random.Random(99)
+    ks = b"".join(rng.randrange(coracle.FR_P).to_bytes(32, "little") for _ in range(n * batch))
+    ks = ks[: 32 * n * 4] + bytes(32 * n)                    # last vector all zero -> infinity
+    got = ctx.g1_msm_batch(srs, ks, n)
+    for b in range(batch):
+        assert got[b] == _oracle_msm_be(srs_bytes, ks[32 * n * b : 32 * n * (b + 1)], n)
+    srs.close()
+
+
+# ------------------------------------------------------------------ seam C
+@pytest.mark.parametrize("log2n", [1, 2, 5, 9, 10, 11, 13, 14])
+def test_ntt_matches_oracle(ctx, log2n):
+    from oracle.pyref.ring import ROOT_OF_UNITY_2048, _sqrt_mod_prime
+
+    n = 1 << log2n
+    root, size = ROOT_OF_UNITY_2048, 2048
+    while size < n:
+        root, size = _sqrt_mod_prime(root), size * 2
+    omega = pow(root, size // n, P)
+    rng = random.Random(log2n)
+    batch = 3
+    data = b"".join(rng.randrange(P).to_bytes(32, "little") for _ in range(n * batch))
+    fwd = ctx.ntt(data, log2n, omega)
+    for b in range(batch):
+        assert fwd[32 * n * b : 32 * n * (b + 1)] == coracle.ntt_raw(data[32 * n * b : 32 * n * (b + 1)], n, omega)
+    back = ctx.ntt(fwd, log2n, pow(omega, -1, P), pow(n, -1, P))
+    assert back == data
