@@ -42,6 +42,8 @@ _PROTOTYPES = {
     "dr_bsn_msm_groups": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, c_size_t, c_void_p]),
     "dr_fr_sqrt": (c_int, [c_char_p, c_void_p]),
     "dr_srs_load": (c_int, [c_void_p, c_char_p, c_size_t, POINTER(c_void_p)]),
+    "dr_srs_synthetic": (c_int, [c_void_p, c_char_p, c_uint, c_size_t, POINTER(c_void_p)]),
+    "dr_srs_download": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "dr_srs_destroy": (None, [c_void_p]),
     "dr_srs_size": (c_size_t, [c_void_p]),
     "dr_g1_msm": (c_int, [c_void_p, c_void_p, c_size_t, c_char_p, c_size_t, c_void_p, POINTER(c_int)]),
@@ -49,6 +51,7 @@ _PROTOTYPES = {
     "dr_g1_msm_batch": (c_int, [c_void_p, c_void_p, c_char_p, c_size_t, c_size_t, c_void_p, POINTER(c_int)]),
     "dr_g1_msm_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, POINTER(c_int)]),
     "dr_g1_msm_points": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, c_void_p, POINTER(c_int)]),
+    "dr_g1_sum": (c_int, [c_char_p, c_size_t, c_void_p, POINTER(c_int)]),
     "dr_g1_compress": (c_int, [c_char_p, c_int, c_void_p]),
     "dr_g1_decompress": (c_int, [c_char_p, c_void_p, POINTER(c_int)]),
     "dr_g1_serialize_check": (c_int, [c_char_p]),
@@ -120,13 +123,22 @@ class DeviceBuffer:
 class Srs:
     """SRS bases resident in HBM (Montgomery-form affine)."""
 
-    def __init__(self, ctx: "Context", g1_be_xy: bytes):
-        if len(g1_be_xy) % 96:
-            raise ValueError("SRS bytes must be a multiple of 96")
+    def __init__(self, ctx: "Context", g1_be_xy: bytes | None = None, *, synthetic_seed: bytes | None = None, first: int = 1, count: int = 0):
         self.ctx = ctx
         self.handle = c_void_p()
+        if synthetic_seed is not None:
+            self.count = count
+            _check(lib().dr_srs_synthetic(ctx.handle, synthetic_seed, first, count, byref(self.handle)))
+            return
+        if g1_be_xy is None or len(g1_be_xy) % 96:
+            raise ValueError("SRS bytes must be a multiple of 96")
         self.count = len(g1_be_xy) // 96
         _check(lib().dr_srs_load(ctx.handle, g1_be_xy, self.count, byref(self.handle)))
+
+    def download(self, offset: int, count: int) -> bytes:
+        out = ctypes.create_string_buffer(max(96 * count, 1))
+        _check(lib().dr_srs_download(self.ctx.handle, self.handle, offset, count, out))
+        return out.raw[: 96 * count]
 
     def close(self) -> None:
         if self.handle:
@@ -204,6 +216,10 @@ class Context:
     def srs_load(self, g1_be_xy: bytes) -> Srs:
         return Srs(self, g1_be_xy)
 
+    def srs_synthetic(self, seed_be_xy: bytes, count: int, first: int = 1) -> Srs:
+        """bases[i] = (first+i) * seed, generated on the GPU."""
+        return Srs(self, synthetic_seed=seed_be_xy, first=first, count=count)
+
     def g1_msm(self, srs: Srs, scalars: bytes, offset: int = 0) -> bytes | None:
         """Affine BE x||y (96 bytes) or None for the point at infinity."""
         n = len(scalars) // 32
@@ -260,6 +276,14 @@ def fr_sqrt(v: int) -> int:
     out = ctypes.create_string_buffer(32)
     _check(lib().dr_fr_sqrt(int(v).to_bytes(32, "little"), out))
     return int.from_bytes(out.raw, "little")
+
+
+def g1_sum(points: list) -> bytes | None:
+    """Host-side sum of a few affine points (96-byte BE records or None)."""
+    raw = b"".join(bytes(96) if p is None else p for p in points)
+    out, inf = ctypes.create_string_buffer(96), c_int(0)
+    _check(lib().dr_g1_sum(raw, len(points), out, byref(inf)))
+    return None if inf.value else out.raw
 
 
 def g1_compress(xy: bytes | None) -> bytes:

@@ -134,13 +134,16 @@ int prof_collect(dr_ctx* ctx) {
 
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
-// ---- window size for the GPU Pippenger.  Work ~ W*(n*batch) mixed adds + W*batch*2^(c-1)*(2 full adds);
-// a full add costs ~1.4 mixed adds; pick the c minimising that, within [4,16].
+// ---- window plan for the GPU Pippenger.  Scalars are reduced mod r (< 2^255) on the device and the 256 bits
+// are tiled by W = ceil(256/c) windows of width cmax or cmax-1 (see WindowTable).  Work ~ W*n mixed adds +
+// W*2^(c-1)*(2 full adds) + per-chunk scalar multiplications; a full add costs ~1.4 mixed adds; pick the c
+// minimising that, within [7,16] (W <= 37 fits the table).
+bool window_ok(int c) { return c >= 7 && c <= 16; }
 int pick_window(size_t n) {
-    int best = 4;
+    int best = 7;
     double best_cost = 1e300;
-    for (int c = 4; c <= 16; c++) {
-        int W = 256 / c + 1;
+    for (int c = 7; c <= 16; c++) {
+        int W = (256 + c - 1) / c;
         double cost = (double)W * ((double)n + 2.8 * (double)(1u << (c - 1)) + 40.0 * (double)((1u << (c - 1)) / 16 + 1));
         if (cost < best_cost) { best_cost = cost; best = c; }
     }
@@ -148,14 +151,25 @@ int pick_window(size_t n) {
 }
 
 struct MsmPlan {
-    int c, W;
+    dr::WindowTable wt;
+    int W;
     uint32_t H, L, T;
 };
 MsmPlan make_plan(size_t n, int force_c) {
     MsmPlan p;
-    p.c = force_c > 0 ? force_c : pick_window(n);
-    p.W = 256 / p.c + 1;
-    p.H = 1u << (p.c - 1);
+    int c = window_ok(force_c) ? force_c : pick_window(n);
+    p.W = (256 + c - 1) / c;
+    int base = 256 / p.W, rem = 256 % p.W;       // `rem` windows of width base+1 (placed on top), the rest base
+    p.wt.W = p.W;
+    p.wt.cmax = base + (rem ? 1 : 0);
+    int bit = 0;
+    for (int w = 0; w < p.W; w++) {
+        int width = base + (w >= p.W - rem ? 1 : 0);
+        p.wt.start[w] = (uint8_t)bit;
+        p.wt.width[w] = (uint8_t)width;
+        bit += width;
+    }
+    p.H = 1u << (p.wt.cmax - 1);
     p.L = std::min<uint32_t>(p.H, 16);
     p.T = p.H / p.L;
     return p;
@@ -191,7 +205,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
 
     TRY(launch(ctx, "k_g1_digits", [&] {
         hipLaunchKernelGGL(dr::k_g1_digits, dim3(div_up(n * batch, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n,
-                           (uint32_t)batch, pl.c, pl.W, ctx->digits.as<int32_t>(), ctx->counts.as<uint32_t>());
+                           (uint32_t)batch, pl.wt, ctx->digits.as<int32_t>(), ctx->counts.as<uint32_t>());
     }));
     TRY(launch(ctx, "k_scan", [&] {
         hipLaunchKernelGGL(dr::k_scan_tiles, dim3(ntiles), dim3(dr::SCAN_BLOCK), 0, st, ctx->counts.as<uint32_t>(),
@@ -203,7 +217,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     }));
     TRY(launch(ctx, "k_g1_scatter", [&] {
         hipLaunchKernelGGL(dr::k_g1_scatter, dim3(div_up(ndigits, 256)), dim3(256), 0, st, ctx->digits.as<int32_t>(),
-                           (uint32_t)n, windows, pl.c, ctx->offsets.as<uint32_t>(), ctx->cursor.as<uint32_t>(),
+                           (uint32_t)n, windows, pl.H, ctx->offsets.as<uint32_t>(), ctx->cursor.as<uint32_t>(),
                            ctx->sorted.as<uint32_t>());
     }));
     TRY(launch(ctx, "k_g1_accumulate", [&] {
@@ -226,9 +240,9 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         std::vector<drh::G1> ws(pl.W);
         HIP_TRY(hipMemcpyAsync(ws.data(), ctx->winsum.p, (size_t)pl.W * 192, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        drh::G1 acc = drh::G1::inf();
-        for (int w = pl.W - 1; w >= 0; w--) {
-            for (int j = 0; j < pl.c; j++) acc = drh::g1_dbl(acc);
+        drh::G1 acc = ws[pl.W - 1];
+        for (int w = pl.W - 2; w >= 0; w--) {
+            for (int j = 0; j < pl.wt.width[w]; j++) acc = drh::g1_dbl(acc);
             acc = drh::g1_add(acc, ws[w]);
         }
         results[0] = acc;
@@ -236,7 +250,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         TRY(ctx->result.reserve(batch * 192));
         TRY(launch(ctx, "k_g1_horner", [&] {
             hipLaunchKernelGGL(dr::k_g1_horner, dim3(div_up(batch, 64)), dim3(64), 0, st, ctx->winsum.as<uint32_t>(),
-                               (uint32_t)batch, pl.W, pl.c, ctx->result.as<uint32_t>());
+                               (uint32_t)batch, pl.wt, ctx->result.as<uint32_t>());
         }));
         HIP_TRY(hipMemcpyAsync(results.data(), ctx->result.p, batch * 192, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -311,7 +325,7 @@ int dr_ctx_create(int device_id, dr_ctx** out) {
     }
     const char* fc = std::getenv("DOTRING_MSM_WINDOW");
     g_force_c = fc ? std::atoi(fc) : 0;
-    if (g_force_c < 0 || g_force_c > 16 || (g_force_c > 0 && g_force_c < 2)) g_force_c = 0;
+    if (!window_ok(g_force_c)) g_force_c = 0;
     *out = ctx;
     return DR_OK;
 }
@@ -510,6 +524,56 @@ int dr_srs_load(dr_ctx* ctx, const uint8_t* g1_be_xy, size_t m, dr_srs** out) {
     return DR_OK;
 }
 
+int dr_srs_synthetic(dr_ctx* ctx, const uint8_t seed_be_xy[96], uint32_t first, size_t count, dr_srs** out) {
+    TRY(use_ctx(ctx));
+    if (!out || !seed_be_xy) return fail(DR_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (count == 0 || count >= (1ull << 31) || (uint64_t)first + count >= (1ull << 32) || first == 0)
+        return fail(DR_ERR_INVALID, "bad synthetic SRS range");
+    std::vector<uint8_t> le;
+    TRY(g1_be_to_le_limbs(seed_be_xy, 1, le, true));
+    dr_srs* s = new (std::nothrow) dr_srs();
+    if (!s) return fail(DR_ERR_NOMEM, "out of host memory");
+    s->device = ctx->device;
+    s->count = count;
+    uint32_t* d_seed = nullptr;
+    hipError_t e = hipMalloc((void**)&s->d_bases, count * 96);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_seed, 96);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_seed, le.data(), 96, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dr::k_g1_bases_to_mont, dim3(1), dim3(64), 0, ctx->stream, d_seed, 1u);
+        hipLaunchKernelGGL(dr::k_g1_synth_bases, dim3(div_up(count, 128)), dim3(128), 0, ctx->stream, s->d_bases, (uint32_t)count, first, d_seed);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (d_seed) (void)hipFree(d_seed);
+    if (e != hipSuccess) {
+        if (s->d_bases) (void)hipFree(s->d_bases);
+        delete s;
+        return fail(e == hipErrorOutOfMemory ? DR_ERR_NOMEM : DR_ERR_DEVICE, std::string("synthetic SRS: ") + hipGetErrorString(e));
+    }
+    *out = s;
+    return DR_OK;
+}
+
+int dr_srs_download(dr_ctx* ctx, const dr_srs* srs, size_t offset, size_t count, uint8_t* out_be_xy) {
+    TRY(use_ctx(ctx));
+    if (!srs || !out_be_xy) return fail(DR_ERR_INVALID, "null argument");
+    if (offset > srs->count || count > srs->count - offset) return fail(DR_ERR_INVALID, "range exceeds SRS size");
+    if (count == 0) return DR_OK;
+    TRY(ctx->io_a.reserve(count * 96));
+    hipLaunchKernelGGL(dr::k_g1_bases_from_mont, dim3(div_up(count, 256)), dim3(256), 0, ctx->stream,
+                       srs->d_bases + offset * 24, ctx->io_a.as<uint32_t>(), (uint32_t)count);
+    std::vector<uint8_t> le(count * 96);
+    HIP_TRY(hipMemcpyAsync(le.data(), ctx->io_a.p, count * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < count; i++)
+        for (int j = 0; j < 48; j++) {
+            out_be_xy[96 * i + j] = le[96 * i + 47 - j];
+            out_be_xy[96 * i + 48 + j] = le[96 * i + 95 - j];
+        }
+    return DR_OK;
+}
+
 void dr_srs_destroy(dr_srs* srs) {
     if (!srs) return;
     (void)hipSetDevice(srs->device);
@@ -576,6 +640,26 @@ int dr_g1_msm_points(dr_ctx* ctx, const uint8_t* pts_be_xy, const uint8_t* scala
     std::vector<drh::G1> res;
     TRY(msm_device(ctx, ctx->io_a.as<uint32_t>(), ctx->scalars.as<uint32_t>(), n, 1, res));
     g1_result_to_bytes(res[0], out_be_xy, is_inf);
+    return DR_OK;
+}
+
+int dr_g1_sum(const uint8_t* pts_be_xy, size_t n, uint8_t out_be_xy[96], int* is_inf) {
+    if (!out_be_xy || (n && !pts_be_xy)) return fail(DR_ERR_INVALID, "null buffer");
+    std::vector<uint8_t> le;
+    TRY(g1_be_to_le_limbs(pts_be_xy, n, le, true));
+    drh::G1 acc = drh::G1::inf();
+    for (size_t i = 0; i < n; i++) {
+        drh::G1 p;
+        bool allz = true;
+        for (int j = 0; j < 96; j++) if (le[96 * i + j]) { allz = false; break; }
+        if (allz) continue;
+        drh::Fq::load_le(p.x, le.data() + 96 * i);
+        drh::Fq::load_le(p.y, le.data() + 96 * i + 48);
+        p.zz = drh::Fq::one();
+        p.zzz = drh::Fq::one();
+        acc = drh::g1_add(acc, p);
+    }
+    g1_result_to_bytes(acc, out_be_xy, is_inf);
     return DR_OK;
 }
 

@@ -63,9 +63,59 @@ __global__ void k_g1_bases_to_mont(uint32_t* bases, uint32_t n) {
     store_fq(p + 12, to_mont(load_fq(p + 12)));
 }
 
+// XYZZ -> affine (Montgomery); infinity -> (0,0)
+DR_DEV G1Affine g1_to_affine_dev(const G1Xyzz& p) {
+    G1Affine a;
+    if (p.is_inf()) { a.x = Fq::zero(); a.y = Fq::zero(); return a; }
+    Fq zi3 = inv(p.zzz);
+    Fq t = mul(p.zz, zi3);
+    a.x = mul(p.x, sqr(t));
+    a.y = mul(p.y, zi3);
+    return a;
+}
+
+// synthetic bases for full-size measurements: bases[i] = (first + i) * seed   (seed affine, Montgomery)
+__global__ void k_g1_synth_bases(uint32_t* bases, uint32_t n, uint32_t first, const uint32_t* seed) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine s = load_affine(seed, 0);
+    uint32_t k = first + i;
+    G1Xyzz acc = g1_inf();
+#pragma unroll 1
+    for (int bit = 31 - __clz(k | 1); bit >= 0; bit--) {
+        acc = g1_dbl(acc);
+        if ((k >> bit) & 1) acc = g1_madd(acc, s);
+    }
+    G1Affine a = g1_to_affine_dev(acc);
+    uint32_t* p = bases + (size_t)i * 24;
+    store_fq(p, a.x);
+    store_fq(p + 12, a.y);
+}
+
+// Montgomery affine -> standard-form little-endian limbs (SRS download)
+__global__ void k_g1_bases_from_mont(const uint32_t* bases, uint32_t* out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* p = bases + (size_t)i * 24;
+    uint32_t* q = out + (size_t)i * 24;
+    store_fq(q, from_mont(load_fq(p)));
+    store_fq(q + 12, from_mont(load_fq(p + 12)));
+}
+
+// Window table: the 256 scalar bits are tiled by W windows of width cmax or cmax-1 (wider ones on top), so every
+// window has about the same number of live buckets.  A narrow top window would otherwise hold only a few bits
+// and funnel n/2^t points into each of its few buckets — one lane then walks a chain thousands of points long.
+struct WindowTable {
+    int W, cmax;
+    uint8_t start[40];   // first bit of window w   (W <= 40: widths >= 7 ... see make_plan)
+    uint8_t width[40];
+};
+constexpr int MAX_WINDOWS = 40;
+
 // ---- 1. signed window digits + bucket histogram.  One lane per scalar.
-__global__ void k_g1_digits(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t batch, int c, int W,
+__global__ void k_g1_digits(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t batch, WindowTable wt,
                             int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
+    const int W = wt.W;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)n * batch) return;
     uint32_t b = (uint32_t)(gid / n), i = (uint32_t)(gid % n);
@@ -76,18 +126,28 @@ __global__ void k_g1_digits(const uint32_t* __restrict__ scalars, uint32_t n, ui
         k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
         k[8] = 0;
     }
-    const uint32_t H = 1u << (c - 1), mask = (1u << c) - 1;
+    // scalars are taken mod r (the group order): 2^256 < 3r, so two conditional subtractions.  k < r < 2^255 and
+    // the windows tile 256 bits, so the top window has a spare bit and the signed recoding never carries out.
+    {
+        constexpr uint32_t R[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+#pragma unroll 1
+        for (int it = 0; it < 2; it++) {
+            uint32_t d[8], borrow = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) d[j] = subb(k[j], R[j], borrow);
+#pragma unroll
+            for (int j = 0; j < 8; j++) k[j] = borrow ? k[j] : d[j];
+        }
+    }
+    const uint32_t H = 1u << (wt.cmax - 1);     // bucket stride per window
     uint32_t carry = 0;
     for (int w = 0; w < W; w++) {
-        int bit = w * c, li = bit >> 5, sh = bit & 31;
-        uint32_t raw = 0;
-        if (li < 8) {
-            uint64_t two = (uint64_t)k[li] | ((uint64_t)k[li + 1] << 32);
-            raw = (uint32_t)(two >> sh) & mask;
-        }
-        raw += carry;
+        const int bit = wt.start[w], c = wt.width[w], li = bit >> 5, sh = bit & 31;
+        const uint32_t half = 1u << (c - 1);
+        uint64_t two = (uint64_t)k[li] | ((uint64_t)k[li + 1] << 32);
+        uint32_t raw = ((uint32_t)(two >> sh) & ((1u << c) - 1)) + carry;
         int32_t d;
-        if (raw > H) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
+        if (raw > half) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
         else { d = (int32_t)raw; carry = 0; }
         size_t win = (size_t)b * W + w;
         digits[win * n + i] = d;
@@ -162,7 +222,7 @@ __global__ void k_scan_add(uint32_t* out, const uint32_t* tile_sums, size_t n) {
 }
 
 // ---- 3. counting-sort scatter: group (index|sign) by bucket
-__global__ void k_g1_scatter(const int32_t* __restrict__ digits, uint32_t n, size_t windows, int c,
+__global__ void k_g1_scatter(const int32_t* __restrict__ digits, uint32_t n, size_t windows, uint32_t H,
                              const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
                              uint32_t* __restrict__ sorted) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -171,7 +231,6 @@ __global__ void k_g1_scatter(const int32_t* __restrict__ digits, uint32_t n, siz
     if (d == 0) return;
     size_t win = gid / n;
     uint32_t i = (uint32_t)(gid % n);
-    const uint32_t H = 1u << (c - 1);
     uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
     size_t bucket = win * H + (mag - 1);
     uint32_t pos = offsets[bucket] + atomicAdd(&cursor[bucket], 1u);
@@ -251,16 +310,16 @@ __global__ __launch_bounds__(RW_BLOCK) void k_g1_reduce_windows(const uint32_t* 
     if (threadIdx.x == 0) store_xyzz(winsum, win, acc);
 }
 
-// ---- 6. (batch > 1) combine the W window sums of each MSM on the device: Horner over windows, c doublings each.
-__global__ void k_g1_horner(const uint32_t* __restrict__ winsum, uint32_t batch, int W, int c, uint32_t* __restrict__ out) {
+// ---- 6. (batch > 1) combine the W window sums of each MSM on the device: Horner over windows, width[w] doublings each.
+__global__ void k_g1_horner(const uint32_t* __restrict__ winsum, uint32_t batch, WindowTable wt, uint32_t* __restrict__ out) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
-    G1Xyzz acc = g1_inf();
+    G1Xyzz acc = load_xyzz(winsum, (size_t)b * wt.W + wt.W - 1);
 #pragma unroll 1
-    for (int w = W - 1; w >= 0; w--) {
+    for (int w = wt.W - 2; w >= 0; w--) {
 #pragma unroll 1
-        for (int j = 0; j < c; j++) acc = g1_dbl(acc);
-        acc = g1_add(acc, load_xyzz(winsum, (size_t)b * W + w));
+        for (int j = 0; j < wt.width[w]; j++) acc = g1_dbl(acc);
+        acc = g1_add(acc, load_xyzz(winsum, (size_t)b * wt.W + w));
     }
     store_xyzz(out, b, acc);
 }

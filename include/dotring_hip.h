@@ -97,6 +97,11 @@ DR_API int dr_fr_sqrt(const uint8_t in[32], uint8_t out[32]);
  * and the SRS memory built in dot_ring/ring_proof/pcs/srs.py:98-114.
  */
 DR_API int dr_srs_load(dr_ctx *ctx, const uint8_t *g1_be_xy /* m*96 */, size_t m, dr_srs **out);
+/* Synthetic bases for sizes no SRS file covers: base[i] = (first+i) * seed (first >= 1), generated on
+ * the GPU.  With these bases an MSM has the closed form [sum_i k_i*(first+i)] * seed — a size-independent check. */
+DR_API int dr_srs_synthetic(dr_ctx *ctx, const uint8_t seed_be_xy[96], uint32_t first, size_t count, dr_srs **out);
+/* copy `count` bases starting at `offset` back to the host as BE x||y records */
+DR_API int dr_srs_download(dr_ctx *ctx, const dr_srs *srs, size_t offset, size_t count, uint8_t *out_be_xy);
 DR_API void dr_srs_destroy(dr_srs *srs);
 DR_API size_t dr_srs_size(const dr_srs *srs);
 
@@ -113,6 +118,9 @@ DR_API int dr_g1_msm_batch_dev(dr_ctx *ctx, const dr_srs *srs, const void *d_sca
 /* MSM over caller-supplied points (verifier folds, kzg.py:295-301,332-338) */
 DR_API int dr_g1_msm_points(dr_ctx *ctx, const uint8_t *pts_be_xy /* n*96 */, const uint8_t *scalars, size_t n,
                      uint8_t out_be_xy[96], int *is_inf);
+
+/* host-side sum of a few affine points (combining per-GPU partial MSM results after an all-gather) */
+DR_API int dr_g1_sum(const uint8_t *pts_be_xy /* n*96 */, size_t n, uint8_t out_be_xy[96], int *is_inf);
 
 /* zcash encodings, host-side */
 DR_API int dr_g1_compress(const uint8_t xy[96], int is_inf, uint8_t out[48]);
