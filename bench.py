@@ -70,7 +70,7 @@ def main() -> int:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from dot_ring_amd import _native
+    from dot_ring_amd import _native, parallel
 
     ctx = _native.Context(local_rank)
     n = 1 << args.log2n
@@ -92,11 +92,7 @@ def main() -> int:
         part = ctx.g1_msm_dev(srs, d_scalars, n)
         if dist is None:
             return part
-        mine = torch.frombuffer(bytearray(part if part is not None else bytes(96)), dtype=torch.uint8).cuda()
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        pts = [bytes(g.cpu().numpy().tobytes()) for g in gathered]
-        return _native.g1_sum([None if p == bytes(96) else p for p in pts])
+        return parallel.combine_partials(part)
 
     for _ in range(args.warmup):
         step()
