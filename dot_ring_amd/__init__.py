@@ -1,8 +1,17 @@
 """dot_ring_amd — MI355X-native (gfx950) Ring-VRF hot path behind dot-ring's Python API.
 
 The arithmetic lives in libdotring_hip.so (hand-written HIP, see dot_ring_amd/csrc and include/dotring_hip.h);
-this package is the host-side mirror of the reference interface.  There is no CPU fallback.
+this package mirrors the reference's public names (dot_ring/__init__.py:3-19) for the Bandersnatch suites:
+    TinyVRF, PedersenVRF, RingVRF, Ring, RingRoot, RingProofParams, Bandersnatch, Bandersnatch_SHAKE128
+plus the additive prove_batch() entry points.  There is no CPU fallback for the kernels.
 """
 from . import _native  # noqa: F401
+from .curve import Bandersnatch, Bandersnatch_SHAKE128
+from .ring_proof.params import RingProofParams
+from .ring_proof.pcs import KZG
+from .vrf.pedersen import PedersenVRF
+from .vrf.ring_vrf import Ring, RingRoot, RingVRF
+from .vrf.tiny import TinyVRF
 
-__all__ = ["_native"]
+__all__ = ["TinyVRF", "PedersenVRF", "RingVRF", "Ring", "RingRoot", "RingProofParams", "KZG",
+           "Bandersnatch", "Bandersnatch_SHAKE128"]

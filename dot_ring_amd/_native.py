@@ -52,6 +52,7 @@ _PROTOTYPES = {
     "dr_g1_msm_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, POINTER(c_int)]),
     "dr_g1_msm_points": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, c_void_p, POINTER(c_int)]),
     "dr_g1_sum": (c_int, [c_char_p, c_size_t, c_void_p, POINTER(c_int)]),
+    "dr_pairing_check": (c_int, [c_char_p, c_char_p, c_size_t, POINTER(c_int)]),
     "dr_g1_compress": (c_int, [c_char_p, c_int, c_void_p]),
     "dr_g1_decompress": (c_int, [c_char_p, c_void_p, POINTER(c_int)]),
     "dr_g1_serialize_check": (c_int, [c_char_p]),
@@ -284,6 +285,23 @@ def g1_sum(points: list) -> bytes | None:
     out, inf = ctypes.create_string_buffer(96), c_int(0)
     _check(lib().dr_g1_sum(raw, len(points), out, byref(inf)))
     return None if inf.value else out.raw
+
+
+def pairing_check(pairs: list) -> bool:
+    """True iff prod e(P_i, Q_i) == 1; pairs = [(g1_96_bytes_or_None, g2_192_bytes), ...]. Host-side."""
+    g1 = b"".join(bytes(96) if p is None else p for p, _ in pairs)
+    g2 = b"".join(q for _, q in pairs)
+    ok = c_int(0)
+    _check(lib().dr_pairing_check(g1, g2, len(pairs), byref(ok)))
+    return bool(ok.value)
+
+
+def g1_neg(xy: bytes | None) -> bytes | None:
+    if xy is None:
+        return None
+    y = int.from_bytes(xy[48:], "big")
+    p = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    return xy[:48] + ((p - y) % p).to_bytes(48, "big")
 
 
 def g1_compress(xy: bytes | None) -> bytes:

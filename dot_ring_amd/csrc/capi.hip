@@ -11,6 +11,7 @@
 
 #include "../../include/dotring_hip.h"
 #include "hostmath.hpp"
+#include "hostpairing.hpp"
 #include "kernels_bsn.cuh"
 #include "kernels_g1.cuh"
 #include "kernels_ntt.cuh"
@@ -660,6 +661,33 @@ int dr_g1_sum(const uint8_t* pts_be_xy, size_t n, uint8_t out_be_xy[96], int* is
         acc = drh::g1_add(acc, p);
     }
     g1_result_to_bytes(acc, out_be_xy, is_inf);
+    return DR_OK;
+}
+
+int dr_pairing_check(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, int* ok) {
+    if (!ok || (n && (!g1_be_xy || !g2_be))) return fail(DR_ERR_INVALID, "null buffer");
+    std::vector<uint8_t> le;
+    TRY(g1_be_to_le_limbs(g1_be_xy, n, le, true));
+    drh::Fq12 f = drh::Fq12::one();
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t* q = g2_be + 192 * i;
+        drh::G2Affine Q;
+        bool allz = true;
+        for (int j = 0; j < 192; j++) if (q[j]) { allz = false; break; }
+        Q.inf = allz || (q[0] & 0x40);
+        bool p_inf = true;
+        for (int j = 0; j < 96; j++) if (le[96 * i + j]) { p_inf = false; break; }
+        if (Q.inf || p_inf) continue;                       // e(O, Q) = e(P, O) = 1
+        // zcash layout: x.c1 || x.c0 || y.c1 || y.c0, 48-byte big-endian each (pcs/srs.py:78-88)
+        if (!drh::Fq::load_be(Q.x.c1, q) || !drh::Fq::load_be(Q.x.c0, q + 48) || !drh::Fq::load_be(Q.y.c1, q + 96) ||
+            !drh::Fq::load_be(Q.y.c0, q + 144) || !drh::g2_on_curve(Q))
+            return fail(DR_ERR_INVALID, "invalid BLS12-381 G2 encoding");
+        drh::Fq px, py;
+        drh::Fq::load_le(px, le.data() + 96 * i);
+        drh::Fq::load_le(py, le.data() + 96 * i + 48);
+        f = f * drh::miller_loop(px, py, Q);
+    }
+    *ok = drh::final_exponentiation(f) == drh::Fq12::one() ? 1 : 0;
     return DR_OK;
 }
 

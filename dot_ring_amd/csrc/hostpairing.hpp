@@ -1,0 +1,137 @@
+// Host-side BLS12-381 optimal-ate pairing product check:  prod_i e(P_i, Q_i) == 1.
+// The KZG verifier needs two Miller loops and one final exponentiation per *batch* (reference:
+// dot_ring/ring_proof/pcs/kzg.py:216-230,298-301,335-338 through blst's PT / finalverify, pcs/pairing.py:24-31);
+// SURVEY §8 keeps this on the CPU.  Written for clarity, not speed: tower Fq2 = Fq[u]/(u^2+1),
+// Fq6 = Fq2[v]/(v^3 - (u+1)), Fq12 = Fq6[w]/(w^2 - v); affine G2 arithmetic in the Miller loop; the final
+// exponentiation is ((f^(p^6-1))^(p^2+1))^((p^4-p^2+1)/r) with the last two powers as plain square-and-multiply
+// (pairing_consts.hpp holds p^2+1 and (p^4-p^2+1)/r, generated from the curve parameters with Python big ints).
+//
+// Line functions: for the M-type twist E': y^2 = x^3 + 4(u+1) and T = (xT, yT) in E'(Fq2), slope s, P = (xP, yP):
+//   l * w^3 = (s*xT - yT) + (-s*xP) * v + yP * v*w          (w^3 lies in Fq4, killed by the final exponentiation)
+#pragma once
+#include "hostmath.hpp"
+#include "pairing_consts.hpp"
+
+namespace drh {
+
+struct Fq2 {
+    Fq c0, c1;
+    static Fq2 zero() { return {Fq::zero(), Fq::zero()}; }
+    static Fq2 one() { return {Fq::one(), Fq::zero()}; }
+    bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    bool operator==(const Fq2& o) const { return c0 == o.c0 && c1 == o.c1; }
+    Fq2 operator+(const Fq2& o) const { return {c0 + o.c0, c1 + o.c1}; }
+    Fq2 operator-(const Fq2& o) const { return {c0 - o.c0, c1 - o.c1}; }
+    Fq2 neg() const { return {c0.neg(), c1.neg()}; }
+    Fq2 operator*(const Fq2& o) const {
+        Fq a = c0 * o.c0, b = c1 * o.c1;
+        return {a - b, (c0 + c1) * (o.c0 + o.c1) - a - b};
+    }
+    Fq2 sqr() const { return *this * *this; }
+    Fq2 scale(const Fq& k) const { return {c0 * k, c1 * k}; }
+    Fq2 mul_xi() const { return {c0 - c1, c0 + c1}; }          // * (1 + u)
+    Fq2 conj() const { return {c0, c1.neg()}; }
+    Fq2 inv() const {
+        Fq n = (c0.sqr() + c1.sqr()).inv();
+        return {c0 * n, (c1 * n).neg()};
+    }
+};
+
+struct Fq6 {
+    Fq2 c0, c1, c2;
+    static Fq6 zero() { return {Fq2::zero(), Fq2::zero(), Fq2::zero()}; }
+    static Fq6 one() { return {Fq2::one(), Fq2::zero(), Fq2::zero()}; }
+    bool operator==(const Fq6& o) const { return c0 == o.c0 && c1 == o.c1 && c2 == o.c2; }
+    Fq6 operator+(const Fq6& o) const { return {c0 + o.c0, c1 + o.c1, c2 + o.c2}; }
+    Fq6 operator-(const Fq6& o) const { return {c0 - o.c0, c1 - o.c1, c2 - o.c2}; }
+    Fq6 neg() const { return {c0.neg(), c1.neg(), c2.neg()}; }
+    Fq6 operator*(const Fq6& o) const {      // schoolbook with v^3 = xi
+        Fq2 t0 = c0 * o.c0, t1 = c1 * o.c1, t2 = c2 * o.c2;
+        Fq2 r0 = t0 + ((c1 + c2) * (o.c1 + o.c2) - t1 - t2).mul_xi();
+        Fq2 r1 = (c0 + c1) * (o.c0 + o.c1) - t0 - t1 + t2.mul_xi();
+        Fq2 r2 = (c0 + c2) * (o.c0 + o.c2) - t0 - t2 + t1;
+        return {r0, r1, r2};
+    }
+    Fq6 mul_v() const { return {c2.mul_xi(), c0, c1}; }
+    Fq6 inv() const {
+        Fq2 a = c0.sqr() - (c1 * c2).mul_xi();
+        Fq2 b = c2.sqr().mul_xi() - c0 * c1;
+        Fq2 c = c1.sqr() - c0 * c2;
+        Fq2 d = ((c2 * b + c1 * c).mul_xi() + c0 * a).inv();
+        return {a * d, b * d, c * d};
+    }
+};
+
+struct Fq12 {
+    Fq6 c0, c1;
+    static Fq12 one() { return {Fq6::one(), Fq6::zero()}; }
+    bool operator==(const Fq12& o) const { return c0 == o.c0 && c1 == o.c1; }
+    Fq12 operator*(const Fq12& o) const {
+        Fq6 a = c0 * o.c0, b = c1 * o.c1;
+        return {a + b.mul_v(), (c0 + c1) * (o.c0 + o.c1) - a - b};
+    }
+    Fq12 sqr() const { return *this * *this; }
+    Fq12 conj() const { return {c0, c1.neg()}; }               // = x^(p^6)
+    Fq12 inv() const {
+        Fq6 d = (c0 * c0 - (c1 * c1).mul_v()).inv();
+        return {c0 * d, (c1 * d).neg()};
+    }
+    Fq12 pow(const uint64_t* e, int len) const {
+        Fq12 r = one();
+        bool started = false;
+        for (int i = len - 1; i >= 0; i--)
+            for (int b = 63; b >= 0; b--) {
+                if (started) r = r.sqr();
+                if ((e[i] >> b) & 1) { r = started ? r * *this : *this; started = true; }
+            }
+        return r;
+    }
+};
+
+struct G2Affine {
+    Fq2 x, y;
+    bool inf;
+};
+
+inline bool g2_on_curve(const G2Affine& q) {
+    if (q.inf) return true;
+    Fq2 b = Fq2{Fq::from_u64(4), Fq::from_u64(4)};
+    return q.y.sqr() == q.x.sqr() * q.x + b;
+}
+
+// one Miller loop f_{|x|,Q}(P), conjugated for the negative BLS parameter x = -0xd201000000010000
+inline Fq12 miller_loop(const Fq& px, const Fq& py, const G2Affine& q) {
+    const uint64_t X = 0xd201000000010000ULL;
+    Fq2 tx = q.x, ty = q.y;
+    Fq12 f = Fq12::one();
+    auto line = [&](const Fq2& s, const Fq2& lx, const Fq2& ly) {
+        Fq12 l;
+        l.c0 = {s * lx - ly, s.scale(px).neg(), Fq2::zero()};
+        l.c1 = {Fq2::zero(), Fq2{py, Fq::zero()}, Fq2::zero()};
+        return l;
+    };
+    Fq three = Fq::from_u64(3);
+    for (int b = 62; b >= 0; b--) {
+        Fq2 s = tx.sqr().scale(three) * (ty + ty).inv();
+        f = f.sqr() * line(s, tx, ty);
+        Fq2 nx = s.sqr() - tx - tx;
+        ty = s * (tx - nx) - ty;
+        tx = nx;
+        if ((X >> b) & 1) {
+            Fq2 s2 = (q.y - ty) * (q.x - tx).inv();
+            f = f * line(s2, tx, ty);
+            Fq2 ax = s2.sqr() - tx - q.x;
+            ty = s2 * (tx - ax) - ty;
+            tx = ax;
+        }
+    }
+    return f.conj();
+}
+
+inline Fq12 final_exponentiation(const Fq12& f) {
+    Fq12 t = f.conj() * f.inv();                       // f^(p^6 - 1)
+    t = t.pow(FE_EASY2, FE_EASY2_LEN);                 // ^(p^2 + 1)
+    return t.pow(FE_HARD, FE_HARD_LEN);                // ^((p^4 - p^2 + 1)/r)
+}
+
+}  // namespace drh

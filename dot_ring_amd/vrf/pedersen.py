@@ -1,0 +1,161 @@
+"""Pedersen VRF (dot_ring/vrf/pedersen/vrf.py:32-243).  Envelope: gamma || Y_bar || R || O_k || s || s_b."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+from ..curve import scalar_mul_batch
+from .base import VRF
+from .codec import dec_points, dec_scalar, dec_scalar_mod, enc_point, enc_scalar, point_len, scalar_len
+from .primitives import (CHALLENGE_LEN, DomSep, VrfIo, challenge, nonce, point_to_hash, squeeze_transcript_bytes,
+                         vrf_transcript)
+
+
+@dataclass(frozen=True)
+class PedersenVRF(VRF):
+    output_point: object
+    blinded_pk: object
+    result_point: object
+    ok: object
+    s: int
+    sb: int
+    _blinding_factor: int = 0
+
+    @classmethod
+    def proof_len(cls) -> int:
+        return 4 * point_len(cls.cv) + 2 * scalar_len(cls.cv)
+
+    @classmethod
+    def _blinding_base(cls):
+        bb = cls.cv.curve.params.auxiliary_points.blinding_base
+        if not bb:
+            raise ValueError("Curve does not have a blinding base point for Pedersen VRF")
+        return cls.cv.point_type(*bb)
+
+    @classmethod
+    def decode(cls, proof: bytes) -> "PedersenVRF":
+        pl, sl = point_len(cls.cv), scalar_len(cls.cv)
+        if len(proof) != cls.proof_len():
+            raise ValueError(f"invalid Pedersen VRF proof length: expected {cls.proof_len()}, got {len(proof)}")
+        try:
+            out, blinded, r, ok = dec_points(cls.cv, [proof[pl * i : pl * (i + 1)] for i in range(4)])
+        except ValueError as exc:
+            raise ValueError("Invalid point in proof") from exc
+        s = dec_scalar(cls.cv, proof[4 * pl : 4 * pl + sl])
+        sb = dec_scalar(cls.cv, proof[4 * pl + sl :])
+        return cls(output_point=out, blinded_pk=blinded, result_point=r, ok=ok, s=s, sb=sb)
+
+    def encode(self) -> bytes:
+        return (enc_point(self.output_point) + enc_point(self.blinded_pk) + enc_point(self.result_point)
+                + enc_point(self.ok) + enc_scalar(self.cv, self.s) + enc_scalar(self.cv, self.sb))
+
+    @classmethod
+    def blinding_scalar(cls, secret_scalar: int, transcript) -> int:
+        t = transcript.copy()
+        t.absorb(bytes([DomSep.PEDERSEN_BLINDING]))
+        return nonce(cls.cv, secret_scalar, t)
+
+    @classmethod
+    def prove_batch(cls, alphas, secret_keys, additional_data, salts=None) -> list:
+        """Additive API: element i equals prove(alphas[i], secret_keys[i], additional_data[i]).
+        Three kernel launches for the whole batch (the transcript forces the three phases)."""
+        cv = cls.cv
+        count = len(alphas)
+        salts = salts or [b""] * count
+        gen, bb = cv.point_type.generator_point(), cls._blinding_base()
+        order = cv.curve.params.subgroup_order
+        xs = [dec_scalar_mod(cv, sk) for sk in secret_keys]
+        inputs = [cv.point_type.encode_to_curve(a, s) for a, s in zip(alphas, salts)]
+        firsts = scalar_mul_batch([gen] * count + inputs, xs + xs)                    # pk_i, O_i
+        pks, outs = firsts[:count], firsts[count:]
+        transcripts, blindings = [], []
+        for i in range(count):
+            t, _ = vrf_transcript(cv, DomSep.PEDERSEN_VRF, [VrfIo(inputs[i], outs[i])], additional_data[i])
+            transcripts.append(t)
+            blindings.append(cls.blinding_scalar(xs[i], t))
+        blinds = scalar_mul_batch([bb] * count, blindings)                              # b_i * B
+        blinded, ks, kbs = [], [], []
+        for i in range(count):
+            y_bar = pks[i] + blinds[i]
+            transcripts[i].absorb(enc_point(y_bar))
+            blinded.append(y_bar)
+            ks.append(nonce(cv, xs[i], transcripts[i]))
+            kbs.append(nonce(cv, blindings[i], transcripts[i]))
+        third = scalar_mul_batch([gen] * count + [bb] * count + inputs, ks + kbs + ks)  # kG, kb*B, k*I
+        proofs = []
+        for i in range(count):
+            result_point = third[i] + third[count + i]
+            ok = third[2 * count + i]
+            c = challenge(cv, [result_point, ok], transcripts[i])
+            proofs.append(cls(output_point=outs[i], blinded_pk=blinded[i], result_point=result_point, ok=ok,
+                              s=(ks[i] + c * xs[i]) % order, sb=(kbs[i] + c * blindings[i]) % order,
+                              _blinding_factor=blindings[i]))
+        return proofs
+
+    @classmethod
+    def prove(cls, alpha: bytes, secret_key: bytes, additional_data: bytes, salt: bytes = b"") -> "PedersenVRF":
+        return cls.prove_batch([alpha], [secret_key], [additional_data], [salt])[0]
+
+    def _challenge(self, input: bytes, additional_data: bytes, salt: bytes):
+        cv = self.cv
+        input_point = cv.point_type.encode_to_curve(input, salt)
+        transcript, merged = vrf_transcript(cv, DomSep.PEDERSEN_VRF, [VrfIo(input_point, self.output_point)], additional_data)
+        transcript.absorb(enc_point(self.blinded_pk))
+        return input_point, merged, challenge(cv, [self.result_point, self.ok], transcript)
+
+    def verify(self, input: bytes, additional_data: bytes, salt: bytes = b"") -> bool:
+        cv = self.cv
+        _, merged, c = self._challenge(input, additional_data, salt)
+        if cv.point_type.msm([merged.input, merged.output], [self.s, -c]) != self.ok:
+            return False
+        lhs2 = cv.point_type.msm([cv.point_type.generator_point(), self._blinding_base(), self.blinded_pk], [self.s, self.sb, -c])
+        return lhs2 == self.result_point
+
+    def verify_unblinding(self, public_key: bytes, blinding_factor: int) -> bool:
+        from .codec import dec_point
+
+        if not 0 <= blinding_factor < self.cv.curve.params.subgroup_order:
+            return False
+        return dec_point(self.cv, public_key) + self._blinding_base() * blinding_factor == self.blinded_pk
+
+    @classmethod
+    def proof_to_hash(cls, gamma, mul_cofactor: bool = False) -> bytes:
+        if mul_cofactor:
+            gamma = gamma.double().double()
+        return point_to_hash(cls.cv, gamma)
+
+    @classmethod
+    def batch_verify(cls, proofs, inputs, additional_data, salts=None) -> bool:
+        """pedersen/vrf.py:171 — one (5B+2)-point MSM on the GPU instead of 2B small ones."""
+        cv = cls.cv
+        if salts is None:
+            salts = [b""] * len(proofs)
+        order = cv.curve.params.subgroup_order
+        items, coeff_bytes = [], bytearray()
+        try:
+            for proof, input_value, ad, salt in zip(proofs, inputs, additional_data, salts, strict=True):
+                input_point, _, c = proof._challenge(input_value, ad, salt)
+                items.append((proof, input_point, c))
+                coeff_bytes += enc_scalar(cv, c) + enc_scalar(cv, proof.s) + enc_scalar(cv, proof.sb)
+        except (AttributeError, TypeError, ValueError):
+            return False
+        if not items:
+            return True
+        absorbed = bytes(cv.curve.params.suite_id) + bytes([DomSep.BATCH_VERIFY]) + bytes(coeff_bytes)
+        weights = squeeze_transcript_bytes(cv.curve.params.hash_fn, absorbed, 2 * CHALLENGE_LEN * len(items))
+        points, scalars = [], []
+        gen_scalar = blind_scalar = 0
+        for index, (proof, input_point, c) in enumerate(items):
+            off = 2 * CHALLENGE_LEN * index
+            w_io = dec_scalar_mod(cv, weights[off : off + CHALLENGE_LEN])
+            w_cm = dec_scalar_mod(cv, weights[off + CHALLENGE_LEN : off + 2 * CHALLENGE_LEN])
+            points += [proof.ok, proof.output_point, input_point, proof.result_point, proof.blinded_pk]
+            scalars += [w_io, w_io * c, -w_io * proof.s, w_cm, w_cm * c]
+            gen_scalar = (gen_scalar - w_cm * proof.s) % order
+            blind_scalar = (blind_scalar - w_cm * proof.sb) % order
+        if gen_scalar:
+            points.append(cv.point_type.generator_point())
+            scalars.append(gen_scalar)
+        if blind_scalar:
+            points.append(cls._blinding_base())
+            scalars.append(blind_scalar)
+        return cv.point_type.msm(points, scalars).is_identity()

@@ -1,0 +1,328 @@
+"""Ring, RingRoot and RingVRF (dot_ring/vrf/ring/{members,root,vrf}.py, ring_proof/proof_payload.py)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from functools import lru_cache
+
+from ..curve import valid_points
+from ..ring_proof.columns import Column
+from ..ring_proof.params import RingProofParams
+from ..ring_proof.pcs import KZG
+from ..ring_proof.poly import inverse_fft_batch
+from ..ring_proof.prover import build_ring_proofs
+from ..ring_proof.transcript import FiatShamirTranscript, serialize_verifier_key
+from ..ring_proof.verifier import linear_pcs_verifications
+from .base import VRF
+from .codec import point_len
+from .pedersen import PedersenVRF
+
+RING_SCALAR_LEN = 32
+
+
+# ------------------------------------------------------------------ Ring (members.py:18-101)
+class Ring:
+    def __init__(self, keys, params: RingProofParams | None = None):
+        if params is None:
+            params = RingProofParams.from_ring_size(len(keys))
+        self.params = params
+        aux = params.cv.curve.params.auxiliary_points
+        if not aux.padding_point:
+            raise ValueError("padding point is not configured in curve parameters")
+        if len(keys) > params.max_ring_size:
+            raise ValueError(f"ring size {len(keys)} exceeds max supported size {params.max_ring_size}")
+        points = [pt if pt is not None else aux.padding_point for pt in self._decode_keys(keys)]
+        points += [aux.padding_point] * (params.max_ring_size - len(points))
+        fill = params.domain_size - params.padding_rows - len(points)
+        if fill > 0:
+            if not aux.blinding_base:
+                raise ValueError("blinding base is not configured in curve parameters")
+            points += list(_blinding_base_powers(params.cv.point_type, aux.blinding_base, fill))
+        points += [(0, 0)] * params.padding_rows
+        self.nm_points = tuple(points)
+
+    def _decode_keys(self, keys):
+        """Decode + subgroup-check all keys with two kernel launches; invalid / identity keys -> None."""
+        cv = self.params.cv
+        pts, slots = [], []
+        for i, key in enumerate(keys):
+            try:
+                if len(key) != point_len(cv):
+                    raise ValueError("bad length")
+                pts.append(cv.point_type.string_to_point(key))
+                slots.append(i)
+            except ValueError:
+                pass
+        ok = valid_points(pts)
+        out = [None] * len(keys)
+        for slot, pt, good in zip(slots, pts, ok):
+            if good and not pt.is_identity():
+                out[slot] = (pt.x, pt.y)
+        return out
+
+    @classmethod
+    def from_keys(cls, keys, params: RingProofParams | None = None) -> "Ring":
+        return _ring(tuple(bytes(k) for k in keys))
+
+    def index_of(self, key: bytes) -> int:
+        padding = self.params.cv.curve.params.auxiliary_points.padding_point
+        point = self._decode_keys([key])[0]
+        if point is None:
+            raise ValueError("invalid ring key")
+        if point == padding:
+            raise ValueError("producer key is not in ring")
+        try:
+            return self.nm_points[: self.params.max_ring_size].index(point)
+        except ValueError as exc:
+            raise ValueError("producer key is not in ring") from exc
+
+
+@lru_cache(maxsize=8)
+def _blinding_base_powers(point_type, blinding_base, count):
+    out, point = [], point_type(*blinding_base)
+    for _ in range(count):
+        out.append((point.x, point.y))
+        point = point + point
+    return tuple(out)
+
+
+@lru_cache(maxsize=2)
+def _params(keys_len: int) -> RingProofParams:
+    return RingProofParams.from_ring_size(keys_len)
+
+
+@lru_cache(maxsize=8)
+def _ring(keys: tuple) -> Ring:
+    return Ring(keys, _params(len(keys)))
+
+
+# ------------------------------------------------------------------ RingRoot (root.py:14-173)
+@dataclass
+class RingRoot:
+    px: Column
+    py: Column
+    s: Column
+    params: RingProofParams | None = None
+
+    @classmethod
+    def from_ring(cls, ring: Ring, params: RingProofParams | None = None) -> "RingRoot":
+        if params is None:
+            params = ring.params
+        n = params.domain_size
+        s_evals, s_coeffs, s_cm = _selector_column_data(n, params.max_ring_size, params.omega, params.prime, params.pcs)
+        px_e, px_c, px_cm, py_e, py_c, py_cm = _public_keys_column_data(ring.nm_points, n, params.omega, params.prime, params.pcs)
+        return cls(px=Column("px", list(px_e), coeffs=list(px_c), _commitment=px_cm, size=n, _has_commitment=True),
+                   py=Column("py", list(py_e), coeffs=list(py_c), _commitment=py_cm, size=n, _has_commitment=True),
+                   s=Column("s", list(s_evals), coeffs=list(s_coeffs), _commitment=s_cm, size=n, _has_commitment=True),
+                   params=params)
+
+    def fixed_commitments(self) -> list:
+        return [self.px.commitment, self.py.commitment, self.s.commitment]
+
+    def verifier_transcript_prefix(self, transcript_challenge: bytes | None = None) -> FiatShamirTranscript:
+        if self.params is None:
+            raise ValueError("Ring root verifier transcript requires ring proof parameters")
+        pcs = self.params.pcs
+        srs = pcs._srs() if hasattr(pcs, "_srs") else pcs.srs
+        vk = serialize_verifier_key(srs.g1_raw[:96], srs.g2_raw, [pcs.serialize_g1_uncompressed(c) for c in self.fixed_commitments()])
+        if transcript_challenge is None:
+            transcript_challenge = self.params.cv.curve.params.suite_id
+        t = FiatShamirTranscript(self.params.prime, transcript_challenge)
+        t.absorb_labeled(b"vk", vk)
+        return t
+
+    @staticmethod
+    def encoded_len(params: RingProofParams | None = None) -> int:
+        return 3 * (params.pcs.commitment_size if params is not None else KZG.commitment_size)
+
+    def encode(self) -> bytes:
+        pcs = self.params.pcs if self.params is not None else KZG
+        return b"".join(pcs.compress_g1(c) for c in self.fixed_commitments())
+
+    @classmethod
+    def decode(cls, data: bytes, ring=None) -> "RingRoot":
+        params = ring.params if isinstance(ring, Ring) else ring
+        if params is None:
+            params = RingProofParams()
+        size = params.pcs.commitment_size
+        if len(data) != cls.encoded_len(params):
+            raise ValueError(f"invalid ring root length: ring root must be exactly {cls.encoded_len(params)} bytes, got {len(data)}")
+        cms = [params.pcs.decompress_g1(data[size * i : size * (i + 1)]) for i in range(3)]
+        n = params.domain_size
+        cols = [Column(name, [], _commitment=cm, size=n, _has_commitment=True) for name, cm in zip(("px", "py", "s"), cms)]
+        return cls(px=cols[0], py=cols[1], s=cols[2], params=params)
+
+    def matches_ring(self, ring: Ring) -> bool:
+        return RingRoot.from_ring(ring).encode() == self.encode()
+
+
+@lru_cache(maxsize=2)
+def _selector_column_data(domain_size, max_ring_size, omega, prime, pcs):
+    evals = [1 if i < max_ring_size else 0 for i in range(domain_size)]
+    coeffs = inverse_fft_batch([evals], omega, prime)[0]
+    return tuple(evals), tuple(coeffs), pcs.commit(coeffs)
+
+
+@lru_cache(maxsize=8)
+def _public_keys_column_data(nm_points, domain_size, omega, prime, pcs):
+    px_e, py_e = [pt[0] for pt in nm_points], [pt[1] for pt in nm_points]
+    px_c, py_c = inverse_fft_batch([px_e, py_e], omega, prime)
+    if hasattr(pcs, "commit_batch"):
+        px_cm, py_cm = pcs.commit_batch([px_c, py_c])
+    else:
+        px_cm, py_cm = pcs.commit(px_c), pcs.commit(py_c)
+    return tuple(px_e), tuple(px_c), px_cm, tuple(py_e), tuple(py_c), py_cm
+
+
+# ------------------------------------------------------------------ RingVRF (vrf.py:30-305, proof_payload.py)
+@dataclass
+class RingVRF(VRF):
+    pedersen_proof: PedersenVRF
+    c_b: Column
+    c_accip: Column
+    c_accx: Column
+    c_accy: Column
+    px_zeta: int
+    py_zeta: int
+    s_zeta: int
+    b_zeta: int
+    accip_zeta: int
+    accx_zeta: int
+    accy_zeta: int
+    c_q: Column
+    l_zeta_omega: int
+    open_agg_zeta: object
+    open_l_zeta_omega: object
+
+    @classmethod
+    def _payload_len(cls, params) -> int:
+        return 7 * params.pcs.commitment_size + 8 * RING_SCALAR_LEN
+
+    @classmethod
+    def proof_len(cls) -> int:
+        return PedersenVRF[cls.cv].proof_len() + cls._payload_len(RingProofParams(cv=cls.cv))
+
+    def encode(self) -> bytes:
+        pcs = RingProofParams(cv=self.cv).pcs
+        le = lambda v: int(v).to_bytes(RING_SCALAR_LEN, "little")
+        return (self.pedersen_proof.encode()
+                + b"".join(pcs.compress_g1(c.commitment) for c in (self.c_b, self.c_accip, self.c_accx, self.c_accy))
+                + b"".join(le(v) for v in (self.px_zeta, self.py_zeta, self.s_zeta, self.b_zeta, self.accip_zeta, self.accx_zeta, self.accy_zeta))
+                + pcs.compress_g1(self.c_q.commitment) + le(self.l_zeta_omega)
+                + pcs.compress_g1(self.open_agg_zeta) + pcs.compress_g1(self.open_l_zeta_omega))
+
+    @classmethod
+    def decode(cls, proof: bytes) -> "RingVRF":
+        expected = cls.proof_len()
+        if len(proof) != expected:
+            raise ValueError(f"invalid Ring VRF proof length: Ring VRF proof must be exactly {expected} bytes, got {len(proof)}")
+        ped_len = PedersenVRF[cls.cv].proof_len()
+        pedersen_proof = PedersenVRF[cls.cv].decode(proof[:ped_len])
+        params = RingProofParams(cv=cls.cv)
+        data, off = proof[ped_len:], 0
+        size = params.pcs.commitment_size
+
+        def commitment():
+            nonlocal off
+            cm = params.pcs.decompress_g1(data[off : off + size])
+            off += size
+            return cm
+
+        def scalar():
+            nonlocal off
+            v = int.from_bytes(data[off : off + RING_SCALAR_LEN], "little")
+            if v >= params.prime:
+                raise ValueError("scalar is not canonical")
+            off += RING_SCALAR_LEN
+            return v
+
+        def col(name):
+            return Column(name=name, evals=[], _commitment=commitment(), _has_commitment=True)
+
+        fields = [col("c_b"), col("c_accip"), col("c_accx"), col("c_accy")]
+        fields += [scalar() for _ in range(7)]
+        fields += [col("c_q"), scalar(), commitment(), commitment()]
+        if off != len(data):
+            raise ValueError(f"trailing bytes in ring proof payload: {len(data) - off}")
+        return cls(pedersen_proof, *fields)
+
+    # -- proving
+    @classmethod
+    def prove_batch(cls, alphas, additional_data, secret_keys, producer_keys, ring: Ring, ring_root: RingRoot | None = None,
+                    salts=None) -> list:
+        """Additive API: a batch of proofs over ONE ring; element i equals
+        prove(alphas[i], additional_data[i], secret_keys[i], producer_keys[i], ring, ring_root)."""
+        count = len(alphas)
+        if not (len(additional_data) == len(secret_keys) == len(producer_keys) == count):
+            raise ValueError("batch arguments must have equal lengths")
+        cv = cls.cv
+        from ..curve import scalar_mul_batch
+
+        gen = cv.point_type.generator_point()
+        derived = scalar_mul_batch([gen] * count, [int.from_bytes(sk, "little") for sk in secret_keys])
+        for pk, pt in zip(producer_keys, derived):
+            if pk != pt.point_to_string():
+                raise ValueError("producer_key does not match secret_key")
+        pedersen = PedersenVRF[cv].prove_batch(alphas, secret_keys, additional_data, salts)
+        root = ring_root
+        if root is None or root.px.coeffs is None or root.py.coeffs is None or root.s.coeffs is None or len(root.s.evals) < ring.params.domain_size:
+            computed = RingRoot.from_ring(ring, ring.params)
+            if root is not None and computed.encode() != root.encode():
+                raise ValueError("ring_root does not match ring")
+            root = computed
+        payloads = build_ring_proofs(ring, root, producer_keys, [pp._blinding_factor for pp in pedersen])
+        return [cls(pp, *payload) for pp, payload in zip(pedersen, payloads)]
+
+    @classmethod
+    def prove(cls, alpha: bytes, additional_data: bytes, secret_key: bytes, producer_key: bytes, ring: Ring,
+              ring_root: RingRoot | None = None, salt: bytes = b"") -> "RingVRF":
+        return cls.prove_batch([alpha], [additional_data], [secret_key], [producer_key], ring, ring_root, [salt])[0]
+
+    @classmethod
+    def parse_keys(cls, keys: bytes) -> list:
+        size = point_len(cls.cv)
+        if len(keys) % size != 0:
+            raise ValueError(f"invalid concatenated key length: expected multiple of {size}, got {len(keys)}")
+        return [keys[size * i : size * (i + 1)] for i in range(len(keys) // size)]
+
+    # -- verification
+    def _linear_claims(self, message, ring: Ring, ring_root: RingRoot):
+        cv = ring.params.cv
+        if isinstance(message, (bytes, bytearray)):
+            try:
+                message = cv.point_type.string_to_point(bytes(message))
+            except ValueError as exc:
+                raise ValueError("Invalid message point") from exc
+        aux = cv.curve.params.auxiliary_points
+        if not aux.accumulator_base:
+            raise ValueError("Curve does not have an accumulator base point for Ring VRF")
+        seed = cv.point_type(*aux.accumulator_base)
+        return linear_pcs_verifications(self, ring_root.fixed_commitments(), message, seed + message, seed, ring.params,
+                                        ring_root.verifier_transcript_prefix())
+
+    def verify_ring_proof(self, message, ring: Ring, ring_root: RingRoot) -> bool:
+        if not ring_root.matches_ring(ring):
+            return False
+        return bool(ring.params.pcs.batch_verify_linear_preconverted(list(self._linear_claims(message, ring, ring_root))))
+
+    def verify(self, input: bytes, ad_data: bytes, ring: Ring, ring_root: RingRoot) -> bool:
+        p_ok = self.pedersen_proof.verify(input, ad_data)
+        r_ok = self.verify_ring_proof(self.pedersen_proof.blinded_pk, ring, ring_root)
+        return p_ok and r_ok
+
+    @classmethod
+    def proof_to_hash(cls, gamma, mul_cofactor: bool = False) -> bytes:
+        return PedersenVRF[cls.cv].proof_to_hash(gamma, mul_cofactor)
+
+    @classmethod
+    def batch_verify(cls, proofs, inputs, additional_data, ring: Ring, ring_root: RingRoot) -> bool:
+        if not ring_root.matches_ring(ring):
+            return False
+        if not PedersenVRF[cls.cv].batch_verify([p.pedersen_proof for p in proofs], inputs, additional_data):
+            return False
+        claims = []
+        try:
+            for proof in proofs:
+                claims.extend(proof._linear_claims(proof.pedersen_proof.blinded_pk, ring, ring_root))
+        except (AssertionError, AttributeError, TypeError, ValueError):
+            return False
+        return bool(ring.params.pcs.batch_verify_linear_preconverted(claims))

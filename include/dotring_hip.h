@@ -122,6 +122,11 @@ DR_API int dr_g1_msm_points(dr_ctx *ctx, const uint8_t *pts_be_xy /* n*96 */, co
 /* host-side sum of a few affine points (combining per-GPU partial MSM results after an all-gather) */
 DR_API int dr_g1_sum(const uint8_t *pts_be_xy /* n*96 */, size_t n, uint8_t out_be_xy[96], int *is_inf);
 
+/* Host-side pairing product check: *ok = 1 iff prod_i e(P_i, Q_i) == 1.  G2 points are 192-byte records in the SRS
+ * file layout x.c1 || x.c0 || y.c1 || y.c0 (big-endian, dot_ring/ring_proof/pcs/srs.py:78-88).  Replaces
+ * blst.PT + PT.finalverify (dot_ring/ring_proof/pcs/pairing.py:24-31); stays on the CPU (2 Miller loops per batch). */
+DR_API int dr_pairing_check(const uint8_t *g1_be_xy /* n*96 */, const uint8_t *g2_be /* n*192 */, size_t n, int *ok);
+
 /* zcash encodings, host-side */
 DR_API int dr_g1_compress(const uint8_t xy[96], int is_inf, uint8_t out[48]);
 DR_API int dr_g1_decompress(const uint8_t in[48], uint8_t out_xy[96], int *is_inf);   /* on-curve check, no subgroup check (as blst P1_Affine(bytes)) */

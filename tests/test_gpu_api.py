@@ -1,0 +1,177 @@
+"""GPU: the public API mirror (TinyVRF / PedersenVRF / RingVRF / Ring / RingRoot on the HIP kernels) against the
+reference's own known-answer vectors — same assertions as /root/reference/tests/test_bandersnatch_ark.py,
+tests/test_ring_vrf/test_ring_vrf.py, tests/test_dot_ring_vectors.py, byte for byte."""
+import json
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, rel):
+    with open(os.path.join(golden_dir, rel)) as f:
+        return json.load(f)
+
+
+def _cv(name):
+    import dot_ring_amd as d
+
+    return {"sha512": d.Bandersnatch, "shake128": d.Bandersnatch_SHAKE128}[name]
+
+
+TINY = [("sha512", "ark-vrf/bandersnatch_sha-512_ell2_tiny.json"), ("sha512", "ark-vrf/bandersnatch_ed_sha512_ell2_ietf.json"),
+        ("shake128", "ark-vrf/bandersnatch_shake128_ell2_tiny.json"), ("sha512", "dot-ring/bandersnatch_sha-512_ell2_tiny.json")]
+PEDERSEN = [("sha512", "ark-vrf/bandersnatch_sha-512_ell2_pedersen.json"), ("shake128", "ark-vrf/bandersnatch_shake128_ell2_pedersen.json"),
+            ("sha512", "dot-ring/bandersnatch_sha-512_ell2_pedersen.json")]
+RING = [("sha512", "ark-vrf/bandersnatch_ed_sha512_ell2_ring.json"), ("shake128", "ark-vrf/bandersnatch_shake128_ell2_ring.json"),
+        ("sha512", "dot-ring/bandersnatch_sha-512_ell2_ring.json")]
+
+
+def test_keygen_and_h2c_kats(ctx):
+    import dot_ring_amd as d
+
+    pk, sk = d.Bandersnatch.secret_from_seed((0).to_bytes(32, "little"))
+    assert pk.hex() == "dff68d8158281c3ee65e678d75c7f5c007de51d0c3a800675208b7c61d2e6f98"
+    assert sk.hex() == "cc1a43aef9a710b8def623da1eae8f35d7992f46302c08242e0a2bb823ccac08"
+    pk2, sk2 = d.Bandersnatch.secret_from_seed((2**32 - 1).to_bytes(32, "little"))
+    assert pk2 == d.Bandersnatch.public_key_from_secret(sk2)
+    with pytest.raises(TypeError):
+        d.Bandersnatch.secret_from_seed("not-bytes")
+    u = d.Bandersnatch.point_type.encode_to_curve(b"foo")
+    assert u.x == 41706851287321768980670436615954402659160947743433584884323702829779219804533
+    assert u.y == 45261115535002764022712885934321790255618221679857277845409327068867281988279
+
+
+@pytest.mark.parametrize("suite,rel", TINY)
+def test_tiny_vrf_vectors(ctx, golden_dir, suite, rel):
+    import dot_ring_amd as d
+
+    cv = _cv(suite)
+    vrf = d.TinyVRF[cv]
+    vectors = _load(golden_dir, rel)
+    for v in vectors:
+        sk, al, ad = (bytes.fromhex(v[k]) for k in ("sk", "alpha", "ad"))
+        assert cv.public_key_from_secret(sk).hex() == v["pk"]
+        proof = vrf.prove(al, sk, ad)
+        assert proof.encode().hex() == v["gamma"] + v["proof_c"] + v["proof_s"]
+        assert proof.verify(bytes.fromhex(v["pk"]), al, ad)
+        rt = vrf.decode(proof.encode())
+        assert rt.encode() == proof.encode() and rt.verify(bytes.fromhex(v["pk"]), al, ad)
+        assert not proof.verify(bytes.fromhex(v["pk"]), al, ad + b"\x01")
+        assert vrf.proof_to_hash(proof.output_point).hex() == v["beta"][:64]
+    # batched proving == looped proving
+    batch = vrf.prove_batch([bytes.fromhex(v["alpha"]) for v in vectors], [bytes.fromhex(v["sk"]) for v in vectors],
+                            [bytes.fromhex(v["ad"]) for v in vectors])
+    assert [p.encode().hex() for p in batch] == [v["gamma"] + v["proof_c"] + v["proof_s"] for v in vectors]
+    with pytest.raises(ValueError):
+        vrf.decode(bytes(79))
+
+
+@pytest.mark.parametrize("suite,rel", PEDERSEN)
+def test_pedersen_vrf_vectors(ctx, golden_dir, suite, rel):
+    import dot_ring_amd as d
+
+    vrf = d.PedersenVRF[_cv(suite)]
+    vectors = _load(golden_dir, rel)
+    proofs = []
+    for v in vectors:
+        sk, al, ad = (bytes.fromhex(v[k]) for k in ("sk", "alpha", "ad"))
+        proof = vrf.prove(al, sk, ad)
+        want = v["gamma"] + v["proof_pk_com"] + v["proof_r"] + v["proof_ok"] + v["proof_s"] + v["proof_sb"]
+        assert proof.encode().hex() == want
+        assert proof._blinding_factor.to_bytes(32, "little").hex() == v["blinding"]
+        assert proof.verify(al, ad)
+        assert vrf.decode(proof.encode()).verify(al, ad)
+        assert not proof.verify(al + b"x", ad)
+        assert proof.verify_unblinding(bytes.fromhex(v["pk"]), proof._blinding_factor)
+        proofs.append(proof)
+    als, ads = [bytes.fromhex(v["alpha"]) for v in vectors], [bytes.fromhex(v["ad"]) for v in vectors]
+    assert vrf.batch_verify(proofs, als, ads)
+    assert not vrf.batch_verify(proofs, als[::-1], ads)
+    assert vrf.batch_verify([], [], [])
+    batch = vrf.prove_batch(als, [bytes.fromhex(v["sk"]) for v in vectors], ads)
+    assert [p.encode() for p in batch] == [p.encode() for p in proofs]
+    with pytest.raises(ValueError):
+        vrf.decode(bytes(192))            # identity / invalid points
+
+
+@pytest.mark.parametrize("suite,rel", RING)
+def test_ring_vrf_vectors_byte_exact(ctx, golden_dir, suite, rel):
+    import dot_ring_amd as d
+
+    cv = _cv(suite)
+    vrf = d.RingVRF[cv]
+    vectors = _load(golden_dir, rel)
+    for v in vectors[:3]:
+        sk, al, ad = (bytes.fromhex(v[k]) for k in ("sk", "alpha", "ad"))
+        keys = vrf.parse_keys(bytes.fromhex(v["ring_pks"]))
+        params = d.RingProofParams(test_vectors=True, cv=cv)
+        ring = d.Ring(keys, params)
+        root = d.RingRoot.from_ring(ring, params)
+        pk = cv.public_key_from_secret(sk)
+        assert pk.hex() == v["pk"]
+        assert root.encode().hex() == v["ring_pks_com"]
+        proof = vrf.prove(al, ad, sk, pk, ring, root)
+        want = (v["gamma"] + v["proof_pk_com"] + v["proof_r"] + v["proof_ok"] + v["proof_s"] + v["proof_sb"] + v["ring_proof"])
+        assert proof.encode().hex() == want
+        assert proof.verify(al, ad, ring, root)
+        rt = vrf.decode(proof.encode())
+        assert rt.encode() == proof.encode()
+        assert rt.verify(al, ad, ring, d.RingRoot.decode(root.encode(), ring))
+        assert not proof.verify(al, ad + b"!", ring, root)
+        assert vrf.batch_verify([proof, rt], [al, al], [ad, ad], ring, root)
+        assert not vrf.batch_verify([proof, rt], [al, al + b"x"], [ad, ad], ring, root)
+
+
+def test_ring_vrf_prove_batch_matches_loop_and_root_mismatch(ctx, golden_dir):
+    import dot_ring_amd as d
+
+    cv = d.Bandersnatch
+    vrf = d.RingVRF[cv]
+    vectors = _load(golden_dir, "ark-vrf/bandersnatch_sha-512_ell2_ring.json")
+    v0 = vectors[0]
+    keys = vrf.parse_keys(bytes.fromhex(v0["ring_pks"]))
+    params = d.RingProofParams(test_vectors=True, cv=cv)
+    ring = d.Ring(keys, params)
+    root = d.RingRoot.from_ring(ring, params)
+    same_ring = [v for v in vectors if v["ring_pks"] == v0["ring_pks"]][:4]
+    sks = [bytes.fromhex(v["sk"]) for v in same_ring]
+    batch = vrf.prove_batch([bytes.fromhex(v["alpha"]) for v in same_ring], [bytes.fromhex(v["ad"]) for v in same_ring],
+                            sks, [cv.public_key_from_secret(sk) for sk in sks], ring, root)
+    for proof, v in zip(batch, same_ring):
+        assert proof.encode().hex() == (v["gamma"] + v["proof_pk_com"] + v["proof_r"] + v["proof_ok"] + v["proof_s"]
+                                        + v["proof_sb"] + v["ring_proof"])
+    # wrong producer key, wrong ring root, key not in ring  (test_audit_regressions.py:65-105)
+    other_pk, other_sk = cv.secret_from_seed((7).to_bytes(32, "little"))
+    with pytest.raises(ValueError, match="producer_key does not match secret_key"):
+        vrf.prove(b"a", b"", sks[0], other_pk, ring, root)
+    with pytest.raises(ValueError, match="producer key is not in ring"):
+        vrf.prove(b"a", b"", other_sk, other_pk, ring, root)
+    other_ring = d.Ring(keys[::-1], params)
+    assert not batch[0].verify(bytes.fromhex(same_ring[0]["alpha"]), bytes.fromhex(same_ring[0]["ad"]), other_ring, root)
+    # invalid keys are replaced by the padding point; oversize rings are rejected
+    bad = d.Ring([bytes(32), b"\xff" * 32] + keys[2:], params)
+    assert bad.nm_points[0] == cv.curve.params.auxiliary_points.padding_point == bad.nm_points[1]
+    with pytest.raises(ValueError):
+        d.Ring(keys * 40, params)
+    with pytest.raises(ValueError):
+        d.RingRoot.decode(bytes(143))
+
+
+def test_ring_zk_rows_are_random_without_test_vectors(ctx, golden_dir):
+    import dot_ring_amd as d
+
+    cv = d.Bandersnatch
+    vrf = d.RingVRF[cv]
+    v = _load(golden_dir, "ark-vrf/bandersnatch_sha-512_ell2_ring.json")[0]
+    keys = vrf.parse_keys(bytes.fromhex(v["ring_pks"]))
+    ring = d.Ring(keys)                      # default params: hidden rows drawn with secrets
+    root = d.RingRoot.from_ring(ring)
+    sk = bytes.fromhex(v["sk"])
+    pk = cv.public_key_from_secret(sk)
+    p1 = vrf.prove(b"x", b"y", sk, pk, ring, root)
+    p2 = vrf.prove(b"x", b"y", sk, pk, ring, root)
+    assert p1.encode()[:192] == p2.encode()[:192]          # Pedersen part is deterministic
+    assert p1.encode() != p2.encode()                       # ring part is not (tests/test_vectors.py:472-502)
+    assert p1.verify(b"x", b"y", ring, root) and p2.verify(b"x", b"y", ring, root)
