@@ -56,6 +56,14 @@ _PROTOTYPES = {
     "dr_g1_compress": (c_int, [c_char_p, c_int, c_void_p]),
     "dr_g1_decompress": (c_int, [c_char_p, c_void_p, POINTER(c_int)]),
     "dr_g1_serialize_check": (c_int, [c_char_p]),
+    "dr_ring_prover_create": (c_int, [c_void_p, c_void_p, c_uint, c_uint, c_char_p, c_char_p, c_char_p, c_char_p, POINTER(c_void_p)]),
+    "dr_ring_prover_destroy": (None, [c_void_p]),
+    "dr_ring_prover_root": (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
+    "dr_ring_prover_fixed_coeffs": (c_int, [c_void_p, c_void_p]),
+    "dr_ring_prove_witness": (c_int, [c_void_p, c_size_t, c_void_p, c_char_p, c_char_p, c_void_p, c_void_p, POINTER(c_int)]),
+    "dr_ring_prove_quotient": (c_int, [c_void_p, c_size_t, c_char_p, c_void_p, POINTER(c_int)]),
+    "dr_ring_prove_evals": (c_int, [c_void_p, c_size_t, c_char_p, c_void_p]),
+    "dr_ring_prove_openings": (c_int, [c_void_p, c_size_t, c_char_p, c_void_p, POINTER(c_int)]),
     "dr_ntt": (c_int, [c_void_p, c_void_p, c_uint, c_size_t, c_char_p, c_char_p]),
     "dr_ntt_dev": (c_int, [c_void_p, c_void_p, c_uint, c_size_t, c_char_p, c_char_p]),
 }
@@ -145,6 +153,58 @@ class Srs:
         if self.handle:
             lib().dr_srs_destroy(self.handle)
             self.handle = c_void_p()
+
+
+class RingProver:
+    """Device-resident batched ring prover for one ring (dr_ring_prover_*)."""
+
+    def __init__(self, ctx: "Context", srs: Srs, log2n: int, max_ring: int, omega_n: int, omega_4n: int, nm_points_xy: bytes, seed_xy: bytes):
+        self.ctx, self.srs = ctx, srs
+        self.n = 1 << log2n
+        self.handle = c_void_p()
+        _check(lib().dr_ring_prover_create(ctx.handle, srs.handle, log2n, max_ring, omega_n.to_bytes(32, "little"),
+                                           omega_4n.to_bytes(32, "little"), nm_points_xy, seed_xy, byref(self.handle)))
+
+    def close(self) -> None:
+        if self.handle:
+            lib().dr_ring_prover_destroy(self.handle)
+            self.handle = c_void_p()
+
+    @staticmethod
+    def _points(raw: bytes, inf, count: int) -> list:
+        return [None if inf[i] else raw[96 * i : 96 * i + 96] for i in range(count)]
+
+    def root(self) -> list:
+        out, inf = ctypes.create_string_buffer(3 * 96), (c_int * 3)()
+        _check(lib().dr_ring_prover_root(self.handle, out, inf))
+        return self._points(out.raw, inf, 3)
+
+    def fixed_coeffs(self) -> bytes:
+        out = ctypes.create_string_buffer(3 * self.n * 32)
+        _check(lib().dr_ring_prover_fixed_coeffs(self.handle, out))
+        return out.raw
+
+    def witness(self, producer_index: list, blinding: bytes, zk_rows: bytes | None):
+        batch = len(producer_index)
+        idx = (ctypes.c_uint32 * batch)(*producer_index)
+        rel, cms, inf = ctypes.create_string_buffer(64 * batch), ctypes.create_string_buffer(4 * 96 * batch), (c_int * (4 * batch))()
+        _check(lib().dr_ring_prove_witness(self.handle, batch, idx, blinding, zk_rows, rel, cms, inf))
+        return rel.raw, self._points(cms.raw, inf, 4 * batch)
+
+    def quotient(self, batch: int, alphas: bytes) -> list:
+        out, inf = ctypes.create_string_buffer(96 * batch), (c_int * batch)()
+        _check(lib().dr_ring_prove_quotient(self.handle, batch, alphas, out, inf))
+        return self._points(out.raw, inf, batch)
+
+    def evals(self, batch: int, zetas: bytes) -> bytes:
+        out = ctypes.create_string_buffer(8 * 32 * batch)
+        _check(lib().dr_ring_prove_evals(self.handle, batch, zetas, out))
+        return out.raw
+
+    def openings(self, batch: int, nus: bytes) -> list:
+        out, inf = ctypes.create_string_buffer(2 * 96 * batch), (c_int * (2 * batch))()
+        _check(lib().dr_ring_prove_openings(self.handle, batch, nus, out, inf))
+        return self._points(out.raw, inf, 2 * batch)
 
 
 class Context:

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -15,6 +16,7 @@
 #include "kernels_bsn.cuh"
 #include "kernels_g1.cuh"
 #include "kernels_ntt.cuh"
+#include "kernels_ring.cuh"
 
 namespace {
 
@@ -253,10 +255,46 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
             hipLaunchKernelGGL(dr::k_g1_horner, dim3(div_up(batch, 64)), dim3(64), 0, st, ctx->winsum.as<uint32_t>(),
                                (uint32_t)batch, pl.wt, ctx->result.as<uint32_t>());
         }));
-        HIP_TRY(hipMemcpyAsync(results.data(), ctx->result.p, batch * 192, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        // results stay in ctx->result; msm_batch_results_to_bytes() finishes them on the device
     }
     if (ctx->prof) TRY(prof_collect(ctx));
+    return DR_OK;
+}
+
+void g1_result_to_bytes(const drh::G1& r, uint8_t* out96, int* is_inf);
+int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, int* is_inf);
+
+// MSM(s) with results written as BE affine records
+int msm_to_bytes(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch, uint8_t* out_be_xy, int* is_inf) {
+    std::vector<drh::G1> res;
+    TRY(msm_device(ctx, d_bases, d_scalars, n, batch, res));
+    if (batch == 1 || n == 0) {
+        for (size_t b = 0; b < batch; b++) g1_result_to_bytes(res[b], out_be_xy + 96 * b, is_inf ? is_inf + b : nullptr);
+        return DR_OK;
+    }
+    return msm_batch_results_to_bytes(ctx, batch, out_be_xy, is_inf);
+}
+
+// batch > 1: results were left in ctx->result (XYZZ); convert to affine on the device and emit BE records
+int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, int* is_inf) {
+    TRY(ctx->io_c.reserve(batch * 96));
+    TRY(launch(ctx, "k_g1_results_affine", [&] {
+        hipLaunchKernelGGL(dr::k_g1_results_affine, dim3(div_up(batch, 64)), dim3(64), 0, ctx->stream, ctx->result.as<uint32_t>(),
+                           (uint32_t)batch, ctx->io_c.as<uint32_t>());
+    }));
+    std::vector<uint8_t> le(batch * 96);
+    HIP_TRY(hipMemcpyAsync(le.data(), ctx->io_c.p, batch * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) TRY(prof_collect(ctx));
+    for (size_t b = 0; b < batch; b++) {
+        bool allz = true;
+        for (int j = 0; j < 96; j++) if (le[96 * b + j]) { allz = false; break; }
+        if (is_inf) is_inf[b] = allz ? 1 : 0;
+        for (int j = 0; j < 48; j++) {
+            out_be_xy[96 * b + j] = le[96 * b + 47 - j];
+            out_be_xy[96 * b + 48 + j] = le[96 * b + 95 - j];
+        }
+    }
     return DR_OK;
 }
 
@@ -589,10 +627,7 @@ int dr_g1_msm_batch_dev(dr_ctx* ctx, const dr_srs* srs, const void* d_scalars, s
     if (!srs || !out_be_xy) return fail(DR_ERR_INVALID, "null argument");
     if (srs->device != ctx->device) return fail(DR_ERR_INVALID, "SRS lives on another device");
     if (n > srs->count) return fail(DR_ERR_INVALID, "polynomial degree exceeds SRS size");
-    std::vector<drh::G1> res;
-    TRY(msm_device(ctx, srs->d_bases, (const uint32_t*)d_scalars, n, batch, res));
-    for (size_t b = 0; b < batch; b++) g1_result_to_bytes(res[b], out_be_xy + 96 * b, is_inf ? is_inf + b : nullptr);
-    return DR_OK;
+    return msm_to_bytes(ctx, srs->d_bases, (const uint32_t*)d_scalars, n, batch, out_be_xy, is_inf);
 }
 
 int dr_g1_msm_batch(dr_ctx* ctx, const dr_srs* srs, const uint8_t* scalars, size_t n, size_t batch, uint8_t* out_be_xy, int* is_inf) {
@@ -776,6 +811,302 @@ int dr_ntt(dr_ctx* ctx, uint8_t* data, unsigned log2n, size_t batch, const uint8
     TRY(dr_ntt_dev(ctx, ctx->io_a.p, log2n, batch, omega, scale));
     HIP_TRY(hipMemcpyAsync(data, ctx->io_a.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DR_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------- batched ring prover
+struct dr_ring_prover {
+    dr_ctx* ctx = nullptr;
+    const dr_srs* srs = nullptr;
+    dr::RingConsts rc{};
+    drh::Fr omega_n, omega_4n;          // Montgomery
+    // per-ring tables
+    Scratch ring_pts_mont;              // [N][16]
+    Scratch fixed_coef;                 // [3][N][8] std (px, py, s coefficients)
+    Scratch fixed4, lag4, not_last;     // Montgomery tables on the 4N domain
+    uint8_t root[3 * 96];
+    int root_inf[3];
+    // per-batch state
+    size_t batch = 0;
+    Scratch idx, blind, zk, chain_ext, prefix, chain_aff, cnt, relation, rps, cols, wit4, alphas, agg, q, zetas, evals, ks, lin,
+        nus, aggo, chunkv, quot1, quot2;
+};
+
+namespace {
+
+int ring_ntt(dr_ring_prover* p, uint32_t* d_data, unsigned log2n, size_t batch, bool inverse) {
+    dr_ctx* ctx = p->ctx;
+    const drh::Fr& w = log2n == p->rc.log2n ? p->omega_n : p->omega_4n;
+    drh::Fr wi = inverse ? w.inv() : w;
+    drh::Fr scale;
+    if (inverse) scale = drh::Fr::from_u64((uint64_t)1 << log2n).inv();
+    // dr_ntt limits one launch to 65535 transforms (grid.y): split larger batches
+    for (size_t done = 0; done < batch;) {
+        size_t take = std::min<size_t>(batch - done, 65535);
+        int rc = dr::ntt_run(ctx->stream, [&](const char* name, auto&& f) { return launch(ctx, name, f); }, ctx->twiddles, ctx->io_b,
+                             d_data + done * ((size_t)8 << log2n), log2n, take, wi, inverse ? &scale : nullptr,
+                             [&]() -> int { return DR_OK; });
+        if (rc != DR_OK) return rc == DR_ERR_NOMEM ? fail(rc, "out of device memory in NTT") : fail(rc, "NTT launch failed");
+        done += take;
+    }
+    return DR_OK;
+}
+
+dr::FrArg arg_of(const drh::Fr& v) { return dr::to_arg(v); }
+
+}  // namespace
+
+extern "C" {
+
+int dr_ring_prover_create(dr_ctx* ctx, const dr_srs* srs, unsigned log2n, uint32_t max_ring, const uint8_t omega_n[32],
+                          const uint8_t omega_4n[32], const uint8_t* nm_points_xy, const uint8_t seed_xy[64], dr_ring_prover** out) {
+    TRY(use_ctx(ctx));
+    if (!out || !srs || !omega_n || !omega_4n || !nm_points_xy || !seed_xy) return fail(DR_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (log2n < 9 || log2n > 12) return fail(DR_ERR_INVALID, "domain_size must be between 512 and 4096");
+    const uint32_t n = 1u << log2n, m = 4 * n;
+    if (max_ring + 253 + 4 > n) return fail(DR_ERR_INVALID, "max_ring_size exceeds supported size");
+    if (srs->count < 3 * (size_t)n + 1) return fail(DR_ERR_INVALID, "polynomial degree exceeds SRS size");
+    TRY(check_fr_elems(nm_points_xy, 2 * (size_t)n, "ring point"));
+    TRY(check_fr_elems(seed_xy, 2, "seed point"));
+    dr_ring_prover* p = new (std::nothrow) dr_ring_prover();
+    if (!p) return fail(DR_ERR_NOMEM, "out of host memory");
+    std::unique_ptr<dr_ring_prover, void (*)(dr_ring_prover*)> guard(p, [](dr_ring_prover* q) { dr_ring_prover_destroy(q); });
+    p->ctx = ctx;
+    p->srs = srs;
+    if (!drh::Fr::load_le(p->omega_n, omega_n) || !drh::Fr::load_le(p->omega_4n, omega_4n))
+        return fail(DR_ERR_INVALID, "omega is not a canonical field element");
+    dr::RingConsts& rc = p->rc;
+    rc.log2n = log2n; rc.n = n; rc.max_ring = max_ring; rc.rows = n - 4;
+    drh::Fr sx, sy;
+    drh::Fr::load_le(sx, seed_xy);
+    drh::Fr::load_le(sy, seed_xy + 32);
+    rc.seed_x = arg_of(sx); rc.seed_y = arg_of(sy);
+    rc.omega = arg_of(p->omega_n);
+    // domain[-k] = w^-k ; last_x = w^(N-4) = w^-4
+    drh::Fr winv = p->omega_n.inv();
+    drh::Fr w1 = winv, w2 = winv * winv, w3 = w2 * winv, w4 = w2 * w2;
+    rc.last_x = arg_of(w4);
+    // tail(X) = (X - w^-1)(X - w^-2)(X - w^-3)
+    drh::Fr e1 = w1 + w2 + w3, e2 = w1 * w2 + w1 * w3 + w2 * w3, e3 = w1 * w2 * w3;
+    rc.tail[0] = arg_of(e3.neg()); rc.tail[1] = arg_of(e2); rc.tail[2] = arg_of(e1.neg()); rc.tail[3] = arg_of(drh::Fr::one());
+    hipStream_t st = ctx->stream;
+    // ring points -> Montgomery table ; fixed evaluation columns
+    TRY(p->ring_pts_mont.reserve((size_t)n * 64));
+    HIP_TRY(hipMemcpyAsync(p->ring_pts_mont.p, nm_points_xy, (size_t)n * 64, hipMemcpyHostToDevice, st));
+    TRY(p->fixed_coef.reserve((size_t)3 * n * 32));
+    hipLaunchKernelGGL(dr::k_ring_fixed_evals, dim3(div_up(n, 256)), dim3(256), 0, st, p->ring_pts_mont.as<uint32_t>(), n, max_ring,
+                       p->fixed_coef.as<uint32_t>());
+    hipLaunchKernelGGL(dr::k_fr_to_mont, dim3(div_up((size_t)2 * n, 256)), dim3(256), 0, st, p->ring_pts_mont.as<uint32_t>(), (size_t)2 * n);
+    TRY(ring_ntt(p, p->fixed_coef.as<uint32_t>(), log2n, 3, true));            // interpolate px, py, s
+    TRY(msm_to_bytes(ctx, srs->d_bases, p->fixed_coef.as<uint32_t>(), n, 3, p->root, p->root_inf));
+    // 4N-domain tables (Montgomery)
+    TRY(p->fixed4.reserve((size_t)3 * m * 32));
+    hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up((size_t)3 * m, 256)), dim3(256), 0, st, p->fixed_coef.as<uint32_t>(), n,
+                       p->fixed4.as<uint32_t>(), m, (size_t)3);
+    TRY(ring_ntt(p, p->fixed4.as<uint32_t>(), log2n + 2, 3, false));
+    hipLaunchKernelGGL(dr::k_fr_to_mont, dim3(div_up((size_t)3 * m, 256)), dim3(256), 0, st, p->fixed4.as<uint32_t>(), (size_t)3 * m);
+    Scratch lagc;
+    TRY(lagc.reserve((size_t)2 * n * 32));
+    hipLaunchKernelGGL(dr::k_ring_lagrange, dim3(div_up(n, 256)), dim3(256), 0, st, lagc.as<uint32_t>(), n,
+                       arg_of(drh::Fr::from_u64(n).inv()), arg_of(w4.inv()));
+    TRY(p->lag4.reserve((size_t)2 * m * 32));
+    hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up((size_t)2 * m, 256)), dim3(256), 0, st, lagc.as<uint32_t>(), n, p->lag4.as<uint32_t>(), m, (size_t)2);
+    TRY(ring_ntt(p, p->lag4.as<uint32_t>(), log2n + 2, 2, false));
+    hipLaunchKernelGGL(dr::k_fr_to_mont, dim3(div_up((size_t)2 * m, 256)), dim3(256), 0, st, p->lag4.as<uint32_t>(), (size_t)2 * m);
+    TRY(p->not_last.reserve((size_t)m * 32));
+    hipLaunchKernelGGL(dr::k_ring_not_last, dim3(div_up(m, 256)), dim3(256), 0, st, p->not_last.as<uint32_t>(), m, arg_of(p->omega_4n), arg_of(w4));
+    HIP_TRY(hipStreamSynchronize(st));
+    lagc.release();
+    HIP_TRY(hipGetLastError());
+    guard.release();
+    *out = p;
+    return DR_OK;
+}
+
+void dr_ring_prover_destroy(dr_ring_prover* p) {
+    if (!p) return;
+    if (p->ctx) (void)hipSetDevice(p->ctx->device);
+    for (Scratch* s : {&p->ring_pts_mont, &p->fixed_coef, &p->fixed4, &p->lag4, &p->not_last, &p->idx, &p->blind, &p->zk, &p->chain_ext,
+                       &p->prefix, &p->chain_aff, &p->cnt, &p->relation, &p->rps, &p->cols, &p->wit4, &p->alphas, &p->agg, &p->q, &p->zetas,
+                       &p->evals, &p->ks, &p->lin, &p->nus, &p->aggo, &p->chunkv, &p->quot1, &p->quot2})
+        s->release();
+    delete p;
+}
+
+int dr_ring_prover_root(const dr_ring_prover* p, uint8_t out_commitments[3 * 96], int is_inf[3]) {
+    if (!p || !out_commitments) return fail(DR_ERR_INVALID, "null argument");
+    std::memcpy(out_commitments, p->root, sizeof p->root);
+    if (is_inf) std::memcpy(is_inf, p->root_inf, sizeof p->root_inf);
+    return DR_OK;
+}
+
+int dr_ring_prover_fixed_coeffs(dr_ring_prover* p, uint8_t* out /* 3*N*32: px, py, s */) {
+    if (!p || !out) return fail(DR_ERR_INVALID, "null argument");
+    TRY(use_ctx(p->ctx));
+    HIP_TRY(hipMemcpyAsync(out, p->fixed_coef.p, (size_t)3 * p->rc.n * 32, hipMemcpyDeviceToHost, p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    return DR_OK;
+}
+
+// phase A: witness columns, interpolation, 4 commitments per proof (order b, accip, accx, accy)
+int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* producer_index, const uint8_t* blinding, const uint8_t* zk_rows,
+                          uint8_t* out_relation_xy, uint8_t* out_commitments, int* is_inf) {
+    if (!p || !producer_index || !blinding || !out_relation_xy || !out_commitments) return fail(DR_ERR_INVALID, "null argument");
+    dr_ctx* ctx = p->ctx;
+    TRY(use_ctx(ctx));
+    if (batch == 0 || batch > 16383) return fail(DR_ERR_INVALID, "batch must be in 1..16383");
+    const dr::RingConsts& rc = p->rc;
+    const uint32_t n = rc.n;
+    for (size_t i = 0; i < batch; i++)
+        if (producer_index[i] >= rc.max_ring) return fail(DR_ERR_INVALID, "producer key is not in ring");
+    TRY(check_fr_elems(blinding, batch, "blinding factor"));
+    if (zk_rows) TRY(check_fr_elems(zk_rows, batch * 12, "hidden row"));
+    p->batch = batch;
+    hipStream_t st = ctx->stream;
+    TRY(p->idx.reserve(batch * 4));
+    TRY(p->blind.reserve(batch * 32));
+    TRY(p->chain_ext.reserve(batch * dr::RING_CHAIN * 128));
+    TRY(p->prefix.reserve(batch * dr::RING_CHAIN * 32));
+    TRY(p->chain_aff.reserve(batch * dr::RING_CHAIN * 64));
+    TRY(p->cnt.reserve(batch * 4));
+    TRY(p->relation.reserve(batch * 64));
+    TRY(p->rps.reserve(batch * 64));
+    TRY(p->cols.reserve(batch * 4 * (size_t)n * 32));
+    HIP_TRY(hipMemcpyAsync(p->idx.p, producer_index, batch * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(p->blind.p, blinding, batch * 32, hipMemcpyHostToDevice, st));
+    if (zk_rows) {
+        TRY(p->zk.reserve(batch * 12 * 32));
+        HIP_TRY(hipMemcpyAsync(p->zk.p, zk_rows, batch * 12 * 32, hipMemcpyHostToDevice, st));
+    }
+    TRY(launch(ctx, "k_ring_chain", [&] {
+        hipLaunchKernelGGL(dr::k_ring_chain, dim3(div_up(batch, 64)), dim3(64), 0, st, p->ring_pts_mont.as<uint32_t>(), p->idx.as<uint32_t>(),
+                           p->blind.as<uint32_t>(), rc, (uint32_t)batch, p->chain_ext.as<uint32_t>(), p->prefix.as<uint32_t>(),
+                           p->chain_aff.as<uint32_t>(), p->cnt.as<uint32_t>());
+    }));
+    TRY(launch(ctx, "k_ring_columns", [&] {
+        hipLaunchKernelGGL(dr::k_ring_relations, dim3(div_up(batch, 64)), dim3(64), 0, st, p->chain_aff.as<uint32_t>(), p->cnt.as<uint32_t>(),
+                           (uint32_t)batch, p->relation.as<uint32_t>(), p->rps.as<uint32_t>());
+        hipLaunchKernelGGL(dr::k_ring_columns, dim3(div_up(batch * n, 256)), dim3(256), 0, st, p->idx.as<uint32_t>(), p->blind.as<uint32_t>(),
+                           p->chain_aff.as<uint32_t>(), zk_rows ? p->zk.as<uint32_t>() : nullptr, rc, (uint32_t)batch, p->cols.as<uint32_t>());
+    }));
+    TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true));
+    HIP_TRY(hipMemcpyAsync(out_relation_xy, p->relation.p, batch * 64, hipMemcpyDeviceToHost, st));
+    return msm_to_bytes(ctx, p->srs->d_bases, p->cols.as<uint32_t>(), n, batch * 4, out_commitments, is_inf);
+}
+
+// phase B: constraints on the 4N domain, aggregation with the alphas, quotient polynomial and its commitment
+int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alphas, uint8_t* out_cq, int* is_inf) {
+    if (!p || !alphas || !out_cq) return fail(DR_ERR_INVALID, "null argument");
+    dr_ctx* ctx = p->ctx;
+    TRY(use_ctx(ctx));
+    if (batch != p->batch || batch == 0) return fail(DR_ERR_INVALID, "phase called with a different batch size");
+    TRY(check_fr_elems(alphas, batch * 7, "alpha"));
+    const dr::RingConsts& rc = p->rc;
+    const uint32_t n = rc.n, m = 4 * n, qn = 3 * n + 1;
+    hipStream_t st = ctx->stream;
+    TRY(p->alphas.reserve(batch * 7 * 32));
+    TRY(p->wit4.reserve(batch * 4 * (size_t)m * 32));
+    TRY(p->agg.reserve(batch * (size_t)m * 32));
+    TRY(p->q.reserve(batch * (size_t)qn * 32));
+    HIP_TRY(hipMemcpyAsync(p->alphas.p, alphas, batch * 7 * 32, hipMemcpyHostToDevice, st));
+    TRY(launch(ctx, "k_ring_pad", [&] {
+        hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up(batch * 4 * m, 256)), dim3(256), 0, st, p->cols.as<uint32_t>(), n, p->wit4.as<uint32_t>(), m,
+                           batch * 4);
+    }));
+    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch * 4, false));
+    TRY(launch(ctx, "k_ring_constraints", [&] {
+        hipLaunchKernelGGL(dr::k_ring_constraints, dim3(div_up(batch * m, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(), p->fixed4.as<uint32_t>(),
+                           p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas.as<uint32_t>(), p->rps.as<uint32_t>(), rc,
+                           (uint32_t)batch, p->agg.as<uint32_t>());
+    }));
+    TRY(ring_ntt(p, p->agg.as<uint32_t>(), rc.log2n + 2, batch, true));
+    TRY(launch(ctx, "k_ring_quotient", [&] {
+        hipLaunchKernelGGL(dr::k_ring_quotient, dim3(div_up(batch * qn, 256)), dim3(256), 0, st, p->agg.as<uint32_t>(), rc, (uint32_t)batch,
+                           p->q.as<uint32_t>());
+    }));
+    return msm_to_bytes(ctx, p->srs->d_bases, p->q.as<uint32_t>(), qn, batch, out_cq, is_inf);
+}
+
+// phase C1: register evaluations at zeta, linearisation polynomial and its value at zeta*omega
+int dr_ring_prove_evals(dr_ring_prover* p, size_t batch, const uint8_t* zetas, uint8_t* out_evals /* B*8*32 */) {
+    if (!p || !zetas || !out_evals) return fail(DR_ERR_INVALID, "null argument");
+    dr_ctx* ctx = p->ctx;
+    TRY(use_ctx(ctx));
+    if (batch != p->batch || batch == 0) return fail(DR_ERR_INVALID, "phase called with a different batch size");
+    TRY(check_fr_elems(zetas, batch, "zeta"));
+    const dr::RingConsts& rc = p->rc;
+    const uint32_t n = rc.n;
+    hipStream_t st = ctx->stream;
+    TRY(p->zetas.reserve(batch * 32));
+    TRY(p->evals.reserve(batch * 8 * 32));
+    TRY(p->ks.reserve(batch * 3 * 32));
+    TRY(p->lin.reserve(batch * (size_t)n * 32));
+    HIP_TRY(hipMemcpyAsync(p->zetas.p, zetas, batch * 32, hipMemcpyHostToDevice, st));
+    TRY(launch(ctx, "k_ring_eval", [&] {
+        hipLaunchKernelGGL(dr::k_ring_eval, dim3(7, (unsigned)batch), dim3(dr::EV_BLOCK), 0, st, p->fixed_coef.as<uint32_t>(), 3u,
+                           p->cols.as<uint32_t>(), 4u, n, p->zetas.as<uint32_t>(), 0, rc, p->evals.as<uint32_t>(), 8u, 0u);
+    }));
+    TRY(launch(ctx, "k_ring_linpoly", [&] {
+        hipLaunchKernelGGL(dr::k_ring_lin_scalars, dim3(div_up(batch, 64)), dim3(64), 0, st, p->evals.as<uint32_t>(), p->alphas.as<uint32_t>(),
+                           p->zetas.as<uint32_t>(), rc, (uint32_t)batch, p->ks.as<uint32_t>());
+        hipLaunchKernelGGL(dr::k_ring_linpoly, dim3(div_up(batch * n, 256)), dim3(256), 0, st, p->cols.as<uint32_t>(), p->ks.as<uint32_t>(), n,
+                           (uint32_t)batch, p->lin.as<uint32_t>());
+    }));
+    TRY(launch(ctx, "k_ring_eval", [&] {
+        hipLaunchKernelGGL(dr::k_ring_eval, dim3(1, (unsigned)batch), dim3(dr::EV_BLOCK), 0, st, (const uint32_t*)nullptr, 0u, p->lin.as<uint32_t>(),
+                           1u, n, p->zetas.as<uint32_t>(), 1, rc, p->evals.as<uint32_t>(), 8u, 7u);
+    }));
+    HIP_TRY(hipMemcpyAsync(out_evals, p->evals.p, batch * 8 * 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ctx->prof) TRY(prof_collect(ctx));
+    return DR_OK;
+}
+
+// phase C2: nu-aggregated polynomial, the two opening quotients and their commitments (agg at zeta, lin at zeta*omega)
+int dr_ring_prove_openings(dr_ring_prover* p, size_t batch, const uint8_t* nus, uint8_t* out_openings /* B*2*96 */, int* is_inf /* B*2 */) {
+    if (!p || !nus || !out_openings) return fail(DR_ERR_INVALID, "null argument");
+    dr_ctx* ctx = p->ctx;
+    TRY(use_ctx(ctx));
+    if (batch != p->batch || batch == 0) return fail(DR_ERR_INVALID, "phase called with a different batch size");
+    TRY(check_fr_elems(nus, batch * 8, "nu"));
+    const dr::RingConsts& rc = p->rc;
+    const uint32_t n = rc.n, qn = 3 * n + 1;
+    hipStream_t st = ctx->stream;
+    TRY(p->nus.reserve(batch * 8 * 32));
+    TRY(p->aggo.reserve(batch * (size_t)qn * 32));
+    const uint32_t nch1 = (qn + dr::SD_CHUNK - 1) / dr::SD_CHUNK, nch2 = (n + dr::SD_CHUNK - 1) / dr::SD_CHUNK;
+    TRY(p->chunkv.reserve(batch * (size_t)nch1 * 32));
+    TRY(p->quot1.reserve(batch * (size_t)(qn - 1) * 32));
+    TRY(p->quot2.reserve(batch * (size_t)(n - 1) * 32));
+    HIP_TRY(hipMemcpyAsync(p->nus.p, nus, batch * 8 * 32, hipMemcpyHostToDevice, st));
+    TRY(launch(ctx, "k_ring_aggpoly", [&] {
+        hipLaunchKernelGGL(dr::k_ring_aggpoly, dim3(div_up(batch * qn, 256)), dim3(256), 0, st, p->fixed_coef.as<uint32_t>(), p->cols.as<uint32_t>(),
+                           p->q.as<uint32_t>(), p->nus.as<uint32_t>(), n, (uint32_t)batch, p->aggo.as<uint32_t>());
+    }));
+    auto syndiv = [&](const uint32_t* poly, uint32_t len, int mul_omega, uint32_t* quot, uint32_t nch) -> int {
+        return launch(ctx, "k_syndiv", [&] {
+            hipLaunchKernelGGL(dr::k_syndiv_local, dim3(div_up(batch * nch, 128)), dim3(128), 0, st, poly, len, p->zetas.as<uint32_t>(), mul_omega, rc,
+                               (uint32_t)batch, p->chunkv.as<uint32_t>());
+            hipLaunchKernelGGL(dr::k_syndiv_link, dim3(div_up(batch, 64)), dim3(64), 0, st, p->chunkv.as<uint32_t>(), len, p->zetas.as<uint32_t>(),
+                               mul_omega, rc, (uint32_t)batch);
+            hipLaunchKernelGGL(dr::k_syndiv_write, dim3(div_up(batch * nch, 128)), dim3(128), 0, st, poly, len, p->zetas.as<uint32_t>(), mul_omega, rc,
+                               (uint32_t)batch, p->chunkv.as<uint32_t>(), quot);
+        });
+    };
+    TRY(syndiv(p->aggo.as<uint32_t>(), qn, 0, p->quot1.as<uint32_t>(), nch1));
+    TRY(syndiv(p->lin.as<uint32_t>(), n, 1, p->quot2.as<uint32_t>(), nch2));
+    std::vector<uint8_t> o1(batch * 96), o2(batch * 96);
+    std::vector<int> i1(batch), i2(batch);
+    TRY(msm_to_bytes(ctx, p->srs->d_bases, p->quot1.as<uint32_t>(), qn - 1, batch, o1.data(), i1.data()));
+    TRY(msm_to_bytes(ctx, p->srs->d_bases, p->quot2.as<uint32_t>(), n - 1, batch, o2.data(), i2.data()));
+    for (size_t b = 0; b < batch; b++) {
+        std::memcpy(out_openings + 192 * b, o1.data() + 96 * b, 96);
+        std::memcpy(out_openings + 192 * b + 96, o2.data() + 96 * b, 96);
+        if (is_inf) { is_inf[2 * b] = i1[b]; is_inf[2 * b + 1] = i2[b]; }
+    }
     return DR_OK;
 }
 

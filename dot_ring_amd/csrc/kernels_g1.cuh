@@ -324,4 +324,13 @@ __global__ void k_g1_horner(const uint32_t* __restrict__ winsum, uint32_t batch,
     store_xyzz(out, b, acc);
 }
 
+// batched results: XYZZ (Montgomery) -> affine standard-form little-endian limbs, (0,0) for infinity
+__global__ void k_g1_results_affine(const uint32_t* __restrict__ xyzz, uint32_t count, uint32_t* __restrict__ out /* count*24 */) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    G1Affine a = g1_to_affine_dev(load_xyzz(xyzz, i));
+    store_fq(out + (size_t)i * 24, from_mont(a.x));
+    store_fq(out + (size_t)i * 24 + 12, from_mont(a.y));
+}
+
 }  // namespace dr

@@ -1,0 +1,447 @@
+// Batched ring-proof prover kernels (K7 constraint evaluation, K8 polynomial passes, witness generation).
+// Replaces, for a batch of proofs over ONE ring, the interpreted loops of the reference's prover:
+//   witness columns            dot_ring/ring_proof/columns/columns.py:111-146
+//   constraints c1..c7 + alpha dot_ring/ring_proof/constraints/constraints.py:64-151, proof_builder.py:165-180
+//   tail factor / vanishing    dot_ring/ring_proof/proof_builder.py:182-195, polynomial/ops.py:207-224
+//   Horner evaluations         dot_ring/ring_proof/polynomial/ops.py:170-176 (proof_builder.py:235-250)
+//   linearisation / nu-aggregation  proof_builder.py:197-233, 288-315
+//   synthetic division         dot_ring/ring_proof/pcs/utils.py:27-35
+// Conventions: per-proof data arrays cross kernel boundaries in STANDARD form (32-byte little-endian field
+// elements — what the NTT and MSM kernels consume); per-ring tables (fixed columns on the 4N domain, Lagrange
+// rows, x - w^(N-4), ring points) are kept in MONTGOMERY form.  Batch-major layouts: [proof][column][index].
+#pragma once
+#include "kernels_bsn.cuh"
+#include "kernels_ntt.cuh"
+
+namespace dr {
+
+DR_DEV Fr ld_std(const uint32_t* p) { return to_mont(gload_fr(p)); }
+DR_DEV void st_std(uint32_t* p, const Fr& v) { gstore_fr(p, from_mont(v)); }
+DR_DEV Fr fr_from_u32(uint32_t v) {       // small integer -> Montgomery
+    Fr r = Fr::zero();
+    r.l[0] = v;
+    return to_mont(r);
+}
+DR_DEV Fr fr_pow_u32(Fr base, uint32_t e) {
+    Fr r = Fr::one();
+    for (; e; e >>= 1) {
+        if (e & 1) r = mul(r, base);
+        base = sqr(base);
+    }
+    return r;
+}
+
+// ---- per-ring setup ------------------------------------------------------------------------------------------
+// split the ring points into the px / py evaluation columns (standard form) and the selector column
+__global__ void k_ring_fixed_evals(const uint32_t* __restrict__ pts_std /* N*16 */, uint32_t n, uint32_t max_ring,
+                                   uint32_t* __restrict__ cols /* [3][N][8]: px, py, s */) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    gstore_fr(cols + ((size_t)0 * n + i) * 8, gload_fr(pts_std + (size_t)i * 16));
+    gstore_fr(cols + ((size_t)1 * n + i) * 8, gload_fr(pts_std + (size_t)i * 16 + 8));
+    Fr s = Fr::zero();
+    s.l[0] = i < max_ring ? 1u : 0u;
+    gstore_fr(cols + ((size_t)2 * n + i) * 8, s);
+}
+// zero-padded copy of `count` coefficient vectors of length n into vectors of length m >= n (std form)
+__global__ void k_ring_pad(const uint32_t* __restrict__ src, uint32_t n, uint32_t* __restrict__ dst, uint32_t m, size_t count) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= count * m) return;
+    size_t v = gid / m;
+    uint32_t j = (uint32_t)(gid % m);
+    Fr x = j < n ? gload_fr(src + (v * n + j) * 8) : Fr::zero();
+    gstore_fr(dst + gid * 8, x);
+}
+// Lagrange basis coefficients over the size-n domain for rows 0 and `last`: L_i(X) = (1/n) sum_j (x_i^-1)^j X^j
+__global__ void k_ring_lagrange(uint32_t* __restrict__ out /* [2][n][8] std */, uint32_t n, FrArg inv_n_mont, FrArg inv_xlast_mont) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    Fr inv_n = from_arg(inv_n_mont);
+    st_std(out + (size_t)j * 8, inv_n);                                         // row 0: x_0 = 1
+    st_std(out + ((size_t)n + j) * 8, mul(inv_n, fr_pow_u32(from_arg(inv_xlast_mont), j)));
+}
+// in place: standard -> Montgomery
+__global__ void k_fr_to_mont(uint32_t* data, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) gstore_fr(data + i * 8, to_mont(gload_fr(data + i * 8)));
+}
+// not_last[i] = w4^i - w_N^(N-4)   (Montgomery), i < m
+__global__ void k_ring_not_last(uint32_t* __restrict__ out, uint32_t m, FrArg w4_mont, FrArg last_root_mont) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    gstore_fr(out + (size_t)i * 8, sub(fr_pow_u32(from_arg(w4_mont), i), from_arg(last_root_mont)));
+}
+
+// ---- witness generation --------------------------------------------------------------------------------------
+constexpr int RING_CHAIN = 256;    // seed, +PK_k, one per set blinding bit (<= 253), relation
+
+struct RingConsts {
+    uint32_t log2n, n, max_ring, rows;   // rows = n - 4
+    FrArg seed_x, seed_y;                // accumulator base, Montgomery
+    FrArg tail[4];                       // (X - w^-1)(X - w^-2)(X - w^-3) coefficients, Montgomery, low first
+    FrArg omega;                         // w_N, Montgomery
+    FrArg last_x;                        // w_N^(N-4), Montgomery
+};
+
+// One lane per proof: the conditional-sum accumulator visits at most 255 distinct values (seed, then one addition
+// for the producer key and one per set bit of the blinding factor).  They are produced in extended coordinates,
+// normalised together with ONE inversion (Montgomery's trick) and written as affine Montgomery pairs;
+// entry [cnt] is the relation point (last value minus the seed).  cnt_out[proof] = number of accumulator values.
+__global__ void k_ring_chain(const uint32_t* __restrict__ ring_pts_mont /* N*16: x,y Montgomery */,
+                             const uint32_t* __restrict__ producer_idx, const uint32_t* __restrict__ blinding /* B*8 */,
+                             RingConsts rc, uint32_t batch,
+                             uint32_t* __restrict__ chain_ext /* B*256*32 scratch */, uint32_t* __restrict__ prefix /* B*256*8 scratch */,
+                             uint32_t* __restrict__ chain_aff /* B*256*16 */, uint32_t* __restrict__ cnt_out) {
+    uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= batch) return;
+    uint32_t* ext = chain_ext + (size_t)pid * RING_CHAIN * 32;
+    uint32_t* pre = prefix + (size_t)pid * RING_CHAIN * 8;
+    uint32_t* aff = chain_aff + (size_t)pid * RING_CHAIN * 16;
+    auto put = [&](uint32_t idx, const TePoint& p) {
+        gstore_fr(ext + idx * 32, p.x); gstore_fr(ext + idx * 32 + 8, p.y);
+        gstore_fr(ext + idx * 32 + 16, p.z); gstore_fr(ext + idx * 32 + 24, p.t);
+    };
+    auto ring_point = [&](uint32_t row) {
+        TePoint p;
+        p.x = gload_fr(ring_pts_mont + (size_t)row * 16);
+        p.y = gload_fr(ring_pts_mont + (size_t)row * 16 + 8);
+        p.z = Fr::one();
+        p.t = mul(p.x, p.y);
+        return p;
+    };
+    TePoint acc;
+    acc.x = from_arg(rc.seed_x); acc.y = from_arg(rc.seed_y); acc.z = Fr::one(); acc.t = mul(acc.x, acc.y);
+    TePoint seed = acc;
+    uint32_t cnt = 0;
+    put(cnt++, acc);
+    acc = te_add(acc, ring_point(producer_idx[pid]));
+    put(cnt++, acc);
+    uint32_t t[8];
+    {
+        Fr tt = gload_fr(blinding + (size_t)pid * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = tt.l[j];
+    }
+#pragma unroll 1
+    for (uint32_t j = 0; j < 253; j++) {
+        if ((t[j >> 5] >> (j & 31)) & 1) {
+            acc = te_add(acc, ring_point(rc.max_ring + j));
+            put(cnt++, acc);
+        }
+    }
+    cnt_out[pid] = cnt;
+    put(cnt, te_add(acc, te_cneg(seed, true)));           // relation = result - seed
+    const uint32_t total = cnt + 1;
+    // batch inversion of the Z coordinates
+    Fr run = Fr::one();
+#pragma unroll 1
+    for (uint32_t i = 0; i < total; i++) {
+        gstore_fr(pre + i * 8, run);
+        run = mul(run, gload_fr(ext + i * 32 + 16));
+    }
+    Fr inv_run = inv(run);
+#pragma unroll 1
+    for (int i = (int)total - 1; i >= 0; i--) {
+        Fr z = gload_fr(ext + i * 32 + 16);
+        Fr zi = mul(inv_run, gload_fr(pre + i * 8));
+        inv_run = mul(inv_run, z);
+        gstore_fr(aff + i * 16, mul(gload_fr(ext + i * 32), zi));
+        gstore_fr(aff + i * 16 + 8, mul(gload_fr(ext + i * 32 + 8), zi));
+    }
+}
+
+// One lane per (proof, row): the four witness columns in transcript order  b, accip, accx, accy  (standard form).
+// Rows [0, n-4] follow columns.py:111-146; the last three rows are the hidden rows (zk != NULL) or zero.
+__global__ void k_ring_columns(const uint32_t* __restrict__ producer_idx, const uint32_t* __restrict__ blinding,
+                               const uint32_t* __restrict__ chain_aff, const uint32_t* __restrict__ zk /* B*4*3*8 std or NULL */,
+                               RingConsts rc, uint32_t batch, uint32_t* __restrict__ cols /* [B][4][n][8] */) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)batch * rc.n) return;
+    uint32_t pid = (uint32_t)(gid / rc.n), i = (uint32_t)(gid % rc.n);
+    uint32_t* out = cols + (size_t)pid * 4 * rc.n * 8;
+    Fr vb = Fr::zero(), vip = Fr::zero(), vx = Fr::zero(), vy = Fr::zero();
+    if (i <= rc.rows) {
+        uint32_t k = producer_idx[pid];
+        uint32_t t[8];
+        {
+            Fr tt = gload_fr(blinding + (size_t)pid * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) t[j] = tt.l[j];
+        }
+        // b[i]
+        uint32_t bit = 0;
+        if (i < rc.max_ring) bit = i == k;
+        else if (i - rc.max_ring < 253) bit = (t[(i - rc.max_ring) >> 5] >> ((i - rc.max_ring) & 31)) & 1;
+        if (i == rc.rows) bit = 0;                      // the appended padding bit
+        vb.l[0] = bit;
+        // number of additions applied before row i
+        uint32_t adds = k < i ? 1u : 0u;
+        if (i > rc.max_ring) {
+            uint32_t nb = i - rc.max_ring;              // blinding bits j < nb are below row i
+            if (nb > 253) nb = 253;
+#pragma unroll
+            for (int w = 0; w < 8; w++) {
+                uint32_t lo = w * 32;
+                if (nb >= lo + 32) adds += __popc(t[w]);
+                else if (nb > lo) adds += __popc(t[w] & ((1u << (nb - lo)) - 1));
+            }
+        }
+        vip.l[0] = k < i ? 1u : 0u;
+        const uint32_t* a = chain_aff + ((size_t)pid * RING_CHAIN + adds) * 16;
+        vx = from_mont(gload_fr(a));
+        vy = from_mont(gload_fr(a + 8));
+    } else if (zk != nullptr) {
+        uint32_t r = i - (rc.rows + 1);                 // hidden row 0..2
+        const uint32_t* z = zk + (size_t)pid * 4 * 3 * 8;
+        vb = gload_fr(z + (0 * 3 + r) * 8);
+        vip = gload_fr(z + (1 * 3 + r) * 8);
+        vx = gload_fr(z + (2 * 3 + r) * 8);
+        vy = gload_fr(z + (3 * 3 + r) * 8);
+    }
+    gstore_fr(out + ((size_t)0 * rc.n + i) * 8, vb);
+    gstore_fr(out + ((size_t)1 * rc.n + i) * 8, vip);
+    gstore_fr(out + ((size_t)2 * rc.n + i) * 8, vx);
+    gstore_fr(out + ((size_t)3 * rc.n + i) * 8, vy);
+}
+
+// result points for the host transcript: relation (x,y) and result+seed, standard form
+__global__ void k_ring_relations(const uint32_t* __restrict__ chain_aff, const uint32_t* __restrict__ cnt, uint32_t batch,
+                                 uint32_t* __restrict__ relation_std /* B*16 */, uint32_t* __restrict__ rps_mont /* B*16 */) {
+    uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= batch) return;
+    uint32_t c = cnt[pid];
+    const uint32_t* rel = chain_aff + ((size_t)pid * RING_CHAIN + c) * 16;
+    const uint32_t* last = chain_aff + ((size_t)pid * RING_CHAIN + c - 1) * 16;
+    gstore_fr(relation_std + (size_t)pid * 16, from_mont(gload_fr(rel)));
+    gstore_fr(relation_std + (size_t)pid * 16 + 8, from_mont(gload_fr(rel + 8)));
+    gstore_fr(rps_mont + (size_t)pid * 16, gload_fr(last));
+    gstore_fr(rps_mont + (size_t)pid * 16 + 8, gload_fr(last + 8));
+}
+
+// ---- K7: the seven constraints, fused with the alpha aggregation ------------------------------------------------
+// One lane per (proof, point of the 4N domain).  Reads the four witness columns at i and at i + 4 (the w_N shift),
+// the per-ring tables at i, and writes sum_k alpha_k * c_k(i)   (constraints.py:83-151, proof_builder.py:175-180).
+__global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __restrict__ wit4 /* [B][4][m][8] std: b, accip, accx, accy */,
+                                                          const uint32_t* __restrict__ fixed4 /* [3][m][8] mont: px, py, s */,
+                                                          const uint32_t* __restrict__ lag4 /* [2][m][8] mont: L0, Llast */,
+                                                          const uint32_t* __restrict__ not_last /* [m][8] mont */,
+                                                          const uint32_t* __restrict__ alphas /* [B][7][8] std */,
+                                                          const uint32_t* __restrict__ rps_mont /* [B][16] */,
+                                                          RingConsts rc, uint32_t batch, uint32_t* __restrict__ agg /* [B][m][8] std */) {
+    const uint32_t m = rc.n * 4;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)batch * m) return;
+    uint32_t pid = (uint32_t)(gid / m), i = (uint32_t)(gid % m);
+    uint32_t k = i + 4;
+    if (k >= m) k -= m;
+    const uint32_t* w = wit4 + (size_t)pid * 4 * m * 8;
+    Fr b = ld_std(w + ((size_t)0 * m + i) * 8);
+    Fr ip = ld_std(w + ((size_t)1 * m + i) * 8), ip_n = ld_std(w + ((size_t)1 * m + k) * 8);
+    Fr x1 = ld_std(w + ((size_t)2 * m + i) * 8), x3 = ld_std(w + ((size_t)2 * m + k) * 8);
+    Fr y1 = ld_std(w + ((size_t)3 * m + i) * 8), y3 = ld_std(w + ((size_t)3 * m + k) * 8);
+    Fr x2 = gload_fr(fixed4 + ((size_t)0 * m + i) * 8), y2 = gload_fr(fixed4 + ((size_t)1 * m + i) * 8);
+    Fr s = gload_fr(fixed4 + ((size_t)2 * m + i) * 8);
+    Fr l0 = gload_fr(lag4 + (size_t)i * 8), ln = gload_fr(lag4 + ((size_t)m + i) * 8);
+    Fr nl = gload_fr(not_last + (size_t)i * 8);
+    const uint32_t* al = alphas + (size_t)pid * 7 * 8;
+    Fr one = Fr::one();
+    Fr omb = sub(one, b);
+    Fr x1y1 = mul(x1, y1), x2y2 = mul(x2, y2), x1x2 = mul(x1, x2), y1y2 = mul(y1, y2);
+    // c1 = (accip' - accip - b*s) * nl
+    Fr acc = mul(ld_std(al + 0 * 8), mul(sub(sub(ip_n, ip), mul(b, s)), nl));
+    // c2 = (b*(x3*(y1y2 + a x1x2) - (x1y1 + x2y2)) + (1-b)(x3 - x1)) * nl ,  a = -5
+    Fr t2 = sub(mul(x3, add(y1y2, te_mul_a(x1x2))), add(x1y1, x2y2));
+    Fr c2 = mul(add(mul(b, t2), mul(omb, sub(x3, x1))), nl);
+    acc = add(acc, mul(ld_std(al + 1 * 8), c2));
+    // c3 = (b*(y3*(x1y2 - x2y1) - (x1y1 - x2y2)) + (1-b)(y3 - y1)) * nl
+    Fr t3 = sub(mul(y3, sub(mul(x1, y2), mul(x2, y1))), sub(x1y1, x2y2));
+    Fr c3 = mul(add(mul(b, t3), mul(omb, sub(y3, y1))), nl);
+    acc = add(acc, mul(ld_std(al + 2 * 8), c3));
+    // c4 = b(1-b)
+    acc = add(acc, mul(ld_std(al + 3 * 8), mul(b, omb)));
+    // c5/c6 = (acc - seed)*L0 + (acc - (result+seed))*Llast ; c7 = accip*L0 + (accip-1)*Llast
+    Fr rx = gload_fr(rps_mont + (size_t)pid * 16), ry = gload_fr(rps_mont + (size_t)pid * 16 + 8);
+    Fr c5 = add(mul(sub(x1, from_arg(rc.seed_x)), l0), mul(sub(x1, rx), ln));
+    Fr c6 = add(mul(sub(y1, from_arg(rc.seed_y)), l0), mul(sub(y1, ry), ln));
+    Fr c7 = add(mul(ip, l0), mul(sub(ip, one), ln));
+    acc = add(acc, mul(ld_std(al + 4 * 8), c5));
+    acc = add(acc, mul(ld_std(al + 5 * 8), c6));
+    acc = add(acc, mul(ld_std(al + 6 * 8), c7));
+    st_std(agg + gid * 8, acc);
+}
+
+// ---- K8: coefficient-space passes ---------------------------------------------------------------------------
+// quotient: c_agg = tail (cubic) * agg_poly ;  q_j = sum_{i>=1} c_agg[j + i*N],  j < 3N+1
+__global__ void k_ring_quotient(const uint32_t* __restrict__ agg_poly /* [B][4N][8] std */, RingConsts rc, uint32_t batch,
+                                uint32_t* __restrict__ q /* [B][3N+1][8] std */) {
+    const uint32_t n = rc.n, m = 4 * n, qn = 3 * n + 1;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)batch * qn) return;
+    uint32_t pid = (uint32_t)(gid / qn), j = (uint32_t)(gid % qn);
+    const uint32_t* a = agg_poly + (size_t)pid * m * 8;
+    Fr acc = Fr::zero();
+#pragma unroll 1
+    for (uint32_t i = 1; i <= 4; i++) {
+        uint32_t kidx = j + i * n;                       // index into c_agg (length m + 3)
+        if (kidx >= m + 3) break;
+#pragma unroll
+        for (uint32_t d = 0; d < 4; d++) {
+            if (kidx >= d && kidx - d < m) acc = add(acc, mul(from_arg(rc.tail[d]), ld_std(a + (size_t)(kidx - d) * 8)));
+        }
+    }
+    st_std(q + gid * 8, acc);
+}
+
+// Horner evaluation of `npoly` polynomials per proof at that proof's point: one workgroup per (proof, poly).
+// poly p < nfixed comes from the per-ring array `fixed` (std, [nfixed][len]); the others from `perproof`
+// ([B][nper][len] std).  out[pid*out_stride + out_off + p] (std).
+constexpr int EV_BLOCK = 256;
+__global__ __launch_bounds__(EV_BLOCK) void k_ring_eval(const uint32_t* __restrict__ fixed, uint32_t nfixed,
+                                                        const uint32_t* __restrict__ perproof, uint32_t nper, uint32_t len,
+                                                        const uint32_t* __restrict__ points /* [B][8] std */, int mul_omega, RingConsts rc,
+                                                        uint32_t* __restrict__ out, uint32_t out_stride, uint32_t out_off) {
+    __shared__ uint32_t red[EV_BLOCK * 8];
+    const uint32_t pid = blockIdx.y, p = blockIdx.x;
+    const uint32_t* src = p < nfixed ? fixed + (size_t)p * len * 8 : perproof + ((size_t)pid * nper + (p - nfixed)) * len * 8;
+    Fr x = ld_std(points + (size_t)pid * 8);
+    if (mul_omega) x = mul(x, from_arg(rc.omega));
+    const uint32_t per = (len + EV_BLOCK - 1) / EV_BLOCK;
+    const uint32_t lo = threadIdx.x * per;
+    Fr acc = Fr::zero();
+    if (lo < len) {
+        uint32_t hi = lo + per < len ? lo + per : len;
+#pragma unroll 1
+        for (int j = (int)hi - 1; j >= (int)lo; j--) acc = add(mul(acc, x), ld_std(src + (size_t)j * 8));
+        acc = mul(acc, fr_pow_u32(x, lo));
+    }
+#pragma unroll
+    for (int l = 0; l < 8; l++) red[l * EV_BLOCK + threadIdx.x] = acc.l[l];
+    __syncthreads();
+    for (int s = EV_BLOCK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            Fr a, b;
+#pragma unroll
+            for (int l = 0; l < 8; l++) { a.l[l] = red[l * EV_BLOCK + threadIdx.x]; b.l[l] = red[l * EV_BLOCK + threadIdx.x + s]; }
+            a = add(a, b);
+#pragma unroll
+            for (int l = 0; l < 8; l++) red[l * EV_BLOCK + threadIdx.x] = a.l[l];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        Fr r;
+#pragma unroll
+        for (int l = 0; l < 8; l++) r.l[l] = red[l * EV_BLOCK];
+        st_std(out + ((size_t)pid * out_stride + out_off + p) * 8, r);
+    }
+}
+
+// linearisation scalars per proof (proof_builder.py:253-286): k0 = a0*term, k1 = a1*fx*term, k2 = a2*fy*term
+__global__ void k_ring_lin_scalars(const uint32_t* __restrict__ evals /* [B][8][8] std: px,py,s,b,accip,accx,accy,(l) */,
+                                   const uint32_t* __restrict__ alphas, const uint32_t* __restrict__ zetas, RingConsts rc,
+                                   uint32_t batch, uint32_t* __restrict__ ks /* [B][3][8] mont */) {
+    uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= batch) return;
+    const uint32_t* e = evals + (size_t)pid * 8 * 8;
+    Fr pxz = ld_std(e), pyz = ld_std(e + 8), bz = ld_std(e + 3 * 8), axz = ld_std(e + 5 * 8), ayz = ld_std(e + 6 * 8);
+    Fr term = sub(ld_std(zetas + (size_t)pid * 8), from_arg(rc.last_x));
+    Fr omb = sub(Fr::one(), bz);
+    Fr fx = mul(add(mul(bz, add(mul(ayz, pyz), te_mul_a(mul(axz, pxz)))), omb), term);
+    Fr fy = mul(add(mul(bz, sub(mul(axz, pyz), mul(pxz, ayz))), omb), term);
+    const uint32_t* al = alphas + (size_t)pid * 7 * 8;
+    gstore_fr(ks + ((size_t)pid * 3 + 0) * 8, mul(ld_std(al), term));
+    gstore_fr(ks + ((size_t)pid * 3 + 1) * 8, mul(ld_std(al + 8), fx));
+    gstore_fr(ks + ((size_t)pid * 3 + 2) * 8, mul(ld_std(al + 16), fy));
+}
+// lin[j] = k0*accip[j] + k1*accx[j] + k2*accy[j]
+__global__ void k_ring_linpoly(const uint32_t* __restrict__ cols /* [B][4][n][8] std coefficient columns */,
+                               const uint32_t* __restrict__ ks, uint32_t n, uint32_t batch, uint32_t* __restrict__ lin /* [B][n][8] */) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)batch * n) return;
+    uint32_t pid = (uint32_t)(gid / n), j = (uint32_t)(gid % n);
+    const uint32_t* c = cols + (size_t)pid * 4 * n * 8;
+    Fr v = mul(gload_fr(ks + ((size_t)pid * 3 + 0) * 8), ld_std(c + ((size_t)1 * n + j) * 8));
+    v = add(v, mul(gload_fr(ks + ((size_t)pid * 3 + 1) * 8), ld_std(c + ((size_t)2 * n + j) * 8)));
+    v = add(v, mul(gload_fr(ks + ((size_t)pid * 3 + 2) * 8), ld_std(c + ((size_t)3 * n + j) * 8)));
+    st_std(lin + gid * 8, v);
+}
+// aggregated opening polynomial: sum of nu_i * poly_i over (px, py, s, b, accip, accx, accy, q)
+__global__ void k_ring_aggpoly(const uint32_t* __restrict__ fixed /* [3][n][8] std */, const uint32_t* __restrict__ cols,
+                               const uint32_t* __restrict__ q /* [B][3n+1][8] */, const uint32_t* __restrict__ nus /* [B][8][8] std */,
+                               uint32_t n, uint32_t batch, uint32_t* __restrict__ out /* [B][3n+1][8] */) {
+    const uint32_t qn = 3 * n + 1;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)batch * qn) return;
+    uint32_t pid = (uint32_t)(gid / qn), j = (uint32_t)(gid % qn);
+    const uint32_t* nu = nus + (size_t)pid * 8 * 8;
+    Fr v = mul(ld_std(nu + 7 * 8), ld_std(q + gid * 8));
+    if (j < n) {
+#pragma unroll 1
+        for (uint32_t p = 0; p < 3; p++) v = add(v, mul(ld_std(nu + p * 8), ld_std(fixed + ((size_t)p * n + j) * 8)));
+        const uint32_t* c = cols + (size_t)pid * 4 * n * 8;
+#pragma unroll 1
+        for (uint32_t p = 0; p < 4; p++) v = add(v, mul(ld_std(nu + (3 + p) * 8), ld_std(c + ((size_t)p * n + j) * 8)));
+    }
+    st_std(out + gid * 8, v);
+}
+
+// Synthetic division by (X - x): quotient Q_{i-1} = S_i with S_i = a_i + x*S_{i+1} (suffix Horner values).
+// Chunked scan: pass 1 gives every chunk's local Horner value, pass 2 links the chunks serially per proof,
+// pass 3 replays each chunk with its incoming value and writes the quotient.
+constexpr uint32_t SD_CHUNK = 32;
+__global__ void k_syndiv_local(const uint32_t* __restrict__ poly, uint32_t len, const uint32_t* __restrict__ points, int mul_omega,
+                               RingConsts rc, uint32_t batch, uint32_t* __restrict__ chunk_val /* [B][nchunks][8] mont */) {
+    const uint32_t nch = (len + SD_CHUNK - 1) / SD_CHUNK;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)batch * nch) return;
+    uint32_t pid = (uint32_t)(gid / nch), ch = (uint32_t)(gid % nch);
+    Fr x = ld_std(points + (size_t)pid * 8);
+    if (mul_omega) x = mul(x, from_arg(rc.omega));
+    uint32_t lo = ch * SD_CHUNK, hi = lo + SD_CHUNK < len ? lo + SD_CHUNK : len;
+    const uint32_t* a = poly + (size_t)pid * len * 8;
+    Fr acc = Fr::zero();
+#pragma unroll 1
+    for (int j = (int)hi - 1; j >= (int)lo; j--) acc = add(mul(acc, x), ld_std(a + (size_t)j * 8));
+    gstore_fr(chunk_val + gid * 8, acc);
+}
+__global__ void k_syndiv_link(uint32_t* __restrict__ chunk_val, uint32_t len, const uint32_t* __restrict__ points, int mul_omega,
+                              RingConsts rc, uint32_t batch) {
+    const uint32_t nch = (len + SD_CHUNK - 1) / SD_CHUNK;
+    uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= batch) return;
+    Fr x = ld_std(points + (size_t)pid * 8);
+    if (mul_omega) x = mul(x, from_arg(rc.omega));
+    Fr xc = fr_pow_u32(x, SD_CHUNK);
+    uint32_t* cv = chunk_val + (size_t)pid * nch * 8;
+    // after this pass cv[ch] = S at the END of chunk ch (the value entering it from above)
+    Fr incoming = Fr::zero();
+#pragma unroll 1
+    for (int ch = (int)nch - 1; ch >= 0; ch--) {
+        Fr local = gload_fr(cv + (size_t)ch * 8);
+        gstore_fr(cv + (size_t)ch * 8, incoming);
+        uint32_t lo = ch * SD_CHUNK, hi = lo + SD_CHUNK < len ? lo + SD_CHUNK : len;
+        Fr shift = (hi - lo) == SD_CHUNK ? xc : fr_pow_u32(x, hi - lo);
+        incoming = add(local, mul(shift, incoming));
+    }
+}
+__global__ void k_syndiv_write(const uint32_t* __restrict__ poly, uint32_t len, const uint32_t* __restrict__ points, int mul_omega,
+                               RingConsts rc, uint32_t batch, const uint32_t* __restrict__ chunk_val,
+                               uint32_t* __restrict__ quot /* [B][len-1][8] std */) {
+    const uint32_t nch = (len + SD_CHUNK - 1) / SD_CHUNK;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)batch * nch) return;
+    uint32_t pid = (uint32_t)(gid / nch), ch = (uint32_t)(gid % nch);
+    Fr x = ld_std(points + (size_t)pid * 8);
+    if (mul_omega) x = mul(x, from_arg(rc.omega));
+    uint32_t lo = ch * SD_CHUNK, hi = lo + SD_CHUNK < len ? lo + SD_CHUNK : len;
+    const uint32_t* a = poly + (size_t)pid * len * 8;
+    uint32_t* qo = quot + (size_t)pid * (len - 1) * 8;
+    Fr s = gload_fr(chunk_val + gid * 8);
+#pragma unroll 1
+    for (int j = (int)hi - 1; j >= (int)lo; j--) {
+        s = add(mul(s, x), ld_std(a + (size_t)j * 8));      // S_j
+        if (j >= 1) st_std(qo + (size_t)(j - 1) * 8, s);
+    }
+}
+
+}  // namespace dr

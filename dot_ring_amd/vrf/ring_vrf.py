@@ -9,6 +9,7 @@ from ..ring_proof.columns import Column
 from ..ring_proof.params import RingProofParams
 from ..ring_proof.pcs import KZG
 from ..ring_proof.poly import inverse_fft_batch
+from ..ring_proof import device_prover
 from ..ring_proof.prover import build_ring_proofs
 from ..ring_proof.transcript import FiatShamirTranscript, serialize_verifier_key
 from ..ring_proof.verifier import linear_pcs_verifications
@@ -63,17 +64,26 @@ class Ring:
     def from_keys(cls, keys, params: RingProofParams | None = None) -> "Ring":
         return _ring(tuple(bytes(k) for k in keys))
 
-    def index_of(self, key: bytes) -> int:
+    def indices_of(self, keys) -> list:
+        """index_of for several keys with two kernel launches in total."""
         padding = self.params.cv.curve.params.auxiliary_points.padding_point
-        point = self._decode_keys([key])[0]
-        if point is None:
-            raise ValueError("invalid ring key")
-        if point == padding:
-            raise ValueError("producer key is not in ring")
-        try:
-            return self.nm_points[: self.params.max_ring_size].index(point)
-        except ValueError as exc:
-            raise ValueError("producer key is not in ring") from exc
+        lookup = getattr(self, "_row_of", None)
+        if lookup is None:
+            lookup = {}
+            for row, pt in enumerate(self.nm_points[: self.params.max_ring_size]):
+                lookup.setdefault(pt, row)
+            self._row_of = lookup
+        out = []
+        for point in self._decode_keys(keys):
+            if point is None:
+                raise ValueError("invalid ring key")
+            if point == padding or point not in lookup:
+                raise ValueError("producer key is not in ring")
+            out.append(lookup[point])
+        return out
+
+    def index_of(self, key: bytes) -> int:
+        return self.indices_of([key])[0]
 
 
 @lru_cache(maxsize=8)
@@ -269,7 +279,11 @@ class RingVRF(VRF):
             if root is not None and computed.encode() != root.encode():
                 raise ValueError("ring_root does not match ring")
             root = computed
-        payloads = build_ring_proofs(ring, root, producer_keys, [pp._blinding_factor for pp in pedersen])
+        blindings = [pp._blinding_factor for pp in pedersen]
+        if device_prover.supported(ring.params):
+            payloads = device_prover.build_ring_proofs_device(ring, root, ring.indices_of(producer_keys), blindings)
+        else:       # custom PCS / domain layout: generic phase-batched prover (NTT + MSM seams only)
+            payloads = build_ring_proofs(ring, root, producer_keys, blindings)
         return [cls(pp, *payload) for pp, payload in zip(pedersen, payloads)]
 
     @classmethod

@@ -141,6 +141,35 @@ DR_API int dr_g1_serialize_check(const uint8_t xy[96]);                         
 DR_API int dr_ntt(dr_ctx *ctx, uint8_t *data, unsigned log2n, size_t batch, const uint8_t omega[32], const uint8_t *scale);
 DR_API int dr_ntt_dev(dr_ctx *ctx, void *d_data, unsigned log2n, size_t batch, const uint8_t omega[32], const uint8_t *scale);
 
+/* ---- batched ring prover ---------------------------------------------------------------------------
+ * Device-resident prover for MANY proofs over ONE ring (additive API): replaces the interpreted loops of
+ * dot_ring/ring_proof/proof_builder.py:38-315, columns/columns.py:111-167 and constraints/constraints.py:43-151.
+ * The Fiat-Shamir transcript stays on the host (hashlib), so proving is four phases, each ending where the
+ * reference squeezes challenges; everything between the hashes stays in HBM.
+ *   create    ring rows nm_points (N * 64 bytes, x||y LE; rows as built by Ring(): keys, padding, 2^i*B, 4 x (0,0)),
+ *             omega_n / omega_4n primitive roots of the N and 4N domains, seed = accumulator base
+ *   root      the three fixed-column commitments px, py, s (RingRoot.from_ring, vrf/ring/root.py:21-44)
+ *   witness   in: producer row index and blinding factor per proof, optional 12 hidden-row values per proof
+ *             (columns b, accip, accx, accy x 3 rows; NULL = test-vector mode, zeros)
+ *             out: relation point Y_bar (x||y LE) and the four witness commitments (b, accip, accx, accy)
+ *   quotient  in: seven alphas per proof; out: quotient commitment C_q
+ *   evals     in: zeta per proof; out: px,py,s,b,accip,accx,accy at zeta and l(zeta*omega)   (8 x 32 bytes LE)
+ *   openings  in: eight nus per proof; out: the two opening proofs (at zeta, at zeta*omega)
+ * All four phase calls of one batch must use the same `batch`.  Scalars are 32-byte LE canonical field elements.
+ */
+typedef struct dr_ring_prover dr_ring_prover;
+DR_API int dr_ring_prover_create(dr_ctx *ctx, const dr_srs *srs, unsigned log2n, uint32_t max_ring, const uint8_t omega_n[32],
+                                 const uint8_t omega_4n[32], const uint8_t *nm_points_xy, const uint8_t seed_xy[64],
+                                 dr_ring_prover **out);
+DR_API void dr_ring_prover_destroy(dr_ring_prover *p);
+DR_API int dr_ring_prover_root(const dr_ring_prover *p, uint8_t out_commitments[3 * 96], int is_inf[3]);
+DR_API int dr_ring_prover_fixed_coeffs(dr_ring_prover *p, uint8_t *out /* 3*N*32: px, py, s coefficients */);
+DR_API int dr_ring_prove_witness(dr_ring_prover *p, size_t batch, const uint32_t *producer_index, const uint8_t *blinding,
+                                 const uint8_t *zk_rows, uint8_t *out_relation_xy, uint8_t *out_commitments, int *is_inf);
+DR_API int dr_ring_prove_quotient(dr_ring_prover *p, size_t batch, const uint8_t *alphas, uint8_t *out_cq, int *is_inf);
+DR_API int dr_ring_prove_evals(dr_ring_prover *p, size_t batch, const uint8_t *zetas, uint8_t *out_evals);
+DR_API int dr_ring_prove_openings(dr_ring_prover *p, size_t batch, const uint8_t *nus, uint8_t *out_openings, int *is_inf);
+
 #ifdef __cplusplus
 }
 #endif
