@@ -40,6 +40,7 @@ _PROTOTYPES = {
     "dr_bsn_scalar_mul_batch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dr_bsn_msm": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, c_void_p]),
     "dr_bsn_msm_groups": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, c_size_t, c_void_p]),
+    "dr_bsn_encode_to_curve_batch": (c_int, [c_void_p, c_char_p, c_size_t, c_void_p]),
     "dr_fr_sqrt": (c_int, [c_char_p, c_void_p]),
     "dr_srs_load": (c_int, [c_void_p, c_char_p, c_size_t, POINTER(c_void_p)]),
     "dr_srs_synthetic": (c_int, [c_void_p, c_char_p, c_uint, c_size_t, POINTER(c_void_p)]),
@@ -272,6 +273,14 @@ class Context:
         out = ctypes.create_string_buffer(max(64 * groups, 1))
         _check(lib().dr_bsn_msm_groups(self.handle, pts_xy, scalars, groups, m, out))
         return out.raw[: 64 * groups]
+
+    def bsn_encode_to_curve_batch(self, u_pairs: bytes) -> bytes:
+        n = len(u_pairs) // 64
+        if len(u_pairs) != 64 * n:
+            raise ValueError("u_pairs must be n * 64 bytes")
+        out = ctypes.create_string_buffer(max(64 * n, 1))
+        _check(lib().dr_bsn_encode_to_curve_batch(self.handle, u_pairs, n, out))
+        return out.raw[: 64 * n]
 
     # ---- seam B
     def srs_load(self, g1_be_xy: bytes) -> Srs:

@@ -522,6 +522,25 @@ int dr_bsn_msm(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars, size_
     }
 }
 
+int dr_bsn_encode_to_curve_batch(dr_ctx* ctx, const uint8_t* u_pairs, size_t n, uint8_t* out_xy) {
+    TRY(use_ctx(ctx));
+    if (n == 0) return DR_OK;
+    if (!u_pairs || !out_xy) return fail(DR_ERR_INVALID, "null buffer");
+    if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "batch too large");
+    TRY(check_fr_elems(u_pairs, 2 * n, "field element"));
+    TRY(ctx->io_a.reserve(n * 64));
+    TRY(ctx->io_c.reserve(n * 64));
+    HIP_TRY(hipMemcpyAsync(ctx->io_a.p, u_pairs, n * 64, hipMemcpyHostToDevice, ctx->stream));
+    TRY(launch(ctx, "k_bsn_encode_to_curve", [&] {
+        hipLaunchKernelGGL(dr::k_bsn_encode_to_curve, dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, ctx->io_a.as<uint32_t>(),
+                           ctx->io_c.as<uint32_t>(), (uint32_t)n);
+    }));
+    HIP_TRY(hipMemcpyAsync(out_xy, ctx->io_c.p, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) TRY(prof_collect(ctx));
+    return DR_OK;
+}
+
 int dr_fr_sqrt(const uint8_t in[32], uint8_t out[32]) {
     if (!in || !out) return fail(DR_ERR_INVALID, "null buffer");
     drh::Fr x, r;

@@ -182,4 +182,128 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_msm_groups(const uint32_t* __
     if (g < groups && j == 0) te_store_affine(out + (size_t)g * 16, acc);
 }
 
+// ---- Elligator 2 hash-to-curve, device side --------------------------------------------------------------------
+// out = clear_cofactor(map(u0) + map(u1))  — the field work of TEAffinePoint._e2c_ell2_ro
+// (dot_ring/curve/twisted_edwards/te_affine_point.py:212-295, te_curve.py:48-95); hash_to_field stays on the host.
+// One lane per input.  Square roots: Tonelli-Shanks with p-1 = Q*2^32 and the non-residue 5, as the reference's
+// sqrt_mod_bls_scalar_cy (bandersnatch_te.pyx:421); which root comes out is irrelevant (the map fixes the sign).
+DR_DEV Fr fr_const(uint32_t l0, uint32_t l1, uint32_t l2, uint32_t l3, uint32_t l4, uint32_t l5, uint32_t l6, uint32_t l7) {
+    Fr r;
+    r.l[0] = l0; r.l[1] = l1; r.l[2] = l2; r.l[3] = l3; r.l[4] = l4; r.l[5] = l5; r.l[6] = l6; r.l[7] = l7;
+    return r;
+}
+// a^e for a 256-bit exponent given as plain limbs (MSB-first square and multiply)
+DR_DEV Fr fr_pow_limbs(const Fr& a, const uint32_t (&e)[8]) {
+    Fr r = Fr::one();
+    bool started = false;
+#pragma unroll 1
+    for (int i = 7; i >= 0; i--) {
+#pragma unroll 1
+        for (int b = 31; b >= 0; b--) {
+            if (started) r = sqr(r);
+            if ((e[i] >> b) & 1) {
+                r = started ? mul(r, a) : a;
+                started = true;
+            }
+        }
+    }
+    return r;
+}
+DR_DEV bool fr_is_square(const Fr& a) {
+    if (a.is_zero()) return true;
+    constexpr uint32_t HALF[8] = {0x80000000u, 0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u};
+    uint32_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = HALF[i];
+    return fr_pow_limbs(a, e) == Fr::one();
+}
+// sqrt of a quadratic residue (caller guarantees it)
+DR_DEV Fr fr_sqrt_qr(const Fr& x) {
+    if (x.is_zero()) return x;
+    constexpr uint32_t Q[8] = {0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u, 0u};
+    constexpr uint32_t Q1H[8] = {0x80000000u, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u, 0u};
+    uint32_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = Q[i];
+    Fr t = fr_pow_limbs(x, e);
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = Q1H[i];
+    Fr R = fr_pow_limbs(x, e);
+    // c = 5^Q (Montgomery)
+    Fr c = fr_const(0x3f21cd85u, 0x4f89b9a6u, 0xd1b4c0f7u, 0x5a6c1ae9u, 0x9e0f51eeu, 0x2c8a0d3du, 0xbd6b4b1cu, 0x07d4a6f0u);
+    {   // derive c on the fly instead of trusting a typed constant: 5^Q
+        Fr five = Fr::zero();
+        five.l[0] = 5;
+        five = to_mont(five);
+#pragma unroll
+        for (int i = 0; i < 8; i++) e[i] = Q[i];
+        c = fr_pow_limbs(five, e);
+    }
+    int M = 32;
+    const Fr one = Fr::one();
+#pragma unroll 1
+    for (int guard = 0; guard < 40; guard++) {
+        if (t == one) break;
+        int i = 1;
+        Fr tmp = sqr(t);
+#pragma unroll 1
+        while (!(tmp == one) && i < M) { tmp = sqr(tmp); i++; }
+        Fr b = c;
+#pragma unroll 1
+        for (int j = 0; j < M - i - 1; j++) b = sqr(b);
+        M = i;
+        c = sqr(b);
+        t = mul(t, c);
+        R = mul(R, b);
+    }
+    return R;
+}
+
+// Elligator 2 onto the Montgomery model, then the birational map to the twisted Edwards model (extended coords)
+DR_DEV TePoint bsn_map_to_curve(const Fr& u) {
+    // curve constants in Montgomery form, derived from a = -5, d:  A_M = 2(a+d)/(a-d), B_M = 4/(a-d)
+    const Fr a_over_b = fr_const(0xfd6a5ca7u, 0x2ac0c0e0u, 0x3e35ba05u, 0x0d58a5bfu, 0x4e7d4d5fu, 0x4a1ad39bu, 0x2b5d7f39u, 0x6ba1bd6eu);
+    (void)a_over_b;
+    // computed from first principles to avoid typed constants
+    Fr five = Fr::zero(); five.l[0] = 5; five = to_mont(five);
+    Fr a = neg(five), d = te_d_mont();
+    Fr inv_den = inv(sub(a, d));
+    Fr mont_a = mul(dbl(add(a, d)), inv_den), mont_b = mul(dbl(dbl(Fr::one())), inv_den);
+    Fr aob = mul(mont_a, inv(mont_b));
+    Fr inv_b2 = inv(sqr(mont_b));
+    Fr tv1 = mul(five, sqr(u));                        // Z = 5
+    if (add(tv1, Fr::one()).is_zero()) tv1 = Fr::zero();
+    Fr x1 = neg(mul(aob, inv(add(tv1, Fr::one()))));
+    Fr gx1 = mul(add(mul(add(x1, aob), x1), inv_b2), x1);
+    bool e2 = fr_is_square(gx1);
+    Fr x = e2 ? x1 : sub(neg(x1), aob);
+    Fr y2 = e2 ? gx1 : mul(tv1, gx1);
+    Fr y = fr_sqrt_qr(y2);
+    bool odd = (from_mont(y).l[0] & 1u) != 0;
+    if (e2 != odd) y = neg(y);                          // e2 XOR e3 -> negate
+    Fr s = mul(x, mont_b), t = mul(y, mont_b);
+    // (s,t) -> (v,w) = (s/t ... ) : v = tv2*tv1*s, w = tv2*t*(s-1) with tv2 = 1/((s+1)*t), exceptional case -> (0,1)
+    Fr sp1 = add(s, Fr::one());
+    Fr den = mul(sp1, t);
+    TePoint r;
+    if (den.is_zero()) return te_identity();
+    Fr tv2 = inv(den);
+    r.x = mul(mul(tv2, sp1), s);
+    r.y = mul(mul(tv2, t), sub(s, Fr::one()));
+    r.z = Fr::one();
+    r.t = mul(r.x, r.y);
+    return r;
+}
+
+__global__ void k_bsn_encode_to_curve(const uint32_t* __restrict__ us /* n*2*8 std */, uint32_t* __restrict__ out /* n*16 std */, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    TePoint q0 = bsn_map_to_curve(to_mont(load_fr_std(us + (size_t)i * 16)));
+    TePoint q1 = bsn_map_to_curve(to_mont(load_fr_std(us + (size_t)i * 16 + 8)));
+    TePoint r = te_add(q0, q1);
+    r = te_dbl<false>(r);
+    r = te_dbl<false>(r);
+    te_store_affine(out + (size_t)i * 16, r);
+}
+
 }  // namespace dr

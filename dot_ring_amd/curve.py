@@ -216,6 +216,16 @@ class BandersnatchPoint:
         return r.double().double()
 
     @classmethod
+    def encode_to_curve_batch(cls, alpha_strings, salts=None):
+        """encode_to_curve for many inputs: hash_to_field on the host, Elligator2 + cofactor clearing on the GPU."""
+        count = len(alpha_strings)
+        if count == 0:
+            return []
+        salts = salts or [b""] * count
+        us = b"".join(u.to_bytes(32, "little") for a, s in zip(alpha_strings, salts) for u in cls.curve.hash_to_field(s + a, 2))
+        return unpack_points(cls, runtime.context().bsn_encode_to_curve_batch(us))
+
+    @classmethod
     def map_to_curve(cls, u: int):
         inv_den = pow((_A - _D) % _P, -1, _P)
         mont_a, mont_b = 2 * (_A + _D) * inv_den % _P, 4 * inv_den % _P

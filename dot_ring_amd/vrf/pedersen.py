@@ -64,7 +64,7 @@ class PedersenVRF(VRF):
         gen, bb = cv.point_type.generator_point(), cls._blinding_base()
         order = cv.curve.params.subgroup_order
         xs = [dec_scalar_mod(cv, sk) for sk in secret_keys]
-        inputs = [cv.point_type.encode_to_curve(a, s) for a, s in zip(alphas, salts)]
+        inputs = cv.point_type.encode_to_curve_batch(alphas, salts)
         firsts = scalar_mul_batch([gen] * count + inputs, xs + xs)                    # pk_i, O_i
         pks, outs = firsts[:count], firsts[count:]
         transcripts, blindings = [], []

@@ -74,7 +74,9 @@ class Ring:
                 lookup.setdefault(pt, row)
             self._row_of = lookup
         out = []
-        for point in self._decode_keys(keys):
+        distinct = list(dict.fromkeys(bytes(k) for k in keys))          # a batch usually repeats few producer keys
+        decoded = dict(zip(distinct, self._decode_keys(distinct)))
+        for point in (decoded[bytes(k)] for k in keys):
             if point is None:
                 raise ValueError("invalid ring key")
             if point == padding or point not in lookup:

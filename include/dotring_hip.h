@@ -88,6 +88,11 @@ DR_API int dr_bsn_msm(dr_ctx *ctx, const uint8_t *pts_xy, const uint8_t *scalars
 DR_API int dr_bsn_msm_groups(dr_ctx *ctx, const uint8_t *pts_xy, const uint8_t *scalars, size_t groups, size_t m,
                       uint8_t *out_xy /* groups*64 */);
 
+/* Elligator 2 hash-to-curve field work for n inputs: out[i] = clear_cofactor(map(u[2i]) + map(u[2i+1])), i.e.
+ * TEAffinePoint._e2c_ell2_ro (dot_ring/curve/twisted_edwards/te_affine_point.py:212-295, te_curve.py:48-95) after
+ * hash_to_field, which stays on the host.  u_pairs: n*2 canonical field elements (32-byte LE). */
+DR_API int dr_bsn_encode_to_curve_batch(dr_ctx *ctx, const uint8_t *u_pairs, size_t n, uint8_t *out_xy);
+
 /* square root in the Bandersnatch base field; DR_ERR_NOTSQUARE if none exists. Host-side, no ctx. */
 DR_API int dr_fr_sqrt(const uint8_t in[32], uint8_t out[32]);
 
