@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — headline measurement of the Ring-VRF hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the kernel north_star sets the roofline target on):
-    one BLS12-381 G1 Pippenger MSM over 2^20 bases per GPU (the KZG commit of RingRoot / ring proofs at the
-    size north_star names), scalars uniform in [0, r), bases and scalars resident in HBM before the timed region.
-    Bases are synthetic (no SRS of that size ships): base[i] = (first+i)*G1, generated on the GPU, so
-    the result has the closed form [sum k_i (first+i)]*G1, which is checked on the CPU after the timed region.
-A "step" = one such MSM per rank.  With N > 1 ranks the global MSM is N*2^20 pairs sharded by bases: every
-rank reduces its shard to one point, the points are all-gathered (RCCL, 96 B per rank) and summed on every
-rank — the only exchange step the path has.  value = pairs processed by all ranks / wall time.
+Headline workload (BASELINE.json configs[3], the configuration the metric "RingVRF proofs/sec" is quoted on that
+fits one GPU): RingVRF[Bandersnatch] prove + verify, ring_size = 1024 (PIOP domain N = 2048), batch = 1024
+proofs per GPU.  A "step" = prove_batch of 1024 proofs over the ring followed by batch_verify of those proofs;
+ring keys follow the reference's bench scheme (tests/benchmark/bench_ring_proof.py:47-77: sha256-seeded key
+pairs, signer at index 3; inputs b"bench-batch-input"/b"bench-batch-ad" || LE64(i), :149-150).  The ring, its
+RingRoot, the SRS and the per-ring prover tables are resident in HBM before the timed region; inputs of a step
+are 2 short byte strings per proof.  Hidden (ZK) rows are drawn at random as in production (test_vectors=False);
+a parity subset is proved again with test_vectors=True and compared byte-for-byte with the CPU oracle.
+With N ranks every rank proves and verifies its own 1024 proofs (independent units, no collective).
+
+Secondary measurement in the same JSON line ("g1_msm"): one G1 Pippenger MSM over 2^20 synthetic bases
+(configs[2]), the kernel north_star puts the roofline target on.
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 through torch.distributed.run (one rank per GPU).
 """
@@ -30,7 +34,12 @@ G1_BE = bytes.fromhex(
     "08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1"
 )
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
-ALG_BYTES_PER_PAIR = 128       # 96 B affine base + 32 B scalar
+ALG_BYTES_PER_PAIR = 128       # 96 B affine base + 32 B scalar per (base, scalar) pair
+MSM_KERNELS = ("k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_accumulate", "k_g1_reduce_chunks", "k_g1_reduce_windows",
+               "k_g1_horner", "k_g1_results_affine")
+RING_KERNELS = ("k_bsn_scalar_mul", "k_bsn_encode_to_curve", "k_bsn_msm_groups", "k_ring_chain", "k_ring_columns", "k_ntt_local",
+                "k_ntt_strided", "k_ring_pad", "k_ring_constraints", "k_ring_quotient", "k_ring_eval", "k_ring_linpoly",
+                "k_ring_aggpoly", "k_syndiv")
 
 
 def seeded_scalars(n: int, tag: bytes):
@@ -44,13 +53,76 @@ def be_to_le_points(raw: bytes) -> bytes:
     return b"".join(raw[i : i + 48][::-1] + raw[i + 48 : i + 96][::-1] for i in range(0, len(raw), 96))
 
 
+def _seed(*parts) -> bytes:
+    """tests/benchmark/bench_ring_proof.py:47 — sha256 over the parts, each followed by a zero byte."""
+    h = hashlib.sha256()
+    for part in parts:
+        h.update(part if isinstance(part, bytes) else (part.to_bytes(8, "little") if isinstance(part, int) else part.encode()))
+        h.update(b"\0")
+    return h.digest()
+
+
+def bench_ring_keys(cv, ring_size: int, sample_index: int):
+    """Signer key pair + ring keys of the reference bench (bench_ring_proof.py:60-77), keys derived on the GPU."""
+    from dot_ring_amd.curve import scalar_mul_batch
+    from dot_ring_amd.vrf.primitives import secret_from_seed_scalar
+
+    signer_pk, signer_sk = cv.secret_from_seed(_seed("signer", sample_index, 0))
+    secrets_ = [secret_from_seed_scalar(cv, _seed("ring-member", sample_index, i)) for i in range(ring_size)]
+    keys = [p.point_to_string() for p in scalar_mul_batch([cv.point_type.generator_point()] * ring_size, secrets_)]
+    keys[min(3, ring_size - 1)] = signer_pk
+    return signer_pk, signer_sk, keys
+
+
+def g1_msm_measurement(ctx, log2n: int, steps: int, cpu_sample_log2: int, do_cpu: bool):
+    """Secondary: G1 MSM at 2^log2n synthetic bases. Returns a dict (rank-local)."""
+    n = 1 << log2n
+    srs = ctx.srs_synthetic(G1_BE, n, first=1)
+    vals, raw = seeded_scalars(n, b"\0\0\0\0")
+    d_scalars = ctx.alloc(32 * n).upload(raw)
+    ctx.g1_msm_dev(srs, d_scalars, n)
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    result = None
+    for _ in range(steps):
+        result = ctx.g1_msm_dev(srs, d_scalars, n)
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    acc_ms, acc_n = ctx.prof_get("k_g1_accumulate")
+    out = {"pairs": n, "scalar_muls_per_s": n * steps / elapsed, "ms_per_msm": elapsed / steps * 1e3,
+           "k_g1_accumulate_avg_ms": acc_ms / max(1, acc_n),
+           "roofline_frac_hbm": (ALG_BYTES_PER_PAIR * n / (acc_ms / max(1, acc_n) / 1e3) / 1e9) / HBM_PEAK_GBS if acc_ms else None}
+    if do_cpu:
+        from oracle import coracle
+
+        expect = sum(k * (1 + i) for i, k in enumerate(vals)) % FR
+        want = coracle.g1_unpack1(bytes(coracle.g1_msm_raw(be_to_le_points(G1_BE), expect.to_bytes(32, "little"), 1)))
+        got = None if result is None else (int.from_bytes(result[:48], "big"), int.from_bytes(result[48:], "big"))
+        out["parity_closed_form"] = got == want
+        if cpu_sample_log2 > 0:
+            m = min(n, 1 << cpu_sample_log2)
+            bases = be_to_le_points(srs.download(0, m))
+            t1 = time.perf_counter()
+            cpu_out = coracle.g1_msm_raw(bases, raw[: 32 * m], m)
+            cpu_s = time.perf_counter() - t1
+            gpu_out = ctx.g1_msm_dev(srs, d_scalars, m)
+            out["parity_sample"] = bytes(cpu_out) == (bytes(96) if gpu_out is None else gpu_out[:48][::-1] + gpu_out[48:][::-1])
+            out["cpu_port_scalar_muls_per_s"] = m / cpu_s
+    d_scalars.free()
+    srs.close()
+    return out
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2n", type=int, default=20, help="bases per GPU = 2^log2n")
-    ap.add_argument("--cpu-sample-log2", type=int, default=17, help="pairs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ring-size", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
+    ap.add_argument("--cpu-proofs", type=int, default=6, help="proofs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--msm-log2n", type=int, default=20, help="secondary G1 MSM size (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,16 +142,28 @@ def main() -> int:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from dot_ring_amd import _native, parallel
+    os.environ["DOTRING_DEVICE"] = str(local_rank)
+    import dot_ring_amd as d
+    from dot_ring_amd import runtime
 
-    ctx = _native.Context(local_rank)
-    n = 1 << args.log2n
-    first = 1 + rank * n
-    t_setup = time.time()
-    srs = ctx.srs_synthetic(G1_BE, n, first=first)
-    vals, raw = seeded_scalars(n, rank.to_bytes(4, "little"))
-    d_scalars = ctx.alloc(32 * n).upload(raw)
-    setup_s = time.time() - t_setup
+    ctx = runtime.context()
+    cv = d.Bandersnatch
+    vrf = d.RingVRF[cv]
+    batch = args.batch
+
+    # ---- setup (untimed): ring, ring root, per-ring prover tables in HBM
+    t_setup = time.perf_counter()
+    signer_pk, signer_sk, keys = bench_ring_keys(cv, args.ring_size, 0)
+    t_ring = time.perf_counter()
+    ring = d.Ring(keys)
+    root = d.RingRoot.from_ring(ring)
+    ring_root_s = time.perf_counter() - t_ring
+    base = rank * batch
+    alphas = [b"bench-batch-input" + (base + i).to_bytes(8, "little") for i in range(batch)]
+    ads = [b"bench-batch-ad" + (base + i).to_bytes(8, "little") for i in range(batch)]
+    sks, pks = [signer_sk] * batch, [signer_pk] * batch
+    vrf.prove_batch(alphas[:2], ads[:2], sks[:2], pks[:2], ring, root)          # builds the device prover tables
+    setup_s = time.perf_counter() - t_setup
 
     def barrier():
         ctx.sync()
@@ -88,79 +172,90 @@ def main() -> int:
             dist.barrier()
             torch.cuda.synchronize()
 
+    prove_s = verify_s = 0.0
+
     def step():
-        part = ctx.g1_msm_dev(srs, d_scalars, n)
-        if dist is None:
-            return part
-        return parallel.combine_partials(part)
+        nonlocal prove_s, verify_s
+        t = time.perf_counter()
+        proofs = vrf.prove_batch(alphas, ads, sks, pks, ring, root)
+        t1 = time.perf_counter()
+        ok = vrf.batch_verify(proofs, alphas, ads, ring, root)
+        t2 = time.perf_counter()
+        prove_s += t1 - t
+        verify_s += t2 - t1
+        return proofs, ok
 
     for _ in range(args.warmup):
         step()
+    prove_s = verify_s = 0.0
     ctx.prof_reset()
     ctx.prof_enable(True)
     barrier()
     t0 = time.perf_counter()
-    result = None
+    all_ok = True
+    proofs = None
     for _ in range(args.steps):
-        result = step()
+        proofs, ok = step()
+        all_ok = all_ok and ok
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
-
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, 0.0 if all_ok else 1.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # closed-form check needs every rank's sum_i k_i*(first+i)
-        local = sum(k * (first + i) for i, k in enumerate(vals)) % FR
-        parts = [None] * world
-        dist.all_gather_object(parts, local)
-        expect_scalar = sum(parts) % FR
-    else:
-        expect_scalar = sum(k * (first + i) for i, k in enumerate(vals)) % FR
+        elapsed, all_ok = float(t[0].item()), float(t[1].item()) == 0.0
 
+    kernel_ms = {name: ctx.prof_get(name)[0] / max(1, args.steps) for name in MSM_KERNELS + RING_KERNELS}
     acc_ms, acc_launches = ctx.prof_get("k_g1_accumulate")
-    kernel_ms = {name: ctx.prof_get(name)[0] / max(1, args.steps)
-                 for name in ("k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_accumulate", "k_g1_reduce_chunks", "k_g1_reduce_windows")}
 
     if rank == 0:
-        from oracle import coracle
+        n_dom = ring.params.domain_size
+        pairs_per_proof = 11 * n_dom                       # 4N + (3N+1) + 3N + (N-1)  
+        # ---- parity subset: deterministic proofs (test_vectors=True) byte-compared with the CPU oracle
+        from oracle.pyref import bandersnatch as obsn
+        from oracle.pyref import ring as oring
 
-        # ---- parity of the timed result: closed form [sum k_i (first+i)] * G on the CPU oracle
-        g_le = be_to_le_points(G1_BE)
-        want = coracle.g1_unpack1(bytes(coracle.g1_msm_raw(g_le, expect_scalar.to_bytes(32, "little"), 1)))
-        got = None if result is None else (int.from_bytes(result[:48], "big"), int.from_bytes(result[48:], "big"))
-        parity_ok = got == want
-
-        # ---- CPU baseline: the oracle's Pippenger (a port of the reference algorithm, 1 thread) on a bounded sample
+        parity_ok = all_ok
         cpu = None
-        if args.cpu_sample_log2 > 0:
-            m = min(n, 1 << args.cpu_sample_log2)
-            sample_bases = be_to_le_points(srs.download(0, m))
+        if args.cpu_proofs > 0:
+            tv_params = d.RingProofParams.from_ring_size(args.ring_size, test_vectors=True)
+            tv_ring = d.Ring(keys, tv_params)
+            tv_root = d.RingRoot.from_ring(tv_ring, tv_params)
+            m = args.cpu_proofs
+            gpu_proofs = vrf.prove_batch(alphas[:m], ads[:m], sks[:m], pks[:m], tv_ring, tv_root)
+            o_params = oring.Params.from_ring_size(args.ring_size, test_vectors=True, suite=obsn.SHA512)
+            o_ring = oring.Ring(keys, o_params)
+            o_root = oring.RingRoot(o_ring)
+            parity_ok = parity_ok and o_root.encode() == tv_root.encode() == root.encode()
             t1 = time.perf_counter()
-            cpu_out = coracle.g1_msm_raw(sample_bases, raw[: 32 * m], m)
+            cpu_proofs = [oring.ring_vrf_prove(o_ring, o_root, alphas[i], ads[i], signer_sk) for i in range(m)]
             cpu_s = time.perf_counter() - t1
-            gpu_out = ctx.g1_msm_dev(srs, d_scalars, m)
-            gpu_le = bytes(96) if gpu_out is None else gpu_out[:48][::-1] + gpu_out[48:][::-1]
-            parity_ok = parity_ok and (bytes(cpu_out) == gpu_le)
-            cpu = {"value": m / cpu_s, "unit": "scalar-muls/s", "cores": 1, "kind": "port",
-                   "sample": f"first 2^{m.bit_length() - 1} (base, scalar) pairs of the same workload, oracle/c signed-bucket Pippenger, {cpu_s:.1f} s"}
+            parity_ok = parity_ok and [p.encode() for p in gpu_proofs] == cpu_proofs
+            cpu = {"value": m / cpu_s, "unit": "proofs/s", "cores": 1, "kind": "port",
+                   "sample": f"{m} proofs (prove only) of the same workload through oracle/ (Python orchestration + oracle/c "
+                             f"kernels for NTT and G1 Pippenger), {cpu_s:.1f} s"}
 
-        total_pairs = n * world * args.steps
-        value = total_pairs / elapsed
+        total = batch * world * args.steps
+        value = total / elapsed
         avg_acc_s = (acc_ms / max(1, acc_launches)) / 1e3
-        achieved = ALG_BYTES_PER_PAIR * n / avg_acc_s / 1e9 if avg_acc_s > 0 else 0.0
+        pairs_per_launch = (batch * pairs_per_proof * args.steps + 0.0) / max(1, acc_launches)      # prove-side MSM pairs / launches
+        alg_bytes_launch = ALG_BYTES_PER_PAIR * pairs_per_launch
+        achieved = alg_bytes_launch / avg_acc_s / 1e9 if avg_acc_s > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"g1_msm_2^{args.log2n}", {}).get("k_g1_accumulate_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(f"ringvrf_ring{args.ring_size}_batch{batch}", {}).get("k_g1_accumulate_bytes_per_launch")
             except Exception:
                 traffic = None
+        g1 = None
+        if args.msm_log2n > 0:
+            g1 = g1_msm_measurement(ctx, args.msm_log2n, 10, 17, True)
+            parity_ok = parity_ok and g1.get("parity_closed_form", True) and g1.get("parity_sample", True)
         line = {
-            "metric": "g1_msm_scalar_muls_per_sec",
+            "metric": "ringvrf_proofs_per_sec",
             "value": value,
-            "unit": "scalar-muls/s",
+            "unit": "proofs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -170,14 +265,20 @@ def main() -> int:
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"BLS12-381 G1 Pippenger MSM, 2^{args.log2n} bases per GPU (KZG commit), scalars uniform mod r, HBM-resident",
-                       "pairs_per_step_per_gpu": n, "sharding": "bases sharded per rank, all-gather of one partial point per rank" if world > 1 else "single GPU"},
+            "config": {"workload": f"RingVRF[Bandersnatch] prove_batch + batch_verify, ring_size {args.ring_size} (domain {n_dom}), "
+                                   f"{batch} proofs per GPU per step, ZK rows random, ring/SRS/prover tables HBM-resident",
+                       "ring_size": args.ring_size, "domain_size": n_dom, "batch_per_gpu": batch,
+                       "sharding": "proofs sharded per rank, no collective" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_g1_accumulate", "avg_kernel_ms": avg_acc_s * 1e3,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_PAIR * n},
+                         "launches_per_step": acc_launches / max(1, args.steps), "algorithmic_bytes_per_launch": alg_bytes_launch},
             "cpu_baseline": cpu,
             "parity_ok": parity_ok,
-            "kernel_ms_per_step": kernel_ms,
+            "prove_only_proofs_per_s": batch * args.steps / prove_s if prove_s else None,
+            "verify_only_proofs_per_s": batch * args.steps / verify_s if verify_s else None,
+            "gpu_kernel_ms_per_step": {k: round(v, 3) for k, v in kernel_ms.items() if v > 0.0005},
+            "g1_msm": g1,
+            "ring_root_s": ring_root_s,
             "setup_s": setup_s,
         }
         print(json.dumps(line))

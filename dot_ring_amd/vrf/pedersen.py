@@ -95,9 +95,10 @@ class PedersenVRF(VRF):
     def prove(cls, alpha: bytes, secret_key: bytes, additional_data: bytes, salt: bytes = b"") -> "PedersenVRF":
         return cls.prove_batch([alpha], [secret_key], [additional_data], [salt])[0]
 
-    def _challenge(self, input: bytes, additional_data: bytes, salt: bytes):
+    def _challenge(self, input: bytes, additional_data: bytes, salt: bytes, input_point=None):
         cv = self.cv
-        input_point = cv.point_type.encode_to_curve(input, salt)
+        if input_point is None:
+            input_point = cv.point_type.encode_to_curve(input, salt)
         transcript, merged = vrf_transcript(cv, DomSep.PEDERSEN_VRF, [VrfIo(input_point, self.output_point)], additional_data)
         transcript.absorb(enc_point(self.blinded_pk))
         return input_point, merged, challenge(cv, [self.result_point, self.ok], transcript)
@@ -132,8 +133,11 @@ class PedersenVRF(VRF):
         order = cv.curve.params.subgroup_order
         items, coeff_bytes = [], bytearray()
         try:
-            for proof, input_value, ad, salt in zip(proofs, inputs, additional_data, salts, strict=True):
-                input_point, _, c = proof._challenge(input_value, ad, salt)
+            if not (len(proofs) == len(inputs) == len(additional_data) == len(salts)):
+                raise ValueError("batch arguments must have equal lengths")
+            input_points = cv.point_type.encode_to_curve_batch(list(inputs), list(salts))      # one launch for all proofs
+            for proof, input_value, ad, salt, ipt in zip(proofs, inputs, additional_data, salts, input_points):
+                input_point, _, c = proof._challenge(input_value, ad, salt, ipt)
                 items.append((proof, input_point, c))
                 coeff_bytes += enc_scalar(cv, c) + enc_scalar(cv, proof.s) + enc_scalar(cv, proof.sb)
         except (AttributeError, TypeError, ValueError):

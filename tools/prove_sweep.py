@@ -51,6 +51,14 @@ def main(ring_size, batch, reps=2):
     t = time.perf_counter()
     ok = vrf.batch_verify(proofs[:8], alphas[:8], ads[:8], ring, root)
     print(ok, f"{(time.perf_counter() - t) * 1e3:.1f} ms", flush=True)
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    t = time.perf_counter()
+    ok = vrf.batch_verify(proofs, alphas, ads, ring, root)
+    dt = time.perf_counter() - t
+    pr.disable()
+    print(f"batch_verify({batch}): {ok} {dt * 1e3:.1f} ms -> {batch / dt:.1f} proofs/s", flush=True)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
 
 if __name__ == "__main__":
     main(int(sys.argv[1]), int(sys.argv[2]))
