@@ -44,6 +44,7 @@ _PROTOTYPES = {
     "dr_fr_sqrt": (c_int, [c_char_p, c_void_p]),
     "dr_srs_load": (c_int, [c_void_p, c_char_p, c_size_t, POINTER(c_void_p)]),
     "dr_srs_synthetic": (c_int, [c_void_p, c_char_p, c_uint, c_size_t, POINTER(c_void_p)]),
+    "dr_srs_precompute": (c_int, [c_void_p, c_void_p, c_int]),
     "dr_srs_download": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "dr_srs_destroy": (None, [c_void_p]),
     "dr_srs_size": (c_size_t, [c_void_p]),
@@ -144,6 +145,11 @@ class Srs:
             raise ValueError("SRS bytes must be a multiple of 96")
         self.count = len(g1_be_xy) // 96
         _check(lib().dr_srs_load(ctx.handle, g1_be_xy, self.count, byref(self.handle)))
+
+    def precompute(self, window_bits: int) -> "Srs":
+        """Build (or with 0 drop) the fixed-base window table in HBM."""
+        _check(lib().dr_srs_precompute(self.ctx.handle, self.handle, window_bits))
+        return self
 
     def download(self, offset: int, count: int) -> bytes:
         out = ctypes.create_string_buffer(max(96 * count, 1))

@@ -86,6 +86,9 @@ struct dr_srs {
     int device = 0;
     size_t count = 0;
     uint32_t* d_bases = nullptr;   // G1Affine[count], Montgomery
+    // optional fixed-base window table: table[w][i] = 2^(start_w) * base[i]; all windows share one bucket set
+    uint32_t* d_table = nullptr;
+    dr::WindowTable table_wt{};
 };
 
 namespace {
@@ -142,6 +145,7 @@ inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b);
 // W*2^(c-1)*(2 full adds) + per-chunk scalar multiplications; a full add costs ~1.4 mixed adds; pick the c
 // minimising that, within [7,16] (W <= 37 fits the table).
 bool window_ok(int c) { return c >= 7 && c <= 16; }
+bool table_window_ok(int c) { return c >= 7 && c <= 22; }     // one bucket set per MSM: wider windows stay cheap
 int pick_window(size_t n) {
     int best = 7;
     double best_cost = 1e300;
@@ -158,6 +162,21 @@ struct MsmPlan {
     int W;
     uint32_t H, L, T;
 };
+dr::WindowTable make_window_table(int c) {
+    dr::WindowTable wt;
+    wt.W = (256 + c - 1) / c;
+    int base = 256 / wt.W, rem = 256 % wt.W;
+    wt.cmax = base + (rem ? 1 : 0);
+    int bit = 0;
+    for (int w = 0; w < wt.W; w++) {
+        int width = base + (w >= wt.W - rem ? 1 : 0);
+        wt.start[w] = (uint8_t)bit;
+        wt.width[w] = (uint8_t)width;
+        bit += width;
+    }
+    return wt;
+}
+
 MsmPlan make_plan(size_t n, int force_c) {
     MsmPlan p;
     int c = window_ok(force_c) ? force_c : pick_window(n);
@@ -181,14 +200,38 @@ MsmPlan make_plan(size_t n, int force_c) {
 int g_force_c = 0;   // test hook: DOTRING_MSM_WINDOW
 
 // core: bases/scalars on the device; writes batch results (XYZZ, Montgomery) into host vector
+// Fixed-base table descriptor for msm_device (table == nullptr: plain bases, one bucket set per window).
+struct MsmTable {
+    const uint32_t* table = nullptr;
+    dr::WindowTable wt{};
+    uint32_t stride = 0, offset = 0;
+};
+
 int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch,
-               std::vector<drh::G1>& results) {
+               std::vector<drh::G1>& results, const MsmTable* tbl = nullptr) {
     results.assign(batch, drh::G1::inf());
     if (n == 0 || batch == 0) return DR_OK;
     if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "MSM size must be below 2^31");
-    const MsmPlan pl = make_plan(n, g_force_c);
-    const size_t windows = batch * (size_t)pl.W;
-    const size_t nbuckets = windows * pl.H;
+    const bool single = tbl != nullptr && tbl->table != nullptr;
+    MsmPlan pl = make_plan(n, g_force_c);
+    if (single) {
+        pl.wt = tbl->wt;
+        pl.W = tbl->wt.W;
+        pl.H = 1u << (tbl->wt.cmax - 1);
+        pl.L = std::min<uint32_t>(pl.H, 16);
+        pl.T = pl.H / pl.L;
+        d_bases = tbl->table;
+        if ((uint64_t)pl.W * tbl->stride >= (1ull << 31)) return fail(DR_ERR_INVALID, "window table too large");
+    }
+    // table mode: split the points of each MSM into index groups when one bucket set per MSM would leave lanes idle
+    uint32_t groups = 1;
+    if (single) {
+        const size_t target_lanes = 262144;
+        while (groups < 64 && batch * groups * (size_t)pl.H < target_lanes && (size_t)n / (groups * 2) >= 64) groups *= 2;
+    }
+    const size_t windows = batch * (size_t)pl.W;                   // digit rows
+    const size_t bsets = single ? batch * groups : windows;        // bucket sets
+    const size_t nbuckets = bsets * pl.H;
     const size_t ndigits = windows * n;
     if (nbuckets >= (1ull << 32) || ndigits >= (1ull << 32))
         return fail(DR_ERR_INVALID, "MSM batch too large for one launch (split the batch)");
@@ -200,15 +243,15 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     TRY(ctx->tiles.reserve((size_t)(ntiles + 1) * 4));
     TRY(ctx->sorted.reserve(ndigits * 4));
     TRY(ctx->buckets.reserve(nbuckets * 192));
-    TRY(ctx->partial.reserve(windows * pl.T * 192));
-    TRY(ctx->winsum.reserve(windows * 192));
+    TRY(ctx->partial.reserve(bsets * pl.T * 192));
+    TRY(ctx->winsum.reserve(bsets * 192));
     hipStream_t st = ctx->stream;
     HIP_TRY(hipMemsetAsync(ctx->counts.p, 0, nbuckets * 4, st));
     HIP_TRY(hipMemsetAsync(ctx->cursor.p, 0, nbuckets * 4, st));
 
     TRY(launch(ctx, "k_g1_digits", [&] {
         hipLaunchKernelGGL(dr::k_g1_digits, dim3(div_up(n * batch, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n,
-                           (uint32_t)batch, pl.wt, ctx->digits.as<int32_t>(), ctx->counts.as<uint32_t>());
+                           (uint32_t)batch, pl.wt, single ? 1 : 0, groups, ctx->digits.as<int32_t>(), ctx->counts.as<uint32_t>());
     }));
     TRY(launch(ctx, "k_scan", [&] {
         hipLaunchKernelGGL(dr::k_scan_tiles, dim3(ntiles), dim3(dr::SCAN_BLOCK), 0, st, ctx->counts.as<uint32_t>(),
@@ -220,7 +263,8 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     }));
     TRY(launch(ctx, "k_g1_scatter", [&] {
         hipLaunchKernelGGL(dr::k_g1_scatter, dim3(div_up(ndigits, 256)), dim3(256), 0, st, ctx->digits.as<int32_t>(),
-                           (uint32_t)n, windows, pl.H, ctx->offsets.as<uint32_t>(), ctx->cursor.as<uint32_t>(),
+                           (uint32_t)n, windows, pl.H, single ? pl.W : 0, single ? tbl->stride : 0u, single ? tbl->offset : 0u, groups,
+                           ctx->offsets.as<uint32_t>(), ctx->cursor.as<uint32_t>(),
                            ctx->sorted.as<uint32_t>());
     }));
     TRY(launch(ctx, "k_g1_accumulate", [&] {
@@ -229,16 +273,36 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
                            ctx->buckets.as<uint32_t>(), nbuckets);
     }));
     TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
-        hipLaunchKernelGGL(dr::k_g1_reduce_chunks, dim3(div_up(windows * pl.T, 128)), dim3(128), 0, st,
-                           ctx->buckets.as<uint32_t>(), windows, pl.H, pl.L, ctx->partial.as<uint32_t>());
+        hipLaunchKernelGGL(dr::k_g1_reduce_chunks, dim3(div_up(bsets * pl.T, 128)), dim3(128), 0, st,
+                           ctx->buckets.as<uint32_t>(), bsets, pl.H, pl.L, ctx->partial.as<uint32_t>());
     }));
     TRY(launch(ctx, "k_g1_reduce_windows", [&] {
-        hipLaunchKernelGGL(dr::k_g1_reduce_windows, dim3((unsigned)windows), dim3(dr::RW_BLOCK), 0, st,
+        hipLaunchKernelGGL(dr::k_g1_reduce_windows, dim3((unsigned)bsets), dim3(dr::RW_BLOCK), 0, st,
                            ctx->partial.as<uint32_t>(), pl.T, ctx->winsum.as<uint32_t>());
     }));
 
     static_assert(sizeof(drh::G1) == 192, "XYZZ layout");
-    if (batch == 1) {
+    if (single) {
+        // the bucket-set sum IS the MSM value: no window combination
+        if (groups > 1 || batch == 1) {
+            // few MSMs: fetch the per-group sums and add them on the host (<= 64 additions per MSM)
+            std::vector<drh::G1> parts(bsets);
+            HIP_TRY(hipMemcpyAsync(parts.data(), ctx->winsum.p, bsets * 192, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (size_t b = 0; b < batch; b++) {
+                drh::G1 acc = drh::G1::inf();
+                for (uint32_t g = 0; g < groups; g++) acc = drh::g1_add(acc, parts[b * groups + g]);
+                results[b] = acc;
+            }
+            if (batch > 1) {      // keep the batched contract: results in ctx->result for the device-side affine pass
+                TRY(ctx->result.reserve(batch * 192));
+                HIP_TRY(hipMemcpyAsync(ctx->result.p, results.data(), batch * 192, hipMemcpyHostToDevice, st));
+            }
+        } else {
+            TRY(ctx->result.reserve(batch * 192));
+            HIP_TRY(hipMemcpyAsync(ctx->result.p, ctx->winsum.p, batch * 192, hipMemcpyDeviceToDevice, st));
+        }
+    } else if (batch == 1) {
         // window combination on the host: a 255-doubling serial chain is ~50x faster on one CPU core
         std::vector<drh::G1> ws(pl.W);
         HIP_TRY(hipMemcpyAsync(ws.data(), ctx->winsum.p, (size_t)pl.W * 192, hipMemcpyDeviceToHost, st));
@@ -261,13 +325,25 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     return DR_OK;
 }
 
+MsmTable srs_table(const dr_srs* srs, size_t offset) {
+    MsmTable t;
+    if (srs->d_table) {
+        t.table = srs->d_table;
+        t.wt = srs->table_wt;
+        t.stride = (uint32_t)srs->count;
+        t.offset = (uint32_t)offset;
+    }
+    return t;
+}
+
 void g1_result_to_bytes(const drh::G1& r, uint8_t* out96, int* is_inf);
 int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, int* is_inf);
 
 // MSM(s) with results written as BE affine records
-int msm_to_bytes(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch, uint8_t* out_be_xy, int* is_inf) {
+int msm_to_bytes(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch, uint8_t* out_be_xy, int* is_inf,
+                 const MsmTable* tbl = nullptr) {
     std::vector<drh::G1> res;
-    TRY(msm_device(ctx, d_bases, d_scalars, n, batch, res));
+    TRY(msm_device(ctx, d_bases, d_scalars, n, batch, res, tbl));
     if (batch == 1 || n == 0) {
         for (size_t b = 0; b < batch; b++) g1_result_to_bytes(res[b], out_be_xy + 96 * b, is_inf ? is_inf + b : nullptr);
         return DR_OK;
@@ -632,9 +708,37 @@ int dr_srs_download(dr_ctx* ctx, const dr_srs* srs, size_t offset, size_t count,
     return DR_OK;
 }
 
+int dr_srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits) {
+    TRY(use_ctx(ctx));
+    if (!srs) return fail(DR_ERR_INVALID, "null argument");
+    if (srs->device != ctx->device) return fail(DR_ERR_INVALID, "SRS lives on another device");
+    if (window_bits == 0) {
+        if (srs->d_table) (void)hipFree(srs->d_table);
+        srs->d_table = nullptr;
+        return DR_OK;
+    }
+    if (!table_window_ok(window_bits)) return fail(DR_ERR_INVALID, "window_bits must be in 7..22 (0 drops the table)");
+    dr::WindowTable wt = make_window_table(window_bits);
+    if ((uint64_t)wt.W * srs->count >= (1ull << 31)) return fail(DR_ERR_INVALID, "window table too large");
+    if (srs->d_table) (void)hipFree(srs->d_table);
+    srs->d_table = nullptr;
+    HIP_TRY(hipMalloc((void**)&srs->d_table, (size_t)wt.W * srs->count * 96));
+    hipLaunchKernelGGL(dr::k_g1_window_table, dim3(div_up(srs->count, 128)), dim3(128), 0, ctx->stream, srs->d_bases, (uint32_t)srs->count, wt,
+                       srs->d_table);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(srs->d_table);
+        srs->d_table = nullptr;
+        return fail(DR_ERR_DEVICE, std::string("window table: ") + hipGetErrorString(e));
+    }
+    srs->table_wt = wt;
+    return DR_OK;
+}
+
 void dr_srs_destroy(dr_srs* srs) {
     if (!srs) return;
     (void)hipSetDevice(srs->device);
+    if (srs->d_table) (void)hipFree(srs->d_table);
     if (srs->d_bases) (void)hipFree(srs->d_bases);
     delete srs;
 }
@@ -646,7 +750,8 @@ int dr_g1_msm_batch_dev(dr_ctx* ctx, const dr_srs* srs, const void* d_scalars, s
     if (!srs || !out_be_xy) return fail(DR_ERR_INVALID, "null argument");
     if (srs->device != ctx->device) return fail(DR_ERR_INVALID, "SRS lives on another device");
     if (n > srs->count) return fail(DR_ERR_INVALID, "polynomial degree exceeds SRS size");
-    return msm_to_bytes(ctx, srs->d_bases, (const uint32_t*)d_scalars, n, batch, out_be_xy, is_inf);
+    MsmTable t = srs_table(srs, 0);
+    return msm_to_bytes(ctx, srs->d_bases, (const uint32_t*)d_scalars, n, batch, out_be_xy, is_inf, &t);
 }
 
 int dr_g1_msm_batch(dr_ctx* ctx, const dr_srs* srs, const uint8_t* scalars, size_t n, size_t batch, uint8_t* out_be_xy, int* is_inf) {
@@ -663,7 +768,8 @@ int dr_g1_msm_dev(dr_ctx* ctx, const dr_srs* srs, size_t offset, const void* d_s
     if (srs->device != ctx->device) return fail(DR_ERR_INVALID, "SRS lives on another device");
     if (offset > srs->count || n > srs->count - offset) return fail(DR_ERR_INVALID, "polynomial degree exceeds SRS size");
     std::vector<drh::G1> res;
-    TRY(msm_device(ctx, srs->d_bases + offset * 24, (const uint32_t*)d_scalars, n, 1, res));
+    MsmTable t = srs_table(srs, offset);
+    TRY(msm_device(ctx, srs->d_bases + offset * 24, (const uint32_t*)d_scalars, n, 1, res, &t));
     g1_result_to_bytes(res[0], out_be_xy, is_inf);
     return DR_OK;
 }
@@ -920,7 +1026,10 @@ int dr_ring_prover_create(dr_ctx* ctx, const dr_srs* srs, unsigned log2n, uint32
                        p->fixed_coef.as<uint32_t>());
     hipLaunchKernelGGL(dr::k_fr_to_mont, dim3(div_up((size_t)2 * n, 256)), dim3(256), 0, st, p->ring_pts_mont.as<uint32_t>(), (size_t)2 * n);
     TRY(ring_ntt(p, p->fixed_coef.as<uint32_t>(), log2n, 3, true));            // interpolate px, py, s
-    TRY(msm_to_bytes(ctx, srs->d_bases, p->fixed_coef.as<uint32_t>(), n, 3, p->root, p->root_inf));
+    {
+        MsmTable t = srs_table(srs, 0);
+        TRY(msm_to_bytes(ctx, srs->d_bases, p->fixed_coef.as<uint32_t>(), n, 3, p->root, p->root_inf, &t));
+    }
     // 4N-domain tables (Montgomery)
     TRY(p->fixed4.reserve((size_t)3 * m * 32));
     hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up((size_t)3 * m, 256)), dim3(256), 0, st, p->fixed_coef.as<uint32_t>(), n,
@@ -1013,7 +1122,8 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
     }));
     TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true));
     HIP_TRY(hipMemcpyAsync(out_relation_xy, p->relation.p, batch * 64, hipMemcpyDeviceToHost, st));
-    return msm_to_bytes(ctx, p->srs->d_bases, p->cols.as<uint32_t>(), n, batch * 4, out_commitments, is_inf);
+    MsmTable t = srs_table(p->srs, 0);
+    return msm_to_bytes(ctx, p->srs->d_bases, p->cols.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t);
 }
 
 // phase B: constraints on the 4N domain, aggregation with the alphas, quotient polynomial and its commitment
@@ -1046,7 +1156,8 @@ int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alpha
         hipLaunchKernelGGL(dr::k_ring_quotient, dim3(div_up(batch * qn, 256)), dim3(256), 0, st, p->agg.as<uint32_t>(), rc, (uint32_t)batch,
                            p->q.as<uint32_t>());
     }));
-    return msm_to_bytes(ctx, p->srs->d_bases, p->q.as<uint32_t>(), qn, batch, out_cq, is_inf);
+    MsmTable t = srs_table(p->srs, 0);
+    return msm_to_bytes(ctx, p->srs->d_bases, p->q.as<uint32_t>(), qn, batch, out_cq, is_inf, &t);
 }
 
 // phase C1: register evaluations at zeta, linearisation polynomial and its value at zeta*omega
@@ -1119,8 +1230,9 @@ int dr_ring_prove_openings(dr_ring_prover* p, size_t batch, const uint8_t* nus, 
     TRY(syndiv(p->lin.as<uint32_t>(), n, 1, p->quot2.as<uint32_t>(), nch2));
     std::vector<uint8_t> o1(batch * 96), o2(batch * 96);
     std::vector<int> i1(batch), i2(batch);
-    TRY(msm_to_bytes(ctx, p->srs->d_bases, p->quot1.as<uint32_t>(), qn - 1, batch, o1.data(), i1.data()));
-    TRY(msm_to_bytes(ctx, p->srs->d_bases, p->quot2.as<uint32_t>(), n - 1, batch, o2.data(), i2.data()));
+    MsmTable t = srs_table(p->srs, 0);
+    TRY(msm_to_bytes(ctx, p->srs->d_bases, p->quot1.as<uint32_t>(), qn - 1, batch, o1.data(), i1.data(), &t));
+    TRY(msm_to_bytes(ctx, p->srs->d_bases, p->quot2.as<uint32_t>(), n - 1, batch, o2.data(), i2.data(), &t));
     for (size_t b = 0; b < batch; b++) {
         std::memcpy(out_openings + 192 * b, o1.data() + 96 * b, 96);
         std::memcpy(out_openings + 192 * b + 96, o2.data() + 96 * b, 96);

@@ -113,7 +113,10 @@ struct WindowTable {
 constexpr int MAX_WINDOWS = 40;
 
 // ---- 1. signed window digits + bucket histogram.  One lane per scalar.
-__global__ void k_g1_digits(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t batch, WindowTable wt,
+// `single` = the bases are a fixed-base window table (k_g1_window_table): all windows of an MSM share ONE bucket set.
+// In that mode the points of one MSM may be split into `groups` index ranges, each with its own bucket set, so that
+// a single huge MSM still fills the chip (bucket set id = b*groups + i*groups/n).
+__global__ void k_g1_digits(const uint32_t* __restrict__ scalars, uint32_t n, uint32_t batch, WindowTable wt, int single, uint32_t groups,
                             int32_t* __restrict__ digits, uint32_t* __restrict__ counts) {
     const int W = wt.W;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,7 +156,8 @@ __global__ void k_g1_digits(const uint32_t* __restrict__ scalars, uint32_t n, ui
         digits[win * n + i] = d;
         if (d != 0) {
             uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-            atomicAdd(&counts[win * H + (mag - 1)], 1u);
+            size_t bset = single ? (size_t)b * groups + (size_t)(((uint64_t)i * groups) / n) : win;
+            atomicAdd(&counts[bset * H + (mag - 1)], 1u);
         }
     }
 }
@@ -222,8 +226,9 @@ __global__ void k_scan_add(uint32_t* out, const uint32_t* tile_sums, size_t n) {
 }
 
 // ---- 3. counting-sort scatter: group (index|sign) by bucket
-__global__ void k_g1_scatter(const int32_t* __restrict__ digits, uint32_t n, size_t windows, uint32_t H,
-                             const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+// W > 0 selects the fixed-base-table mode: the entry indexes table[w][tbl_offset + i] and the bucket set is per MSM.
+__global__ void k_g1_scatter(const int32_t* __restrict__ digits, uint32_t n, size_t windows, uint32_t H, int W, uint32_t tbl_stride,
+                             uint32_t tbl_offset, uint32_t groups, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
                              uint32_t* __restrict__ sorted) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= windows * n) return;
@@ -232,9 +237,34 @@ __global__ void k_g1_scatter(const int32_t* __restrict__ digits, uint32_t n, siz
     size_t win = gid / n;
     uint32_t i = (uint32_t)(gid % n);
     uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-    size_t bucket = win * H + (mag - 1);
+    size_t bset = win;
+    uint32_t entry = i;
+    if (W > 0) {
+        bset = (win / W) * groups + (size_t)(((uint64_t)i * groups) / n);
+        entry = (uint32_t)(win % W) * tbl_stride + tbl_offset + i;
+    }
+    size_t bucket = bset * H + (mag - 1);
     uint32_t pos = offsets[bucket] + atomicAdd(&cursor[bucket], 1u);
-    sorted[pos] = i | (d < 0 ? 0x80000000u : 0u);
+    sorted[pos] = entry | (d < 0 ? 0x80000000u : 0u);
+}
+
+// fixed-base window table: table[w][i] = 2^(start_w) * base[i]  (affine, Montgomery), one lane per base
+__global__ void k_g1_window_table(const uint32_t* __restrict__ bases, uint32_t n, WindowTable wt, uint32_t* __restrict__ table) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine a = load_affine(bases, i);
+    G1Xyzz cur = g1_from_affine(a);
+#pragma unroll 1
+    for (int w = 0; w < wt.W; w++) {
+        if (w > 0) {
+#pragma unroll 1
+            for (int j = 0; j < wt.width[w - 1]; j++) cur = g1_dbl(cur);
+            a = g1_to_affine_dev(cur);
+        }
+        uint32_t* p = table + ((size_t)w * n + i) * 24;
+        store_fq(p, a.x);
+        store_fq(p + 12, a.y);
+    }
 }
 
 // ---- 4. bucket accumulation: one lane per bucket walks its segment with mixed additions.  DOMINANT KERNEL.

@@ -94,9 +94,13 @@ class SRS:
         return out
 
     def device(self) -> _native.Srs:
+        """The SRS in HBM, with its fixed-base window table (DOTRING_SRS_WINDOW bits per window, default 12; 0 = none)."""
         ctx = runtime.context()
         if self._device is None or self._device.ctx is not ctx:
             self._device = ctx.srs_load(self.g1_raw)
+            bits = int(os.environ.get("DOTRING_SRS_WINDOW", "12"))
+            if bits:
+                self._device.precompute(bits)
         return self._device
 
     @classmethod

@@ -105,6 +105,11 @@ DR_API int dr_srs_load(dr_ctx *ctx, const uint8_t *g1_be_xy /* m*96 */, size_t m
 /* Synthetic bases for sizes no SRS file covers: base[i] = (first+i) * seed (first >= 1), generated on
  * the GPU.  With these bases an MSM has the closed form [sum_i k_i*(first+i)] * seed — a size-independent check. */
 DR_API int dr_srs_synthetic(dr_ctx *ctx, const uint8_t seed_be_xy[96], uint32_t first, size_t count, dr_srs **out);
+/* Fixed-base window table for this SRS, kept in HBM: table[w][i] = 2^(start_w) * base[i] for the W = ceil(256/c)
+ * windows of width ~c = window_bits (7..22; 0 drops the table).  Costs W * count * 96 bytes (13 MB for the shipped
+ * 6145-point SRS at c = 12, 1.6 GB for 2^20 bases at c = 16) and makes every later MSM over this SRS use ONE bucket
+ * set per MSM: a single bucket reduction instead of W and no window combination.  Results are unchanged. */
+DR_API int dr_srs_precompute(dr_ctx *ctx, dr_srs *srs, int window_bits);
 /* copy `count` bases starting at `offset` back to the host as BE x||y records */
 DR_API int dr_srs_download(dr_ctx *ctx, const dr_srs *srs, size_t offset, size_t count, uint8_t *out_be_xy);
 DR_API void dr_srs_destroy(dr_srs *srs);

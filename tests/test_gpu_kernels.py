@@ -143,6 +143,28 @@ def test_g1_msm_batch_matches_singles(ctx, srs_bytes, window):
     srs.close()
 
 
+@pytest.mark.parametrize("bits", [7, 12, 16])
+def test_g1_msm_fixed_base_table_matches_plain(ctx, srs_bytes, bits):
+    """dr_srs_precompute: one bucket set per MSM over the window table — identical results, single and batched."""
+    rng = random.Random(bits)
+    plain = ctx.srs_load(srs_bytes[: 96 * 1500])
+    tabled = ctx.srs_load(srs_bytes[: 96 * 1500]).precompute(bits)
+    for n, offset in ((1, 0), (2, 7), (333, 100), (1500, 0)):
+        ks = b"".join(rng.randrange(coracle.FR_P).to_bytes(32, "little") for _ in range(n))
+        want = _oracle_msm_be(srs_bytes[96 * offset :], ks, n)
+        assert ctx.g1_msm(tabled, ks, offset=offset) == want == ctx.g1_msm(plain, ks, offset=offset)
+    n, batch = 256, 4
+    ks = b"".join(rng.randrange(coracle.FR_P).to_bytes(32, "little") for _ in range(n * (batch - 1))) + bytes(32 * n)
+    assert ctx.g1_msm_batch(tabled, ks, n) == ctx.g1_msm_batch(plain, ks, n)
+    vals = [1, 0, coracle.FR_P - 1, (1 << 256) - 1, 2**255, 5]
+    ks = b"".join(v.to_bytes(32, "little") for v in vals)
+    assert ctx.g1_msm(tabled, ks) == ctx.g1_msm(plain, ks)
+    tabled.precompute(0)                                   # drop the table again
+    assert ctx.g1_msm(tabled, ks) == ctx.g1_msm(plain, ks)
+    plain.close()
+    tabled.close()
+
+
 # ------------------------------------------------------------------ seam C
 @pytest.mark.parametrize("log2n", [1, 2, 5, 9, 10, 11, 13, 14])
 def test_ntt_matches_oracle(ctx, log2n):
