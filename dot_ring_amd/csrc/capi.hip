@@ -78,7 +78,7 @@ struct dr_ctx {
     std::map<std::string, ProfEntry> prof_data;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
     // MSM workspaces
-    Scratch scalars, digits, counts, offsets, cursor, tiles, sorted, buckets, partial, winsum, result, io_a, io_b, io_c;
+    Scratch scalars, digits, counts, offsets, cursor, tiles, sorted, buckets, partial, winsum, result, io_a, io_b, io_c, perm, cells, cell_off;
     dr::TwiddleCache twiddles;
 };
 
@@ -239,8 +239,12 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     TRY(ctx->counts.reserve(nbuckets * 4));
     TRY(ctx->offsets.reserve((nbuckets + 1) * 4));
     TRY(ctx->cursor.reserve(nbuckets * 4));
-    const unsigned ntiles = div_up(nbuckets, dr::SCAN_TILE);
-    TRY(ctx->tiles.reserve((size_t)(ntiles + 1) * 4));
+    const unsigned szblocks = div_up(nbuckets, dr::SZ_TILE);
+    const size_t ncells = (size_t)dr::SZ_CLASSES * szblocks;
+    TRY(ctx->tiles.reserve((size_t)(div_up(std::max(ncells, nbuckets), dr::SCAN_TILE) + 1) * 4));
+    TRY(ctx->perm.reserve(nbuckets * 4));
+    TRY(ctx->cells.reserve(ncells * 4));
+    TRY(ctx->cell_off.reserve(ncells * 4));
     TRY(ctx->sorted.reserve(ndigits * 4));
     TRY(ctx->buckets.reserve(nbuckets * 192));
     TRY(ctx->partial.reserve(bsets * pl.T * 192));
@@ -253,13 +257,20 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         hipLaunchKernelGGL(dr::k_g1_digits, dim3(div_up(n * batch, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n,
                            (uint32_t)batch, pl.wt, single ? 1 : 0, groups, ctx->digits.as<int32_t>(), ctx->counts.as<uint32_t>());
     }));
-    TRY(launch(ctx, "k_scan", [&] {
-        hipLaunchKernelGGL(dr::k_scan_tiles, dim3(ntiles), dim3(dr::SCAN_BLOCK), 0, st, ctx->counts.as<uint32_t>(),
-                           ctx->offsets.as<uint32_t>(), ctx->tiles.as<uint32_t>(), nbuckets);
-        hipLaunchKernelGGL(dr::k_scan_tile_sums, dim3(1), dim3(dr::SCAN_BLOCK), 0, st, ctx->tiles.as<uint32_t>(), ntiles,
-                           ctx->tiles.as<uint32_t>() + ntiles);
-        hipLaunchKernelGGL(dr::k_scan_add, dim3(div_up(nbuckets, 256)), dim3(256), 0, st, ctx->offsets.as<uint32_t>(),
-                           ctx->tiles.as<uint32_t>(), nbuckets);
+    auto exclusive_scan = [&](const uint32_t* in, uint32_t* out, size_t count) {
+        const unsigned nt = div_up(count, dr::SCAN_TILE);
+        hipLaunchKernelGGL(dr::k_scan_tiles, dim3(nt), dim3(dr::SCAN_BLOCK), 0, st, in, out, ctx->tiles.as<uint32_t>(), count);
+        hipLaunchKernelGGL(dr::k_scan_tile_sums, dim3(1), dim3(dr::SCAN_BLOCK), 0, st, ctx->tiles.as<uint32_t>(), nt, ctx->tiles.as<uint32_t>() + nt);
+        hipLaunchKernelGGL(dr::k_scan_add, dim3(div_up(count, 256)), dim3(256), 0, st, out, ctx->tiles.as<uint32_t>(), count);
+    };
+    TRY(launch(ctx, "k_scan", [&] { exclusive_scan(ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), nbuckets); }));
+    // size-ordered bucket permutation for the accumulate kernel
+    TRY(launch(ctx, "k_size_sort", [&] {
+        hipLaunchKernelGGL(dr::k_size_hist, dim3(szblocks), dim3(dr::SZ_BLOCK), 0, st, ctx->counts.as<uint32_t>(), nbuckets, szblocks,
+                           ctx->cells.as<uint32_t>());
+        exclusive_scan(ctx->cells.as<uint32_t>(), ctx->cell_off.as<uint32_t>(), ncells);
+        hipLaunchKernelGGL(dr::k_size_place, dim3(szblocks), dim3(dr::SZ_BLOCK), 0, st, ctx->counts.as<uint32_t>(), nbuckets, szblocks,
+                           ctx->cell_off.as<uint32_t>(), ctx->perm.as<uint32_t>());
     }));
     TRY(launch(ctx, "k_g1_scatter", [&] {
         hipLaunchKernelGGL(dr::k_g1_scatter, dim3(div_up(ndigits, 256)), dim3(256), 0, st, ctx->digits.as<int32_t>(),
@@ -269,7 +280,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     }));
     TRY(launch(ctx, "k_g1_accumulate", [&] {
         hipLaunchKernelGGL(dr::k_g1_accumulate, dim3(div_up(nbuckets, 256)), dim3(256), 0, st, d_bases,
-                           ctx->sorted.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(),
+                           ctx->sorted.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(),
                            ctx->buckets.as<uint32_t>(), nbuckets);
     }));
     TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
@@ -450,7 +461,8 @@ void dr_ctx_destroy(dr_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (Scratch* s : {&ctx->scalars, &ctx->digits, &ctx->counts, &ctx->offsets, &ctx->cursor, &ctx->tiles, &ctx->sorted,
-                       &ctx->buckets, &ctx->partial, &ctx->winsum, &ctx->result, &ctx->io_a, &ctx->io_b, &ctx->io_c})
+                       &ctx->buckets, &ctx->partial, &ctx->winsum, &ctx->result, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->perm, &ctx->cells,
+                       &ctx->cell_off})
         s->release();
     for (auto& it : ctx->prof_pending) {
         (void)hipEventDestroy(it.second.first);
