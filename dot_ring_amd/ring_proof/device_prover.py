@@ -30,7 +30,8 @@ def supported(params) -> bool:
 def get_device_prover(ring) -> _native.RingProver:
     """One device prover per Ring object and context (tables for the ring live in HBM)."""
     ctx = runtime.context()
-    cached = getattr(ring, "_device_prover", None)
+    provers = ring.__dict__.setdefault("_device_provers", {})
+    cached = provers.get(id(ctx))
     if cached is not None and cached.ctx is ctx and cached.handle:
         return cached
     params = ring.params
@@ -41,7 +42,7 @@ def get_device_prover(ring) -> _native.RingProver:
     seed = params.cv.curve.params.auxiliary_points.accumulator_base
     prover = _native.RingProver(ctx, srs, params.domain_size.bit_length() - 1, params.max_ring_size, params.omega, params.radix_omega,
                                 pts, int(seed[0]).to_bytes(32, "little") + int(seed[1]).to_bytes(32, "little"))
-    ring._device_prover = prover
+    provers[id(ctx)] = prover
     return prover
 
 

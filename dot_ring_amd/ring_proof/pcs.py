@@ -75,7 +75,7 @@ class SRS:
         self.g1_raw = g1_raw                                   # count * 96 bytes, BE x||y
         self.g2_raw = g2_raw                                   # two 192-byte records in file byte order
         self.count = len(g1_raw) // 96
-        self._device = None
+        self._devices = {}          # id(ctx) -> (ctx, device handle): one upload per context/thread
 
     @property
     def g1(self):
@@ -96,12 +96,15 @@ class SRS:
     def device(self) -> _native.Srs:
         """The SRS in HBM, with its fixed-base window table (DOTRING_SRS_WINDOW bits per window, default 12; 0 = none)."""
         ctx = runtime.context()
-        if self._device is None or self._device.ctx is not ctx:
-            self._device = ctx.srs_load(self.g1_raw)
+        hit = self._devices.get(id(ctx))
+        if hit is None or hit[0] is not ctx:
+            dev = ctx.srs_load(self.g1_raw)
             bits = int(os.environ.get("DOTRING_SRS_WINDOW", "12"))
             if bits:
-                self._device.precompute(bits)
-        return self._device
+                dev.precompute(bits)
+            hit = (ctx, dev)
+            self._devices[id(ctx)] = hit
+        return hit[1]
 
     @classmethod
     def from_loaded(cls, max_deg: int) -> "SRS":

@@ -31,7 +31,7 @@ def main(ring_size, batch, reps=2):
     alphas = [b"bench-batch-input" + i.to_bytes(8, "little") for i in range(batch)]
     ads = [b"bench-batch-ad" + i.to_bytes(8, "little") for i in range(batch)]
     ctx = runtime.context()
-    proofs = vrf.prove_batch(alphas[:2], ads[:2], [signer_sk] * 2, [signer_pk] * 2, ring, root)   # warm-up
+    proofs = vrf.prove_batch(alphas[:512], ads[:512], [signer_sk] * 512, [signer_pk] * 512, ring, root)   # warm-up (both pipeline workers)
     for r in range(reps):
         ctx.prof_reset(); ctx.prof_enable(True)
         t = time.perf_counter()
