@@ -1,0 +1,159 @@
+"""GPU: the device-resident batched ring prover (dr_ring_prover_*), the device Elligator map and robustness cases,
+against the CPU oracle.  Bit-exact."""
+import hashlib
+import random
+
+import pytest
+
+from oracle import coracle
+from oracle.pyref import bandersnatch as obsn
+from oracle.pyref import ring as oring
+from oracle.pyref import vrf as ovrf
+
+pytestmark = pytest.mark.gpu
+
+
+def _keys(count, tag=b"k"):
+    out = []
+    for i in range(count):
+        sk = int.from_bytes(hashlib.sha256(tag + i.to_bytes(4, "little")).digest(), "little") % obsn.N
+        out.append(obsn.enc_point(coracle.te_mul(obsn.G, sk or 1)))
+    return out
+
+
+def _oracle_payload(o_ring, o_root, key, blinding, zk_rows=None):
+    return oring.prove_ring(o_ring, o_root, key, blinding, zk_rows)
+
+
+def _encode_payload(vrf_cls, payload):
+    """784-byte proof minus the Pedersen part, from the API's payload tuple."""
+    import dot_ring_amd as d
+
+    pcs = d.KZG
+    cols, evals, c_q, l_zw, o1, o2 = payload[:4], payload[4:11], payload[11], payload[12], payload[13], payload[14]
+    le = lambda v: int(v).to_bytes(32, "little")
+    return (b"".join(pcs.compress_g1(c.commitment) for c in cols) + b"".join(le(v) for v in evals)
+            + pcs.compress_g1(c_q.commitment) + le(l_zw) + pcs.compress_g1(o1) + pcs.compress_g1(o2))
+
+
+@pytest.mark.parametrize("ring_size,domain", [(8, 512), (300, 1024)])
+def test_device_prover_matches_oracle_with_edge_blindings(ctx, ring_size, domain):
+    import dot_ring_amd as d
+    from dot_ring_amd.ring_proof import device_prover, prover
+
+    keys = _keys(ring_size)
+    keys[1] = bytes(32)                         # invalid key -> padding point (members.py:35-41)
+    params = d.RingProofParams.from_ring_size(ring_size, test_vectors=True)
+    assert params.domain_size == domain
+    ring = d.Ring(keys, params)
+    root = d.RingRoot.from_ring(ring, params)
+    o_params = oring.Params.from_ring_size(ring_size, test_vectors=True)
+    o_ring = oring.Ring(keys, o_params)
+    o_root = oring.RingRoot(o_ring)
+    assert root.encode() == o_root.encode()
+    n = obsn.N
+    blindings = [1, 2, n - 1, 1 << 252, (1 << 252) - 1, 0x5555555555555555555555555555555555555555555555555555555555555555 % n,
+                 random.Random(3).randrange(n)]
+    producers = [0, 2, ring_size - 1, 3, 5 % ring_size, 2, 7 % ring_size]
+    producers = [p if p != 1 else 2 for p in producers]
+    got = device_prover.build_ring_proofs_device(ring, root, ring.indices_of([keys[p] for p in producers]), blindings)
+    for payload, p, t in zip(got, producers, blindings):
+        assert _encode_payload(d.RingVRF[d.Bandersnatch], payload) == _oracle_payload(o_ring, o_root, keys[p], t)
+    # the phase-batched generic prover (NTT + MSM seams, host big-int algebra) gives the same bytes
+    generic = prover.build_ring_proofs(ring, root, [keys[p] for p in producers[:2]], blindings[:2])
+    for a, b in zip(generic, got[:2]):
+        assert _encode_payload(None, a) == _encode_payload(None, b)
+
+
+def test_device_prover_explicit_hidden_rows(ctx):
+    """Production mode (test_vectors=False): pin the three hidden rows of each witness column and compare."""
+    import dot_ring_amd as d
+    from dot_ring_amd import runtime
+    from dot_ring_amd.ring_proof import device_prover
+    from dot_ring_amd.ring_proof.transcript import phase1_alphas_after_vk, phase2_eval_point, phase3_nu_vector
+
+    keys = _keys(20, b"zk")
+    params = d.RingProofParams.from_ring_size(20)
+    ring = d.Ring(keys, params)
+    root = d.RingRoot.from_ring(ring, params)
+    o_ring = oring.Ring(keys, oring.Params.from_ring_size(20))
+    o_root = oring.RingRoot(o_ring)
+    rng = random.Random(9)
+    rows = {name: [rng.randrange(obsn.P) for _ in range(3)] for name in ("b", "accip", "accx", "accy")}
+    t = rng.randrange(obsn.N)
+    want = oring.prove_ring(o_ring, o_root, keys[4], t, rows)
+    dp = device_prover.get_device_prover(ring)
+    zk = b"".join(v.to_bytes(32, "little") for name in ("b", "accip", "accx", "accy") for v in rows[name])
+    rel, wit = dp.witness([4], t.to_bytes(32, "little"), zk)
+    pcs = params.pcs
+    prefix = root.verifier_transcript_prefix()
+    tr, alphas = phase1_alphas_after_vk(prefix.copy(), device_prover._RawPoint(rel), b"".join(pcs.serialize_g1_uncompressed(c) for c in wit))
+    (c_q,) = dp.quotient(1, b"".join(a.to_bytes(32, "little") for a in alphas))
+    tr, zeta = phase2_eval_point(tr, pcs.serialize_g1_uncompressed(c_q))
+    ev = dp.evals(1, zeta.to_bytes(32, "little"))
+    vals = [int.from_bytes(ev[32 * i : 32 * i + 32], "little") for i in range(8)]
+    nus = phase3_nu_vector(tr, vals[:7], vals[7])
+    o1, o2 = dp.openings(1, b"".join(v.to_bytes(32, "little") for v in nus))
+    got = (b"".join(pcs.compress_g1(c) for c in wit) + b"".join(v.to_bytes(32, "little") for v in vals[:7])
+           + pcs.compress_g1(c_q) + vals[7].to_bytes(32, "little") + pcs.compress_g1(o1) + pcs.compress_g1(o2))
+    assert got == want
+    # error behaviour of the phase API
+    with pytest.raises(ValueError):
+        dp.witness([params.max_ring_size], t.to_bytes(32, "little"), None)        # producer row outside the ring
+    with pytest.raises(ValueError):
+        dp.quotient(2, bytes(2 * 7 * 32))                                           # batch differs from the witness phase
+    with pytest.raises(ValueError):
+        dp.witness([0], obsn.P.to_bytes(32, "little"), None)                        # non-canonical blinding
+
+
+def test_ring_1024_domain_2048_matches_oracle(ctx):
+    """BASELINE config 4 shape: ring of 1024 keys (N = 2048), deterministic mode, two proofs byte-compared."""
+    import dot_ring_amd as d
+
+    keys = _keys(1024, b"big")
+    sk = (12345).to_bytes(32, "little")
+    pk = d.Bandersnatch.public_key_from_secret(sk)
+    keys[3] = pk
+    params = d.RingProofParams.from_ring_size(1024, test_vectors=True)
+    ring = d.Ring(keys, params)
+    root = d.RingRoot.from_ring(ring, params)
+    o_ring = oring.Ring(keys, oring.Params.from_ring_size(1024, test_vectors=True))
+    o_root = oring.RingRoot(o_ring)
+    assert root.encode() == o_root.encode()
+    proofs = d.RingVRF[d.Bandersnatch].prove_batch([b"a", b"b"], [b"", b"ad"], [sk, sk], [pk, pk], ring, root)
+    assert proofs[0].encode() == oring.ring_vrf_prove(o_ring, o_root, b"a", b"", sk)
+    assert proofs[1].encode() == oring.ring_vrf_prove(o_ring, o_root, b"b", b"ad", sk)
+    assert proofs[1].verify(b"b", b"ad", ring, root)
+    assert d.RingVRF[d.Bandersnatch].batch_verify(proofs, [b"a", b"b"], [b"", b"ad"], ring, root)
+
+
+@pytest.mark.parametrize("suite", ["sha512", "shake128"])
+def test_device_elligator_matches_oracle(ctx, suite):
+    import dot_ring_amd as d
+
+    cv = {"sha512": d.Bandersnatch, "shake128": d.Bandersnatch_SHAKE128}[suite]
+    osuite = {"sha512": obsn.SHA512, "shake128": obsn.SHAKE128}[suite]
+    msgs = [b"", b"foo", b"\x00" * 100] + [hashlib.sha256(bytes([i])).digest()[: i % 33] for i in range(70)]
+    salts = [b""] * 40 + [b"salt"] * (len(msgs) - 40)
+    got = cv.point_type.encode_to_curve_batch(msgs, salts)
+    for pt, m, s in zip(got, msgs, salts):
+        assert (pt.x, pt.y) == obsn.encode_to_curve(osuite, m, s)
+        single = cv.point_type.encode_to_curve(m, s)         # host big-int path of the single-call API agrees
+        assert (single.x, single.y) == (pt.x, pt.y)
+    assert cv.point_type.encode_to_curve_batch([]) == []
+
+
+def test_msm_skewed_scalars_stay_correct(ctx, srs_bytes):
+    """All-equal and 0/1 scalars put every point into one bucket per window: correctness must not depend on balance."""
+    n = 4096
+    srs = ctx.srs_load(srs_bytes[: 96 * n])
+    tab = ctx.srs_load(srs_bytes[: 96 * n]).precompute(12)
+    le = b"".join(srs_bytes[96 * i : 96 * i + 48][::-1] + srs_bytes[96 * i + 48 : 96 * i + 96][::-1] for i in range(n))
+    for vals in ([0x1234567890ABCDEF1234567890ABCDEF] * n, [i & 1 for i in range(n)], [coracle.FR_P - 1] * n):
+        ks = b"".join(v.to_bytes(32, "little") for v in vals)
+        want = coracle.g1_msm_raw(le, ks, n)
+        want_be = None if want == bytes(96) else want[:48][::-1] + want[48:][::-1]
+        assert ctx.g1_msm(srs, ks) == want_be
+        assert ctx.g1_msm(tab, ks) == want_be
+    srs.close()
+    tab.close()
