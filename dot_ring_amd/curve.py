@@ -113,6 +113,14 @@ class BandersnatchPoint:
             if not _on_curve(x, y):
                 raise ValueError("Point is not on the curve")
 
+    @classmethod
+    def _trusted(cls, x: int, y: int):
+        """Construct from coordinates that are already known to be on the curve (kernel outputs): skips the
+        range / on-curve checks of __init__."""
+        pt = object.__new__(cls)
+        pt.x, pt.y = x, y
+        return pt
+
     # -- basics
     def __eq__(self, other):
         return isinstance(other, BandersnatchPoint) and self.x == other.x and self.y == other.y
@@ -260,8 +268,9 @@ def pack_scalars(scalars) -> bytes:
 
 
 def unpack_points(cls, raw: bytes):
-    return [cls(int.from_bytes(raw[i : i + 32], "little"), int.from_bytes(raw[i + 32 : i + 64], "little"))
-            for i in range(0, len(raw), 64)]
+    """Kernel outputs are group elements by construction: no per-point curve check."""
+    frm, mk = int.from_bytes, cls._trusted
+    return [mk(frm(raw[i : i + 32], "little"), frm(raw[i + 32 : i + 64], "little")) for i in range(0, len(raw), 64)]
 
 
 def scalar_mul_batch(points, scalars):

@@ -58,7 +58,10 @@ def build_ring_proofs_device(ring, ring_root, producer_indices, blinding_factors
         batch = len(idx)
         zk = None
         if not params.test_vectors:
-            zk = b"".join(secrets.randbelow(p).to_bytes(32, "little") for _ in range(batch * 4 * ZK_ROWS))
+            # hidden rows: uniform field elements from the OS CSPRNG (48 random bytes reduced mod p: bias < 2^-128;
+            # the reference draws them with secrets.randbelow, columns.py:43-48)
+            raw = secrets.token_bytes(48 * batch * 4 * ZK_ROWS)
+            zk = b"".join((int.from_bytes(raw[i : i + 48], "little") % p).to_bytes(32, "little") for i in range(0, len(raw), 48))
         relation_raw, wit = prover.witness(idx, b"".join(int(t).to_bytes(32, "little") for t in blinds), zk)
         transcripts, alphas = [], []
         for j in range(batch):

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
-from ..curve import scalar_mul_batch
+from ..curve import msm_groups, scalar_mul_batch
 from .base import VRF
 from .codec import dec_points, dec_scalar, dec_scalar_mod, enc_point, enc_scalar, point_len, scalar_len
 from .primitives import (CHALLENGE_LEN, DomSep, VrfIo, challenge, nonce, point_to_hash, squeeze_transcript_bytes,
@@ -65,26 +65,28 @@ class PedersenVRF(VRF):
         order = cv.curve.params.subgroup_order
         xs = [dec_scalar_mod(cv, sk) for sk in secret_keys]
         inputs = cv.point_type.encode_to_curve_batch(alphas, salts)
-        firsts = scalar_mul_batch([gen] * count + inputs, xs + xs)                    # pk_i, O_i
-        pks, outs = firsts[:count], firsts[count:]
+        outs = scalar_mul_batch(inputs, xs)                                             # O_i = x_i * I_i
         transcripts, blindings = [], []
         for i in range(count):
             t, _ = vrf_transcript(cv, DomSep.PEDERSEN_VRF, [VrfIo(inputs[i], outs[i])], additional_data[i])
             transcripts.append(t)
             blindings.append(cls.blinding_scalar(xs[i], t))
-        blinds = scalar_mul_batch([bb] * count, blindings)                              # b_i * B
-        blinded, ks, kbs = [], [], []
+        # Y_bar_i = x_i*G + b_i*B  (= public key + b*B): one grouped 2-term MSM launch for the whole batch
+        gb = [gen, bb] * count
+        blinded = msm_groups(gb, [s for pair in zip(xs, blindings) for s in pair], 2)
+        ks, kbs = [], []
         for i in range(count):
-            y_bar = pks[i] + blinds[i]
-            transcripts[i].absorb(enc_point(y_bar))
-            blinded.append(y_bar)
+            transcripts[i].absorb(enc_point(blinded[i]))
             ks.append(nonce(cv, xs[i], transcripts[i]))
             kbs.append(nonce(cv, blindings[i], transcripts[i]))
-        third = scalar_mul_batch([gen] * count + [bb] * count + inputs, ks + kbs + ks)  # kG, kb*B, k*I
+        # R_i = k_i*G + kb_i*B and Ok_i = k_i*I_i + 0*I_i in ONE grouped launch
+        identity_scalar = 0
+        pts = gb + [p for inp in inputs for p in (inp, inp)]
+        scs = [s for pair in zip(ks, kbs) for s in pair] + [s for k in ks for s in (k, identity_scalar)]
+        third = msm_groups(pts, scs, 2)
         proofs = []
         for i in range(count):
-            result_point = third[i] + third[count + i]
-            ok = third[2 * count + i]
+            result_point, ok = third[i], third[count + i]
             c = challenge(cv, [result_point, ok], transcripts[i])
             proofs.append(cls(output_point=outs[i], blinded_pk=blinded[i], result_point=result_point, ok=ok,
                               s=(ks[i] + c * xs[i]) % order, sb=(kbs[i] + c * blindings[i]) % order,

@@ -303,9 +303,11 @@ class RingVRF(VRF):
         from ..curve import scalar_mul_batch
 
         gen = cv.point_type.generator_point()
-        derived = scalar_mul_batch([gen] * count, [int.from_bytes(sk, "little") for sk in secret_keys])
-        for pk, pt in zip(producer_keys, derived):
-            if pk != pt.point_to_string():
+        distinct = list(dict.fromkeys(bytes(sk) for sk in secret_keys))      # one scalar multiplication per distinct key
+        derived = scalar_mul_batch([gen] * len(distinct), [int.from_bytes(sk, "little") for sk in distinct])
+        pk_of = {sk: pt.point_to_string() for sk, pt in zip(distinct, derived)}
+        for sk, pk in zip(secret_keys, producer_keys):
+            if pk != pk_of[bytes(sk)]:
                 raise ValueError("producer_key does not match secret_key")
         pedersen = PedersenVRF[cv].prove_batch(alphas, secret_keys, additional_data, salts)
         root = ring_root

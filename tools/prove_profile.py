@@ -7,7 +7,7 @@ import prove_sweep, dot_ring_amd as d
 from dot_ring_amd.curve import scalar_mul_batch
 from dot_ring_amd.vrf.primitives import secret_from_seed_scalar
 cv = d.Bandersnatch; vrf = d.RingVRF[cv]
-ring_size, batch = 1024, 512
+ring_size, batch = 1024, 1024
 pk, sk = cv.secret_from_seed(prove_sweep.seed("signer", 0, 0))
 sks = [secret_from_seed_scalar(cv, prove_sweep.seed("ring-member", 0, i)) for i in range(ring_size)]
 keys = [p.point_to_string() for p in scalar_mul_batch([cv.point_type.generator_point()] * ring_size, sks)]
@@ -18,4 +18,4 @@ vrf.prove_batch(al[:2], al[:2], [sk] * 2, [pk] * 2, ring, root)
 pr = cProfile.Profile(); pr.enable()
 vrf.prove_batch(al, al, [sk] * batch, [pk] * batch, ring, root)
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
