@@ -224,14 +224,22 @@ class BandersnatchPoint:
         return r.double().double()
 
     @classmethod
+    def hash_to_field_pairs(cls, alpha_strings, salts=None) -> bytes:
+        """Host half of encode_to_curve for many inputs: two field elements per input, packed little-endian."""
+        salts = salts or [b""] * len(alpha_strings)
+        return b"".join(u.to_bytes(32, "little") for a, s in zip(alpha_strings, salts) for u in cls.curve.hash_to_field(s + a, 2))
+
+    @classmethod
+    def encode_to_curve_from_field(cls, us: bytes):
+        """Device half: Elligator2 maps, addition and cofactor clearing for packed (u0, u1) pairs."""
+        if not us:
+            return []
+        return unpack_points(cls, runtime.context().bsn_encode_to_curve_batch(us))
+
+    @classmethod
     def encode_to_curve_batch(cls, alpha_strings, salts=None):
         """encode_to_curve for many inputs: hash_to_field on the host, Elligator2 + cofactor clearing on the GPU."""
-        count = len(alpha_strings)
-        if count == 0:
-            return []
-        salts = salts or [b""] * count
-        us = b"".join(u.to_bytes(32, "little") for a, s in zip(alpha_strings, salts) for u in cls.curve.hash_to_field(s + a, 2))
-        return unpack_points(cls, runtime.context().bsn_encode_to_curve_batch(us))
+        return cls.encode_to_curve_from_field(cls.hash_to_field_pairs(alpha_strings, salts))
 
     @classmethod
     def map_to_curve(cls, u: int):

@@ -27,11 +27,12 @@ def supported(params) -> bool:
     return params.pcs is KZG and params.padding_rows == 4 and params.radix_domain_size == 4 * params.domain_size
 
 
-def get_device_prover(ring) -> _native.RingProver:
-    """One device prover per Ring object and context (tables for the ring live in HBM)."""
+def get_device_prover(ring, slot: int = 0) -> _native.RingProver:
+    """Device prover for a Ring object: per-ring tables + the phase state of ONE batch in flight.  Pipelined slices
+    of a batch use different slots (each slot owns its own phase state; the tables are ~15 MB per slot)."""
     ctx = runtime.context()
     provers = ring.__dict__.setdefault("_device_provers", {})
-    cached = provers.get(id(ctx))
+    cached = provers.get((id(ctx), slot))
     if cached is not None and cached.ctx is ctx and cached.handle:
         return cached
     params = ring.params
@@ -42,19 +43,20 @@ def get_device_prover(ring) -> _native.RingProver:
     seed = params.cv.curve.params.auxiliary_points.accumulator_base
     prover = _native.RingProver(ctx, srs, params.domain_size.bit_length() - 1, params.max_ring_size, params.omega, params.radix_omega,
                                 pts, int(seed[0]).to_bytes(32, "little") + int(seed[1]).to_bytes(32, "little"))
-    provers[id(ctx)] = prover
+    provers[(id(ctx), slot)] = prover
     return prover
 
 
-def build_ring_proofs_device(ring, ring_root, producer_indices, blinding_factors, transcript_challenge=None):
+def ring_proofs_gen(ring, ring_root, producer_indices, blinding_factors, transcript_challenge=None, slot: int = 0):
+    """Generator form (dot_ring_amd/pipeline.py): yields the four device phases, returns the payload tuples."""
     params = ring.params
     pcs, p = params.pcs, params.prime
-    prover = get_device_prover(ring)
     prefix = ring_root.verifier_transcript_prefix(transcript_challenge or params.cv.curve.params.suite_id)
     payloads = []
+    ser = pcs.serialize_g1_uncompressed
     for start in range(0, len(producer_indices), MAX_DEVICE_BATCH):
         idx = list(producer_indices[start : start + MAX_DEVICE_BATCH])
-        blinds = blinding_factors[start : start + MAX_DEVICE_BATCH]
+        blinds = b"".join(int(t).to_bytes(32, "little") for t in blinding_factors[start : start + MAX_DEVICE_BATCH])
         batch = len(idx)
         zk = None
         if not params.test_vectors:
@@ -62,27 +64,36 @@ def build_ring_proofs_device(ring, ring_root, producer_indices, blinding_factors
             # the reference draws them with secrets.randbelow, columns.py:43-48)
             raw = secrets.token_bytes(48 * batch * 4 * ZK_ROWS)
             zk = b"".join((int.from_bytes(raw[i : i + 48], "little") % p).to_bytes(32, "little") for i in range(0, len(raw), 48))
-        relation_raw, wit = prover.witness(idx, b"".join(int(t).to_bytes(32, "little") for t in blinds), zk)
+        relation_raw, wit = yield (lambda: get_device_prover(ring, slot).witness(idx, blinds, zk))
         transcripts, alphas = [], []
         for j in range(batch):
-            wit_ser = b"".join(pcs.serialize_g1_uncompressed(c) for c in wit[4 * j : 4 * j + 4])
+            wit_ser = b"".join(ser(c) for c in wit[4 * j : 4 * j + 4])
             t, al = phase1_alphas_after_vk(prefix.copy(), _RawPoint(relation_raw[64 * j : 64 * j + 64]), wit_ser)
             transcripts.append(t)
             alphas.append(al)
-        c_qs = prover.quotient(batch, b"".join(a.to_bytes(32, "little") for al in alphas for a in al))
+        alpha_raw = b"".join(a.to_bytes(32, "little") for al in alphas for a in al)
+        c_qs = yield (lambda: get_device_prover(ring, slot).quotient(batch, alpha_raw))
         zetas = []
         for j in range(batch):
-            transcripts[j], zeta = phase2_eval_point(transcripts[j], pcs.serialize_g1_uncompressed(c_qs[j]))
+            transcripts[j], zeta = phase2_eval_point(transcripts[j], ser(c_qs[j]))
             zetas.append(zeta)
-        ev_raw = prover.evals(batch, b"".join(z.to_bytes(32, "little") for z in zetas))
+        zeta_raw = b"".join(z.to_bytes(32, "little") for z in zetas)
+        ev_raw = yield (lambda: get_device_prover(ring, slot).evals(batch, zeta_raw))
         evals, nus = [], []
         for j in range(batch):
             vals = [int.from_bytes(ev_raw[256 * j + 32 * i : 256 * j + 32 * i + 32], "little") for i in range(8)]
             evals.append(vals)
             nus.append(phase3_nu_vector(transcripts[j], vals[:7], vals[7]))
-        opens = prover.openings(batch, b"".join(v.to_bytes(32, "little") for nu in nus for v in nu))
+        nu_raw = b"".join(v.to_bytes(32, "little") for nu in nus for v in nu)
+        opens = yield (lambda: get_device_prover(ring, slot).openings(batch, nu_raw))
         for j in range(batch):
             cols = [Column(name, [], _commitment=wit[4 * j + i], _has_commitment=True) for i, name in enumerate(("c_b", "c_accip", "c_accx", "c_accy"))]
             c_q = Column("C_q", [], _commitment=c_qs[j], _has_commitment=True)
             payloads.append((*cols, *evals[j][:7], c_q, evals[j][7], opens[2 * j], opens[2 * j + 1]))
     return payloads
+
+
+def build_ring_proofs_device(ring, ring_root, producer_indices, blinding_factors, transcript_challenge=None):
+    from ..pipeline import drive
+
+    return drive(ring_proofs_gen(ring, ring_root, producer_indices, blinding_factors, transcript_challenge))

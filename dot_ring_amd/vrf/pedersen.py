@@ -55,17 +55,22 @@ class PedersenVRF(VRF):
         return nonce(cls.cv, secret_scalar, t)
 
     @classmethod
-    def prove_batch(cls, alphas, secret_keys, additional_data, salts=None) -> list:
-        """Additive API: element i equals prove(alphas[i], secret_keys[i], additional_data[i]).
-        Three kernel launches for the whole batch (the transcript forces the three phases)."""
+    def _prove_gen(cls, alphas, secret_keys, additional_data, salts=None):
+        """Generator form of prove_batch (see dot_ring_amd/pipeline.py): yields GPU callables, returns the proofs.
+        Three device round trips for the whole batch (the transcript forces the three phases)."""
         cv = cls.cv
         count = len(alphas)
         salts = salts or [b""] * count
         gen, bb = cv.point_type.generator_point(), cls._blinding_base()
         order = cv.curve.params.subgroup_order
         xs = [dec_scalar_mod(cv, sk) for sk in secret_keys]
-        inputs = cv.point_type.encode_to_curve_batch(alphas, salts)
-        outs = scalar_mul_batch(inputs, xs)                                             # O_i = x_i * I_i
+        us = cv.point_type.hash_to_field_pairs(alphas, salts)
+
+        def first():
+            inputs = cv.point_type.encode_to_curve_from_field(us)
+            return inputs, scalar_mul_batch(inputs, xs)                                  # I_i, O_i = x_i * I_i
+
+        inputs, outs = yield first
         transcripts, blindings = [], []
         for i in range(count):
             t, _ = vrf_transcript(cv, DomSep.PEDERSEN_VRF, [VrfIo(inputs[i], outs[i])], additional_data[i])
@@ -73,17 +78,17 @@ class PedersenVRF(VRF):
             blindings.append(cls.blinding_scalar(xs[i], t))
         # Y_bar_i = x_i*G + b_i*B  (= public key + b*B): one grouped 2-term MSM launch for the whole batch
         gb = [gen, bb] * count
-        blinded = msm_groups(gb, [s for pair in zip(xs, blindings) for s in pair], 2)
+        blind_scalars = [s for pair in zip(xs, blindings) for s in pair]
+        blinded = yield (lambda: msm_groups(gb, blind_scalars, 2))
         ks, kbs = [], []
         for i in range(count):
             transcripts[i].absorb(enc_point(blinded[i]))
             ks.append(nonce(cv, xs[i], transcripts[i]))
             kbs.append(nonce(cv, blindings[i], transcripts[i]))
         # R_i = k_i*G + kb_i*B and Ok_i = k_i*I_i + 0*I_i in ONE grouped launch
-        identity_scalar = 0
         pts = gb + [p for inp in inputs for p in (inp, inp)]
-        scs = [s for pair in zip(ks, kbs) for s in pair] + [s for k in ks for s in (k, identity_scalar)]
-        third = msm_groups(pts, scs, 2)
+        scs = [s for pair in zip(ks, kbs) for s in pair] + [s for k in ks for s in (k, 0)]
+        third = yield (lambda: msm_groups(pts, scs, 2))
         proofs = []
         for i in range(count):
             result_point, ok = third[i], third[count + i]
@@ -92,6 +97,13 @@ class PedersenVRF(VRF):
                               s=(ks[i] + c * xs[i]) % order, sb=(kbs[i] + c * blindings[i]) % order,
                               _blinding_factor=blindings[i]))
         return proofs
+
+    @classmethod
+    def prove_batch(cls, alphas, secret_keys, additional_data, salts=None) -> list:
+        """Additive API: element i equals prove(alphas[i], secret_keys[i], additional_data[i])."""
+        from ..pipeline import drive
+
+        return drive(cls._prove_gen(alphas, secret_keys, additional_data, salts))
 
     @classmethod
     def prove(cls, alpha: bytes, secret_key: bytes, additional_data: bytes, salt: bytes = b"") -> "PedersenVRF":

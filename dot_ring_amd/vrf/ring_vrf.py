@@ -2,7 +2,6 @@
 from __future__ import annotations
 
 import os
-from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 from functools import lru_cache
 
@@ -14,22 +13,13 @@ from ..ring_proof.poly import inverse_fft_batch
 from ..ring_proof import device_prover
 from ..ring_proof.prover import build_ring_proofs
 from ..ring_proof.transcript import FiatShamirTranscript, serialize_verifier_key
-from ..ring_proof.verifier import linear_pcs_verifications
+from ..ring_proof.verifier import batch_inverse, linear_pcs_verifications, replay_challenges, zeta_denominators
 from .base import VRF
 from .codec import point_len
 from .pedersen import PedersenVRF
 
 RING_SCALAR_LEN = 32
 
-_pools: dict = {}
-
-
-def _prove_pool(workers: int) -> ThreadPoolExecutor:
-    """Long-lived worker threads: each keeps its own GPU context, SRS table and per-ring prover tables."""
-    pool = _pools.get(workers)
-    if pool is None:
-        pool = _pools[workers] = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="dotring-prove")
-    return pool
 
 
 # ------------------------------------------------------------------ Ring (members.py:18-101)
@@ -271,36 +261,35 @@ class RingVRF(VRF):
 
     # -- proving
     @classmethod
+    def _prove_gen(cls, alphas, additional_data, secret_keys, producer_keys, ring, root, salts, slot=0):
+        """One slice of a batch as a generator of GPU tasks: Pedersen part, then the ring part."""
+        cv = cls.cv
+        pedersen = yield from PedersenVRF[cv]._prove_gen(alphas, secret_keys, additional_data, salts)
+        blindings = [pp._blinding_factor for pp in pedersen]
+        if device_prover.supported(ring.params):
+            indices = yield (lambda: ring.indices_of(producer_keys))
+            payloads = yield from device_prover.ring_proofs_gen(ring, root, indices, blindings, slot=slot)
+        else:       # custom PCS / domain layout: generic phase-batched prover (NTT + MSM seams only)
+            payloads = yield (lambda: build_ring_proofs(ring, root, producer_keys, blindings))
+        return [cls(pp, *payload) for pp, payload in zip(pedersen, payloads)]
+
+    @classmethod
     def prove_batch(cls, alphas, additional_data, secret_keys, producer_keys, ring: Ring, ring_root: RingRoot | None = None,
                     salts=None, pipeline: int | None = None) -> list:
         """Additive API: a batch of proofs over ONE ring; element i equals
         prove(alphas[i], additional_data[i], secret_keys[i], producer_keys[i], ring, ring_root).
-        pipeline = number of worker threads (each with its own GPU context/stream) the batch is split across, so that
-        one slice's transcript hashing on the host overlaps another slice's kernels (measured gain <= 10 %: opt-in, default 1,
-        env DOTRING_PROVE_PIPELINE)."""
+        pipeline = number of slices the batch is cut into; the slices' GPU phases run back to back on one stream while
+        the calling thread hashes the transcripts of the other slices (dot_ring_amd/pipeline.py).  Measured on MI355X the
+        fixed-latency kernels of the extra slices cost what the overlap saves (+0..4 %), so the default is 1 slice
+        (env DOTRING_PROVE_PIPELINE)."""
         count = len(alphas)
-        if pipeline is None:
-            pipeline = int(os.environ.get("DOTRING_PROVE_PIPELINE", "1")) if count >= 256 else 1
-        if pipeline > 1 and count >= 2 * pipeline:
-            if ring_root is None or ring_root.px.coeffs is None:
-                ring_root = RingRoot.from_ring(ring, ring.params)       # build once, outside the workers
-            salts_ = salts or [b""] * count
-            cuts = [count * i // pipeline for i in range(pipeline + 1)]
-
-            def work(i):
-                lo, hi = cuts[i], cuts[i + 1]
-                return cls.prove_batch(alphas[lo:hi], additional_data[lo:hi], secret_keys[lo:hi], producer_keys[lo:hi], ring,
-                                       ring_root, salts_[lo:hi], pipeline=1)
-
-            pool = _prove_pool(pipeline)
-            out = []
-            for part in pool.map(work, range(pipeline)):
-                out.extend(part)
-            return out
         if not (len(additional_data) == len(secret_keys) == len(producer_keys) == count):
             raise ValueError("batch arguments must have equal lengths")
+        if count == 0:
+            return []
         cv = cls.cv
         from ..curve import scalar_mul_batch
+        from ..pipeline import run_pipelined
 
         gen = cv.point_type.generator_point()
         distinct = list(dict.fromkeys(bytes(sk) for sk in secret_keys))      # one scalar multiplication per distinct key
@@ -309,19 +298,24 @@ class RingVRF(VRF):
         for sk, pk in zip(secret_keys, producer_keys):
             if pk != pk_of[bytes(sk)]:
                 raise ValueError("producer_key does not match secret_key")
-        pedersen = PedersenVRF[cv].prove_batch(alphas, secret_keys, additional_data, salts)
         root = ring_root
         if root is None or root.px.coeffs is None or root.py.coeffs is None or root.s.coeffs is None or len(root.s.evals) < ring.params.domain_size:
             computed = RingRoot.from_ring(ring, ring.params)
             if root is not None and computed.encode() != root.encode():
                 raise ValueError("ring_root does not match ring")
             root = computed
-        blindings = [pp._blinding_factor for pp in pedersen]
+        if pipeline is None:
+            pipeline = int(os.environ.get("DOTRING_PROVE_PIPELINE", "1"))
+        pipeline = max(1, min(pipeline, count))
         if device_prover.supported(ring.params):
-            payloads = device_prover.build_ring_proofs_device(ring, root, ring.indices_of(producer_keys), blindings)
-        else:       # custom PCS / domain layout: generic phase-batched prover (NTT + MSM seams only)
-            payloads = build_ring_proofs(ring, root, producer_keys, blindings)
-        return [cls(pp, *payload) for pp, payload in zip(pedersen, payloads)]
+            for slot in range(pipeline):
+                device_prover.get_device_prover(ring, slot)                    # per-ring tables, built outside the pipeline
+        salts_ = salts or [b""] * count
+        cuts = [count * i // pipeline for i in range(pipeline + 1)]
+        parts = run_pipelined(
+            cls._prove_gen(alphas[lo:hi], additional_data[lo:hi], secret_keys[lo:hi], producer_keys[lo:hi], ring, root, salts_[lo:hi], slot)
+            for slot, (lo, hi) in enumerate(zip(cuts, cuts[1:])))
+        return [proof for part in parts for proof in part]
 
     @classmethod
     def prove(cls, alpha: bytes, additional_data: bytes, secret_key: bytes, producer_key: bytes, ring: Ring,
@@ -372,8 +366,20 @@ class RingVRF(VRF):
             return False
         claims = []
         try:
-            for proof in proofs:
-                claims.extend(proof._linear_claims(proof.pedersen_proof.blinded_pk, ring, ring_root))
+            params = ring.params
+            cv = params.cv
+            seed = cv.point_type(*cv.curve.params.auxiliary_points.accumulator_base)
+            prefix = ring_root.verifier_transcript_prefix()
+            fixed = ring_root.fixed_commitments()
+            domain = params.domain
+            replays = [replay_challenges(pr, pr.pedersen_proof.blinded_pk, params, prefix) for pr in proofs]
+            # one modular inversion for the whole batch instead of three per proof
+            dens = [d for rp in replays for d in zeta_denominators(rp[3], domain, params.prime)]
+            invs = batch_inverse(dens, params.prime)
+            for j, (proof, rp) in enumerate(zip(proofs, replays)):
+                relation = proof.pedersen_proof.blinded_pk
+                claims.extend(linear_pcs_verifications(proof, fixed, relation, seed + relation, seed, params, prefix, replay=rp,
+                                                       inverses=invs[3 * j : 3 * j + 3], domain=domain))
         except (AssertionError, AttributeError, TypeError, ValueError):
             return False
         return bool(ring.params.pcs.batch_verify_linear_preconverted(claims))
