@@ -2,7 +2,7 @@
 
 The arithmetic lives in libdotring_hip.so (hand-written HIP, see dot_ring_amd/csrc and include/dotring_hip.h);
 this package mirrors the reference's public names (dot_ring/__init__.py:3-19) for the Bandersnatch suites:
-    TinyVRF, PedersenVRF, RingVRF, Ring, RingRoot, RingProofParams, Bandersnatch, Bandersnatch_SHAKE128
+    TinyVRF, ThinVRF, PedersenVRF, RingVRF, Ring, RingRoot, RingProofParams, Bandersnatch, Bandersnatch_SHAKE128
 plus the additive prove_batch() entry points.  There is no CPU fallback for the kernels.
 """
 from . import _native  # noqa: F401
@@ -11,7 +11,8 @@ from .ring_proof.params import RingProofParams
 from .ring_proof.pcs import KZG
 from .vrf.pedersen import PedersenVRF
 from .vrf.ring_vrf import Ring, RingRoot, RingVRF
+from .vrf.thin import ThinVRF
 from .vrf.tiny import TinyVRF
 
-__all__ = ["TinyVRF", "PedersenVRF", "RingVRF", "Ring", "RingRoot", "RingProofParams", "KZG",
+__all__ = ["TinyVRF", "ThinVRF", "PedersenVRF", "RingVRF", "Ring", "RingRoot", "RingProofParams", "KZG",
            "Bandersnatch", "Bandersnatch_SHAKE128"]

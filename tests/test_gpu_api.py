@@ -68,6 +68,32 @@ def test_tiny_vrf_vectors(ctx, golden_dir, suite, rel):
         vrf.decode(bytes(79))
 
 
+THIN = [("sha512", "ark-vrf/bandersnatch_sha-512_ell2_thin.json"), ("shake128", "ark-vrf/bandersnatch_shake128_ell2_thin.json"),
+        ("sha512", "dot-ring/bandersnatch_sha-512_ell2_thin.json")]
+
+
+@pytest.mark.parametrize("suite,rel", THIN)
+def test_thin_vrf_vectors(ctx, golden_dir, suite, rel):
+    import dot_ring_amd as d
+
+    vrf = d.ThinVRF[_cv(suite)]
+    vectors = _load(golden_dir, rel)
+    proofs = []
+    for v in vectors:
+        sk, al, ad, pk = (bytes.fromhex(v[k]) for k in ("sk", "alpha", "ad", "pk"))
+        proof = vrf.prove(al, sk, ad)
+        assert proof.encode().hex() == v["gamma"] + v["proof_r"] + v["proof_s"]
+        assert proof.verify(pk, al, ad) and vrf.decode(proof.encode()).verify(pk, al, ad)
+        assert not proof.verify(pk, al + b"x", ad)
+        proofs.append(proof)
+    pks = [bytes.fromhex(v["pk"]) for v in vectors]
+    als, ads = [bytes.fromhex(v["alpha"]) for v in vectors], [bytes.fromhex(v["ad"]) for v in vectors]
+    assert vrf.batch_verify(proofs, pks, als, ads)
+    assert not vrf.batch_verify(proofs, pks, als[::-1], ads)
+    assert not vrf.batch_verify(proofs, [bytes(32)] * len(proofs), als, ads)       # invalid public keys
+    assert [p.encode() for p in vrf.prove_batch(als, [bytes.fromhex(v["sk"]) for v in vectors], ads)] == [p.encode() for p in proofs]
+
+
 @pytest.mark.parametrize("suite,rel", PEDERSEN)
 def test_pedersen_vrf_vectors(ctx, golden_dir, suite, rel):
     import dot_ring_amd as d
