@@ -235,35 +235,57 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     const size_t ndigits = windows * n;
     if (nbuckets >= (1ull << 32) || ndigits >= (1ull << 32))
         return fail(DR_ERR_INVALID, "MSM batch too large for one launch (split the batch)");
-    TRY(ctx->digits.reserve(ndigits * 4));
     TRY(ctx->counts.reserve(nbuckets * 4));
     TRY(ctx->offsets.reserve((nbuckets + 1) * 4));
-    TRY(ctx->cursor.reserve(nbuckets * 4));
     const unsigned szblocks = div_up(nbuckets, dr::SZ_TILE);
     const size_t ncells = (size_t)dr::SZ_CLASSES * szblocks;
     TRY(ctx->tiles.reserve((size_t)(div_up(std::max(ncells, nbuckets), dr::SCAN_TILE) + 1) * 4));
     TRY(ctx->perm.reserve(nbuckets * 4));
     TRY(ctx->cells.reserve(ncells * 4));
     TRY(ctx->cell_off.reserve(ncells * 4));
-    TRY(ctx->sorted.reserve(ndigits * 4));
     TRY(ctx->buckets.reserve(nbuckets * 192));
     TRY(ctx->partial.reserve(bsets * pl.T * 192));
     TRY(ctx->winsum.reserve(bsets * 192));
     hipStream_t st = ctx->stream;
-    HIP_TRY(hipMemsetAsync(ctx->counts.p, 0, nbuckets * 4, st));
-    HIP_TRY(hipMemsetAsync(ctx->cursor.p, 0, nbuckets * 4, st));
-
-    TRY(launch(ctx, "k_g1_digits", [&] {
-        hipLaunchKernelGGL(dr::k_g1_digits, dim3(div_up(n * batch, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n,
-                           (uint32_t)batch, pl.wt, single ? 1 : 0, groups, ctx->digits.as<int32_t>(), ctx->counts.as<uint32_t>());
-    }));
     auto exclusive_scan = [&](const uint32_t* in, uint32_t* out, size_t count) {
         const unsigned nt = div_up(count, dr::SCAN_TILE);
         hipLaunchKernelGGL(dr::k_scan_tiles, dim3(nt), dim3(dr::SCAN_BLOCK), 0, st, in, out, ctx->tiles.as<uint32_t>(), count);
         hipLaunchKernelGGL(dr::k_scan_tile_sums, dim3(1), dim3(dr::SCAN_BLOCK), 0, st, ctx->tiles.as<uint32_t>(), nt, ctx->tiles.as<uint32_t>() + nt);
         hipLaunchKernelGGL(dr::k_scan_add, dim3(div_up(count, 256)), dim3(256), 0, st, out, ctx->tiles.as<uint32_t>(), count);
     };
-    TRY(launch(ctx, "k_scan", [&] { exclusive_scan(ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), nbuckets); }));
+    // Sorting the digits by bucket.  Small bucket sets fed by a bounded number of digits (the batched prover) are
+    // sorted by one workgroup each, entirely in LDS; a few huge sets (one 2^20-point MSM) use global atomics.
+    const size_t per_set_scalars = single ? (n + groups - 1) / groups : n;
+    const size_t per_set_digits = single ? per_set_scalars * (size_t)pl.W : n;
+    const bool lds_sort = pl.H <= dr::SORT_MAX_H && bsets >= 64 && per_set_digits <= 262144 && bsets * per_set_digits < (1ull << 32);
+    if (lds_sort) {
+        dr::SortSetParams sp;
+        sp.n = (uint32_t)n; sp.batch = (uint32_t)batch; sp.H = pl.H; sp.groups = groups; sp.single = single ? 1 : 0;
+        sp.tbl_stride = single ? tbl->stride : 0; sp.tbl_offset = single ? tbl->offset : 0;
+        sp.capacity = (uint32_t)per_set_digits;
+        TRY(ctx->sorted.reserve(bsets * per_set_digits * 4));
+        TRY(launch(ctx, "k_g1_sort_sets", [&] {
+            hipLaunchKernelGGL(dr::k_g1_sort_sets, dim3((unsigned)bsets), dim3(dr::SORT_BLOCK), 0, st, d_scalars, pl.wt, sp,
+                               ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
+        }));
+    } else {
+        TRY(ctx->digits.reserve(ndigits * 4));
+        TRY(ctx->cursor.reserve(nbuckets * 4));
+        TRY(ctx->sorted.reserve(ndigits * 4));
+        HIP_TRY(hipMemsetAsync(ctx->counts.p, 0, nbuckets * 4, st));
+        HIP_TRY(hipMemsetAsync(ctx->cursor.p, 0, nbuckets * 4, st));
+        TRY(launch(ctx, "k_g1_digits", [&] {
+            hipLaunchKernelGGL(dr::k_g1_digits, dim3(div_up(n * batch, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n,
+                               (uint32_t)batch, pl.wt, single ? 1 : 0, groups, ctx->digits.as<int32_t>(), ctx->counts.as<uint32_t>());
+        }));
+        TRY(launch(ctx, "k_scan", [&] { exclusive_scan(ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), nbuckets); }));
+        TRY(launch(ctx, "k_g1_scatter", [&] {
+            hipLaunchKernelGGL(dr::k_g1_scatter, dim3(div_up(ndigits, 256)), dim3(256), 0, st, ctx->digits.as<int32_t>(),
+                               (uint32_t)n, windows, pl.H, single ? pl.W : 0, single ? tbl->stride : 0u, single ? tbl->offset : 0u, groups,
+                               ctx->offsets.as<uint32_t>(), ctx->cursor.as<uint32_t>(),
+                               ctx->sorted.as<uint32_t>());
+        }));
+    }
     // size-ordered bucket permutation for the accumulate kernel
     TRY(launch(ctx, "k_size_sort", [&] {
         hipLaunchKernelGGL(dr::k_size_hist, dim3(szblocks), dim3(dr::SZ_BLOCK), 0, st, ctx->counts.as<uint32_t>(), nbuckets, szblocks,
@@ -271,12 +293,6 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         exclusive_scan(ctx->cells.as<uint32_t>(), ctx->cell_off.as<uint32_t>(), ncells);
         hipLaunchKernelGGL(dr::k_size_place, dim3(szblocks), dim3(dr::SZ_BLOCK), 0, st, ctx->counts.as<uint32_t>(), nbuckets, szblocks,
                            ctx->cell_off.as<uint32_t>(), ctx->perm.as<uint32_t>());
-    }));
-    TRY(launch(ctx, "k_g1_scatter", [&] {
-        hipLaunchKernelGGL(dr::k_g1_scatter, dim3(div_up(ndigits, 256)), dim3(256), 0, st, ctx->digits.as<int32_t>(),
-                           (uint32_t)n, windows, pl.H, single ? pl.W : 0, single ? tbl->stride : 0u, single ? tbl->offset : 0u, groups,
-                           ctx->offsets.as<uint32_t>(), ctx->cursor.as<uint32_t>(),
-                           ctx->sorted.as<uint32_t>());
     }));
     TRY(launch(ctx, "k_g1_accumulate", [&] {
         hipLaunchKernelGGL(dr::k_g1_accumulate, dim3(div_up(nbuckets, 256)), dim3(256), 0, st, d_bases,

@@ -267,6 +267,112 @@ __global__ void k_g1_window_table(const uint32_t* __restrict__ bases, uint32_t n
     }
 }
 
+// ---- 1'-3'. LDS counting sort: ONE workgroup owns one bucket set.  When a bucket set is small (H <= 8192 counters =
+// 32 KiB of LDS) and fed by a bounded number of digits (the batched prover: 7k MSMs x 2048 buckets), the histogram,
+// its exclusive scan and the placement all happen in LDS: no digit array in HBM, no global atomics, no global scan.
+// Each set gets a fixed-capacity segment of `sorted` (capacity = the most digits it can receive), so segment bases
+// need no cross-set scan.  Pass 1 counts, pass 2 recomputes the digits and places them.
+constexpr int SORT_BLOCK = 256;
+constexpr uint32_t SORT_MAX_H = 8192;
+
+struct SortSetParams {
+    uint32_t n, batch, H, groups;      // groups: table-mode index groups per MSM (1 otherwise)
+    int single;                         // 1: window-table mode (set = MSM x group, all windows), 0: set = (MSM, window)
+    uint32_t tbl_stride, tbl_offset;
+    uint32_t capacity;                  // entries reserved per set in `sorted`
+};
+
+DR_DEV void load_scalar_mod_r(const uint32_t* __restrict__ scalars, size_t idx, uint32_t (&k)[9]) {
+    const uint4* q = reinterpret_cast<const uint4*>(scalars + idx * 8);
+    uint4 lo = q[0], hi = q[1];
+    k[0] = lo.x; k[1] = lo.y; k[2] = lo.z; k[3] = lo.w; k[4] = hi.x; k[5] = hi.y; k[6] = hi.z; k[7] = hi.w;
+    k[8] = 0;
+    constexpr uint32_t R[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+#pragma unroll 1
+    for (int it = 0; it < 2; it++) {
+        uint32_t d[8], borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) d[j] = subb(k[j], R[j], borrow);
+#pragma unroll
+        for (int j = 0; j < 8; j++) k[j] = borrow ? k[j] : d[j];
+    }
+}
+
+// visit the signed digits of scalar k: f(window, digit) for windows [w_lo, w_hi) (the carry chain always starts at 0)
+template <class F>
+DR_DEV void for_each_digit(const uint32_t (&k)[9], const WindowTable& wt, int w_lo, int w_hi, F&& f) {
+    uint32_t carry = 0;
+    for (int w = 0; w < w_hi; w++) {
+        const int bit = wt.start[w], c = wt.width[w], li = bit >> 5, sh = bit & 31;
+        const uint32_t half = 1u << (c - 1);
+        uint64_t two = (uint64_t)k[li] | ((uint64_t)k[li + 1] << 32);
+        uint32_t raw = ((uint32_t)(two >> sh) & ((1u << c) - 1)) + carry;
+        int32_t d;
+        if (raw > half) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
+        else { d = (int32_t)raw; carry = 0; }
+        if (w >= w_lo && d != 0) f(w, d);
+    }
+}
+
+__global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __restrict__ scalars, WindowTable wt, SortSetParams sp,
+                                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                                             uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t bins[SORT_MAX_H];
+    __shared__ uint32_t smem[SORT_BLOCK / 64];
+    const uint32_t H = sp.H, set = blockIdx.x;
+    // which scalars and windows feed this set
+    uint32_t b, i_lo, i_hi;
+    int w_lo, w_hi;
+    if (sp.single) {
+        b = set / sp.groups;
+        uint32_t g = set % sp.groups;
+        i_lo = (uint32_t)(((uint64_t)g * sp.n + sp.groups - 1) / sp.groups);
+        i_hi = (uint32_t)(((uint64_t)(g + 1) * sp.n + sp.groups - 1) / sp.groups);
+        w_lo = 0; w_hi = wt.W;
+    } else {
+        b = set / wt.W;
+        w_lo = (int)(set % wt.W); w_hi = w_lo + 1;
+        i_lo = 0; i_hi = sp.n;
+    }
+    for (uint32_t j = threadIdx.x; j < H; j += SORT_BLOCK) bins[j] = 0;
+    __syncthreads();
+    // pass 1: histogram
+    for (uint32_t i = i_lo + threadIdx.x; i < i_hi; i += SORT_BLOCK) {
+        uint32_t k[9];
+        load_scalar_mod_r(scalars, (size_t)b * sp.n + i, k);
+        for_each_digit(k, wt, w_lo, w_hi, [&](int, int32_t d) { atomicAdd(&bins[(d < 0 ? -d : d) - 1], 1u); });
+    }
+    __syncthreads();
+    // counts out; in-place exclusive scan of the H bins (each lane owns H/SORT_BLOCK consecutive bins)
+    const uint32_t per = (H + SORT_BLOCK - 1) / SORT_BLOCK, lo = threadIdx.x * per, hi = lo + per < H ? lo + per : H;
+    uint32_t local = 0;
+    for (uint32_t j = lo; j < hi; j++) {
+        uint32_t c = bins[j];
+        counts[(size_t)set * H + j] = c;
+        local += c;
+    }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(local, smem, total);
+    const uint32_t base = set * sp.capacity;
+    for (uint32_t j = lo; j < hi; j++) {
+        uint32_t c = bins[j];
+        bins[j] = run;                                  // becomes the placement cursor
+        offsets[(size_t)set * H + j] = base + run;
+        run += c;
+    }
+    __syncthreads();
+    // pass 2: placement
+    for (uint32_t i = i_lo + threadIdx.x; i < i_hi; i += SORT_BLOCK) {
+        uint32_t k[9];
+        load_scalar_mod_r(scalars, (size_t)b * sp.n + i, k);
+        for_each_digit(k, wt, w_lo, w_hi, [&](int w, int32_t d) {
+            uint32_t pos = atomicAdd(&bins[(d < 0 ? -d : d) - 1], 1u);
+            uint32_t entry = sp.single ? (uint32_t)w * sp.tbl_stride + sp.tbl_offset + i : i;
+            sorted[base + pos] = entry | (d < 0 ? 0x80000000u : 0u);
+        });
+    }
+}
+
 // ---- 3b. order buckets by size (descending) so that the 64 lanes of a wave walk chains of nearly equal length.
 // A wave otherwise waits for its longest bucket: with ~20 points per bucket (Poisson) a third of the lane-cycles idle.
 // Counting sort over 256 size classes (sizes >= 255 share the first class): per-workgroup histograms in LDS, a scan
