@@ -89,6 +89,8 @@ struct dr_srs {
     // optional fixed-base window table: table[w][i] = 2^(start_w) * base[i]; all windows share one bucket set
     uint32_t* d_table = nullptr;
     dr::WindowTable table_wt{};
+    // derived bases for summation-by-parts commitments, keyed by log2(domain size): PS_j = sum_{i<=j} L_i(tau) G
+    std::map<unsigned, dr_srs*> lagrange_prefix;
 };
 
 namespace {
@@ -157,6 +159,8 @@ int pick_window(size_t n) {
     return best;
 }
 
+uint32_t g_chunk_len = 16;   // buckets per lane in k_g1_reduce_chunks (DOTRING_MSM_CHUNK)
+
 struct MsmPlan {
     dr::WindowTable wt;
     int W;
@@ -192,7 +196,7 @@ MsmPlan make_plan(size_t n, int force_c) {
         bit += width;
     }
     p.H = 1u << (p.wt.cmax - 1);
-    p.L = std::min<uint32_t>(p.H, 16);
+    p.L = std::min<uint32_t>(p.H, g_chunk_len);
     p.T = p.H / p.L;
     return p;
 }
@@ -218,7 +222,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         pl.wt = tbl->wt;
         pl.W = tbl->wt.W;
         pl.H = 1u << (tbl->wt.cmax - 1);
-        pl.L = std::min<uint32_t>(pl.H, 16);
+        pl.L = std::min<uint32_t>(pl.H, g_chunk_len);
         pl.T = pl.H / pl.L;
         d_bases = tbl->table;
         if ((uint64_t)pl.W * tbl->stride >= (1ull << 31)) return fail(DR_ERR_INVALID, "window table too large");
@@ -468,6 +472,11 @@ int dr_ctx_create(int device_id, dr_ctx** out) {
     const char* fc = std::getenv("DOTRING_MSM_WINDOW");
     g_force_c = fc ? std::atoi(fc) : 0;
     if (!window_ok(g_force_c)) g_force_c = 0;
+    const char* cl = std::getenv("DOTRING_MSM_CHUNK");
+    if (cl) {
+        int v = std::atoi(cl);
+        if (v == 8 || v == 16 || v == 32 || v == 64 || v == 128) g_chunk_len = (uint32_t)v;
+    }
     *out = ctx;
     return DR_OK;
 }
@@ -766,6 +775,8 @@ int dr_srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits) {
 void dr_srs_destroy(dr_srs* srs) {
     if (!srs) return;
     (void)hipSetDevice(srs->device);
+    for (auto& it : srs->lagrange_prefix) dr_srs_destroy(it.second);
+    srs->lagrange_prefix.clear();
     if (srs->d_table) (void)hipFree(srs->d_table);
     if (srs->d_bases) (void)hipFree(srs->d_bases);
     delete srs;
@@ -975,6 +986,7 @@ struct dr_ring_prover {
     const dr_srs* srs = nullptr;
     dr::RingConsts rc{};
     drh::Fr omega_n, omega_4n;          // Montgomery
+    const dr_srs* ps_srs = nullptr;      // prefix-summed Lagrange bases of this domain (owned by srs->lagrange_prefix)
     // per-ring tables
     Scratch ring_pts_mont;              // [N][16]
     Scratch fixed_coef;                 // [3][N][8] std (px, py, s coefficients)
@@ -984,7 +996,7 @@ struct dr_ring_prover {
     // per-batch state
     size_t batch = 0;
     Scratch idx, blind, zk, chain_ext, prefix, chain_aff, cnt, relation, rps, cols, wit4, alphas, agg, q, zetas, evals, ks, lin,
-        nus, aggo, chunkv, quot1, quot2;
+        nus, aggo, chunkv, quot1, quot2, diffs;
 };
 
 namespace {
@@ -1009,6 +1021,40 @@ int ring_ntt(dr_ring_prover* p, uint32_t* d_data, unsigned log2n, size_t batch, 
 
 dr::FrArg arg_of(const drh::Fr& v) { return dr::to_arg(v); }
 
+// PS_j = sum_{i<=j} L_i(tau) G for the size-2^log2n domain, as a derived dr_srs with its own window table.
+// One batched MSM (N MSMs of N points) over the monomial SRS; cached in srs->lagrange_prefix.
+int lagrange_prefix_srs(dr_ctx* ctx, const dr_srs* srs_c, unsigned log2n, const drh::Fr& omega_n, const dr_srs** out) {
+    dr_srs* srs = const_cast<dr_srs*>(srs_c);
+    auto hit = srs->lagrange_prefix.find(log2n);
+    if (hit != srs->lagrange_prefix.end()) { *out = hit->second; return DR_OK; }
+    const uint32_t n = 1u << log2n;
+    if (srs->count < n) return fail(DR_ERR_INVALID, "polynomial degree exceeds SRS size");
+    hipStream_t st = ctx->stream;
+    Scratch mat;
+    TRY(mat.reserve((size_t)n * n * 32));
+    hipLaunchKernelGGL(dr::k_ring_ps_scalars, dim3(div_up(n, 64)), dim3(64), 0, st, mat.as<uint32_t>(), n, arg_of(omega_n.inv()),
+                       arg_of(drh::Fr::from_u64(n).inv()));
+    std::vector<uint8_t> be((size_t)n * 96);
+    std::vector<int> inf(n);
+    MsmTable t = srs_table(srs, 0);
+    int rc = DR_OK;
+    // keep each launch within the 32-bit digit / bucket index limits
+    const size_t step = std::max<size_t>(1, std::min<size_t>(n, (size_t)1 << (26 - log2n)));
+    for (size_t done = 0; done < n && rc == DR_OK; done += step) {
+        size_t take = std::min<size_t>(step, n - done);
+        rc = msm_to_bytes(ctx, srs->d_bases, mat.as<uint32_t>() + done * n * 8, n, take, be.data() + done * 96, inf.data() + done, &t);
+    }
+    mat.release();
+    if (rc != DR_OK) return rc;
+    dr_srs* ps = nullptr;
+    TRY(dr_srs_load(ctx, be.data(), n, &ps));
+    rc = dr_srs_precompute(ctx, ps, srs->d_table ? srs->table_wt.cmax : 12);
+    if (rc != DR_OK) { dr_srs_destroy(ps); return rc; }
+    srs->lagrange_prefix[log2n] = ps;
+    *out = ps;
+    return DR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1031,6 +1077,8 @@ int dr_ring_prover_create(dr_ctx* ctx, const dr_srs* srs, unsigned log2n, uint32
     p->srs = srs;
     if (!drh::Fr::load_le(p->omega_n, omega_n) || !drh::Fr::load_le(p->omega_4n, omega_4n))
         return fail(DR_ERR_INVALID, "omega is not a canonical field element");
+    if (std::getenv("DOTRING_WITNESS_BY_PARTS") == nullptr || std::atoi(std::getenv("DOTRING_WITNESS_BY_PARTS")) != 0)
+        TRY(lagrange_prefix_srs(ctx, srs, log2n, p->omega_n, &p->ps_srs));
     dr::RingConsts& rc = p->rc;
     rc.log2n = log2n; rc.n = n; rc.max_ring = max_ring; rc.rows = n - 4;
     drh::Fr sx, sy;
@@ -1087,7 +1135,7 @@ void dr_ring_prover_destroy(dr_ring_prover* p) {
     if (p->ctx) (void)hipSetDevice(p->ctx->device);
     for (Scratch* s : {&p->ring_pts_mont, &p->fixed_coef, &p->fixed4, &p->lag4, &p->not_last, &p->idx, &p->blind, &p->zk, &p->chain_ext,
                        &p->prefix, &p->chain_aff, &p->cnt, &p->relation, &p->rps, &p->cols, &p->wit4, &p->alphas, &p->agg, &p->q, &p->zetas,
-                       &p->evals, &p->ks, &p->lin, &p->nus, &p->aggo, &p->chunkv, &p->quot1, &p->quot2})
+                       &p->evals, &p->ks, &p->lin, &p->nus, &p->aggo, &p->chunkv, &p->quot1, &p->quot2, &p->diffs})
         s->release();
     delete p;
 }
@@ -1148,8 +1196,19 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
         hipLaunchKernelGGL(dr::k_ring_columns, dim3(div_up(batch * n, 256)), dim3(256), 0, st, p->idx.as<uint32_t>(), p->blind.as<uint32_t>(),
                            p->chain_aff.as<uint32_t>(), zk_rows ? p->zk.as<uint32_t>() : nullptr, rc, (uint32_t)batch, p->cols.as<uint32_t>());
     }));
-    TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true));
     HIP_TRY(hipMemcpyAsync(out_relation_xy, p->relation.p, batch * 64, hipMemcpyDeviceToHost, st));
+    if (p->ps_srs) {
+        // commit in evaluation form by summation by parts (sparse scalars), then interpolate for the later phases
+        TRY(p->diffs.reserve(batch * 4 * (size_t)n * 32));
+        TRY(launch(ctx, "k_ring_diff", [&] {
+            hipLaunchKernelGGL(dr::k_ring_diff, dim3(div_up(batch * 4 * n, 256)), dim3(256), 0, st, p->cols.as<uint32_t>(), n, batch * 4,
+                               p->diffs.as<uint32_t>());
+        }));
+        TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true));
+        MsmTable t = srs_table(p->ps_srs, 0);
+        return msm_to_bytes(ctx, p->ps_srs->d_bases, p->diffs.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t);
+    }
+    TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true));
     MsmTable t = srs_table(p->srs, 0);
     return msm_to_bytes(ctx, p->srs->d_bases, p->cols.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t);
 }

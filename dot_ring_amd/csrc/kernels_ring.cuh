@@ -72,6 +72,36 @@ __global__ void k_ring_not_last(uint32_t* __restrict__ out, uint32_t m, FrArg w4
     gstore_fr(out + (size_t)i * 8, sub(fr_pow_u32(from_arg(w4_mont), i), from_arg(last_root_mont)));
 }
 
+// ---- summation-by-parts commitments of the witness columns ------------------------------------------------------
+// The witness columns are piecewise constant in EVALUATION form (one-hot / bit rows, an accumulator that changes at
+// <= 254 rows), so   sum_j e_j * L_j(tau) G  =  sum_j (e_j - e_{j+1}) * PS_j   with  PS_j = sum_{i<=j} L_i(tau) G
+// has ~270 non-zero scalars per column instead of N dense coefficients — the same group element, ~8x fewer
+// bucket additions.  PS_j = sum_m S[j][m] * [tau^m] G with S[j][m] = (1/N) sum_{i<=j} w^(-i*m): one batched MSM over
+// the monomial SRS at setup (k_ring_ps_scalars builds the N x N scalar matrix, lane m walks column m).
+__global__ void k_ring_ps_scalars(uint32_t* __restrict__ out /* [N][N][8] std, row j = scalars of PS_j */, uint32_t n,
+                                  FrArg winv_mont, FrArg inv_n_mont) {
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    Fr step = fr_pow_u32(from_arg(winv_mont), m);        // w^-m
+    Fr term = from_arg(inv_n_mont);                      // (1/N) * w^(-i*m), i = 0
+    Fr acc = Fr::zero();
+#pragma unroll 1
+    for (uint32_t j = 0; j < n; j++) {
+        acc = add(acc, term);
+        st_std(out + ((size_t)j * n + m) * 8, acc);
+        term = mul(term, step);
+    }
+}
+// first differences of the evaluation columns: d_j = e_j - e_{j+1} (e_N = 0); standard form in and out
+__global__ void k_ring_diff(const uint32_t* __restrict__ cols /* [count][n][8] */, uint32_t n, size_t count, uint32_t* __restrict__ out) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= count * n) return;
+    uint32_t j = (uint32_t)(gid % n);
+    Fr e = gload_fr(cols + gid * 8);
+    Fr nx = j + 1 < n ? gload_fr(cols + (gid + 1) * 8) : Fr::zero();
+    gstore_fr(out + gid * 8, sub(e, nx));
+}
+
 // ---- witness generation --------------------------------------------------------------------------------------
 constexpr int RING_CHAIN = 256;    // seed, +PK_k, one per set blinding bit (<= 253), relation
 

@@ -39,7 +39,7 @@ def main(ring_size, batch, reps=2):
         dt = time.perf_counter() - t
         ctx.prof_enable(False)
         names = ["k_bsn_scalar_mul", "k_ring_chain", "k_ring_columns", "k_ntt_local", "k_ntt_strided", "k_ring_pad", "k_ring_constraints",
-                 "k_ring_quotient", "k_ring_eval", "k_ring_linpoly", "k_ring_aggpoly", "k_syndiv", "k_g1_digits", "k_scan", "k_g1_scatter",
+                 "k_ring_quotient", "k_ring_eval", "k_ring_linpoly", "k_ring_aggpoly", "k_syndiv", "k_bsn_encode_to_curve", "k_bsn_msm_groups", "k_g1_sort_sets", "k_size_sort", "k_g1_digits", "k_scan", "k_g1_scatter",
                  "k_g1_accumulate", "k_g1_reduce_chunks", "k_g1_reduce_windows", "k_g1_horner", "k_g1_results_affine"]
         parts = {k: ctx.prof_get(k)[0] for k in names}
         gpu_ms = sum(parts.values())
