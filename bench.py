@@ -211,7 +211,11 @@ def main() -> int:
 
     if rank == 0:
         n_dom = ring.params.domain_size
-        pairs_per_proof = 11 * n_dom                       # 4N + (3N+1) + 3N + (N-1)  
+        # dense (base, scalar) pairs per proof: quotient 3N+1, two opening quotients 3N + (N-1)  (SURVEY 3.3); the four
+        # witness columns (4N) are committed by summation by parts: 4N scalars are read, only ~1.1k bases gathered,
+        # so they are priced at the 32 B scalar alone
+        pairs_per_proof = 7 * n_dom
+        scalar_only_per_proof = 4 * n_dom
         # ---- parity subset: deterministic proofs (test_vectors=True) byte-compared with the CPU oracle
         from oracle.pyref import bandersnatch as obsn
         from oracle.pyref import ring as oring
@@ -240,7 +244,7 @@ def main() -> int:
         value = total / elapsed
         avg_acc_s = (acc_ms / max(1, acc_launches)) / 1e3
         pairs_per_launch = (batch * pairs_per_proof * args.steps + 0.0) / max(1, acc_launches)      # prove-side MSM pairs / launches
-        alg_bytes_launch = ALG_BYTES_PER_PAIR * pairs_per_launch
+        alg_bytes_launch = ALG_BYTES_PER_PAIR * pairs_per_launch + 32.0 * batch * scalar_only_per_proof * args.steps / max(1, acc_launches)
         achieved = alg_bytes_launch / avg_acc_s / 1e9 if avg_acc_s > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")

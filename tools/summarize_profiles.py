@@ -1,0 +1,51 @@
+"""Turn one tools/profile_round.sh pass (gpurun_out/<tag>/) into the files committed under profiles/:
+  <tag>_bench_n1.json, <tag>_<workload>_kernel_stats.csv, <tag>_<workload>_pmc_avg_per_launch.json, hbm_traffic.json
+HBM bytes follow the gfx950 rule of /opt/skills/guides/MI355X_MICROARCH.md: (2*FETCH_SIZE + WRITE_SIZE) KiB.
+usage: python tools/summarize_profiles.py r01 [workload-name]"""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+workload = sys.argv[2] if len(sys.argv) > 2 else "ringvrf_ring1024_batch1024"
+src = os.path.join("gpurun_out", tag)
+os.makedirs("profiles", exist_ok=True)
+
+line = open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]
+json.loads(line)
+with open(f"profiles/{tag}_bench_n1.json", "w") as f:
+    f.write(line + "\n")
+
+stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], f"profiles/{tag}_{workload}_kernel_stats.csv")
+
+def short(name):
+    return name.split("(")[0]
+
+sums = collections.defaultdict(lambda: collections.defaultdict(float))
+launches = collections.defaultdict(lambda: collections.defaultdict(int))
+for path in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            k = short(row["Kernel_Name"])
+            sums[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            launches[k][row["Counter_Name"]] += 1
+avg = {k: {c: sums[k][c] / launches[k][c] for c in sorted(sums[k])} for k in sums}
+for k in avg:
+    avg[k]["launches_per_pass"] = max(launches[k].values())
+with open(f"profiles/{tag}_{workload}_pmc_avg_per_launch.json", "w") as f:
+    json.dump(avg, f, indent=1)
+
+acc = avg.get("dr::k_g1_accumulate")
+if acc and "FETCH_SIZE" in acc and "WRITE_SIZE" in acc:
+    traffic = {
+        "_note": "HBM bytes per k_g1_accumulate launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
+                 "(2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction; average over the launches of one bench step",
+        workload: {
+            "k_g1_accumulate_bytes_per_launch": (2 * acc["FETCH_SIZE"] + acc["WRITE_SIZE"]) * 1024,
+            "FETCH_SIZE_KB": acc["FETCH_SIZE"],
+            "WRITE_SIZE_KB": acc["WRITE_SIZE"],
+        },
+    }
+    with open("profiles/hbm_traffic.json", "w") as f:
+        json.dump(traffic, f, indent=1)
+print("wrote profiles for", tag, "; kernels with counters:", len(avg))
