@@ -146,6 +146,7 @@ def main() -> int:
     os.environ["DOTRING_DEVICE"] = str(local_rank)
     import dot_ring_amd as d
     from dot_ring_amd import runtime
+    from dot_ring_amd.ring_proof.pcs import SRS
 
     ctx = runtime.context()
     cv = d.Bandersnatch
@@ -155,9 +156,14 @@ def main() -> int:
     # ---- setup (untimed): ring, ring root, per-ring prover tables in HBM
     t_setup = time.perf_counter()
     signer_pk, signer_sk, keys = bench_ring_keys(cv, args.ring_size, 0)
+    # domains above 2048 need more SRS points than the shipped file holds: known-tau SRS, same on every rank
+    big = d.RingProofParams.from_ring_size(args.ring_size).domain_size > 2048
+    tau = int.from_bytes(hashlib.sha256(b"bench-known-tau").digest(), "little") % d.KZG.scalar_modulus
+    pcs = d.KZG.with_srs(SRS.synthetic(tau, 3 * 4096 + 1)) if big else d.KZG
+    params = d.RingProofParams.from_ring_size(args.ring_size, pcs=pcs)
     t_ring = time.perf_counter()
-    ring = d.Ring(keys)
-    root = d.RingRoot.from_ring(ring)
+    ring = d.Ring(keys, params)
+    root = d.RingRoot.from_ring(ring, params)
     ring_root_s = time.perf_counter() - t_ring
     base = rank * batch
     alphas = [b"bench-batch-input" + (base + i).to_bytes(8, "little") for i in range(batch)]
@@ -223,12 +229,17 @@ def main() -> int:
         parity_ok = all_ok
         cpu = None
         if args.cpu_proofs > 0:
-            tv_params = d.RingProofParams.from_ring_size(args.ring_size, test_vectors=True)
+            tv_params = d.RingProofParams.from_ring_size(args.ring_size, test_vectors=True, pcs=pcs)
             tv_ring = d.Ring(keys, tv_params)
             tv_root = d.RingRoot.from_ring(tv_ring, tv_params)
             m = args.cpu_proofs
             gpu_proofs = vrf.prove_batch(alphas[:m], ads[:m], sks[:m], pks[:m], tv_ring, tv_root)
-            o_params = oring.Params.from_ring_size(args.ring_size, test_vectors=True, suite=obsn.SHA512)
+            o_srs = None
+            if big:
+                from oracle.pyref import kzg as okzg
+                o_srs = okzg.SRS.from_tau(tau, 3 * 4096 + 1)
+                o_srs.g2_raw = list(pcs.srs.g2_raw)
+            o_params = oring.Params.from_ring_size(args.ring_size, test_vectors=True, suite=obsn.SHA512, srs=o_srs)
             o_ring = oring.Ring(keys, o_params)
             o_root = oring.RingRoot(o_ring)
             parity_ok = parity_ok and o_root.encode() == tv_root.encode() == root.encode()
@@ -271,7 +282,8 @@ def main() -> int:
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": f"RingVRF[Bandersnatch] prove_batch + batch_verify, ring_size {args.ring_size} (domain {n_dom}), "
-                                   f"{batch} proofs per GPU per step, ZK rows random, ring/SRS/prover tables HBM-resident",
+                                   f"{batch} proofs per GPU per step, ZK rows random, ring/SRS/prover tables HBM-resident"
+                                   + (", known-tau SRS of 12289 points" if big else ""),
                        "ring_size": args.ring_size, "domain_size": n_dom, "batch_per_gpu": batch,
                        "sharding": "proofs sharded per rank, no collective" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -44,6 +44,8 @@ _PROTOTYPES = {
     "dr_fr_sqrt": (c_int, [c_char_p, c_void_p]),
     "dr_srs_load": (c_int, [c_void_p, c_char_p, c_size_t, POINTER(c_void_p)]),
     "dr_srs_synthetic": (c_int, [c_void_p, c_char_p, c_uint, c_size_t, POINTER(c_void_p)]),
+    "dr_srs_powers": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, POINTER(c_void_p)]),
+    "dr_g2_mul": (c_int, [c_char_p, c_char_p, c_char_p]),
     "dr_srs_precompute": (c_int, [c_void_p, c_void_p, c_int]),
     "dr_srs_download": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "dr_srs_destroy": (None, [c_void_p]),
@@ -134,9 +136,14 @@ class DeviceBuffer:
 class Srs:
     """SRS bases resident in HBM (Montgomery-form affine)."""
 
-    def __init__(self, ctx: "Context", g1_be_xy: bytes | None = None, *, synthetic_seed: bytes | None = None, first: int = 1, count: int = 0):
+    def __init__(self, ctx: "Context", g1_be_xy: bytes | None = None, *, synthetic_seed: bytes | None = None, first: int = 1, count: int = 0,
+                 tau: int | None = None):
         self.ctx = ctx
         self.handle = c_void_p()
+        if tau is not None:
+            self.count = count
+            _check(lib().dr_srs_powers(ctx.handle, synthetic_seed, int(tau).to_bytes(32, "little"), count, byref(self.handle)))
+            return
         if synthetic_seed is not None:
             self.count = count
             _check(lib().dr_srs_synthetic(ctx.handle, synthetic_seed, first, count, byref(self.handle)))
@@ -296,6 +303,10 @@ class Context:
         """bases[i] = (first+i) * seed, generated on the GPU."""
         return Srs(self, synthetic_seed=seed_be_xy, first=first, count=count)
 
+    def srs_powers(self, base_be_xy: bytes, tau: int, count: int) -> Srs:
+        """bases[i] = tau^i * base (known-tau SRS for tests/benchmarks beyond the shipped file), generated on the GPU."""
+        return Srs(self, synthetic_seed=base_be_xy, tau=tau, count=count)
+
     def g1_msm(self, srs: Srs, scalars: bytes, offset: int = 0) -> bytes | None:
         """Affine BE x||y (96 bytes) or None for the point at infinity."""
         n = len(scalars) // 32
@@ -360,6 +371,13 @@ def g1_sum(points: list) -> bytes | None:
     out, inf = ctypes.create_string_buffer(96), c_int(0)
     _check(lib().dr_g1_sum(raw, len(points), out, byref(inf)))
     return None if inf.value else out.raw
+
+
+def g2_mul(g2_be: bytes, scalar: int) -> bytes:
+    """scalar * Q for a 192-byte zcash-layout G2 point (host; setup of known-tau test SRS only)."""
+    out = ctypes.create_string_buffer(192)
+    _check(lib().dr_g2_mul(g2_be, int(scalar).to_bytes(32, "little"), out))
+    return out.raw
 
 
 def pairing_check(pairs: list) -> bool:

@@ -726,6 +726,64 @@ int dr_srs_synthetic(dr_ctx* ctx, const uint8_t seed_be_xy[96], uint32_t first, 
     return DR_OK;
 }
 
+int dr_srs_powers(dr_ctx* ctx, const uint8_t base_be_xy[96], const uint8_t tau_le[32], size_t count, dr_srs** out) {
+    TRY(use_ctx(ctx));
+    if (!out || !base_be_xy || !tau_le) return fail(DR_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (count == 0 || count >= (1ull << 28)) return fail(DR_ERR_INVALID, "bad SRS size");
+    drh::Fr tau;
+    if (!drh::Fr::load_le(tau, tau_le)) return fail(DR_ERR_INVALID, "tau is not a canonical scalar");
+    std::vector<uint8_t> le;
+    TRY(g1_be_to_le_limbs(base_be_xy, 1, le, true));
+    std::vector<uint8_t> pw(count * 32);
+    drh::Fr t = drh::Fr::one();
+    for (size_t i = 0; i < count; i++) {
+        t.store_le(pw.data() + 32 * i);
+        t = t * tau;
+    }
+    dr_srs* s = new (std::nothrow) dr_srs();
+    if (!s) return fail(DR_ERR_NOMEM, "out of host memory");
+    s->device = ctx->device;
+    s->count = count;
+    uint32_t *d_seed = nullptr, *d_pw = nullptr;
+    hipError_t e = hipMalloc((void**)&s->d_bases, count * 96);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_seed, 96);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_pw, count * 32);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_seed, le.data(), 96, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pw, pw.data(), count * 32, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dr::k_g1_bases_to_mont, dim3(1), dim3(64), 0, ctx->stream, d_seed, 1u);
+        hipLaunchKernelGGL(dr::k_g1_scalar_bases, dim3(div_up(count, 64)), dim3(64), 0, ctx->stream, s->d_bases, (uint32_t)count, d_pw, d_seed);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (d_seed) (void)hipFree(d_seed);
+    if (d_pw) (void)hipFree(d_pw);
+    if (e != hipSuccess) {
+        if (s->d_bases) (void)hipFree(s->d_bases);
+        delete s;
+        return fail(e == hipErrorOutOfMemory ? DR_ERR_NOMEM : DR_ERR_DEVICE, std::string("SRS powers: ") + hipGetErrorString(e));
+    }
+    *out = s;
+    return DR_OK;
+}
+
+int dr_g2_mul(const uint8_t g2_be[192], const uint8_t scalar_le[32], uint8_t out_be[192]) {
+    if (!g2_be || !scalar_le || !out_be) return fail(DR_ERR_INVALID, "null buffer");
+    drh::G2Affine Q;
+    Q.inf = false;
+    if (!drh::Fq::load_be(Q.x.c1, g2_be) || !drh::Fq::load_be(Q.x.c0, g2_be + 48) || !drh::Fq::load_be(Q.y.c1, g2_be + 96) ||
+        !drh::Fq::load_be(Q.y.c0, g2_be + 144) || !drh::g2_on_curve(Q))
+        return fail(DR_ERR_INVALID, "invalid BLS12-381 G2 encoding");
+    drh::G2Affine R = drh::g2_mul(Q, scalar_le);
+    std::memset(out_be, 0, 192);
+    if (R.inf) { out_be[0] = 0x40; return DR_OK; }
+    R.x.c1.store_be(out_be);
+    R.x.c0.store_be(out_be + 48);
+    R.y.c1.store_be(out_be + 96);
+    R.y.c0.store_be(out_be + 144);
+    return DR_OK;
+}
+
 int dr_srs_download(dr_ctx* ctx, const dr_srs* srs, size_t offset, size_t count, uint8_t* out_be_xy) {
     TRY(use_ctx(ctx));
     if (!srs || !out_be_xy) return fail(DR_ERR_INVALID, "null argument");

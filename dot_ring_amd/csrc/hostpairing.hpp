@@ -99,6 +99,29 @@ inline bool g2_on_curve(const G2Affine& q) {
     return q.y.sqr() == q.x.sqr() * q.x + b;
 }
 
+// affine group law on the twist (setup-time only: tau * G2 for a known-tau test SRS)
+inline G2Affine g2_add(const G2Affine& a, const G2Affine& b) {
+    if (a.inf) return b;
+    if (b.inf) return a;
+    Fq2 s;
+    if (a.x == b.x) {
+        if (!(a.y == b.y) || a.y.is_zero()) return {Fq2::zero(), Fq2::zero(), true};
+        s = a.x.sqr().scale(Fq::from_u64(3)) * (a.y + a.y).inv();
+    } else {
+        s = (b.y - a.y) * (b.x - a.x).inv();
+    }
+    Fq2 x = s.sqr() - a.x - b.x;
+    return {x, s * (a.x - x) - a.y, false};
+}
+inline G2Affine g2_mul(const G2Affine& q, const uint8_t scalar_le[32]) {
+    G2Affine r{Fq2::zero(), Fq2::zero(), true};
+    for (int bit = 255; bit >= 0; bit--) {
+        r = g2_add(r, r);
+        if ((scalar_le[bit >> 3] >> (bit & 7)) & 1) r = g2_add(r, q);
+    }
+    return r;
+}
+
 // one Miller loop f_{|x|,Q}(P), conjugated for the negative BLS parameter x = -0xd201000000010000
 inline Fq12 miller_loop(const Fq& px, const Fq& py, const G2Affine& q) {
     const uint64_t X = 0xd201000000010000ULL;

@@ -92,6 +92,27 @@ __global__ void k_g1_synth_bases(uint32_t* bases, uint32_t n, uint32_t first, co
     store_fq(p + 12, a.y);
 }
 
+// known-tau SRS for domains the shipped file does not cover: bases[i] = scalars[i] * seed with
+// scalars[i] = tau^i (standard form, < r) prepared by the host; one lane per base
+__global__ void k_g1_scalar_bases(uint32_t* bases, uint32_t n, const uint32_t* __restrict__ scalars, const uint32_t* seed) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) e[j] = scalars[(size_t)i * 8 + j];
+    G1Affine s = load_affine(seed, 0);
+    G1Xyzz acc = g1_inf();
+#pragma unroll 1
+    for (int bit = 254; bit >= 0; bit--) {
+        acc = g1_dbl(acc);
+        if ((e[bit >> 5] >> (bit & 31)) & 1) acc = g1_madd(acc, s);
+    }
+    G1Affine a = g1_to_affine_dev(acc);
+    uint32_t* p = bases + (size_t)i * 24;
+    store_fq(p, a.x);
+    store_fq(p + 12, a.y);
+}
+
 // Montgomery affine -> standard-form little-endian limbs (SRS download)
 __global__ void k_g1_bases_from_mont(const uint32_t* bases, uint32_t* out, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -24,7 +24,7 @@ class _RawPoint:
 
 
 def supported(params) -> bool:
-    return params.pcs is KZG and params.padding_rows == 4 and params.radix_domain_size == 4 * params.domain_size
+    return isinstance(params.pcs, type) and issubclass(params.pcs, KZG) and params.padding_rows == 4 and params.radix_domain_size == 4 * params.domain_size
 
 
 def get_device_prover(ring, slot: int = 0) -> _native.RingProver:

@@ -159,7 +159,7 @@ class RingProofParams:
 
     @classmethod
     def from_ring_size(cls, ring_size: int, padding_rows: int = 4, base_root: int = ROOT_OF_UNITY_2048,
-                       base_root_size: int = 2048, test_vectors: bool = False, cv: CurveVariant = Bandersnatch):
+                       base_root_size: int = 2048, test_vectors: bool = False, cv: CurveVariant = Bandersnatch, pcs: type = KZG):
         if ring_size <= 0:
             raise ValueError(f"ring_size must be positive, got {ring_size}")
         overhead = cv.curve.params.subgroup_order.bit_length() + padding_rows
@@ -168,4 +168,4 @@ class RingProofParams:
         while domain_size < need:
             domain_size *= 2
         return cls(domain_size=domain_size, max_ring_size=domain_size - overhead, padding_rows=padding_rows,
-                   base_root=base_root, base_root_size=base_root_size, test_vectors=test_vectors, cv=cv)
+                   base_root=base_root, base_root_size=base_root_size, test_vectors=test_vectors, cv=cv, pcs=pcs)

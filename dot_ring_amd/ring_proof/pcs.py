@@ -130,6 +130,22 @@ class SRS:
             raise ValueError("Unexpected end-of-file when reading G2 points.")
         return cls(g1_raw, g2_raw)
 
+    @classmethod
+    def synthetic(cls, tau: int, count: int) -> "SRS":
+        """Known-tau SRS [tau^i]G1, [1, tau]G2 for domains the shipped file does not cover (domain 4096 needs 12289
+        points, the file holds 6145: SURVEY R5).  tau is public, so this is for tests and benchmarks only; G1 powers
+        are generated on the GPU, tau*G2 on the host.  Generators = point 0 of the shipped SRS."""
+        base = cls.default()
+        tau %= SCALAR_MODULUS
+        ctx = runtime.context()
+        dev = ctx.srs_powers(base.g1_raw[:96], tau, count)
+        self = cls(dev.download(0, count), [base.g2_raw[0], _native.g2_mul(base.g2_raw[0], tau)])
+        bits = int(os.environ.get("DOTRING_SRS_WINDOW", "12"))
+        if bits:
+            dev.precompute(bits)
+        self._devices[id(ctx)] = (ctx, dev)
+        return self
+
     @staticmethod
     @lru_cache(maxsize=2)
     def default(max_deg: int = 6144) -> "SRS":
@@ -188,6 +204,11 @@ class KZG:
     commitment_size = 48
     scalar_modulus = SCALAR_MODULUS
     srs = None            # set lazily (the reference loads at import; here loading is deferred to first use)
+
+    @classmethod
+    def with_srs(cls, srs: SRS) -> type:
+        """A PCS class bound to its own SRS (pass as RingProofParams(pcs=...)); KZG itself keeps the shipped one."""
+        return type("KZG", (cls,), {"srs": srs})
 
     @classmethod
     def _srs(cls) -> SRS:

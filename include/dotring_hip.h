@@ -105,6 +105,10 @@ DR_API int dr_srs_load(dr_ctx *ctx, const uint8_t *g1_be_xy /* m*96 */, size_t m
 /* Synthetic bases for sizes no SRS file covers: base[i] = (first+i) * seed (first >= 1), generated on
  * the GPU.  With these bases an MSM has the closed form [sum_i k_i*(first+i)] * seed — a size-independent check. */
 DR_API int dr_srs_synthetic(dr_ctx *ctx, const uint8_t seed_be_xy[96], uint32_t first, size_t count, dr_srs **out);
+/* Known-tau SRS for domains the shipped file does not cover (test/bench use only — tau is public):
+ * bases[i] = tau^i * base, i < count, generated on the GPU.  dr_g2_mul (host) gives the matching tau * G2. */
+DR_API int dr_srs_powers(dr_ctx *ctx, const uint8_t base_be_xy[96], const uint8_t tau_le[32], size_t count, dr_srs **out);
+DR_API int dr_g2_mul(const uint8_t g2_be[192], const uint8_t scalar_le[32], uint8_t out_be[192]);
 /* Fixed-base window table for this SRS, kept in HBM: table[w][i] = 2^(start_w) * base[i] for the W = ceil(256/c)
  * windows of width ~c = window_bits (7..22; 0 drops the table).  Costs W * count * 96 bytes (13 MB for the shipped
  * 6145-point SRS at c = 12, 1.6 GB for 2^20 bases at c = 16) and makes every later MSM over this SRS use ONE bucket

@@ -127,6 +127,45 @@ def test_ring_1024_domain_2048_matches_oracle(ctx):
     assert d.RingVRF[d.Bandersnatch].batch_verify(proofs, [b"a", b"b"], [b"", b"ad"], ring, root)
 
 
+def test_domain_4096_with_known_tau_srs_matches_oracle(ctx):
+    """BASELINE config 5 shape: domain 4096 needs 12289 SRS points, the shipped file holds 6145, so the
+    SRS is a known-tau one ([tau^i]G1 from dr_srs_powers, tau*G2 from dr_g2_mul).  The oracle builds the same G1
+    powers independently (C scalar multiplications); proofs must agree byte for byte and verify under tau*G2."""
+    import dot_ring_amd as d
+    from dot_ring_amd.ring_proof.pcs import SRS
+    from oracle.pyref import kzg as okzg
+
+    tau = int.from_bytes(hashlib.sha256(b"known-tau").digest(), "little") % coracle.FR_P
+    srs = SRS.synthetic(tau, 3 * 4096 + 1)
+    o_srs = okzg.SRS.from_tau(tau, 3 * 4096 + 1)
+    assert srs.g1_points[1] == o_srs.g1[1] and srs.g1_points[12288] == o_srs.g1[12288]
+    assert srs.g1_points[0] == okzg.default_srs().g1[0]
+    o_srs.g2_raw = list(srs.g2_raw)                      # transcript bytes only; tau*G2 itself is checked by verify below
+    keys = _keys(2000, b"huge")
+    sk = (777).to_bytes(32, "little")
+    pk = d.Bandersnatch.public_key_from_secret(sk)
+    keys[1999] = pk
+    params = d.RingProofParams.from_ring_size(2000, test_vectors=True, pcs=d.KZG.with_srs(srs))
+    assert params.domain_size == 4096
+    ring = d.Ring(keys, params)
+    root = d.RingRoot.from_ring(ring, params)
+    o_ring = oring.Ring(keys, oring.Params.from_ring_size(2000, test_vectors=True, srs=o_srs))
+    o_root = oring.RingRoot(o_ring)
+    assert root.encode() == o_root.encode()
+    vrf = d.RingVRF[d.Bandersnatch]
+    proofs = vrf.prove_batch([b"x", b"y", b"z"], [b"", b"ad", b""], [sk] * 3, [pk] * 3, ring, root)
+    assert proofs[0].encode() == oring.ring_vrf_prove(o_ring, o_root, b"x", b"", sk)
+    assert proofs[1].encode() == oring.ring_vrf_prove(o_ring, o_root, b"y", b"ad", sk)
+    assert proofs[2].verify(b"z", b"", ring, root)
+    assert vrf.batch_verify(proofs, [b"x", b"y", b"z"], [b"", b"ad", b""], ring, root)
+    assert not proofs[2].verify(b"w", b"", ring, root)
+    plain = d.RingProofParams.from_ring_size(2000, test_vectors=True)
+    plain_ring = d.Ring(keys, plain)
+    plain_root = d.RingRoot.from_ring(plain_ring, plain)  # degree < 4096 still fits the shipped 6145 points ...
+    with pytest.raises(ValueError):                      # ... the quotient (degree 3N) does not
+        vrf.prove_batch([b"x"], [b""], [sk], [pk], plain_ring, plain_root)
+
+
 @pytest.mark.parametrize("suite", ["sha512", "shake128"])
 def test_device_elligator_matches_oracle(ctx, suite):
     import dot_ring_amd as d
