@@ -71,7 +71,57 @@ _PROTOTYPES = {
     "dr_ntt": (c_int, [c_void_p, c_void_p, c_uint, c_size_t, c_char_p, c_char_p]),
     "dr_ntt_dev": (c_int, [c_void_p, c_void_p, c_uint, c_size_t, c_char_p, c_char_p]),
 }
+
+
+class VrfSuiteStruct(ctypes.Structure):
+    """dr_vrf_suite (include/dotring_hip.h)."""
+    _fields_ = [("suite_id", c_char_p), ("suite_id_len", c_size_t), ("xof", c_int),
+                ("generator_xy", ctypes.c_uint8 * 64), ("blinding_base_xy", ctypes.c_uint8 * 64)]
+
+
+_PROTOTYPES.update({
+    "dr_host_hash": (c_int, [c_int, c_char_p, c_size_t, c_char_p, c_size_t]),
+    "dr_hash_to_field_batch": (c_int, [POINTER(VrfSuiteStruct), c_char_p, POINTER(ctypes.c_uint64), c_size_t, c_char_p]),
+    "dr_ringvrf_prove_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_size_t, c_char_p, POINTER(ctypes.c_uint64), c_char_p,
+                                       POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint32),
+                                       c_char_p, c_size_t, c_char_p, c_char_p, c_char_p]),
+})
+RINGVRF_AUX_BYTES = 960
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
+
+
+def _ragged(items):
+    """Concatenate byte strings -> (blob, uint64 offsets[count+1])."""
+    off = (ctypes.c_uint64 * (len(items) + 1))()
+    pos = 0
+    for i, it in enumerate(items):
+        pos += len(it)
+        off[i + 1] = pos
+    return b"".join(items), off
+
+
+def vrf_suite(suite_id: bytes, xof: bool, generator_xy: bytes, blinding_base_xy: bytes) -> VrfSuiteStruct:
+    s = VrfSuiteStruct()
+    s._keep = bytes(suite_id)
+    s.suite_id, s.suite_id_len, s.xof = s._keep, len(s._keep), 1 if xof else 0
+    ctypes.memmove(s.generator_xy, generator_xy, 64)
+    ctypes.memmove(s.blinding_base_xy, blinding_base_xy, 64)
+    return s
+
+
+def host_hash(kind: int, data: bytes, out_len: int) -> bytes:
+    """kind: 0 SHA-512, 1 SHAKE128, 2 SHAKE256 (the library's own implementations; checked against hashlib in tests)."""
+    out = ctypes.create_string_buffer(out_len)
+    _check(lib().dr_host_hash(kind, data, len(data), out, out_len))
+    return out.raw
+
+
+def hash_to_field_batch(suite: VrfSuiteStruct, msgs) -> bytes:
+    blob, off = _ragged(msgs)
+    out = ctypes.create_string_buffer(max(1, 64 * len(msgs)))
+    _check(lib().dr_hash_to_field_batch(byref(suite), blob, off, len(msgs), out))
+    return out.raw[: 64 * len(msgs)]
+
 
 
 def lib() -> ctypes.CDLL:
@@ -219,6 +269,20 @@ class RingProver:
         out, inf = ctypes.create_string_buffer(2 * 96 * batch), (c_int * (2 * batch))()
         _check(lib().dr_ring_prove_openings(self.handle, batch, nus, out, inf))
         return self._points(out.raw, inf, 2 * batch)
+
+    def ringvrf_prove_batch(self, suite: "VrfSuiteStruct", alphas, ads, salts, secret_scalars: bytes, producer_index: list,
+                            fs_prefix: bytes, zk_random48: bytes | None):
+        """dr_ringvrf_prove_batch: the whole batch (hashing on the library's worker threads, GPU phases in between).
+        Returns (batch * 784 proof bytes, batch * 960 auxiliary bytes)."""
+        batch = len(alphas)
+        a_blob, a_off = _ragged(alphas)
+        d_blob, d_off = _ragged(ads)
+        s_blob, s_off = (None, None) if not salts or not any(salts) else _ragged(salts)
+        idx = (ctypes.c_uint32 * batch)(*producer_index)
+        out, aux = ctypes.create_string_buffer(784 * batch), ctypes.create_string_buffer(RINGVRF_AUX_BYTES * batch)
+        _check(lib().dr_ringvrf_prove_batch(self.handle, byref(suite), batch, a_blob, a_off, d_blob, d_off, s_blob, s_off, secret_scalars, idx,
+                                            fs_prefix, len(fs_prefix), zk_random48, out, aux))
+        return out.raw, aux.raw
 
 
 class Context:

@@ -13,6 +13,7 @@
 #include "../../include/dotring_hip.h"
 #include "hostmath.hpp"
 #include "hostpairing.hpp"
+#include "hostproto.hpp"
 #include "kernels_bsn.cuh"
 #include "kernels_g1.cuh"
 #include "kernels_ntt.cuh"
@@ -1383,6 +1384,219 @@ int dr_ring_prove_openings(dr_ring_prover* p, size_t batch, const uint8_t* nus, 
         std::memcpy(out_openings + 192 * b + 96, o2.data() + 96 * b, 96);
         if (is_inf) { is_inf[2 * b] = i1[b]; is_inf[2 * b + 1] = i2[b]; }
     }
+    return DR_OK;
+}
+
+// ---- host hashing exposed for tests and callers that batch their own transcripts ----------------------------------
+int dr_host_hash(int kind, const uint8_t* data, size_t len, uint8_t* out, size_t out_len) {
+    if ((len && !data) || !out) return fail(DR_ERR_INVALID, "null buffer");
+    switch (kind) {
+        case DR_HASH_SHA512:
+            if (out_len != 64) return fail(DR_ERR_INVALID, "SHA-512 digests are 64 bytes");
+            drh::Sha512::hash(data, len, out);
+            return DR_OK;
+        case DR_HASH_SHAKE128: { drh::Shake128 s; s.update(data, len); s.digest(out, out_len); return DR_OK; }
+        case DR_HASH_SHAKE256: { drh::Shake256 s; s.update(data, len); s.digest(out, out_len); return DR_OK; }
+    }
+    return fail(DR_ERR_INVALID, "unknown hash kind");
+}
+
+namespace {
+int load_suite(const dr_vrf_suite* s, drh::VrfSuite& out) {
+    if (!s || !s->suite_id || s->suite_id_len == 0 || s->suite_id_len > 200) return fail(DR_ERR_INVALID, "bad VRF suite");
+    out.suite_id.assign(s->suite_id, s->suite_id + s->suite_id_len);
+    out.xof = s->xof != 0;
+    std::memcpy(out.generator, s->generator_xy, 64);
+    std::memcpy(out.blinding_base, s->blinding_base_xy, 64);
+    return DR_OK;
+}
+}  // namespace
+
+int dr_hash_to_field_batch(const dr_vrf_suite* suite, const uint8_t* msgs, const uint64_t* off, size_t count, uint8_t* out_u_pairs) {
+    drh::VrfSuite su;
+    TRY(load_suite(suite, su));
+    if (count && (!off || !out_u_pairs || (off[count] && !msgs))) return fail(DR_ERR_INVALID, "null buffer");
+    for (size_t i = 0; i < count; i++)
+        if (off[i + 1] < off[i]) return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
+    drh::parallel_for(count, [&](size_t i) { drh::hash_to_field2(su, msgs + off[i], off[i + 1] - off[i], out_u_pairs + 64 * i); });
+    return DR_OK;
+}
+
+// The whole batch in one call: Pedersen VRF part (pedersen/vrf.py:86-126) then the ring proof
+// (proof_builder.py:38-315) — GPU phases through the entry points above, the hashing between them on worker threads.
+int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t batch, const uint8_t* alphas, const uint64_t* alpha_off,
+                           const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
+                           const uint8_t* secret_scalars, const uint32_t* producer_index, const uint8_t* fs_prefix, size_t fs_prefix_len,
+                           const uint8_t* zk_random48, uint8_t* out_proofs, uint8_t* out_aux) {
+    if (!p || !alpha_off || !ad_off || !secret_scalars || !producer_index || !fs_prefix || !out_proofs) return fail(DR_ERR_INVALID, "null argument");
+    if (batch == 0) return DR_OK;
+    if (batch > 4096) return fail(DR_ERR_INVALID, "batch must be at most 4096 per call");
+    drh::VrfSuite su;
+    TRY(load_suite(suite, su));
+    for (size_t i = 0; i < batch; i++)
+        if (alpha_off[i + 1] < alpha_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
+            return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
+    dr_ctx* ctx = p->ctx;
+    const drh::Mod256& mn = drh::mod_n();
+    const size_t B = batch;
+
+    // 1. hash_to_field(salt || alpha), secrets mod n
+    std::vector<uint8_t> us(B * 64), xs(B * 32);
+    drh::parallel_for(B, [&](size_t i) {
+        drh::Bytes msg;
+        if (salt_off) drh::put(msg, salts + salt_off[i], salt_off[i + 1] - salt_off[i]);
+        drh::put(msg, alphas + alpha_off[i], alpha_off[i + 1] - alpha_off[i]);
+        drh::hash_to_field2(su, msg.data(), msg.size(), us.data() + 64 * i);
+        uint64_t x[4];
+        mn.reduce_bytes(secret_scalars + 32 * i, 32, false, x);
+        drh::store_le32(x, xs.data() + 32 * i);
+    });
+    // 2. I_i = encode_to_curve, O_i = x_i * I_i
+    std::vector<uint8_t> inputs(B * 64), outs(B * 64);
+    TRY(dr_bsn_encode_to_curve_batch(ctx, us.data(), B, inputs.data()));
+    TRY(dr_bsn_scalar_mul_batch(ctx, inputs.data(), xs.data(), B, outs.data()));
+    // 3. transcripts, blinding factors
+    std::vector<drh::Bytes> tr(B);
+    std::vector<uint8_t> blind(B * 32), gb_pts(B * 128), sc(B * 64);
+    std::vector<int> bad(B, 0);
+    drh::parallel_for(B, [&](size_t i) {
+        drh::Bytes& t = tr[i];
+        t = su.suite_id;
+        drh::put8(t, 0x02);                                    // PEDERSEN_VRF
+        drh::put_le64(t, 1);                                   // one (input, output) pair
+        uint8_t enc[32];
+        drh::enc_te_point(inputs.data() + 64 * i, enc); drh::put(t, enc, 32);
+        drh::enc_te_point(outs.data() + 64 * i, enc); drh::put(t, enc, 32);
+        size_t adl = ad_off[i + 1] - ad_off[i];
+        drh::put_le64(t, adl);
+        drh::put(t, ads + ad_off[i], adl);
+        drh::Bytes tb = t;
+        drh::put8(tb, 0x12);                                   // PEDERSEN_BLINDING
+        uint64_t x[4], b[4];
+        drh::load_le32(xs.data() + 32 * i, x);
+        if (!drh::vrf_nonce(su, tb, x, b)) bad[i] = 1;
+        drh::store_le32(b, blind.data() + 32 * i);
+        std::memcpy(gb_pts.data() + 128 * i, su.generator, 64);
+        std::memcpy(gb_pts.data() + 128 * i + 64, su.blinding_base, 64);
+        std::memcpy(sc.data() + 64 * i, xs.data() + 32 * i, 32);
+        std::memcpy(sc.data() + 64 * i + 32, blind.data() + 32 * i, 32);
+    });
+    for (size_t i = 0; i < B; i++) if (bad[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
+    // 4. blinded public keys  Y_bar_i = x_i*G + b_i*B
+    std::vector<uint8_t> ybar(B * 64);
+    TRY(dr_bsn_msm_groups(ctx, gb_pts.data(), sc.data(), B, 2, ybar.data()));
+    // 5. nonces
+    std::vector<uint8_t> ks(B * 32), kbs(B * 32), pts3(2 * B * 128), sc3(2 * B * 64);
+    drh::parallel_for(B, [&](size_t i) {
+        uint8_t enc[32];
+        drh::enc_te_point(ybar.data() + 64 * i, enc);
+        drh::put(tr[i], enc, 32);
+        uint64_t x[4], b[4], k[4], kb[4];
+        drh::load_le32(xs.data() + 32 * i, x);
+        drh::load_le32(blind.data() + 32 * i, b);
+        if (!drh::vrf_nonce(su, tr[i], x, k) || !drh::vrf_nonce(su, tr[i], b, kb)) bad[i] = 1;
+        drh::store_le32(k, ks.data() + 32 * i);
+        drh::store_le32(kb, kbs.data() + 32 * i);
+        // group i: k*G + kb*B ; group B+i: k*I + 0*I
+        std::memcpy(pts3.data() + 128 * i, su.generator, 64);
+        std::memcpy(pts3.data() + 128 * i + 64, su.blinding_base, 64);
+        std::memcpy(sc3.data() + 64 * i, ks.data() + 32 * i, 32);
+        std::memcpy(sc3.data() + 64 * i + 32, kbs.data() + 32 * i, 32);
+        std::memcpy(pts3.data() + 128 * (B + i), inputs.data() + 64 * i, 64);
+        std::memcpy(pts3.data() + 128 * (B + i) + 64, inputs.data() + 64 * i, 64);
+        std::memcpy(sc3.data() + 64 * (B + i), ks.data() + 32 * i, 32);
+        std::memset(sc3.data() + 64 * (B + i) + 32, 0, 32);
+    });
+    for (size_t i = 0; i < B; i++) if (bad[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
+    std::vector<uint8_t> third(2 * B * 64);
+    TRY(dr_bsn_msm_groups(ctx, pts3.data(), sc3.data(), 2 * B, 2, third.data()));
+    // 6. challenge, responses, Pedersen part of the proof
+    drh::parallel_for(B, [&](size_t i) {
+        uint8_t* out = out_proofs + 784 * i;
+        drh::enc_te_point(outs.data() + 64 * i, out);
+        drh::enc_te_point(ybar.data() + 64 * i, out + 32);
+        drh::enc_te_point(third.data() + 64 * i, out + 64);
+        drh::enc_te_point(third.data() + 64 * (B + i), out + 96);
+        uint64_t c[4], x[4], b[4], k[4], kb[4], s[4], sb[4];
+        drh::vrf_challenge(su, tr[i], out + 64, 2, c);
+        drh::load_le32(xs.data() + 32 * i, x);
+        drh::load_le32(blind.data() + 32 * i, b);
+        drh::load_le32(ks.data() + 32 * i, k);
+        drh::load_le32(kbs.data() + 32 * i, kb);
+        mn.mul(c, x, s);  mn.add(s, k, s);
+        mn.mul(c, b, sb); mn.add(sb, kb, sb);
+        drh::store_le32(s, out + 128);
+        drh::store_le32(sb, out + 160);
+        if (out_aux) {
+            uint8_t* a = out_aux + DR_RINGVRF_AUX_BYTES * i;
+            std::memcpy(a, outs.data() + 64 * i, 64);
+            std::memcpy(a + 64, ybar.data() + 64 * i, 64);
+            std::memcpy(a + 128, third.data() + 64 * i, 64);
+            std::memcpy(a + 192, third.data() + 64 * (B + i), 64);
+            std::memcpy(a + 256, blind.data() + 32 * i, 32);
+        }
+    });
+    tr.clear();
+
+    // 7. ring proof: witness columns
+    std::vector<uint8_t> zk;
+    if (zk_random48) {
+        zk.resize(B * 12 * 32);
+        drh::parallel_for(B * 12, [&](size_t j) {
+            uint64_t v[4];
+            drh::mod_p().reduce_bytes(zk_random48 + 48 * j, 48, false, v);
+            drh::store_le32(v, zk.data() + 32 * j);
+        });
+    }
+    std::vector<uint8_t> relation(B * 64), wit(B * 4 * 96), cq(B * 96), evals(B * 256), opens(B * 192);
+    std::vector<int> wit_inf(B * 4), cq_inf(B), open_inf(B * 2);
+    TRY(dr_ring_prove_witness(p, B, producer_index, blind.data(), zk_random48 ? zk.data() : nullptr, relation.data(), wit.data(), wit_inf.data()));
+    drh::FsTranscript base;
+    base.sh.update(fs_prefix, fs_prefix_len);
+    std::vector<drh::FsTranscript> fs(B, base);
+    std::vector<uint8_t> alphas7(B * 7 * 32), zetas(B * 32), nus(B * 8 * 32);
+    drh::parallel_for(B, [&](size_t i) {
+        fs[i].absorb_labeled("instance", relation.data() + 64 * i, 64);
+        uint8_t ser[4 * 96];
+        for (int c = 0; c < 4; c++) drh::g1_serialized(wit.data() + 96 * (4 * i + c), wit_inf[4 * i + c], ser + 96 * c);
+        fs[i].absorb_labeled("committed_cols", ser, sizeof ser);
+        fs[i].challenges("constraints_aggregation", 7, alphas7.data() + 224 * i);
+    });
+    TRY(dr_ring_prove_quotient(p, B, alphas7.data(), cq.data(), cq_inf.data()));
+    drh::parallel_for(B, [&](size_t i) {
+        uint8_t ser[96];
+        drh::g1_serialized(cq.data() + 96 * i, cq_inf[i], ser);
+        fs[i].absorb_labeled("quotient", ser, 96);
+        fs[i].challenges("evaluation_point", 1, zetas.data() + 32 * i);
+    });
+    TRY(dr_ring_prove_evals(p, B, zetas.data(), evals.data()));
+    drh::parallel_for(B, [&](size_t i) {
+        fs[i].absorb_labeled("register_evaluations", evals.data() + 256 * i, 224);
+        fs[i].absorb_labeled("shifted_linearization_evaluation", evals.data() + 256 * i + 224, 32);
+        fs[i].challenges("kzg_aggregation", 8, nus.data() + 256 * i);
+    });
+    TRY(dr_ring_prove_openings(p, B, nus.data(), opens.data(), open_inf.data()));
+    // 8. payload: 4 compressed commitments, 7 evaluations, C_q, l(zeta*omega), 2 opening proofs  (proof_payload.py:68-117)
+    std::vector<int> rc(B, DR_OK);
+    drh::parallel_for(B, [&](size_t i) {
+        uint8_t* out = out_proofs + 784 * i + 192;
+        int r = DR_OK;
+        for (int c = 0; c < 4 && r == DR_OK; c++) r = dr_g1_compress(wit.data() + 96 * (4 * i + c), wit_inf[4 * i + c], out + 48 * c);
+        std::memcpy(out + 192, evals.data() + 256 * i, 224);
+        if (r == DR_OK) r = dr_g1_compress(cq.data() + 96 * i, cq_inf[i], out + 416);
+        std::memcpy(out + 464, evals.data() + 256 * i + 224, 32);
+        if (r == DR_OK) r = dr_g1_compress(opens.data() + 192 * i, open_inf[2 * i], out + 496);
+        if (r == DR_OK) r = dr_g1_compress(opens.data() + 192 * i + 96, open_inf[2 * i + 1], out + 544);
+        rc[i] = r;
+        if (out_aux) {
+            uint8_t* a = out_aux + DR_RINGVRF_AUX_BYTES * i + 288;
+            for (int c = 0; c < 4; c++) drh::g1_serialized(wit.data() + 96 * (4 * i + c), wit_inf[4 * i + c], a + 96 * c);
+            drh::g1_serialized(cq.data() + 96 * i, cq_inf[i], a + 384);
+            drh::g1_serialized(opens.data() + 192 * i, open_inf[2 * i], a + 480);
+            drh::g1_serialized(opens.data() + 192 * i + 96, open_inf[2 * i + 1], a + 576);
+        }
+    });
+    for (size_t i = 0; i < B; i++) if (rc[i] != DR_OK) return rc[i];
     return DR_OK;
 }
 

@@ -1,0 +1,285 @@
+// Host-side protocol glue of the batched Ring-VRF prover: everything the reference does in interpreted Python
+// BETWEEN the GPU phases of a proof — hash_to_field, the VRF transcript (nonces, challenge), the ring proof's
+// Fiat-Shamir transcript, scalar arithmetic mod the group order, the byte encodings — for a whole batch at once on
+// worker threads.  Follows, as text:
+//   hash_to_field / expand_message_xmd       dot_ring/curve/curve.py:110-185 (Z_pad = 48 zero bytes in this suite)
+//   VRF transcript, nonce, challenge         dot_ring/vrf/primitives.py:26-122
+//   Pedersen prove                           dot_ring/vrf/pedersen/vrf.py:86-126
+//   Fiat-Shamir transcript + phases          dot_ring/ring_proof/transcript/transcript.py:21-136, phases.py:18-69
+//   point / scalar codecs                    dot_ring/vrf/codec.py:9-45, dot_ring/curve/point.py:150-214
+#pragma once
+#include <algorithm>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "hosthash.hpp"
+#include "hostmath.hpp"
+
+namespace drh {
+
+// ---------------------------------------------------------------- worker threads
+inline unsigned host_threads() {
+    static unsigned cached = [] {
+        const char* e = std::getenv("DOTRING_HOST_THREADS");
+        unsigned n = e ? (unsigned)std::atoi(e) : 0;
+        if (n == 0) {
+            n = std::thread::hardware_concurrency();
+            if (n == 0) n = 1;
+            if (n > 16) n = 16;
+        }
+        return n;
+    }();
+    return cached;
+}
+// f(i) for i in [0, n); f must not throw.  Short loops stay on the calling thread.
+template <class F>
+void parallel_for(size_t n, F f) {
+    unsigned t = host_threads();
+    if (t > n / 16) t = (unsigned)(n / 16);
+    if (t <= 1) {
+        for (size_t i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(t);
+    for (unsigned k = 0; k < t; k++)
+        pool.emplace_back([=] {
+            size_t lo = n * k / t, hi = n * (k + 1) / t;
+            for (size_t i = lo; i < hi; i++) f(i);
+        });
+    for (auto& th : pool) th.join();
+}
+
+// ---------------------------------------------------------------- arithmetic modulo a runtime odd 256-bit modulus
+struct Mod256 {
+    uint64_t m[4], r2[4], n0;
+
+    static bool geq(const uint64_t* a, const uint64_t* b) {
+        for (int i = 3; i >= 0; i--) { if (a[i] > b[i]) return true; if (a[i] < b[i]) return false; }
+        return true;
+    }
+    void add(const uint64_t* a, const uint64_t* b, uint64_t* r) const {
+        u128 c = 0; uint64_t t[4];
+        for (int i = 0; i < 4; i++) { c += (u128)a[i] + b[i]; t[i] = (uint64_t)c; c >>= 64; }
+        if (c || geq(t, m)) { uint64_t bw = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)t[i] - m[i] - bw; t[i] = (uint64_t)d; bw = (uint64_t)(d >> 127); } }
+        std::memcpy(r, t, 32);
+    }
+    void sub(const uint64_t* a, const uint64_t* b, uint64_t* r) const {
+        uint64_t t[4], bw = 0;
+        for (int i = 0; i < 4; i++) { u128 d = (u128)a[i] - b[i] - bw; t[i] = (uint64_t)d; bw = (uint64_t)(d >> 127); }
+        if (bw) { u128 c = 0; for (int i = 0; i < 4; i++) { c += (u128)t[i] + m[i]; t[i] = (uint64_t)c; c >>= 64; } }
+        std::memcpy(r, t, 32);
+    }
+    void mont(const uint64_t* a, const uint64_t* b, uint64_t* r) const {      // a*b/R mod m
+        uint64_t t[6] = {0};
+        for (int i = 0; i < 4; i++) {
+            uint64_t c = 0;
+            for (int j = 0; j < 4; j++) { u128 p = (u128)a[j] * b[i] + t[j] + c; t[j] = (uint64_t)p; c = (uint64_t)(p >> 64); }
+            u128 top = (u128)t[4] + c; t[4] = (uint64_t)top; t[5] = (uint64_t)(top >> 64);
+            uint64_t q = t[0] * n0;
+            u128 p = (u128)q * m[0] + t[0]; c = (uint64_t)(p >> 64);
+            for (int j = 1; j < 4; j++) { p = (u128)q * m[j] + t[j] + c; t[j - 1] = (uint64_t)p; c = (uint64_t)(p >> 64); }
+            top = (u128)t[4] + c; t[3] = (uint64_t)top; t[4] = t[5] + (uint64_t)(top >> 64);
+        }
+        if (t[4] || geq(t, m)) { uint64_t bw = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)t[i] - m[i] - bw; t[i] = (uint64_t)d; bw = (uint64_t)(d >> 127); } }
+        std::memcpy(r, t, 32);
+    }
+    void mul(const uint64_t* a, const uint64_t* b, uint64_t* r) const {       // standard form in and out
+        uint64_t t[4];
+        mont(a, b, t);
+        mont(t, r2, r);
+    }
+    void init(const uint64_t mod[4]) {
+        std::memcpy(m, mod, 32);
+        uint64_t inv = 1;
+        for (int i = 0; i < 6; i++) inv *= 2 - m[0] * inv;       // m^-1 mod 2^64
+        n0 = (uint64_t)0 - inv;
+        uint64_t t[4] = {1, 0, 0, 0};
+        for (int i = 0; i < 512; i++) add(t, t, t);              // 2^512 mod m = R^2
+        std::memcpy(r2, t, 32);
+    }
+    // big-endian or little-endian byte string of any length -> value mod m
+    void reduce_bytes(const uint8_t* p, size_t len, bool big_endian, uint64_t out[4]) const {
+        uint64_t acc[4] = {0, 0, 0, 0};
+        const uint64_t shift[4] = {0, 1, 0, 0};                  // 2^64
+        size_t limbs = (len + 7) / 8;
+        for (size_t k = limbs; k-- > 0;) {                       // most significant limb first
+            uint64_t w = 0;
+            for (int j = 7; j >= 0; j--) {
+                size_t idx = 8 * k + j;                          // little-endian byte index
+                if (idx >= len) continue;
+                w = (w << 8) | (big_endian ? p[len - 1 - idx] : p[idx]);
+            }
+            uint64_t limb[4] = {w, 0, 0, 0};
+            mul(acc, shift, acc);
+            add(acc, limb, acc);
+        }
+        std::memcpy(out, acc, 32);
+    }
+    bool is_zero(const uint64_t* a) const { return (a[0] | a[1] | a[2] | a[3]) == 0; }
+};
+inline void store_le32(const uint64_t v[4], uint8_t* out) {
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(v[i] >> (8 * j));
+}
+inline void load_le32(const uint8_t* in, uint64_t v[4]) {
+    for (int i = 0; i < 4; i++) { uint64_t w = 0; for (int j = 7; j >= 0; j--) w = (w << 8) | in[8 * i + j]; v[i] = w; }
+}
+inline const Mod256& mod_n() {       // Bandersnatch prime-order subgroup (bandersnatch.py:58-67)
+    static Mod256 s = [] { Mod256 t; const uint64_t n[4] = {0x74fd06b52876e7e1ULL, 0xff8f870074190471ULL, 0x0cce760202687600ULL, 0x1cfb69d4ca675f52ULL}; t.init(n); return t; }();
+    return s;
+}
+inline const Mod256& mod_p() {       // Bandersnatch base field = BLS12-381 scalar field
+    static Mod256 s = [] { Mod256 t; t.init(FieldParams<4>::P); return t; }();
+    return s;
+}
+
+// ---------------------------------------------------------------- byte helpers
+using Bytes = std::vector<uint8_t>;
+inline void put(Bytes& b, const void* p, size_t n) { const uint8_t* q = (const uint8_t*)p; b.insert(b.end(), q, q + n); }
+inline void put8(Bytes& b, uint8_t v) { b.push_back(v); }
+inline void put_le64(Bytes& b, uint64_t v) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (8 * i))); }
+
+// compressed Twisted-Edwards point: y little-endian, bit 255 set iff x > p - x  (point.py:150-214)
+inline void enc_te_point(const uint8_t xy[64], uint8_t out[32]) {
+    uint64_t x[4], nx[4], zero[4] = {0, 0, 0, 0};
+    load_le32(xy, x);
+    mod_p().sub(zero, x, nx);
+    std::memcpy(out, xy + 32, 32);
+    bool gt = false;
+    for (int i = 3; i >= 0; i--) { if (x[i] != nx[i]) { gt = x[i] > nx[i]; break; } }
+    if (gt) out[31] |= 0x80;
+}
+
+// ---------------------------------------------------------------- VRF transcript (primitives.py:26-55)
+struct VrfSuite {
+    Bytes suite_id;
+    bool xof;                 // SHAKE128 suite; otherwise SHA-512 counter mode
+    uint8_t generator[64], blinding_base[64];
+};
+// squeeze `size` bytes of the stream defined by everything absorbed
+inline void vrf_squeeze(bool xof, const uint8_t* absorbed, size_t len, uint8_t* out, size_t size) {
+    if (xof) {
+        Shake128 s;
+        s.update(absorbed, len);
+        s.digest(out, size);
+        return;
+    }
+    uint8_t seed[72], blk[64];
+    Sha512::hash(absorbed, len, seed);
+    for (size_t off = 0, ctr = 0; off < size; off += 64, ctr++) {
+        for (int i = 0; i < 8; i++) seed[64 + i] = (uint8_t)((uint64_t)ctr >> (8 * i));
+        Sha512::hash(seed, 72, blk);
+        std::memcpy(out + off, blk, std::min<size_t>(64, size - off));
+    }
+}
+// primitives.py:61-79: nonce from a secret scalar and a copy of the transcript; false if the result is zero
+inline bool vrf_nonce(const VrfSuite& su, const Bytes& transcript, const uint64_t secret[4], uint64_t out[4]) {
+    Bytes t = transcript;
+    put8(t, 0x10);                                   // NONCE_EXPAND
+    uint8_t sk[32], exp[64], raw[48];
+    store_le32(secret, sk);
+    put(t, sk, 32);
+    vrf_squeeze(su.xof, t.data(), t.size(), exp, 64);
+    t = transcript;
+    put8(t, 0x11);                                   // NONCE
+    put(t, exp, 64);
+    vrf_squeeze(su.xof, t.data(), t.size(), raw, 48);   // ceil((253 + 128) / 8)
+    mod_n().reduce_bytes(raw, 48, false, out);
+    return !mod_n().is_zero(out);
+}
+// primitives.py:82-88: 128-bit challenge over the given compressed points
+inline void vrf_challenge(const VrfSuite& su, const Bytes& transcript, const uint8_t* enc_points, size_t count, uint64_t out[4]) {
+    Bytes t = transcript;
+    put8(t, 0x40);                                   // CHALLENGE
+    put(t, enc_points, 32 * count);
+    uint8_t raw[16];
+    vrf_squeeze(su.xof, t.data(), t.size(), raw, 16);
+    mod_n().reduce_bytes(raw, 16, false, out);
+}
+
+// curve.py:110-185 hash_to_field(msg, 2): two field elements, 32-byte little-endian each
+inline void hash_to_field2(const VrfSuite& su, const uint8_t* msg, size_t len, uint8_t out[64]) {
+    Bytes dst = su.suite_id;
+    put8(dst, 0x60);                                 // HASH_TO_CURVE
+    put8(dst, (uint8_t)dst.size());                  // DST_prime = DST || len(DST)
+    const size_t L = 96;
+    uint8_t raw[128];
+    if (su.xof) {
+        Shake128 s;
+        s.update(msg, len);
+        const uint8_t lb[2] = {0, (uint8_t)L};
+        s.update(lb, 2);
+        s.update(dst.data(), dst.size());
+        s.digest(raw, L);
+    } else {
+        uint8_t b0[64], zpad[48] = {0};
+        Sha512 h;
+        h.update(zpad, 48);                          // this suite's Z_pad is 48 bytes, not SHA-512's block size
+        h.update(msg, len);
+        const uint8_t lb[3] = {0, (uint8_t)L, 0};
+        h.update(lb, 3);
+        h.update(dst.data(), dst.size());
+        h.final(b0);
+        uint8_t prev[64];
+        for (int i = 1; i <= 2; i++) {
+            Sha512 g;
+            uint8_t x[64];
+            for (int j = 0; j < 64; j++) x[j] = i == 1 ? b0[j] : (uint8_t)(b0[j] ^ prev[j]);
+            g.update(x, 64);
+            uint8_t ib = (uint8_t)i;
+            g.update(&ib, 1);
+            g.update(dst.data(), dst.size());
+            g.final(prev);
+            std::memcpy(raw + 64 * (i - 1), prev, 64);
+        }
+    }
+    for (int k = 0; k < 2; k++) {
+        uint64_t v[4];
+        mod_p().reduce_bytes(raw + 48 * k, 48, true, v);
+        store_le32(v, out + 32 * k);
+    }
+}
+
+// ---------------------------------------------------------------- ring-proof Fiat-Shamir transcript (transcript.py:21-136)
+struct FsTranscript {
+    Shake128 sh;
+    static void be32(uint32_t v, uint8_t o[4]) { o[0] = (uint8_t)(v >> 24); o[1] = (uint8_t)(v >> 16); o[2] = (uint8_t)(v >> 8); o[3] = (uint8_t)v; }
+    void framed(const char* label) {
+        size_t n = std::strlen(label);
+        uint8_t l[4];
+        be32((uint32_t)n, l);
+        sh.update(label, n);
+        sh.update(l, 4);
+    }
+    void absorb_labeled(const char* label, const uint8_t* data, size_t len) {
+        framed(label);
+        uint8_t l[4];
+        be32((uint32_t)len, l);
+        sh.update(data, len);
+        sh.update(l, 4);
+    }
+    // n challenges: 48 squeezed bytes, big-endian, mod p; out = n little-endian 32-byte values
+    void challenges(const char* label, int n, uint8_t* out) {
+        static const uint8_t footer[4] = {0, 0, 0, 9};
+        for (int i = 0; i < n; i++) {
+            if (i > 0) sh.update(footer, 4);
+            framed(label);
+            sh.update("challenge", 9);
+            uint8_t raw[48];
+            sh.digest(raw, 48);
+            uint64_t v[4];
+            mod_p().reduce_bytes(raw, 48, true, v);
+            store_le32(v, out + 32 * i);
+        }
+        sh.update(footer, 4);
+    }
+};
+
+// 96-byte BE x||y record (or infinity) -> serialize() form: infinity = 0x40 || zeros  (kzg.py:133)
+inline void g1_serialized(const uint8_t rec[96], int is_inf, uint8_t out[96]) {
+    if (is_inf) { std::memset(out, 0, 96); out[0] = 0x40; } else std::memcpy(out, rec, 96);
+}
+
+}  // namespace drh

@@ -2,9 +2,11 @@
 from __future__ import annotations
 
 import os
+import secrets
 from dataclasses import dataclass
 from functools import lru_cache
 
+from .. import _native
 from ..curve import valid_points
 from ..ring_proof.columns import Column
 from ..ring_proof.params import RingProofParams
@@ -132,17 +134,27 @@ class RingRoot:
     def fixed_commitments(self) -> list:
         return [self.px.commitment, self.py.commitment, self.s.commitment]
 
-    def verifier_transcript_prefix(self, transcript_challenge: bytes | None = None) -> FiatShamirTranscript:
+    def _verifier_key(self) -> bytes:
         if self.params is None:
             raise ValueError("Ring root verifier transcript requires ring proof parameters")
         pcs = self.params.pcs
         srs = pcs._srs() if hasattr(pcs, "_srs") else pcs.srs
-        vk = serialize_verifier_key(srs.g1_raw[:96], srs.g2_raw, [pcs.serialize_g1_uncompressed(c) for c in self.fixed_commitments()])
+        return serialize_verifier_key(srs.g1_raw[:96], srs.g2_raw, [pcs.serialize_g1_uncompressed(c) for c in self.fixed_commitments()])
+
+    def verifier_transcript_prefix(self, transcript_challenge: bytes | None = None) -> FiatShamirTranscript:
+        vk = self._verifier_key()
         if transcript_challenge is None:
             transcript_challenge = self.params.cv.curve.params.suite_id
         t = FiatShamirTranscript(self.params.prime, transcript_challenge)
         t.absorb_labeled(b"vk", vk)
         return t
+
+    def verifier_transcript_prefix_bytes(self, transcript_challenge: bytes | None = None) -> bytes:
+        """The byte stream verifier_transcript_prefix() has absorbed (input of the native batch prover)."""
+        vk = self._verifier_key()
+        label = transcript_challenge if transcript_challenge is not None else self.params.cv.curve.params.suite_id
+        be = lambda v: len(v).to_bytes(4, "big")
+        return label + be(label) + b"vk" + be(b"vk") + vk + be(vk)
 
     @staticmethod
     def encoded_len(params: RingProofParams | None = None) -> int:
@@ -207,6 +219,38 @@ class RingVRF(VRF):
     open_agg_zeta: object
     open_l_zeta_omega: object
 
+    _FIELDS = ("pedersen_proof", "c_b", "c_accip", "c_accx", "c_accy", "px_zeta", "py_zeta", "s_zeta", "b_zeta", "accip_zeta",
+               "accx_zeta", "accy_zeta", "c_q", "l_zeta_omega", "open_agg_zeta", "open_l_zeta_omega")
+
+    @classmethod
+    def _from_native(cls, raw: bytes, aux: bytes) -> "RingVRF":
+        """Proof produced by dr_ringvrf_prove_batch: keeps the 784 encoded bytes; the object fields are built from the
+        auxiliary record (affine points, uncompressed commitments) the first time one of them is read."""
+        self = object.__new__(cls)
+        self.__dict__["_raw"] = raw
+        self.__dict__["_aux"] = aux
+        return self
+
+    def __getattr__(self, name):
+        d = self.__dict__
+        if name not in RingVRF._FIELDS or "_aux" not in d:
+            raise AttributeError(name)
+        raw, aux = d["_raw"], d.pop("_aux")
+        cv = self.cv
+        pt = lambda i: cv.point_type._trusted(int.from_bytes(aux[64 * i : 64 * i + 32], "little"), int.from_bytes(aux[64 * i + 32 : 64 * i + 64], "little"))
+        le = lambda off: int.from_bytes(raw[off : off + 32], "little")
+        d["pedersen_proof"] = PedersenVRF[cv](output_point=pt(0), blinded_pk=pt(1), result_point=pt(2), ok=pt(3), s=le(128), sb=le(160),
+                                             _blinding_factor=int.from_bytes(aux[256:288], "little"))
+        g1 = lambda i: None if aux[288 + 96 * i] & 0x40 else aux[288 + 96 * i : 384 + 96 * i]
+        for i, nm in enumerate(("c_b", "c_accip", "c_accx", "c_accy")):
+            d[nm] = Column(nm, [], _commitment=g1(i), _has_commitment=True)
+        for i, nm in enumerate(("px_zeta", "py_zeta", "s_zeta", "b_zeta", "accip_zeta", "accx_zeta", "accy_zeta")):
+            d[nm] = le(384 + 32 * i)
+        d["c_q"] = Column("C_q", [], _commitment=g1(4), _has_commitment=True)
+        d["l_zeta_omega"] = le(656)
+        d["open_agg_zeta"], d["open_l_zeta_omega"] = g1(5), g1(6)
+        return d[name]
+
     @classmethod
     def _payload_len(cls, params) -> int:
         return 7 * params.pcs.commitment_size + 8 * RING_SCALAR_LEN
@@ -216,6 +260,9 @@ class RingVRF(VRF):
         return PedersenVRF[cls.cv].proof_len() + cls._payload_len(RingProofParams(cv=cls.cv))
 
     def encode(self) -> bytes:
+        raw = self.__dict__.get("_raw")
+        if raw is not None:
+            return raw
         pcs = RingProofParams(cv=self.cv).pcs
         le = lambda v: int(v).to_bytes(RING_SCALAR_LEN, "little")
         return (self.pedersen_proof.encode()
@@ -307,6 +354,8 @@ class RingVRF(VRF):
         if pipeline is None:
             pipeline = int(os.environ.get("DOTRING_PROVE_PIPELINE", "1"))
         pipeline = max(1, min(pipeline, count))
+        if pipeline == 1 and device_prover.supported(ring.params) and os.environ.get("DOTRING_NATIVE_HOST", "1") != "0":
+            return cls._prove_batch_native(alphas, additional_data, secret_keys, producer_keys, ring, root, salts)
         if device_prover.supported(ring.params):
             for slot in range(pipeline):
                 device_prover.get_device_prover(ring, slot)                    # per-ring tables, built outside the pipeline
@@ -316,6 +365,29 @@ class RingVRF(VRF):
             cls._prove_gen(alphas[lo:hi], additional_data[lo:hi], secret_keys[lo:hi], producer_keys[lo:hi], ring, root, salts_[lo:hi], slot)
             for slot, (lo, hi) in enumerate(zip(cuts, cuts[1:])))
         return [proof for part in parts for proof in part]
+
+    @classmethod
+    def _prove_batch_native(cls, alphas, additional_data, secret_keys, producer_keys, ring, root, salts) -> list:
+        """The batch through dr_ringvrf_prove_batch: transcripts hashed on the library's worker threads between the GPU
+        phases; this method only marshals the inputs and wraps the 784-byte results."""
+        cv = cls.cv
+        sp = cv.curve.params
+        le = lambda v: int(v).to_bytes(32, "little")
+        gen, bb = sp.generator, sp.auxiliary_points.blinding_base
+        suite = _native.vrf_suite(sp.suite_id, sp.xof, le(gen[0]) + le(gen[1]), le(bb[0]) + le(bb[1]))
+        indices = ring.indices_of(producer_keys)
+        prefix = root.verifier_transcript_prefix_bytes()
+        out = []
+        for lo in range(0, len(alphas), device_prover.MAX_DEVICE_BATCH):
+            hi = min(len(alphas), lo + device_prover.MAX_DEVICE_BATCH)
+            zk = None if ring.params.test_vectors else secrets.token_bytes(48 * 12 * (hi - lo))
+            raw, aux = device_prover.get_device_prover(ring, 0).ringvrf_prove_batch(
+                suite, alphas[lo:hi], additional_data[lo:hi], salts[lo:hi] if salts else None,
+                b"".join(bytes(sk) if len(sk) == 32 else le(int.from_bytes(sk, "little") % sp.subgroup_order) for sk in secret_keys[lo:hi]),
+                indices[lo:hi], prefix, zk)
+            ab = _native.RINGVRF_AUX_BYTES
+            out.extend(cls._from_native(raw[784 * i : 784 * i + 784], aux[ab * i : ab * i + ab]) for i in range(hi - lo))
+        return out
 
     @classmethod
     def prove(cls, alpha: bytes, additional_data: bytes, secret_key: bytes, producer_key: bytes, ring: Ring,

@@ -184,6 +184,46 @@ DR_API int dr_ring_prove_quotient(dr_ring_prover *p, size_t batch, const uint8_t
 DR_API int dr_ring_prove_evals(dr_ring_prover *p, size_t batch, const uint8_t *zetas, uint8_t *out_evals);
 DR_API int dr_ring_prove_openings(dr_ring_prover *p, size_t batch, const uint8_t *nus, uint8_t *out_openings, int *is_inf);
 
+
+/* ---- native batch orchestration ------------------------------------------------------------------
+ * The reference runs the hashing between the arithmetic steps of a proof in interpreted Python (hashlib):
+ * hash_to_field (dot_ring/curve/curve.py:110-185), the VRF transcript / nonces / challenge
+ * (dot_ring/vrf/primitives.py:26-122, pedersen/vrf.py:86-126) and the ring proof's Fiat-Shamir transcript
+ * (ring_proof/transcript/transcript.py:21-136, phases.py:18-69).  For a batch that is ~40 small hashes per proof; here
+ * they run on worker threads (DOTRING_HOST_THREADS, default min(16, cores)) inside ONE call per batch, with the GPU
+ * phases above in between.  Results are byte-identical to prove() called per proof.
+ */
+enum { DR_HASH_SHA512 = 0, DR_HASH_SHAKE128 = 1, DR_HASH_SHAKE256 = 2 };
+DR_API int dr_host_hash(int kind, const uint8_t *data, size_t len, uint8_t *out, size_t out_len);
+
+typedef struct dr_vrf_suite {
+    const uint8_t *suite_id;        /* e.g. "Bandersnatch-SHA512-ELL2-v1" (bandersnatch.py:74-87) */
+    size_t suite_id_len;
+    int xof;                        /* 1: SHAKE128 suite, 0: SHA-512 (counter-mode squeeze, expand_message_xmd) */
+    uint8_t generator_xy[64];       /* group generator, x||y little-endian */
+    uint8_t blinding_base_xy[64];   /* Pedersen blinding base (bandersnatch.py:89-102) */
+} dr_vrf_suite;
+
+/* hash_to_field(msg, 2) for `count` messages msgs[off[i]..off[i+1]): out = count * 2 field elements (32-byte LE),
+ * the input format of dr_bsn_encode_to_curve_batch. */
+DR_API int dr_hash_to_field_batch(const dr_vrf_suite *suite, const uint8_t *msgs, const uint64_t *off /* count+1 */, size_t count,
+                                  uint8_t *out_u_pairs);
+
+/* RingVRF.prove for `batch` (<= 4096) proofs over the prover's ring: out_proofs = batch * 784 bytes
+ * (Pedersen 192 || ring payload 592, dot_ring/vrf/ring/vrf.py:51-58).  alphas/ads/salts are concatenated with
+ * (batch+1) offsets (salts may be NULL); secret_scalars batch*32 LE; producer_index = position of each signer's key in
+ * the ring; fs_prefix = the bytes the ring-proof transcript has absorbed before "instance" (initial label and verifier
+ * key, vrf/ring/root.py:54-72); zk_random48 = batch*12 48-byte random strings for the hidden rows (reduced mod p
+ * here), or NULL for the deterministic test-vector mode.  out_aux (nullable, batch * DR_RINGVRF_AUX_BYTES): per proof
+ * the affine Pedersen points O, Y_bar, R, O_k (4*64), the blinding factor (32) and the seven G1 commitments
+ * serialised uncompressed (7*96: C_b, C_accip, C_accx, C_accy, C_q, Phi_zeta, Phi_zeta_omega). */
+#define DR_RINGVRF_AUX_BYTES 960
+DR_API int dr_ringvrf_prove_batch(dr_ring_prover *p, const dr_vrf_suite *suite, size_t batch, const uint8_t *alphas,
+                                  const uint64_t *alpha_off, const uint8_t *ads, const uint64_t *ad_off, const uint8_t *salts,
+                                  const uint64_t *salt_off, const uint8_t *secret_scalars, const uint32_t *producer_index,
+                                  const uint8_t *fs_prefix, size_t fs_prefix_len, const uint8_t *zk_random48, uint8_t *out_proofs,
+                                  uint8_t *out_aux);
+
 #ifdef __cplusplus
 }
 #endif

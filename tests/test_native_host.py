@@ -1,0 +1,29 @@
+"""CPU: the library's host-side hashing (SHA-512, SHAKE128/256, hash_to_field) against hashlib and the oracle.
+These entry points need no GPU."""
+import hashlib
+import random
+
+from dot_ring_amd import _native
+from oracle.pyref import bandersnatch as obsn
+
+
+def test_host_hashes_match_hashlib():
+    rng = random.Random(1)
+    for ln in [0, 1, 55, 111, 112, 113, 127, 128, 129, 135, 136, 137, 167, 168, 169, 200, 335, 336, 337, 1000, 5000]:
+        data = bytes(rng.randrange(256) for _ in range(ln))
+        assert _native.host_hash(0, data, 64) == hashlib.sha512(data).digest()
+        for ol in (1, 16, 48, 64, 135, 136, 137, 167, 168, 169, 400):
+            assert _native.host_hash(1, data, ol) == hashlib.shake_128(data).digest(ol)
+            assert _native.host_hash(2, data, ol) == hashlib.shake_256(data).digest(ol)
+
+
+def test_hash_to_field_batch_matches_oracle():
+    le = lambda v: int(v).to_bytes(32, "little")
+    msgs = [b"", b"abc", b"\x00" * 300] + [hashlib.sha256(bytes([i])).digest() * (i % 5) for i in range(40)]
+    for suite in (obsn.SHA512, obsn.SHAKE128):
+        s = _native.vrf_suite(suite.suite_id, suite.xof, le(obsn.G[0]) + le(obsn.G[1]), le(suite.blinding_base[0]) + le(suite.blinding_base[1]))
+        got = _native.hash_to_field_batch(s, msgs)
+        for i, m in enumerate(msgs):
+            u0, u1 = obsn.hash_to_field(suite, m, 2)
+            assert got[64 * i : 64 * i + 64] == le(u0) + le(u1)
+    assert _native.hash_to_field_batch(s, []) == b""
