@@ -79,7 +79,17 @@ class VrfSuiteStruct(ctypes.Structure):
                 ("generator_xy", ctypes.c_uint8 * 64), ("blinding_base_xy", ctypes.c_uint8 * 64)]
 
 
+class RingVerifierKeyStruct(ctypes.Structure):
+    """dr_ring_verifier_key (include/dotring_hip.h)."""
+    _fields_ = [("log2n", ctypes.c_uint), ("omega_n", ctypes.c_uint8 * 32), ("seed_xy", ctypes.c_uint8 * 64),
+                ("fixed_commitments", ctypes.c_uint8 * 288), ("g1_generator", ctypes.c_uint8 * 96), ("g2", ctypes.c_uint8 * 384),
+                ("fs_prefix", c_char_p), ("fs_prefix_len", c_size_t)]
+
+
 _PROTOTYPES.update({
+    "dr_ringvrf_verify_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), POINTER(RingVerifierKeyStruct), c_size_t, c_char_p, c_char_p,
+                                        POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64),
+                                        c_char_p, POINTER(c_int)]),
     "dr_host_hash": (c_int, [c_int, c_char_p, c_size_t, c_char_p, c_size_t]),
     "dr_hash_to_field_batch": (c_int, [POINTER(VrfSuiteStruct), c_char_p, POINTER(ctypes.c_uint64), c_size_t, c_char_p]),
     "dr_ringvrf_prove_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_size_t, c_char_p, POINTER(ctypes.c_uint64), c_char_p,
@@ -107,6 +117,20 @@ def vrf_suite(suite_id: bytes, xof: bool, generator_xy: bytes, blinding_base_xy:
     ctypes.memmove(s.generator_xy, generator_xy, 64)
     ctypes.memmove(s.blinding_base_xy, blinding_base_xy, 64)
     return s
+
+
+def ring_verifier_key(log2n: int, omega_n: int, seed_xy: bytes, fixed_commitments: bytes, g1_generator: bytes, g2: bytes,
+                      fs_prefix: bytes) -> RingVerifierKeyStruct:
+    vk = RingVerifierKeyStruct()
+    vk.log2n = log2n
+    ctypes.memmove(vk.omega_n, int(omega_n).to_bytes(32, "little"), 32)
+    ctypes.memmove(vk.seed_xy, seed_xy, 64)
+    ctypes.memmove(vk.fixed_commitments, fixed_commitments, 288)
+    ctypes.memmove(vk.g1_generator, g1_generator, 96)
+    ctypes.memmove(vk.g2, g2, 384)
+    vk._keep = bytes(fs_prefix)
+    vk.fs_prefix, vk.fs_prefix_len = vk._keep, len(vk._keep)
+    return vk
 
 
 def host_hash(kind: int, data: bytes, out_len: int) -> bytes:
@@ -366,6 +390,19 @@ class Context:
     def srs_synthetic(self, seed_be_xy: bytes, count: int, first: int = 1) -> Srs:
         """bases[i] = (first+i) * seed, generated on the GPU."""
         return Srs(self, synthetic_seed=seed_be_xy, first=first, count=count)
+
+    def ringvrf_verify_batch(self, suite: "VrfSuiteStruct", vk: "RingVerifierKeyStruct", proofs: bytes, inputs, ads, salts, seed32: bytes) -> bool:
+        """dr_ringvrf_verify_batch over 784-byte encoded proofs (<= 4096 per call)."""
+        batch = len(inputs)
+        if len(proofs) != 784 * batch:
+            raise ValueError("proofs must be 784 bytes each")
+        i_blob, i_off = _ragged(inputs)
+        d_blob, d_off = _ragged(ads)
+        s_blob, s_off = (None, None) if not salts or not any(salts) else _ragged(salts)
+        ok = c_int(0)
+        _check(lib().dr_ringvrf_verify_batch(self.handle, byref(suite), byref(vk), batch, proofs, i_blob, i_off, d_blob, d_off, s_blob, s_off,
+                                             seed32, byref(ok)))
+        return bool(ok.value)
 
     def srs_powers(self, base_be_xy: bytes, tau: int, count: int) -> Srs:
         """bases[i] = tau^i * base (known-tau SRS for tests/benchmarks beyond the shipped file), generated on the GPU."""

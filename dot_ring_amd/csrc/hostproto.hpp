@@ -119,6 +119,27 @@ struct Mod256 {
         std::memcpy(out, acc, 32);
     }
     bool is_zero(const uint64_t* a) const { return (a[0] | a[1] | a[2] | a[3]) == 0; }
+    void pow(const uint64_t* a, const uint64_t e[4], uint64_t* r) const {     // standard form
+        uint64_t acc[4] = {1, 0, 0, 0}, base[4];
+        std::memcpy(base, a, 32);
+        bool started = false;
+        for (int i = 3; i >= 0; i--)
+            for (int b = 63; b >= 0; b--) {
+                if (started) mul(acc, acc, acc);
+                if ((e[i] >> b) & 1) { if (started) mul(acc, base, acc); else std::memcpy(acc, base, 32); started = true; }
+            }
+        std::memcpy(r, acc, 32);
+    }
+    void inv(const uint64_t* a, uint64_t* r) const {                          // a^(m-2); 0 -> 0
+        uint64_t e[4];
+        std::memcpy(e, m, 32);
+        uint64_t bw = 2;
+        for (int i = 0; i < 4 && bw; i++) { uint64_t old = e[i]; e[i] -= bw; bw = old < bw ? 1 : 0; }
+        pow(a, e, r);
+    }
+    void neg(const uint64_t* a, uint64_t* r) const { const uint64_t z[4] = {0, 0, 0, 0}; sub(z, a, r); }
+    void set_u64(uint64_t v, uint64_t* r) const { r[0] = v; r[1] = r[2] = r[3] = 0; }
+    static bool eq(const uint64_t* a, const uint64_t* b) { return ((a[0] ^ b[0]) | (a[1] ^ b[1]) | (a[2] ^ b[2]) | (a[3] ^ b[3])) == 0; }
 };
 inline void store_le32(const uint64_t v[4], uint8_t* out) {
     for (int i = 0; i < 4; i++) for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(v[i] >> (8 * j));
@@ -150,6 +171,27 @@ inline void enc_te_point(const uint8_t xy[64], uint8_t out[32]) {
     bool gt = false;
     for (int i = 3; i >= 0; i--) { if (x[i] != nx[i]) { gt = x[i] > nx[i]; break; } }
     if (gt) out[31] |= 0x80;
+}
+
+// affine twisted-Edwards addition on Bandersnatch (a = -5): the verifier's seed + relation (ring/vrf.py:239-283)
+inline void te_add_affine(const uint8_t p1[64], const uint8_t p2[64], uint8_t out[64]) {
+    static const uint64_t D[4] = {0xb369f2f5188d58e7ULL, 0xcb66677177e54f92ULL, 0xc66e3bf86be3b6d8ULL, 0x6389c12633c267cbULL};
+    const Mod256& f = mod_p();
+    uint64_t x1[4], y1[4], x2[4], y2[4], a[4], b[4], c[4], e[4], t[4], one[4], five[4];
+    load_le32(p1, x1); load_le32(p1 + 32, y1); load_le32(p2, x2); load_le32(p2 + 32, y2);
+    f.set_u64(1, one); f.set_u64(5, five);
+    f.mul(x1, x2, a);                       // x1 x2
+    f.mul(y1, y2, b);                       // y1 y2
+    f.mul(a, b, c); f.mul(c, D, c);         // d x1 x2 y1 y2
+    f.mul(x1, y2, e); f.mul(y1, x2, t); f.add(e, t, e);          // x numerator
+    f.mul(a, five, t); f.add(b, t, t);                           // y numerator: y1 y2 - a x1 x2
+    uint64_t dx[4], dy[4], inv[4];
+    f.add(one, c, dx); f.sub(one, c, dy);
+    f.mul(dx, dy, inv); f.inv(inv, inv);                         // 1 / (dx dy)
+    uint64_t ix[4], iy[4], x3[4], y3[4];
+    f.mul(inv, dy, ix); f.mul(inv, dx, iy);
+    f.mul(e, ix, x3); f.mul(t, iy, y3);
+    store_le32(x3, out); store_le32(y3, out + 32);
 }
 
 // ---------------------------------------------------------------- VRF transcript (primitives.py:26-55)
@@ -276,6 +318,106 @@ struct FsTranscript {
         sh.update(footer, 4);
     }
 };
+
+// ---------------------------------------------------------------- ring-proof verifier scalar pass (verify.py:51-210)
+struct RingVerifierDomain {
+    unsigned log2n;
+    uint64_t omega[4], w_nm1[4], w_nm2[4], w_nm3[4], w_nm4[4], inv_n[4];     // standard form mod p
+    uint64_t seed_x[4], seed_y[4];
+    void init(unsigned log2n_, const uint8_t omega_le[32], const uint8_t seed_xy[64]) {
+        const Mod256& f = mod_p();
+        log2n = log2n_;
+        load_le32(omega_le, omega);
+        uint64_t wi[4], nn[4];
+        f.inv(omega, wi);
+        std::memcpy(w_nm1, wi, 32);                 // w^(n-1) = w^-1
+        f.mul(w_nm1, wi, w_nm2);
+        f.mul(w_nm2, wi, w_nm3);
+        f.mul(w_nm3, wi, w_nm4);
+        f.set_u64((uint64_t)1 << log2n, nn);
+        f.inv(nn, inv_n);
+        load_le32(seed_xy, seed_x);
+        load_le32(seed_xy + 32, seed_y);
+    }
+};
+struct RingClaimScalars {      // what one proof contributes to the folded pairing equation
+    uint64_t nus[8][4];        // commitment scalars of the aggregated opening at zeta (px, py, s, b, accip, accx, accy, q)
+    uint64_t k_ip[4], k_x[4], k_y[4];
+    uint64_t zeta[4], zeta_omega[4], agg_zeta[4], l_zw[4];
+};
+// alphas[7], nus[8], zeta, evals[7] (px py s b accip accx accy), l_zw: 32-byte LE canonical values; result_seed = seed + relation.
+// false when zeta lies in the domain (verify.py raises there).
+inline bool ring_verifier_terms(const RingVerifierDomain& dm, const uint8_t* alphas, const uint8_t* nus, const uint8_t* zeta_le,
+                                const uint8_t* evals, const uint8_t* l_zw_le, const uint8_t result_seed[64], RingClaimScalars& out) {
+    const Mod256& f = mod_p();
+    uint64_t al[7][4], ev[7][4], zeta[4], lzw[4], rsx[4], rsy[4], one[4], five[4];
+    for (int i = 0; i < 7; i++) { load_le32(alphas + 32 * i, al[i]); load_le32(evals + 32 * i, ev[i]); }
+    for (int i = 0; i < 8; i++) load_le32(nus + 32 * i, out.nus[i]);
+    load_le32(zeta_le, zeta); load_le32(l_zw_le, lzw);
+    load_le32(result_seed, rsx); load_le32(result_seed + 32, rsy);
+    f.set_u64(1, one); f.set_u64(5, five);
+    const uint64_t *pxz = ev[0], *pyz = ev[1], *sz = ev[2], *bz = ev[3], *ipz = ev[4], *axz = ev[5], *ayz = ev[6];
+    uint64_t z1[4], d4[4], zn1[4], t[4], u[4];
+    f.sub(zeta, one, z1);
+    f.sub(zeta, dm.w_nm4, d4);
+    std::memcpy(t, zeta, 32);
+    for (unsigned i = 0; i < dm.log2n; i++) f.mul(t, t, t);
+    f.sub(t, one, zn1);
+    if (f.is_zero(zn1)) return false;
+    // one inversion for the three denominators (zeros map to zero)
+    uint64_t iz1[4] = {0, 0, 0, 0}, id4[4] = {0, 0, 0, 0}, izn1[4];
+    {
+        uint64_t a[4], b[4], prod[4], inv[4];
+        std::memcpy(a, f.is_zero(z1) ? one : z1, 32);
+        std::memcpy(b, f.is_zero(d4) ? one : d4, 32);
+        f.mul(a, b, prod); f.mul(prod, zn1, prod);
+        f.inv(prod, inv);
+        f.mul(a, b, t); f.mul(inv, t, izn1);
+        f.mul(inv, zn1, t);                  // 1/(a b)
+        if (!f.is_zero(z1)) f.mul(t, b, iz1);
+        if (!f.is_zero(d4)) f.mul(t, a, id4);
+    }
+    uint64_t l0[4], ln[4];
+    if (f.is_zero(z1)) std::memcpy(l0, one, 32); else { f.mul(dm.inv_n, zn1, l0); f.mul(l0, iz1, l0); }
+    if (f.is_zero(d4)) std::memcpy(ln, one, 32); else { f.mul(dm.w_nm4, dm.inv_n, ln); f.mul(ln, zn1, ln); f.mul(ln, id4, ln); }
+    uint64_t one_b[4], c[7][4], axay[4], pxpy[4];
+    f.sub(one, bz, one_b);
+    f.mul(axz, ayz, axay);
+    f.mul(pxz, pyz, pxpy);
+    // c1 = -(ip + b s) d4
+    f.mul(bz, sz, t); f.add(ipz, t, t); f.neg(t, t); f.mul(t, d4, c[0]);
+    // c2 = (b * -(ax ay + px py) + (1-b) * -ax) d4
+    f.add(axay, pxpy, t); f.neg(t, t); f.mul(bz, t, t); f.neg(axz, u); f.mul(one_b, u, u); f.add(t, u, t); f.mul(t, d4, c[1]);
+    // c3 = (b * -(ax ay - px py) + (1-b) * -ay) d4
+    f.sub(axay, pxpy, t); f.neg(t, t); f.mul(bz, t, t); f.neg(ayz, u); f.mul(one_b, u, u); f.add(t, u, t); f.mul(t, d4, c[2]);
+    // c4 = b (1-b)
+    f.mul(bz, one_b, c[3]);
+    // c5 = (ax - seed.x) L0 + (ax - result_seed.x) Ln ; c6 likewise in y
+    f.sub(axz, dm.seed_x, t); f.mul(t, l0, t); f.sub(axz, rsx, u); f.mul(u, ln, u); f.add(t, u, c[4]);
+    f.sub(ayz, dm.seed_y, t); f.mul(t, l0, t); f.sub(ayz, rsy, u); f.mul(u, ln, u); f.add(t, u, c[5]);
+    // c7 = ip L0 + (ip - 1) Ln
+    f.mul(ipz, l0, t); f.sub(ipz, one, u); f.mul(u, ln, u); f.add(t, u, c[6]);
+    uint64_t lin[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 7; i++) { f.mul(al[i], c[i], t); f.add(lin, t, lin); }
+    uint64_t tail[4], qz[4];
+    f.sub(zeta, dm.w_nm1, tail); f.sub(zeta, dm.w_nm2, t); f.mul(tail, t, tail); f.sub(zeta, dm.w_nm3, t); f.mul(tail, t, tail);
+    f.add(lin, lzw, qz); f.mul(qz, tail, qz); f.mul(qz, izn1, qz);
+    uint64_t agg[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 7; i++) { f.mul(out.nus[i], ev[i], t); f.add(agg, t, agg); }
+    f.mul(out.nus[7], qz, t); f.add(agg, t, agg);
+    // fx = b (ay py + a ax px) + (1-b),  fy = b (ax py - px ay) + (1-b),  a = -5
+    uint64_t fx[4], fy[4];
+    f.mul(ayz, pyz, t); f.mul(axz, pxz, u); f.mul(u, five, u); f.sub(t, u, t); f.mul(bz, t, t); f.add(t, one_b, fx);
+    f.mul(axz, pyz, t); f.mul(pxz, ayz, u); f.sub(t, u, t); f.mul(bz, t, t); f.add(t, one_b, fy);
+    f.mul(al[0], d4, out.k_ip);
+    f.mul(al[1], fx, t); f.mul(t, d4, out.k_x);
+    f.mul(al[2], fy, t); f.mul(t, d4, out.k_y);
+    std::memcpy(out.zeta, zeta, 32);
+    f.mul(zeta, dm.omega, out.zeta_omega);
+    std::memcpy(out.agg_zeta, agg, 32);
+    std::memcpy(out.l_zw, lzw, 32);
+    return true;
+}
 
 // 96-byte BE x||y record (or infinity) -> serialize() form: infinity = 0x40 || zeros  (kzg.py:133)
 inline void g1_serialized(const uint8_t rec[96], int is_inf, uint8_t out[96]) {

@@ -306,4 +306,61 @@ __global__ void k_bsn_encode_to_curve(const uint32_t* __restrict__ us /* n*2*8 s
     te_store_affine(out + (size_t)i * 16, r);
 }
 
+// ---- point decoding for verifiers --------------------------------------------------------------------------------
+// dec_point for a batch (dot_ring/curve/point.py:150-214, te_affine_point.py:297-316, vrf/codec.py:39-45,
+// curve/curve.py:56-67): y = the 255 low bits (rejected when >= p), x^2 = (1 - y^2) / (a - d y^2), the sign bit picks
+// the larger of (x, p - x); the point must be a non-identity member of the prime-order subgroup.  Subgroup test
+// without an unreduced scalar: Q = 4P must not be the identity and [4^-1 mod n] Q must give back P (a torsion
+// component of P is killed by the 4 and would not come back).  One lane per point, ok[i] = 1 when valid.
+__global__ __launch_bounds__(BSN_BLOCK) void k_bsn_decode_points(const uint32_t* __restrict__ enc /* n*8 */, uint32_t* __restrict__ out_xy /* n*16 std */,
+                                                                 uint32_t* __restrict__ ok, uint32_t n) {
+    __shared__ uint32_t tab[BSN_TABLE * BSN_PT_WORDS * BSN_BLOCK];
+    const int lane = threadIdx.x;
+    uint32_t i = blockIdx.x * BSN_BLOCK + lane;
+    const bool live = i < n;
+    if (!live) i = n - 1;
+    Fr ys = load_fr_std(enc + (size_t)i * 8);
+    const bool sign = (ys.l[7] >> 31) != 0;
+    ys.l[7] &= 0x7fffffffu;
+    bool valid = true;
+    {   // y < p
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) (void)subb(ys.l[j], FrParams::P[j], borrow);
+        valid = borrow != 0;
+    }
+    if (!valid) ys = Fr::zero();
+    const Fr one = Fr::one();
+    Fr y = to_mont(ys);
+    Fr y2 = sqr(y);
+    Fr den = sub(te_mul_a(one), mul(te_d_mont(), y2));
+    if (den.is_zero()) { valid = false; den = one; }
+    Fr x2 = mul(sub(one, y2), inv(den));
+    if (!fr_is_square(x2)) { valid = false; x2 = one; }
+    Fr x = fr_sqrt_qr(x2);
+    {
+        Fr xs = from_mont(x), nxs = from_mont(neg(x));
+        bool x_larger = false;
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+            if (xs.l[j] != nxs.l[j]) { x_larger = xs.l[j] > nxs.l[j]; break; }
+        }
+        if (x_larger != sign) x = neg(x);          // sign set: the larger root, otherwise the smaller
+    }
+    TePoint P;
+    P.x = x; P.y = y; P.z = one; P.t = mul(x, y);
+    TePoint Q = te_dbl<false>(te_dbl<false>(P));
+    if (Q.x.is_zero()) { valid = false; Q = P; }    // 4P = O (x = 0 also covers the order-2 point (0,-1), which 4 kills anyway)
+    Fr zi = inv(Q.z.is_zero() ? one : Q.z);
+    Fr qx = mul(Q.x, zi), qy = mul(Q.y, zi);
+    uint32_t kk[8] = {0xde592de9u, 0x17bdc507u, 0x5712c355u, 0xbfaba540u, 0x81ce5880u, 0x899ad881u, 0x97cd877du, 0x15bc8f5fu};   // 4^-1 mod n
+    TePoint R = bsn_scalar_mul_core(tab, lane, qx, qy, kk);
+    if (!(R.x == mul(x, R.z)) || !(R.y == mul(y, R.z))) valid = false;
+    if (live) {
+        store_fr_std(out_xy + (size_t)i * 16, from_mont(x));
+        store_fr_std(out_xy + (size_t)i * 16 + 8, from_mont(y));
+        ok[i] = valid ? 1u : 0u;
+    }
+}
+
 }  // namespace dr

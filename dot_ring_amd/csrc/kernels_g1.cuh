@@ -113,6 +113,61 @@ __global__ void k_g1_scalar_bases(uint32_t* bases, uint32_t n, const uint32_t* _
     store_fq(p + 12, a.y);
 }
 
+// zcash-compressed G1 (48 bytes, big-endian; flag bits: 7 compressed, 6 infinity, 5 "y is the larger root") ->
+// Montgomery affine, the layout the MSM kernels read; (0,0) = infinity.  On-curve by construction, no subgroup
+// check — as blst's P1_Affine(bytes) behind KZG.decompress_g1 (dot_ring/ring_proof/pcs/kzg.py:137-144).
+// ok[i] = 0 for malformed encodings (the point is then written as infinity).
+__global__ void k_g1_decompress(const uint8_t* __restrict__ enc /* n*48 */, uint32_t* __restrict__ bases /* n*24 */, uint32_t* __restrict__ ok, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = enc + (size_t)i * 48;
+    Fq xs;
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const uint8_t* q = p + 44 - 4 * j;
+        xs.l[j] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+    }
+    const uint32_t flags = xs.l[11] >> 29;
+    xs.l[11] &= 0x1fffffffu;
+    bool valid = (flags & 4u) != 0;
+    Fq X = Fq::zero(), Y = Fq::zero();
+    if (flags & 2u) {
+        if (!xs.is_zero() || (flags & 1u)) valid = false;
+    } else {
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) (void)subb(xs.l[j], FqParams::P[j], borrow);
+        if (!borrow) { valid = false; xs = Fq::zero(); }
+        X = to_mont(xs);
+        Fq four = Fq::zero();
+        four.l[0] = 4;
+        Fq rhs = add(mul(sqr(X), X), to_mont(four));
+        // p = 3 mod 4: y = rhs^((p+1)/4)
+        constexpr uint32_t E[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
+                                    0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};
+        Fq y = Fq::one();
+#pragma unroll 1
+        for (int b = 378; b >= 0; b--) {                 // (p+1)/4 has 379 bits
+            y = sqr(y);
+            if ((E[b >> 5] >> (b & 31)) & 1u) y = mul(y, rhs);
+        }
+        if (!(sqr(y) == rhs)) valid = false;
+        Fq ny = neg(y);
+        Fq ys = from_mont(y), nys = from_mont(ny);
+        bool y_larger = false;
+#pragma unroll
+        for (int j = 11; j >= 0; j--) {
+            if (ys.l[j] != nys.l[j]) { y_larger = ys.l[j] > nys.l[j]; break; }
+        }
+        Y = (y_larger != ((flags & 1u) != 0)) ? ny : y;
+        if (!valid) { X = Fq::zero(); Y = Fq::zero(); }
+    }
+    uint32_t* o = bases + (size_t)i * 24;
+    store_fq(o, X);
+    store_fq(o + 12, Y);
+    ok[i] = valid ? 1u : 0u;
+}
+
 // Montgomery affine -> standard-form little-endian limbs (SRS download)
 __global__ void k_g1_bases_from_mont(const uint32_t* bases, uint32_t* out, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

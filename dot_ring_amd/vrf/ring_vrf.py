@@ -6,7 +6,7 @@ import secrets
 from dataclasses import dataclass
 from functools import lru_cache
 
-from .. import _native
+from .. import _native, runtime
 from ..curve import valid_points
 from ..ring_proof.columns import Column
 from ..ring_proof.params import RingProofParams
@@ -373,8 +373,7 @@ class RingVRF(VRF):
         cv = cls.cv
         sp = cv.curve.params
         le = lambda v: int(v).to_bytes(32, "little")
-        gen, bb = sp.generator, sp.auxiliary_points.blinding_base
-        suite = _native.vrf_suite(sp.suite_id, sp.xof, le(gen[0]) + le(gen[1]), le(bb[0]) + le(bb[1]))
+        suite = cls._suite_struct()
         indices = ring.indices_of(producer_keys)
         prefix = root.verifier_transcript_prefix_bytes()
         out = []
@@ -431,9 +430,51 @@ class RingVRF(VRF):
         return PedersenVRF[cls.cv].proof_to_hash(gamma, mul_cofactor)
 
     @classmethod
+    def _suite_struct(cls):
+        sp = cls.cv.curve.params
+        le = lambda v: int(v).to_bytes(32, "little")
+        gen, bb = sp.generator, sp.auxiliary_points.blinding_base
+        return _native.vrf_suite(sp.suite_id, sp.xof, le(gen[0]) + le(gen[1]), le(bb[0]) + le(bb[1]))
+
+    @classmethod
+    def _batch_verify_native(cls, proofs, inputs, additional_data, ring: Ring, ring_root: RingRoot) -> bool:
+        """dr_ringvrf_verify_batch over the encoded proofs: point decoding/validation on the GPU, transcripts on the
+        library's worker threads, one Bandersnatch MSM + two G1 MSMs + one pairing equation for the whole batch."""
+        params = ring.params
+        pcs = params.pcs
+        vk = ring_root.__dict__.get("_native_vk")
+        if vk is None:
+            srs = pcs._srs()
+            seed = params.cv.curve.params.auxiliary_points.accumulator_base
+            le = lambda v: int(v).to_bytes(32, "little")
+            vk = _native.ring_verifier_key(
+                params.domain_size.bit_length() - 1, params.omega, le(seed[0]) + le(seed[1]),
+                b"".join(pcs.serialize_g1_uncompressed(c) for c in ring_root.fixed_commitments()), srs.g1_raw[:96],
+                srs.g2_raw[0] + srs.g2_raw[1], ring_root.verifier_transcript_prefix_bytes())
+            ring_root.__dict__["_native_vk"] = vk
+        suite = cls._suite_struct()
+        try:
+            blobs = [p.encode() for p in proofs]
+            if any(len(b) != 784 for b in blobs) or not (len(blobs) == len(inputs) == len(additional_data)):
+                return False
+        except (AttributeError, TypeError, ValueError):
+            return False
+        ctx = runtime.context()
+        step = device_prover.MAX_DEVICE_BATCH
+        for lo in range(0, len(blobs), step):
+            hi = min(len(blobs), lo + step)
+            if not ctx.ringvrf_verify_batch(suite, vk, b"".join(blobs[lo:hi]), [bytes(x) for x in inputs[lo:hi]],
+                                            [bytes(x) for x in additional_data[lo:hi]], None, secrets.token_bytes(32)):
+                return False
+        return True
+
+    @classmethod
     def batch_verify(cls, proofs, inputs, additional_data, ring: Ring, ring_root: RingRoot) -> bool:
         if not ring_root.matches_ring(ring):
             return False
+        if (device_prover.supported(ring.params) and os.environ.get("DOTRING_NATIVE_HOST", "1") != "0"
+                and cls.proof_len() == 784 and ring_root.params is not None):
+            return cls._batch_verify_native(proofs, inputs, additional_data, ring, ring_root)
         if not PedersenVRF[cls.cv].batch_verify([p.pedersen_proof for p in proofs], inputs, additional_data):
             return False
         claims = []

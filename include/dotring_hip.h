@@ -224,6 +224,30 @@ DR_API int dr_ringvrf_prove_batch(dr_ring_prover *p, const dr_vrf_suite *suite, 
                                   const uint8_t *fs_prefix, size_t fs_prefix_len, const uint8_t *zk_random48, uint8_t *out_proofs,
                                   uint8_t *out_aux);
 
+
+/* What a verifier knows about one ring (RingRoot + RingProofParams + SRS verifier part). */
+typedef struct dr_ring_verifier_key {
+    unsigned log2n;                      /* domain size N = 2^log2n */
+    uint8_t omega_n[32];                 /* primitive N-th root of unity, LE */
+    uint8_t seed_xy[64];                 /* accumulator base point (bandersnatch.py:89-102), x||y LE */
+    uint8_t fixed_commitments[3 * 96];   /* C_px, C_py, C_s serialised uncompressed (BE x||y; infinity = 0x40 || 0) */
+    uint8_t g1_generator[96];            /* SRS G1[0], BE x||y */
+    uint8_t g2[2 * 192];                 /* SRS [1]G2, [tau]G2 in file byte order (pcs/srs.py:78-88) */
+    const uint8_t *fs_prefix;            /* as for dr_ringvrf_prove_batch */
+    size_t fs_prefix_len;
+} dr_ring_verifier_key;
+
+/* RingVRF.batch_verify (dot_ring/vrf/ring/vrf.py:239-283) over `batch` (<= 4096) ENCODED proofs (784 bytes each):
+ * decoding and validating every point (Bandersnatch: canonical, on curve, prime-order subgroup; G1: zcash
+ * decompression) runs on the GPU, the transcript replay and the verifier's scalar pass on worker threads, then one
+ * (5B+2)-point Bandersnatch MSM (Pedersen part) and two G1 MSMs + one pairing equation (ring part).  seed32 = fresh
+ * verifier randomness for the random linear combination.  *ok = 1 iff every proof verifies; malformed proofs give
+ * *ok = 0 with DR_OK. */
+DR_API int dr_ringvrf_verify_batch(dr_ctx *ctx, const dr_vrf_suite *suite, const dr_ring_verifier_key *vk, size_t batch,
+                                   const uint8_t *proofs, const uint8_t *inputs, const uint64_t *in_off, const uint8_t *ads,
+                                   const uint64_t *ad_off, const uint8_t *salts, const uint64_t *salt_off,
+                                   const uint8_t seed32[32], int *ok);
+
 #ifdef __cplusplus
 }
 #endif
