@@ -1827,12 +1827,11 @@ int dr_ringvrf_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_rin
     for (size_t i = 0; i < B; i++) std::memcpy(both.data() + n_g1 * 32 + 224 * i + 160, rhs_sc.data() + 64 * i, 64);
     TRY(ctx->scalars.reserve(2 * n_g1 * 32));
     HIP_TRY(hipMemcpyAsync(ctx->scalars.p, both.data(), 2 * n_g1 * 32, hipMemcpyHostToDevice, st));
-    std::vector<drh::G1> res;
-    TRY(msm_device(ctx, g1_bases.as<uint32_t>(), ctx->scalars.as<uint32_t>(), n_g1, 2, res));
     uint8_t pair_g1[2 * 96];
-    int inf_l = 0, inf_r = 0;
-    g1_result_to_bytes(res[0], pair_g1, &inf_l);
-    g1_result_to_bytes(res[1], pair_g1 + 96, &inf_r);
+    int pair_inf[2] = {0, 0};
+    TRY(msm_to_bytes(ctx, g1_bases.as<uint32_t>(), ctx->scalars.as<uint32_t>(), n_g1, 2, pair_g1, pair_inf));
+    const int inf_r = pair_inf[1];
+    // (a vanishing rhs can only come from r1 = r2 = 0 or infinity openings: the pairing equation then demands lhs = O)
     if (!inf_r) {                                                                 // e(lhs, G2[0]) * e(-rhs, G2[1]) == 1
         drh::Fq y;
         if (!drh::Fq::load_be(y, pair_g1 + 144)) return fail(DR_ERR_DEVICE, "MSM result out of range");

@@ -201,3 +201,87 @@ def test_ring_zk_rows_are_random_without_test_vectors(ctx, golden_dir):
     assert p1.encode()[:192] == p2.encode()[:192]          # Pedersen part is deterministic
     assert p1.encode() != p2.encode()                       # ring part is not (tests/test_vectors.py:472-502)
     assert p1.verify(b"x", b"y", ring, root) and p2.verify(b"x", b"y", ring, root)
+
+
+def test_native_batch_verify_rejects_what_the_python_path_rejects(ctx, monkeypatch):
+    """dr_ringvrf_verify_batch (decoding on the GPU, transcripts on worker threads) against the per-object Python path
+    on good and tampered proofs: wrong input / ad, flipped bits in every section of the 784 bytes, non-canonical and
+    off-subgroup points, bad G1 flag bits, proofs of another ring."""
+    import dot_ring_amd as d
+    from dot_ring_amd.vrf.ring_vrf import RingVRF
+
+    cv = d.Bandersnatch
+    vrf = d.RingVRF[cv]
+    sks = [(1000 + i).to_bytes(32, "little") for i in range(12)]
+    keys = [cv.public_key_from_secret(sk) for sk in sks]
+    ring = d.Ring(keys)
+    root = d.RingRoot.from_ring(ring)
+    n = 6
+    als = [b"in%d" % i for i in range(n)]
+    ads = [b"ad%d" % (i % 2) for i in range(n)]
+    proofs = vrf.prove_batch(als, ads, sks[:n], keys[:n], ring, root)
+    raw = [p.encode() for p in proofs]
+
+    class Blob:                      # anything with encode(): the native verifier only reads the bytes
+        def __init__(self, b):
+            self._b = b
+
+        def encode(self):
+            return self._b
+
+    def native(blobs, a=als, x=ads, rg=ring, rt=root):
+        return vrf.batch_verify([Blob(b) for b in blobs], a, x, rg, rt)
+
+    def python(blobs, a=als, x=ads):
+        monkeypatch.setenv("DOTRING_NATIVE_HOST", "0")
+        try:
+            try:
+                objs = [vrf.decode(b) for b in blobs]
+            except ValueError:
+                return False
+            return vrf.batch_verify(objs, a, x, ring, root)
+        finally:
+            monkeypatch.delenv("DOTRING_NATIVE_HOST")
+
+    assert native(raw) and python(raw)
+    assert native(raw[:1], als[:1], ads[:1])
+    assert not native(raw, als[::-1]) and not python(raw, als[::-1])
+    assert not native(raw, als, ads[::-1]) and not python(raw, als, ads[::-1])
+    # one flipped bit anywhere must be caught: Pedersen points / scalars, commitments, evaluations, openings
+    for off in (0, 33, 70, 100, 130, 170, 192 + 5, 192 + 60, 192 + 192 + 3, 192 + 192 + 100, 192 + 416 + 7, 192 + 464, 192 + 500, 192 + 560):
+        bad = list(raw)
+        b = bytearray(bad[2])
+        b[off] ^= 0x04
+        bad[2] = bytes(b)
+        assert not native(bad), off
+        assert not python(bad), off
+    # non-canonical Bandersnatch y (>= p), identity, a point of order 2, a point outside the prime-order subgroup
+    p = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    for enc in ((p + 1).to_bytes(32, "little"), (1).to_bytes(32, "little"), (p - 1).to_bytes(32, "little")):
+        bad = list(raw)
+        bad[0] = enc + raw[0][32:]
+        assert not native(bad) and not python(bad)
+    from oracle.pyref import bandersnatch as obsn
+    y = 2
+    while True:                      # some curve point with a torsion component
+        try:
+            pt = obsn.decompress((y).to_bytes(32, "little"))
+            if not obsn.in_prime_subgroup(pt):
+                break
+        except ValueError:
+            pass
+        y += 1
+    bad = list(raw)
+    bad[1] = raw[1][:32] + y.to_bytes(32, "little") + raw[1][64:]
+    assert not native(bad) and not python(bad)
+    # G1 encodings: compression flag cleared, infinity flag with non-zero body, x >= p
+    for mod in (lambda b: bytes([b[0] & 0x7F]) + b[1:], lambda b: bytes([b[0] | 0x40]) + b[1:], lambda b: bytes([0x9F]) + b"\xff" * 47):
+        bad = list(raw)
+        bad[3] = raw[3][:192] + mod(raw[3][192:240]) + raw[3][240:]
+        assert not native(bad) and not python(bad)
+    # swapping two proofs breaks the input binding; proofs for another ring fail under this root
+    assert not native([raw[1], raw[0]] + raw[2:])
+    other = d.Ring(keys[:8])
+    other_root = d.RingRoot.from_ring(other)
+    assert not native(raw, als, ads, other, other_root)
+    assert isinstance(proofs[0], RingVRF) and proofs[0].verify(als[0], ads[0], ring, root)
