@@ -35,11 +35,11 @@ G1_BE = bytes.fromhex(
 )
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_PAIR = 128       # 96 B affine base + 32 B scalar per (base, scalar) pair
-MSM_KERNELS = ("k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_accumulate", "k_g1_reduce_chunks", "k_g1_reduce_windows",
-               "k_g1_horner", "k_g1_results_affine")
+MSM_KERNELS = ("k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_sort_sets", "k_size_sort", "k_g1_accumulate", "k_g1_reduce_chunks",
+               "k_g1_reduce_windows", "k_g1_horner", "k_g1_results_affine")
 RING_KERNELS = ("k_bsn_scalar_mul", "k_bsn_encode_to_curve", "k_bsn_msm_groups", "k_ring_chain", "k_ring_columns", "k_ntt_local",
                 "k_ntt_strided", "k_ring_pad", "k_ring_constraints", "k_ring_quotient", "k_ring_eval", "k_ring_linpoly",
-                "k_ring_aggpoly", "k_syndiv")
+                "k_ring_aggpoly", "k_syndiv", "k_ring_diff", "k_bsn_decode_points", "k_g1_decompress")
 
 
 def seeded_scalars(n: int, tag: bytes):

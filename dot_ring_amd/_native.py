@@ -90,6 +90,7 @@ _PROTOTYPES.update({
     "dr_ringvrf_verify_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), POINTER(RingVerifierKeyStruct), c_size_t, c_char_p, c_char_p,
                                         POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64),
                                         c_char_p, POINTER(c_int)]),
+    "dr_pairing_selfcheck": (c_int, [c_char_p, c_char_p, c_size_t, POINTER(c_int)]),
     "dr_host_hash": (c_int, [c_int, c_char_p, c_size_t, c_char_p, c_size_t]),
     "dr_hash_to_field_batch": (c_int, [POINTER(VrfSuiteStruct), c_char_p, POINTER(ctypes.c_uint64), c_size_t, c_char_p]),
     "dr_ringvrf_prove_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_size_t, c_char_p, POINTER(ctypes.c_uint64), c_char_p,

@@ -9,6 +9,8 @@
 // Line functions: for the M-type twist E': y^2 = x^3 + 4(u+1) and T = (xT, yT) in E'(Fq2), slope s, P = (xP, yP):
 //   l * w^3 = (s*xT - yT) + (-s*xP) * v + yP * v*w          (w^3 lies in Fq4, killed by the final exponentiation)
 #pragma once
+#include <vector>
+
 #include "hostmath.hpp"
 #include "pairing_consts.hpp"
 
@@ -70,7 +72,11 @@ struct Fq12 {
         Fq6 a = c0 * o.c0, b = c1 * o.c1;
         return {a + b.mul_v(), (c0 + c1) * (o.c0 + o.c1) - a - b};
     }
-    Fq12 sqr() const { return *this * *this; }
+    Fq12 sqr() const {                                           // complex squaring: 2 Fq6 products
+        Fq6 ab = c0 * c1;
+        Fq6 re = (c0 + c1) * (c0 + c1.mul_v()) - ab - ab.mul_v();
+        return {re, ab + ab};
+    }
     Fq12 conj() const { return {c0, c1.neg()}; }               // = x^(p^6)
     Fq12 inv() const {
         Fq6 d = (c0 * c0 - (c1 * c1).mul_v()).inv();
@@ -151,10 +157,119 @@ inline Fq12 miller_loop(const Fq& px, const Fq& py, const G2Affine& q) {
     return f.conj();
 }
 
+// product of Miller loops with ONE accumulator (one Fq12 squaring per bit for all pairs) and the slope denominators
+// of all pairs inverted together (Montgomery's trick: one Fq2 inversion per step instead of one per pair)
+inline Fq12 multi_miller_loop(const Fq* px, const Fq* py, const G2Affine* qs, size_t n) {
+    const uint64_t X = 0xd201000000010000ULL;
+    Fq12 f = Fq12::one();
+    if (n == 0) return f;
+    std::vector<Fq2> tx(n), ty(n), den(n), pre(n);
+    for (size_t i = 0; i < n; i++) { tx[i] = qs[i].x; ty[i] = qs[i].y; }
+    auto invert_all = [&]() {                              // den[i] <- 1/den[i]
+        Fq2 run = Fq2::one();
+        for (size_t i = 0; i < n; i++) { pre[i] = run; run = run * den[i]; }
+        Fq2 inv = run.inv();
+        for (size_t i = n; i-- > 0;) { Fq2 d = den[i]; den[i] = inv * pre[i]; inv = inv * d; }
+    };
+    auto line = [&](const Fq2& s, const Fq2& lx, const Fq2& ly, const Fq& x, const Fq& y) {
+        Fq12 l;
+        l.c0 = {s * lx - ly, s.scale(x).neg(), Fq2::zero()};
+        l.c1 = {Fq2::zero(), Fq2{y, Fq::zero()}, Fq2::zero()};
+        return l;
+    };
+    Fq three = Fq::from_u64(3);
+    for (int b = 62; b >= 0; b--) {
+        f = f.sqr();
+        for (size_t i = 0; i < n; i++) den[i] = ty[i] + ty[i];
+        invert_all();
+        for (size_t i = 0; i < n; i++) {
+            Fq2 s = tx[i].sqr().scale(three) * den[i];
+            f = f * line(s, tx[i], ty[i], px[i], py[i]);
+            Fq2 nx = s.sqr() - tx[i] - tx[i];
+            ty[i] = s * (tx[i] - nx) - ty[i];
+            tx[i] = nx;
+        }
+        if ((X >> b) & 1) {
+            for (size_t i = 0; i < n; i++) den[i] = qs[i].x - tx[i];
+            invert_all();
+            for (size_t i = 0; i < n; i++) {
+                Fq2 s = (qs[i].y - ty[i]) * den[i];
+                f = f * line(s, tx[i], ty[i], px[i], py[i]);
+                Fq2 ax = s.sqr() - tx[i] - qs[i].x;
+                ty[i] = s * (tx[i] - ax) - ty[i];
+                tx[i] = ax;
+            }
+        }
+    }
+    return f.conj();
+}
+
+// reference form (plain square-and-multiply): f^((p^12 - 1)/r)
 inline Fq12 final_exponentiation(const Fq12& f) {
     Fq12 t = f.conj() * f.inv();                       // f^(p^6 - 1)
     t = t.pow(FE_EASY2, FE_EASY2_LEN);                 // ^(p^2 + 1)
     return t.pow(FE_HARD, FE_HARD_LEN);                // ^((p^4 - p^2 + 1)/r)
+}
+
+// ---- fast form used by the pairing check --------------------------------------------------------------------------
+// Frobenius: with Fq12 = Fq2[w]/(w^6 - xi), an element is sum_k a_k w^k (a_0 = c0.c0, a_1 = c1.c0, a_2 = c0.c1,
+// a_3 = c1.c1, a_4 = c0.c2, a_5 = c1.c2) and a^p = sum_k conj(a_k) * gamma^k * w^k with gamma = xi^((p-1)/6).
+inline Fq2 fq2_pow(const Fq2& a, const uint64_t* e, int len) {
+    Fq2 r = Fq2::one();
+    for (int i = len - 1; i >= 0; i--)
+        for (int b = 63; b >= 0; b--) {
+            r = r.sqr();
+            if ((e[i] >> b) & 1) r = r * a;
+        }
+    return r;
+}
+struct FrobeniusConsts {
+    Fq2 g[6];
+    FrobeniusConsts() {
+        uint64_t e[6];
+        std::memcpy(e, FieldParams<6>::P, sizeof e);
+        e[0] -= 1;                                         // p - 1 (p is odd: no borrow)
+        u128 rem = 0;                                      // / 6
+        for (int i = 5; i >= 0; i--) { u128 cur = (rem << 64) | e[i]; e[i] = (uint64_t)(cur / 6); rem = cur % 6; }
+        Fq2 xi{Fq::one(), Fq::one()};
+        g[0] = Fq2::one();
+        g[1] = fq2_pow(xi, e, 6);
+        for (int k = 2; k < 6; k++) g[k] = g[k - 1] * g[1];
+    }
+};
+inline const FrobeniusConsts& frobenius_consts() { static FrobeniusConsts c; return c; }
+inline Fq12 frobenius(const Fq12& a) {
+    const FrobeniusConsts& fc = frobenius_consts();
+    Fq12 r;
+    r.c0.c0 = a.c0.c0.conj();
+    r.c1.c0 = a.c1.c0.conj() * fc.g[1];
+    r.c0.c1 = a.c0.c1.conj() * fc.g[2];
+    r.c1.c1 = a.c1.c1.conj() * fc.g[3];
+    r.c0.c2 = a.c0.c2.conj() * fc.g[4];
+    r.c1.c2 = a.c1.c2.conj() * fc.g[5];
+    return r;
+}
+// a^x for the (negative) BLS parameter x and a in the cyclotomic subgroup (inverse = conjugate)
+inline Fq12 cyclotomic_exp_x(const Fq12& a) {
+    const uint64_t X = 0xd201000000010000ULL;
+    Fq12 r = a;
+    for (int b = 62; b >= 0; b--) {
+        r = r.sqr();
+        if ((X >> b) & 1) r = r * a;
+    }
+    return r.conj();
+}
+// f^(3 (p^12 - 1)/r): easy part with Frobenius maps, hard part through
+//   3 (p^4 - p^2 + 1)/r = (x - 1)^2 (x + p) (x^2 + p^2 - 1) + 3
+// (five exponentiations by x).  The extra factor 3 is coprime to r, so "== 1" is unchanged.
+inline Fq12 final_exponentiation_check(const Fq12& f) {
+    Fq12 t = f.conj() * f.inv();                       // f^(p^6 - 1)
+    t = frobenius(frobenius(t)) * t;                   // ^(p^2 + 1): now in the cyclotomic subgroup
+    Fq12 a = cyclotomic_exp_x(t) * t.conj();           // t^(x-1)
+    a = cyclotomic_exp_x(a) * a.conj();                // t^((x-1)^2)
+    Fq12 b = cyclotomic_exp_x(a) * frobenius(a);       // ^(x + p)
+    Fq12 c = cyclotomic_exp_x(cyclotomic_exp_x(b)) * frobenius(frobenius(b)) * b.conj();    // ^(x^2 + p^2 - 1)
+    return c * t.sqr() * t;
 }
 
 }  // namespace drh

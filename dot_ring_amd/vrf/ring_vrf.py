@@ -78,9 +78,13 @@ class Ring:
                 lookup.setdefault(pt, row)
             self._row_of = lookup
         out = []
-        distinct = list(dict.fromkeys(bytes(k) for k in keys))          # a batch usually repeats few producer keys
-        decoded = dict(zip(distinct, self._decode_keys(distinct)))
-        for point in (decoded[bytes(k)] for k in keys):
+        memo = self.__dict__.setdefault("_decoded_producers", {})       # key bytes -> decoded point (or None): decode once
+        distinct = [k for k in dict.fromkeys(bytes(k) for k in keys) if k not in memo]   # a batch usually repeats few producer keys
+        if distinct:
+            if len(memo) + len(distinct) > 65536:
+                memo.clear()
+            memo.update(zip(distinct, self._decode_keys(distinct)))
+        for point in (memo[bytes(k)] for k in keys):
             if point is None:
                 raise ValueError("invalid ring key")
             if point == padding or point not in lookup:
@@ -339,11 +343,20 @@ class RingVRF(VRF):
         from ..pipeline import run_pipelined
 
         gen = cv.point_type.generator_point()
-        distinct = list(dict.fromkeys(bytes(sk) for sk in secret_keys))      # one scalar multiplication per distinct key
-        derived = scalar_mul_batch([gen] * len(distinct), [int.from_bytes(sk, "little") for sk in distinct])
-        pk_of = {sk: pt.point_to_string() for sk, pt in zip(distinct, derived)}
+        # one scalar multiplication per distinct key not seen before (sk -> pk is deterministic; a small per-class memo
+        # saves a latency-bound launch per call when a signer proves repeatedly)
+        memo = cls.__dict__.get("_pk_memo")
+        if memo is None:
+            memo = {}
+            cls._pk_memo = memo
+        distinct = [sk for sk in dict.fromkeys(bytes(sk) for sk in secret_keys) if sk not in memo]
+        if distinct:
+            derived = scalar_mul_batch([gen] * len(distinct), [int.from_bytes(sk, "little") for sk in distinct])
+            if len(memo) + len(distinct) > 4096:
+                memo.clear()
+            memo.update((sk, pt.point_to_string()) for sk, pt in zip(distinct, derived))
         for sk, pk in zip(secret_keys, producer_keys):
-            if pk != pk_of[bytes(sk)]:
+            if pk != memo[bytes(sk)]:
                 raise ValueError("producer_key does not match secret_key")
         root = ring_root
         if root is None or root.px.coeffs is None or root.py.coeffs is None or root.s.coeffs is None or len(root.s.evals) < ring.params.domain_size:

@@ -140,6 +140,9 @@ DR_API int dr_g1_sum(const uint8_t *pts_be_xy /* n*96 */, size_t n, uint8_t out_
  * file layout x.c1 || x.c0 || y.c1 || y.c0 (big-endian, dot_ring/ring_proof/pcs/srs.py:78-88).  Replaces
  * blst.PT + PT.finalverify (dot_ring/ring_proof/pcs/pairing.py:24-31); stays on the CPU (2 Miller loops per batch). */
 DR_API int dr_pairing_check(const uint8_t *g1_be_xy /* n*96 */, const uint8_t *g2_be /* n*192 */, size_t n, int *ok);
+/* diagnostic for tests: *consistent = 1 iff the fast final exponentiation used by dr_pairing_check (Frobenius maps +
+ * x-chain, exponent 3(p^12-1)/r) equals the cube of the plain square-and-multiply one on this Miller-loop product */
+DR_API int dr_pairing_selfcheck(const uint8_t *g1_be_xy, const uint8_t *g2_be, size_t n, int *consistent);
 
 /* zcash encodings, host-side */
 DR_API int dr_g1_compress(const uint8_t xy[96], int is_inf, uint8_t out[48]);

@@ -27,3 +27,24 @@ def test_hash_to_field_batch_matches_oracle():
             u0, u1 = obsn.hash_to_field(suite, m, 2)
             assert got[64 * i : 64 * i + 64] == le(u0) + le(u1)
     assert _native.hash_to_field_batch(s, []) == b""
+
+
+def test_pairing_fast_final_exponentiation_matches_reference(srs_bytes):
+    """The pairing check's fast final exponentiation (Frobenius maps + x-chain) equals the cube of the plain
+    square-and-multiply one on real Miller-loop products, and the check accepts/rejects KZG-shaped equations."""
+    import ctypes
+
+    from dot_ring_amd.ring_proof.pcs import SRS
+
+    srs = SRS.default()
+    g2 = srs.g2_raw
+    g, t1, t2 = (srs_bytes[96 * i : 96 * i + 96] for i in range(3))           # G, tau*G, tau^2*G
+    assert _native.pairing_check([(t1, g2[0]), (_native.g1_neg(g), g2[1])])    # e(tau G, H) = e(G, tau H)
+    assert _native.pairing_check([(t2, g2[0]), (_native.g1_neg(t1), g2[1])])
+    assert not _native.pairing_check([(t2, g2[0]), (_native.g1_neg(g), g2[1])])
+    assert _native.pairing_check([(None, g2[0]), (None, g2[1])])
+    lib = _native.lib()
+    for pairs in ([(t1, g2[0]), (_native.g1_neg(g), g2[1])], [(t2, g2[0]), (_native.g1_neg(g), g2[1])], [(t2, g2[1])], [(g, g2[0]), (t1, g2[1]), (t2, g2[0])]):
+        ok = ctypes.c_int(0)
+        assert lib.dr_pairing_selfcheck(b"".join(a for a, _ in pairs), b"".join(b for _, b in pairs), len(pairs), ctypes.byref(ok)) == 0
+        assert ok.value == 1
