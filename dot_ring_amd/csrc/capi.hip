@@ -456,6 +456,32 @@ int dr_device_count(void) {
     return n;
 }
 
+namespace {
+// the Elligator / Tonelli-Shanks constants of kernels_bsn.cuh, computed with the host field and copied to the
+// device's constant block once per context
+int bsn_consts_init(hipStream_t st) {
+    using drh::Fr;
+    static const uint8_t D_LE[32] = {0xe7, 0x58, 0x8d, 0x18, 0xf5, 0xf2, 0x69, 0xb3, 0x92, 0x4f, 0xe5, 0x77, 0x71, 0x67, 0x66, 0xcb,
+                                     0xd8, 0xb6, 0xe3, 0x6b, 0xf8, 0x3b, 0x6e, 0xc6, 0xcb, 0x67, 0xc2, 0x33, 0x26, 0xc1, 0x89, 0x63};
+    Fr d;
+    if (!Fr::load_le(d, D_LE)) return fail(DR_ERR_DEVICE, "bad curve constant");
+    Fr five = Fr::from_u64(5), a = five.neg();
+    Fr inv_den = (a - d).inv();
+    Fr mont_a = (a + d).dbl() * inv_den, mont_b = Fr::from_u64(4) * inv_den;
+    Fr aob = mont_a * mont_b.inv(), inv_b2 = mont_b.sqr().inv();
+    static const uint64_t Q[4] = {0xfffe5bfeffffffffULL, 0x09a1d80553bda402ULL, 0x299d7d483339d808ULL, 0x0000000073eda753ULL};   // (p-1) / 2^32
+    dr::BsnConsts h;
+    auto put = [](uint32_t (&w)[8], const Fr& v) { std::memcpy(w, v.l, 32); };     // Montgomery limbs, same R on host and device
+    put(h.mont_b, mont_b); put(h.a_over_b, aob); put(h.inv_b2, inv_b2);
+    Fr c = five.pow(Q, 4);
+    for (int j = 0; j < 32; j++) { put(h.c_pow[j], c); c = c.sqr(); }
+    if (!(c == Fr::one())) return fail(DR_ERR_DEVICE, "bad Tonelli-Shanks constants");
+    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(dr::g_bsn_consts), &h, sizeof h, 0, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return DR_OK;
+}
+}  // namespace
+
 int dr_ctx_create(int device_id, dr_ctx** out) {
     if (!out) return fail(DR_ERR_INVALID, "null out pointer");
     *out = nullptr;
@@ -478,6 +504,12 @@ int dr_ctx_create(int device_id, dr_ctx** out) {
     if (cl) {
         int v = std::atoi(cl);
         if (v == 8 || v == 16 || v == 32 || v == 64 || v == 128) g_chunk_len = (uint32_t)v;
+    }
+    int rc = bsn_consts_init(ctx->stream);
+    if (rc != DR_OK) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return rc;
     }
     *out = ctx;
     return DR_OK;

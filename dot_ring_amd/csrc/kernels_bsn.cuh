@@ -209,97 +209,98 @@ DR_DEV Fr fr_pow_limbs(const Fr& a, const uint32_t (&e)[8]) {
     }
     return r;
 }
-DR_DEV bool fr_is_square(const Fr& a) {
-    if (a.is_zero()) return true;
-    constexpr uint32_t HALF[8] = {0x80000000u, 0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u};
-    uint32_t e[8];
+// Constants of the Elligator map and of Tonelli-Shanks, in Montgomery form, computed once per context on the host
+// (capi.hip: bsn_consts_init) instead of by every lane: the Montgomery-model coefficients derived from a = -5 and d
+// (A_M = 2(a+d)/(a-d), B_M = 4/(a-d)) and c_pow[j] = (5^Q)^(2^j), 5 the non-residue, p - 1 = Q * 2^32.
+struct BsnConsts {
+    uint32_t mont_b[8], a_over_b[8], inv_b2[8];
+    uint32_t c_pow[32][8];
+};
+__device__ BsnConsts g_bsn_consts;
+DR_DEV Fr bsn_const(const uint32_t (&w)[8]) {
+    Fr r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) e[i] = HALF[i];
-    return fr_pow_limbs(a, e) == Fr::one();
+    for (int i = 0; i < 8; i++) r.l[i] = w[i];
+    return r;
 }
-// sqrt of a quadratic residue (caller guarantees it)
-DR_DEV Fr fr_sqrt_qr(const Fr& x) {
-    if (x.is_zero()) return x;
-    constexpr uint32_t Q[8] = {0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u, 0u};
-    constexpr uint32_t Q1H[8] = {0x80000000u, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u, 0u};
+
+// Tonelli-Shanks (the reference's sqrt_mod_bls_scalar_cy, bandersnatch_te.pyx:421-477) with the squareness test folded
+// in: with w = x^((Q-1)/2), R = w x and t = R w = x^Q; x is a square iff t^(2^31) = 1, which the first pass of the
+// order search finds out anyway — no separate Legendre exponentiation.  Returns false for non-residues.
+DR_DEV bool fr_sqrt(const Fr& x, Fr& root) {
+    root = x;
+    if (x.is_zero()) return true;
+    constexpr uint32_t QM1H[8] = {0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u, 0u};   // (Q-1)/2
     uint32_t e[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) e[i] = Q[i];
-    Fr t = fr_pow_limbs(x, e);
-#pragma unroll
-    for (int i = 0; i < 8; i++) e[i] = Q1H[i];
-    Fr R = fr_pow_limbs(x, e);
-    // c = 5^Q (Montgomery)
-    Fr c = fr_const(0x3f21cd85u, 0x4f89b9a6u, 0xd1b4c0f7u, 0x5a6c1ae9u, 0x9e0f51eeu, 0x2c8a0d3du, 0xbd6b4b1cu, 0x07d4a6f0u);
-    {   // derive c on the fly instead of trusting a typed constant: 5^Q
-        Fr five = Fr::zero();
-        five.l[0] = 5;
-        five = to_mont(five);
-#pragma unroll
-        for (int i = 0; i < 8; i++) e[i] = Q[i];
-        c = fr_pow_limbs(five, e);
-    }
-    int M = 32;
+    for (int i = 0; i < 8; i++) e[i] = QM1H[i];
+    Fr w = fr_pow_limbs(x, e);
+    Fr R = mul(w, x);
+    Fr t = mul(R, w);
     const Fr one = Fr::one();
+    int M = 32, j = 0;             // current c = c_pow[j], of order 2^M
 #pragma unroll 1
-    for (int guard = 0; guard < 40; guard++) {
+    for (int guard = 0; guard < 34; guard++) {
         if (t == one) break;
         int i = 1;
         Fr tmp = sqr(t);
 #pragma unroll 1
         while (!(tmp == one) && i < M) { tmp = sqr(tmp); i++; }
-        Fr b = c;
-#pragma unroll 1
-        for (int j = 0; j < M - i - 1; j++) b = sqr(b);
+        if (i == M) return false;                      // order of t is 2^M: not a square
+        Fr b = bsn_const(g_bsn_consts.c_pow[j + M - i - 1]);
+        j += M - i;
         M = i;
-        c = sqr(b);
-        t = mul(t, c);
+        t = mul(t, bsn_const(g_bsn_consts.c_pow[j]));  // c <- b^2
         R = mul(R, b);
     }
-    return R;
+    root = R;
+    return true;
 }
 
-// Elligator 2 onto the Montgomery model, then the birational map to the twisted Edwards model (extended coords)
-DR_DEV TePoint bsn_map_to_curve(const Fr& u) {
-    // curve constants in Montgomery form, derived from a = -5, d:  A_M = 2(a+d)/(a-d), B_M = 4/(a-d)
-    const Fr a_over_b = fr_const(0xfd6a5ca7u, 0x2ac0c0e0u, 0x3e35ba05u, 0x0d58a5bfu, 0x4e7d4d5fu, 0x4a1ad39bu, 0x2b5d7f39u, 0x6ba1bd6eu);
-    (void)a_over_b;
-    // computed from first principles to avoid typed constants
+// Elligator 2 onto the Montgomery model up to the point (s, t) = (x B_M, y B_M); the inversion 1/(1 + Z u^2) is
+// supplied by the caller so that the two maps of one input share ONE inversion (Montgomery's trick).
+struct EllHalf { Fr tv1, den; };
+DR_DEV EllHalf ell2_prepare(const Fr& u) {
     Fr five = Fr::zero(); five.l[0] = 5; five = to_mont(five);
-    Fr a = neg(five), d = te_d_mont();
-    Fr inv_den = inv(sub(a, d));
-    Fr mont_a = mul(dbl(add(a, d)), inv_den), mont_b = mul(dbl(dbl(Fr::one())), inv_den);
-    Fr aob = mul(mont_a, inv(mont_b));
-    Fr inv_b2 = inv(sqr(mont_b));
-    Fr tv1 = mul(five, sqr(u));                        // Z = 5
-    if (add(tv1, Fr::one()).is_zero()) tv1 = Fr::zero();
-    Fr x1 = neg(mul(aob, inv(add(tv1, Fr::one()))));
+    EllHalf h;
+    h.tv1 = mul(five, sqr(u));                         // Z = 5
+    if (add(h.tv1, Fr::one()).is_zero()) h.tv1 = Fr::zero();
+    h.den = add(h.tv1, Fr::one());
+    return h;
+}
+// second half: the birational map to the twisted Edwards model, inversion-free (extended coordinates)
+DR_DEV TePoint ell2_finish(const EllHalf& h, const Fr& inv_den) {
+    const Fr aob = bsn_const(g_bsn_consts.a_over_b), inv_b2 = bsn_const(g_bsn_consts.inv_b2), mont_b = bsn_const(g_bsn_consts.mont_b);
+    Fr x1 = neg(mul(aob, inv_den));
     Fr gx1 = mul(add(mul(add(x1, aob), x1), inv_b2), x1);
-    bool e2 = fr_is_square(gx1);
-    Fr x = e2 ? x1 : sub(neg(x1), aob);
-    Fr y2 = e2 ? gx1 : mul(tv1, gx1);
-    Fr y = fr_sqrt_qr(y2);
+    Fr y;
+    bool e2 = fr_sqrt(gx1, y);
+    Fr x = x1;
+    if (!e2) {
+        x = sub(neg(x1), aob);
+        (void)fr_sqrt(mul(h.tv1, gx1), y);             // Z u^2 g(x1) is a square when g(x1) is not
+    }
     bool odd = (from_mont(y).l[0] & 1u) != 0;
     if (e2 != odd) y = neg(y);                          // e2 XOR e3 -> negate
     Fr s = mul(x, mont_b), t = mul(y, mont_b);
-    // (s,t) -> (v,w) = (s/t ... ) : v = tv2*tv1*s, w = tv2*t*(s-1) with tv2 = 1/((s+1)*t), exceptional case -> (0,1)
+    // (s,t) -> (v,w) = (s/t, (s-1)/(s+1)); with Z = (s+1) t:  X = s (s+1), Y = (s-1) t; exceptional case -> (0,1)
     Fr sp1 = add(s, Fr::one());
-    Fr den = mul(sp1, t);
+    Fr Z = mul(sp1, t);
+    if (Z.is_zero()) return te_identity();
+    Fr X = mul(s, sp1), Y = mul(sub(s, Fr::one()), t);
     TePoint r;
-    if (den.is_zero()) return te_identity();
-    Fr tv2 = inv(den);
-    r.x = mul(mul(tv2, sp1), s);
-    r.y = mul(mul(tv2, t), sub(s, Fr::one()));
-    r.z = Fr::one();
-    r.t = mul(r.x, r.y);
+    r.x = mul(X, Z); r.y = mul(Y, Z); r.z = sqr(Z); r.t = mul(X, Y);
     return r;
 }
 
 __global__ void k_bsn_encode_to_curve(const uint32_t* __restrict__ us /* n*2*8 std */, uint32_t* __restrict__ out /* n*16 std */, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    TePoint q0 = bsn_map_to_curve(to_mont(load_fr_std(us + (size_t)i * 16)));
-    TePoint q1 = bsn_map_to_curve(to_mont(load_fr_std(us + (size_t)i * 16 + 8)));
+    EllHalf h0 = ell2_prepare(to_mont(load_fr_std(us + (size_t)i * 16)));
+    EllHalf h1 = ell2_prepare(to_mont(load_fr_std(us + (size_t)i * 16 + 8)));
+    Fr both = inv(mul(h0.den, h1.den));                // den = 1 + Z u^2 is never zero here (tv1 = -1 was mapped to 0)
+    TePoint q0 = ell2_finish(h0, mul(both, h1.den));
+    TePoint q1 = ell2_finish(h1, mul(both, h0.den));
     TePoint r = te_add(q0, q1);
     r = te_dbl<false>(r);
     r = te_dbl<false>(r);
@@ -336,8 +337,8 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_decode_points(const uint32_t*
     Fr den = sub(te_mul_a(one), mul(te_d_mont(), y2));
     if (den.is_zero()) { valid = false; den = one; }
     Fr x2 = mul(sub(one, y2), inv(den));
-    if (!fr_is_square(x2)) { valid = false; x2 = one; }
-    Fr x = fr_sqrt_qr(x2);
+    Fr x;
+    if (!fr_sqrt(x2, x)) { valid = false; x = one; }
     {
         Fr xs = from_mont(x), nxs = from_mont(neg(x));
         bool x_larger = false;
