@@ -1161,7 +1161,11 @@ int lagrange_prefix_srs(dr_ctx* ctx, const dr_srs* srs_c, unsigned log2n, const 
     if (rc != DR_OK) return rc;
     dr_srs* ps = nullptr;
     TRY(dr_srs_load(ctx, be.data(), n, &ps));
-    rc = dr_srs_precompute(ctx, ps, srs->d_table ? srs->table_wt.cmax : 12);
+    // the by-parts scalars are sparse (~1.4k non-zero of N per column): a narrower window keeps the bucket sets, and with
+    // them the bucket reduction, small (DOTRING_PS_WINDOW, default 10)
+    int ps_bits = 10;
+    if (const char* e = std::getenv("DOTRING_PS_WINDOW")) { int v = std::atoi(e); if (v >= 7 && v <= 16) ps_bits = v; }
+    rc = dr_srs_precompute(ctx, ps, ps_bits);
     if (rc != DR_OK) { dr_srs_destroy(ps); return rc; }
     srs->lagrange_prefix[log2n] = ps;
     *out = ps;
