@@ -1100,6 +1100,7 @@ struct dr_ring_prover {
     dr::RingConsts rc{};
     drh::Fr omega_n, omega_4n;          // Montgomery
     const dr_srs* ps_srs = nullptr;      // prefix-summed Lagrange bases of this domain (owned by srs->lagrange_prefix)
+    dr_ctx* aux_ctx = nullptr;           // second stream of the same GPU: dr_ringvrf_prove_batch runs the Pedersen tail on it
     // per-ring tables
     Scratch ring_pts_mont;              // [N][16]
     Scratch fixed_coef;                 // [3][N][8] std (px, py, s coefficients)
@@ -1254,6 +1255,7 @@ void dr_ring_prover_destroy(dr_ring_prover* p) {
                        &p->prefix, &p->chain_aff, &p->cnt, &p->relation, &p->rps, &p->cols, &p->wit4, &p->alphas, &p->agg, &p->q, &p->zetas,
                        &p->evals, &p->ks, &p->lin, &p->nus, &p->aggo, &p->chunkv, &p->quot1, &p->quot2, &p->diffs})
         s->release();
+    if (p->aux_ctx) dr_ctx_destroy(p->aux_ctx);
     delete p;
 }
 
@@ -1540,61 +1542,83 @@ int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t 
         std::memcpy(sc.data() + 64 * i + 32, blind.data() + 32 * i, 32);
     });
     for (size_t i = 0; i < B; i++) if (bad[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
-    // 4. blinded public keys  Y_bar_i = x_i*G + b_i*B
-    std::vector<uint8_t> ybar(B * 64);
-    TRY(dr_bsn_msm_groups(ctx, gb_pts.data(), sc.data(), B, 2, ybar.data()));
-    // 5. nonces
-    std::vector<uint8_t> ks(B * 32), kbs(B * 32), pts3(2 * B * 128), sc3(2 * B * 64);
-    drh::parallel_for(B, [&](size_t i) {
-        uint8_t enc[32];
-        drh::enc_te_point(ybar.data() + 64 * i, enc);
-        drh::put(tr[i], enc, 32);
-        uint64_t x[4], b[4], k[4], kb[4];
-        drh::load_le32(xs.data() + 32 * i, x);
-        drh::load_le32(blind.data() + 32 * i, b);
-        if (!drh::vrf_nonce(su, tr[i], x, k) || !drh::vrf_nonce(su, tr[i], b, kb)) bad[i] = 1;
-        drh::store_le32(k, ks.data() + 32 * i);
-        drh::store_le32(kb, kbs.data() + 32 * i);
-        // group i: k*G + kb*B ; group B+i: k*I + 0*I
-        std::memcpy(pts3.data() + 128 * i, su.generator, 64);
-        std::memcpy(pts3.data() + 128 * i + 64, su.blinding_base, 64);
-        std::memcpy(sc3.data() + 64 * i, ks.data() + 32 * i, 32);
-        std::memcpy(sc3.data() + 64 * i + 32, kbs.data() + 32 * i, 32);
-        std::memcpy(pts3.data() + 128 * (B + i), inputs.data() + 64 * i, 64);
-        std::memcpy(pts3.data() + 128 * (B + i) + 64, inputs.data() + 64 * i, 64);
-        std::memcpy(sc3.data() + 64 * (B + i), ks.data() + 32 * i, 32);
-        std::memset(sc3.data() + 64 * (B + i) + 32, 0, 32);
-    });
-    for (size_t i = 0; i < B; i++) if (bad[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
-    std::vector<uint8_t> third(2 * B * 64);
-    TRY(dr_bsn_msm_groups(ctx, pts3.data(), sc3.data(), 2 * B, 2, third.data()));
-    // 6. challenge, responses, Pedersen part of the proof
-    drh::parallel_for(B, [&](size_t i) {
-        uint8_t* out = out_proofs + 784 * i;
-        drh::enc_te_point(outs.data() + 64 * i, out);
-        drh::enc_te_point(ybar.data() + 64 * i, out + 32);
-        drh::enc_te_point(third.data() + 64 * i, out + 64);
-        drh::enc_te_point(third.data() + 64 * (B + i), out + 96);
-        uint64_t c[4], x[4], b[4], k[4], kb[4], s[4], sb[4];
-        drh::vrf_challenge(su, tr[i], out + 64, 2, c);
-        drh::load_le32(xs.data() + 32 * i, x);
-        drh::load_le32(blind.data() + 32 * i, b);
-        drh::load_le32(ks.data() + 32 * i, k);
-        drh::load_le32(kbs.data() + 32 * i, kb);
-        mn.mul(c, x, s);  mn.add(s, k, s);
-        mn.mul(c, b, sb); mn.add(sb, kb, sb);
-        drh::store_le32(s, out + 128);
-        drh::store_le32(sb, out + 160);
-        if (out_aux) {
-            uint8_t* a = out_aux + DR_RINGVRF_AUX_BYTES * i;
-            std::memcpy(a, outs.data() + 64 * i, 64);
-            std::memcpy(a + 64, ybar.data() + 64 * i, 64);
-            std::memcpy(a + 128, third.data() + 64 * i, 64);
-            std::memcpy(a + 192, third.data() + 64 * (B + i), 64);
-            std::memcpy(a + 256, blind.data() + 32 * i, 32);
-        }
-    });
-    tr.clear();
+    // 4.-6. the rest of the Pedersen part needs nothing from the ring proof and the ring proof needs only the blinding
+    // factors: it runs on a second stream (own context: scratch + stream) from a helper thread while this thread drives
+    // the ring phases.  Its kernels are latency-bound (16..64 waves) and hide under the chip-filling MSMs.
+    if (!p->aux_ctx) TRY(dr_ctx_create(ctx->device, &p->aux_ctx));
+    dr_ctx* actx = p->aux_ctx;
+    std::vector<uint8_t> ybar(B * 64), ks(B * 32), kbs(B * 32), pts3(2 * B * 128), sc3(2 * B * 64), third(2 * B * 64);
+    int ped_rc = DR_OK;
+    std::string ped_err;
+    auto pedersen_tail = [&]() -> int {
+        // 4. blinded public keys  Y_bar_i = x_i*G + b_i*B
+        TRY(dr_bsn_msm_groups(actx, gb_pts.data(), sc.data(), B, 2, ybar.data()));
+        // 5. nonces
+        std::vector<int> bad2(B, 0);
+        drh::parallel_for(B, [&](size_t i) {
+            uint8_t enc[32];
+            drh::enc_te_point(ybar.data() + 64 * i, enc);
+            drh::put(tr[i], enc, 32);
+            uint64_t x[4], b[4], k[4], kb[4];
+            drh::load_le32(xs.data() + 32 * i, x);
+            drh::load_le32(blind.data() + 32 * i, b);
+            if (!drh::vrf_nonce(su, tr[i], x, k) || !drh::vrf_nonce(su, tr[i], b, kb)) bad2[i] = 1;
+            drh::store_le32(k, ks.data() + 32 * i);
+            drh::store_le32(kb, kbs.data() + 32 * i);
+            // group i: k*G + kb*B ; group B+i: k*I + 0*I
+            std::memcpy(pts3.data() + 128 * i, su.generator, 64);
+            std::memcpy(pts3.data() + 128 * i + 64, su.blinding_base, 64);
+            std::memcpy(sc3.data() + 64 * i, ks.data() + 32 * i, 32);
+            std::memcpy(sc3.data() + 64 * i + 32, kbs.data() + 32 * i, 32);
+            std::memcpy(pts3.data() + 128 * (B + i), inputs.data() + 64 * i, 64);
+            std::memcpy(pts3.data() + 128 * (B + i) + 64, inputs.data() + 64 * i, 64);
+            std::memcpy(sc3.data() + 64 * (B + i), ks.data() + 32 * i, 32);
+            std::memset(sc3.data() + 64 * (B + i) + 32, 0, 32);
+        });
+        for (size_t i = 0; i < B; i++) if (bad2[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
+        TRY(dr_bsn_msm_groups(actx, pts3.data(), sc3.data(), 2 * B, 2, third.data()));
+        // 6. challenge, responses, Pedersen part of the proof
+        drh::parallel_for(B, [&](size_t i) {
+            uint8_t* out = out_proofs + 784 * i;
+            drh::enc_te_point(outs.data() + 64 * i, out);
+            drh::enc_te_point(ybar.data() + 64 * i, out + 32);
+            drh::enc_te_point(third.data() + 64 * i, out + 64);
+            drh::enc_te_point(third.data() + 64 * (B + i), out + 96);
+            uint64_t c[4], x[4], b[4], k[4], kb[4], s[4], sb[4];
+            drh::vrf_challenge(su, tr[i], out + 64, 2, c);
+            drh::load_le32(xs.data() + 32 * i, x);
+            drh::load_le32(blind.data() + 32 * i, b);
+            drh::load_le32(ks.data() + 32 * i, k);
+            drh::load_le32(kbs.data() + 32 * i, kb);
+            mn.mul(c, x, s);  mn.add(s, k, s);
+            mn.mul(c, b, sb); mn.add(sb, kb, sb);
+            drh::store_le32(s, out + 128);
+            drh::store_le32(sb, out + 160);
+            if (out_aux) {
+                uint8_t* a = out_aux + DR_RINGVRF_AUX_BYTES * i;
+                std::memcpy(a, outs.data() + 64 * i, 64);
+                std::memcpy(a + 64, ybar.data() + 64 * i, 64);
+                std::memcpy(a + 128, third.data() + 64 * i, 64);
+                std::memcpy(a + 192, third.data() + 64 * (B + i), 64);
+                std::memcpy(a + 256, blind.data() + 32 * i, 32);
+            }
+        });
+        return DR_OK;
+    };
+    const bool overlap = std::getenv("DOTRING_PROVE_OVERLAP") == nullptr || std::atoi(std::getenv("DOTRING_PROVE_OVERLAP")) != 0;
+    std::thread ped_thread;
+    if (overlap) {
+        ped_thread = std::thread([&] {
+            ped_rc = pedersen_tail();
+            if (ped_rc != DR_OK) ped_err = dr_last_error();
+        });
+    } else {
+        TRY(pedersen_tail());
+    }
+    struct Joiner {          // every exit path below must wait for the helper before the buffers it uses go away
+        std::thread& t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{ped_thread};
 
     // 7. ring proof: witness columns
     std::vector<uint8_t> zk;
@@ -1655,6 +1679,8 @@ int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t 
         }
     });
     for (size_t i = 0; i < B; i++) if (rc[i] != DR_OK) return rc[i];
+    if (ped_thread.joinable()) ped_thread.join();
+    if (ped_rc != DR_OK) return fail(ped_rc, ped_err.empty() ? "Pedersen part failed" : ped_err);
     return DR_OK;
 }
 
