@@ -140,8 +140,16 @@ def main() -> int:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # rehearsal on a box with fewer GPUs than ranks (never used by the driver): DOTRING_BENCH_SHARE_GPU=1 puts every
+        # rank on device 0 and swaps RCCL for gloo (RCCL refuses two ranks on one GPU)
+        share = os.environ.get("DOTRING_BENCH_SHARE_GPU") == "1"
+        if share:
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        red_device = "cpu" if share else "cuda"
 
     os.environ["DOTRING_DEVICE"] = str(local_rank)
     import dot_ring_amd as d
@@ -208,7 +216,7 @@ def main() -> int:
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
     if dist is not None:
-        t = torch.tensor([elapsed, 0.0 if all_ok else 1.0], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, 0.0 if all_ok else 1.0], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, all_ok = float(t[0].item()), float(t[1].item()) == 0.0
 
