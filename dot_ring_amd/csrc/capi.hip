@@ -162,6 +162,7 @@ int pick_window(size_t n) {
 }
 
 uint32_t g_chunk_len = 16;   // buckets per lane in k_g1_reduce_chunks (DOTRING_MSM_CHUNK)
+bool g_reduce_levels = true; // level-wise bucket reduction for many bucket sets (DOTRING_MSM_LEVELS=0 disables)
 
 struct MsmPlan {
     dr::WindowTable wt;
@@ -305,14 +306,45 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
                            ctx->sorted.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(),
                            ctx->buckets.as<uint32_t>(), nbuckets);
     }));
-    TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
-        hipLaunchKernelGGL(dr::k_g1_reduce_chunks, dim3(div_up(bsets * pl.T, 128)), dim3(128), 0, st,
-                           ctx->buckets.as<uint32_t>(), bsets, pl.H, pl.L, ctx->partial.as<uint32_t>());
-    }));
-    TRY(launch(ctx, "k_g1_reduce_windows", [&] {
-        hipLaunchKernelGGL(dr::k_g1_reduce_windows, dim3((unsigned)bsets), dim3(dr::RW_BLOCK), 0, st,
-                           ctx->partial.as<uint32_t>(), pl.T, ctx->winsum.as<uint32_t>());
-    }));
+    // many bucket sets (batched prover): level-wise reduction, 2 additions per entry and no scalar multiplications;
+    // few sets (single MSMs): chunk sums + double-and-add, whose latency is one short chain
+    const bool leveled = g_reduce_levels && pl.L == 16 && pl.H >= 256 && bsets * (size_t)(pl.H / 16) >= ((size_t)1 << 18);
+    if (leveled) {
+        // level outputs live in ctx->partial: [S | C] per level, sizes sets * H/16, sets * H/256, ...
+        size_t total = 0;
+        for (uint32_t n = pl.H; n > 16; n /= 16) total += 2 * bsets * (n / 16);
+        TRY(ctx->partial.reserve(total * 192));
+        uint32_t* base = ctx->partial.as<uint32_t>();
+        const uint32_t* in_s = ctx->buckets.as<uint32_t>();
+        const uint32_t* in_c = nullptr;
+        uint32_t n = pl.H;
+        int level = 0;
+        size_t off = 0;
+        while (n > 16) {
+            level++;
+            const size_t cnt = bsets * (n / 16);
+            uint32_t* out_s = base + off * 48;
+            uint32_t* out_c = base + (off + cnt) * 48;
+            TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
+                hipLaunchKernelGGL(dr::k_g1_reduce_level, dim3(div_up(cnt, 128)), dim3(128), 0, st, in_s, in_c, bsets, n, 16u, level, out_s, out_c);
+            }));
+            in_s = out_s; in_c = out_c;
+            off += 2 * cnt;
+            n /= 16;
+        }
+        TRY(launch(ctx, "k_g1_reduce_windows", [&] {
+            hipLaunchKernelGGL(dr::k_g1_reduce_final, dim3(div_up(bsets, 64)), dim3(64), 0, st, in_s, in_c, bsets, n, level, ctx->winsum.as<uint32_t>());
+        }));
+    } else {
+        TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
+            hipLaunchKernelGGL(dr::k_g1_reduce_chunks, dim3(div_up(bsets * pl.T, 128)), dim3(128), 0, st,
+                               ctx->buckets.as<uint32_t>(), bsets, pl.H, pl.L, ctx->partial.as<uint32_t>());
+        }));
+        TRY(launch(ctx, "k_g1_reduce_windows", [&] {
+            hipLaunchKernelGGL(dr::k_g1_reduce_windows, dim3((unsigned)bsets), dim3(dr::RW_BLOCK), 0, st,
+                               ctx->partial.as<uint32_t>(), pl.T, ctx->winsum.as<uint32_t>());
+        }));
+    }
 
     static_assert(sizeof(drh::G1) == 192, "XYZZ layout");
     if (single) {
@@ -505,6 +537,7 @@ int dr_ctx_create(int device_id, dr_ctx** out) {
         int v = std::atoi(cl);
         if (v == 8 || v == 16 || v == 32 || v == 64 || v == 128) g_chunk_len = (uint32_t)v;
     }
+    if (const char* lv = std::getenv("DOTRING_MSM_LEVELS")) g_reduce_levels = std::atoi(lv) != 0;
     int rc = bsn_consts_init(ctx->stream);
     if (rc != DR_OK) {
         (void)hipStreamDestroy(ctx->stream);

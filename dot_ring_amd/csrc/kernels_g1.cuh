@@ -558,6 +558,51 @@ __global__ __launch_bounds__(RW_BLOCK) void k_g1_reduce_windows(const uint32_t* 
     if (threadIdx.x == 0) store_xyzz(winsum, win, acc);
 }
 
+// ---- 5b. bucket reduction without scalar multiplications, for MANY bucket sets (the batched prover: 10^7 buckets).
+// With j = t L + i:  sum_j (j+1) B_j = L * sum_t (t+1) S_t - sum_t Q_t,  S_t = sum_i B_{t,i},  Q_t = sum_i (L-1-i) B_{t,i}:
+// the same problem on the T = H/L chunk sums, minus a correction.  Each level costs 2 additions per entry (against
+// 3.25 per bucket for the chunk + double-and-add form above) and shrinks the set by L; corrections are carried along as
+// C (scaled by L^(level-1)), so the value of a set is  L^K * W_K - sum C_K  with W_K the direct running sum over the
+// last <= 16 entries.  Latency is a few serial levels: only worth it when the first level alone fills the chip.
+__global__ __launch_bounds__(128) void k_g1_reduce_level(const uint32_t* __restrict__ in_s, const uint32_t* __restrict__ in_c /* null at level 1 */,
+                                                         size_t sets, uint32_t n_in, uint32_t L, int level,
+                                                         uint32_t* __restrict__ out_s, uint32_t* __restrict__ out_c) {
+    const uint32_t T = n_in / L;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= sets * T) return;
+    size_t set = gid / T;
+    uint32_t s = (uint32_t)(gid % T) * L;
+    G1Xyzz run = g1_inf(), q = g1_inf(), c = g1_inf();
+#pragma unroll 1
+    for (uint32_t i = 0; i < L; i++) {
+        size_t idx = set * n_in + s + i;
+        q = g1_add(q, run);
+        run = g1_add(run, load_xyzz(in_s, idx));
+        if (in_c) c = g1_add(c, load_xyzz(in_c, idx));
+    }
+#pragma unroll 1
+    for (int k = 0; k < 4 * (level - 1); k++) q = g1_dbl(q);          // L = 16: scale by L^(level-1)
+    store_xyzz(out_s, gid, run);
+    store_xyzz(out_c, gid, in_c ? g1_add(c, q) : q);
+}
+// one lane per set: direct running sum over the last n <= 16 entries, then value = L^levels * W - sum C
+__global__ void k_g1_reduce_final(const uint32_t* __restrict__ in_s, const uint32_t* __restrict__ in_c, size_t sets, uint32_t n, int levels,
+                                  uint32_t* __restrict__ winsum) {
+    size_t set = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (set >= sets) return;
+    G1Xyzz run = g1_inf(), w = g1_inf(), c = g1_inf();
+#pragma unroll 1
+    for (int j = (int)n - 1; j >= 0; j--) {
+        run = g1_add(run, load_xyzz(in_s, set * n + j));
+        w = g1_add(w, run);
+        c = g1_add(c, load_xyzz(in_c, set * n + j));
+    }
+#pragma unroll 1
+    for (int k = 0; k < 4 * levels; k++) w = g1_dbl(w);
+    c.y = neg(c.y);
+    store_xyzz(winsum, set, g1_add(w, c));
+}
+
 // ---- 6. (batch > 1) combine the W window sums of each MSM on the device: Horner over windows, width[w] doublings each.
 __global__ void k_g1_horner(const uint32_t* __restrict__ winsum, uint32_t batch, WindowTable wt, uint32_t* __restrict__ out) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -143,6 +143,26 @@ def test_g1_msm_batch_matches_singles(ctx, srs_bytes, window):
     srs.close()
 
 
+@pytest.mark.parametrize("bits,batch", [(12, 2100), (9, 16500)])
+def test_g1_msm_many_bucket_sets_level_reduction(ctx, srs_bytes, bits, batch):
+    """Thousands of small MSMs over a window table take the level-wise bucket reduction (k_g1_reduce_level/_final:
+    two levels at H = 2048, one at H = 256); sampled results against the oracle, plus all-zero and single-term vectors."""
+    n = 24
+    rng = random.Random(bits)
+    tabled = ctx.srs_load(srs_bytes[: 96 * n]).precompute(bits)
+    vecs = [b"".join(rng.randrange(coracle.FR_P).to_bytes(32, "little") for _ in range(n)) for _ in range(5)]
+    vecs.append(bytes(32 * n))                                                     # -> infinity
+    vecs.append((coracle.FR_P - 1).to_bytes(32, "little") + bytes(32 * (n - 1)))   # -G
+    vecs.append(bytes(32 * (n - 1)) + (1).to_bytes(32, "little"))                  # last base
+    ks = b"".join(vecs[i % len(vecs)] for i in range(batch))
+    got = ctx.g1_msm_batch(tabled, ks, n)
+    want = [_oracle_msm_be(srs_bytes, v, n) for v in vecs]
+    assert want[5] is None
+    for i in range(batch):
+        assert got[i] == want[i % len(vecs)], i
+    tabled.close()
+
+
 @pytest.mark.parametrize("bits", [7, 12, 16])
 def test_g1_msm_fixed_base_table_matches_plain(ctx, srs_bytes, bits):
     """dr_srs_precompute: one bucket set per MSM over the window table — identical results, single and batched."""
