@@ -78,7 +78,8 @@ def g1_msm_measurement(ctx, log2n: int, steps: int, cpu_sample_log2: int, do_cpu
     """Secondary: G1 MSM at 2^log2n synthetic bases. Returns a dict (rank-local)."""
     n = 1 << log2n
     srs = ctx.srs_synthetic(G1_BE, n, first=1)
-    srs.precompute(16)          # fixed-base window table in HBM (W * n * 96 B = 1.6 GB at 2^20): one bucket set per MSM
+    # fixed-base window table in HBM (W * n * 96 B = 1.6 GB at 2^20 with 16-bit windows): one bucket set per MSM
+    srs.precompute(16 if log2n >= 18 else 12)
     vals, raw = seeded_scalars(n, b"\0\0\0\0")
     d_scalars = ctx.alloc(32 * n).upload(raw)
     ctx.g1_msm_dev(srs, d_scalars, n)
@@ -276,6 +277,10 @@ def main() -> int:
         if args.msm_log2n > 0:
             g1 = g1_msm_measurement(ctx, args.msm_log2n, 10, 17, True)
             parity_ok = parity_ok and g1.get("parity_closed_form", True) and g1.get("parity_sample", True)
+            if args.msm_log2n > 16:             # BASELINE configs[2] names 2^16 as well
+                small = g1_msm_measurement(ctx, 16, 20, 0, True)
+                parity_ok = parity_ok and small.get("parity_closed_form", True)
+                g1["at_2p16"] = {k: small[k] for k in ("pairs", "scalar_muls_per_s", "ms_per_msm", "parity_closed_form")}
         line = {
             "metric": "ringvrf_proofs_per_sec",
             "value": value,

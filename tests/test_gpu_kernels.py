@@ -143,6 +143,29 @@ def test_g1_msm_batch_matches_singles(ctx, srs_bytes, window):
     srs.close()
 
 
+@pytest.mark.parametrize("log2n,table", [(16, 0), (16, 12), (18, 16)])
+def test_g1_msm_synthetic_bases_closed_form(ctx, log2n, table):
+    """BASELINE configs[2] sizes (2^16; 2^20 runs in bench.py): no SRS of that size exists, so bases are (1+i)*G
+    generated on the GPU and the MSM must equal [sum k_i (1+i)]*G — one oracle scalar multiplication; the first 4096
+    pairs are also checked against the oracle's Pippenger."""
+    import bench
+
+    n = 1 << log2n
+    srs = ctx.srs_synthetic(bench.G1_BE, n, first=1)
+    if table:
+        srs.precompute(table)
+    vals, raw = bench.seeded_scalars(n, b"test")
+    got = ctx.g1_msm(srs, raw)
+    expect = sum(k * (1 + i) for i, k in enumerate(vals)) % coracle.FR_P
+    want = coracle.g1_msm_raw(bench.be_to_le_points(bench.G1_BE), expect.to_bytes(32, "little"), 1)
+    assert got == bytes(want)[:48][::-1] + bytes(want)[48:][::-1]
+    m = 4096
+    cpu = coracle.g1_msm_raw(bench.be_to_le_points(srs.download(0, m)), raw[: 32 * m], m)
+    gpu = ctx.g1_msm(srs, raw[: 32 * m])
+    assert gpu == bytes(cpu)[:48][::-1] + bytes(cpu)[48:][::-1]
+    srs.close()
+
+
 @pytest.mark.parametrize("bits,batch", [(12, 2100), (9, 16500)])
 def test_g1_msm_many_bucket_sets_level_reduction(ctx, srs_bytes, bits, batch):
     """Thousands of small MSMs over a window table take the level-wise bucket reduction (k_g1_reduce_level/_final:
