@@ -81,6 +81,7 @@ struct dr_ctx {
     // MSM workspaces
     Scratch scalars, digits, counts, offsets, cursor, tiles, sorted, buckets, partial, winsum, result, io_a, io_b, io_c, perm, cells, cell_off;
     Scratch vfy_bases, vfy_in, vfy_std;      // dr_ringvrf_verify_batch: decompressed G1 points stay resident between its steps
+    dr_ctx* aux = nullptr;                   // second stream for the latency-bound Bandersnatch side of the batch verifier
     dr::TwiddleCache twiddles;
 };
 
@@ -550,6 +551,7 @@ int dr_ctx_create(int device_id, dr_ctx** out) {
 
 void dr_ctx_destroy(dr_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->aux) { dr_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (Scratch* s : {&ctx->scalars, &ctx->digits, &ctx->counts, &ctx->offsets, &ctx->cursor, &ctx->tiles, &ctx->sorted,
@@ -687,19 +689,37 @@ int dr_bsn_msm(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars, size_
         out_xy[32] = 1;
         return DR_OK;
     }
-    // fold 64 terms at a time on the device; the (few) partial sums are then combined the same way with scalar 1
-    std::vector<uint8_t> pts(pts_xy, pts_xy + n * 64), ks(scalars, scalars + n * 32);
-    while (true) {
-        size_t cur = pts.size() / 64;
-        if (cur <= 64) return dr_bsn_msm_groups(ctx, pts.data(), ks.data(), 1, cur, out_xy);
-        size_t full = cur / 64, rem = cur % 64;
-        std::vector<uint8_t> next((full + (rem ? 1 : 0)) * 64);
-        TRY(dr_bsn_msm_groups(ctx, pts.data(), ks.data(), full, 64, next.data()));
-        if (rem) TRY(dr_bsn_msm_groups(ctx, pts.data() + full * 64 * 64, ks.data() + full * 64 * 32, 1, rem, next.data() + full * 64));
-        pts.swap(next);
-        ks.assign(pts.size() / 2, 0);
-        for (size_t i = 0; i < pts.size() / 64; i++) ks[32 * i] = 1;
+    // fold 64 terms at a time on the device (one launch); the n/64 partial sums are then added on the host in extended
+    // coordinates — a second device pass would pay a full scalar-multiplication latency for scalars that are all 1
+    if (n <= 64) return dr_bsn_msm_groups(ctx, pts_xy, scalars, 1, n, out_xy);
+    const size_t parts = (n + 63) / 64;
+    std::vector<uint8_t> part(parts * 64);
+    if (n % 64 == 0) {
+        TRY(dr_bsn_msm_groups(ctx, pts_xy, scalars, parts, 64, part.data()));
+    } else {        // pad the last group with 0 * (0, 1) so that everything is ONE launch
+        std::vector<uint8_t> pp(parts * 64 * 64, 0), kk(parts * 64 * 32, 0);
+        std::memcpy(pp.data(), pts_xy, n * 64);
+        std::memcpy(kk.data(), scalars, n * 32);
+        for (size_t i = n; i < parts * 64; i++) pp[64 * i + 32] = 1;
+        TRY(dr_bsn_msm_groups(ctx, pp.data(), kk.data(), parts, 64, part.data()));
     }
+    using drh::Fr;
+    static const uint8_t D_LE[32] = {0xe7, 0x58, 0x8d, 0x18, 0xf5, 0xf2, 0x69, 0xb3, 0x92, 0x4f, 0xe5, 0x77, 0x71, 0x67, 0x66, 0xcb,
+                                     0xd8, 0xb6, 0xe3, 0x6b, 0xf8, 0x3b, 0x6e, 0xc6, 0xcb, 0x67, 0xc2, 0x33, 0x26, 0xc1, 0x89, 0x63};
+    Fr d, five = Fr::from_u64(5);
+    if (!Fr::load_le(d, D_LE)) return fail(DR_ERR_DEVICE, "bad curve constant");
+    Fr X = Fr::zero(), Y = Fr::one(), Z = Fr::one(), T = Fr::zero();          // identity
+    for (size_t i = 0; i < parts; i++) {                                      // add-2008-hwcd with Z2 = 1, a = -5
+        Fr x2, y2;
+        if (!Fr::load_le(x2, part.data() + 64 * i) || !Fr::load_le(y2, part.data() + 64 * i + 32)) return fail(DR_ERR_DEVICE, "kernel result out of range");
+        Fr A = X * x2, B = Y * y2, C = T * d * (x2 * y2), D = Z;
+        Fr E = (X + Y) * (x2 + y2) - A - B, F = D - C, G = D + C, H = B + A * five;      // H = B - a*A
+        X = E * F; Y = G * H; T = E * H; Z = F * G;
+    }
+    Fr zi = Z.inv();
+    (X * zi).store_le(out_xy);
+    (Y * zi).store_le(out_xy + 32);
+    return DR_OK;
 }
 
 int dr_bsn_encode_to_curve_batch(dr_ctx* ctx, const uint8_t* u_pairs, size_t n, uint8_t* out_xy) {
@@ -1757,7 +1777,27 @@ int dr_ringvrf_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_rin
     }
     if (!canonical) return DR_OK;
 
-    // ---- 2. GPU: decode + validate the 4B Bandersnatch points, decompress the 7B G1 points, hash the inputs to the curve
+    // ---- 2. GPU: decode + validate the 4B Bandersnatch points, decompress the 7B G1 points; meanwhile a helper thread
+    // hashes the inputs to the curve on a second stream (all three kernels are latency-bound: a few dozen waves)
+    if (!ctx->aux) TRY(dr_ctx_create(ctx->device, &ctx->aux));
+    dr_ctx* actx = ctx->aux;
+    std::vector<uint8_t> us(B * 64), in_pts(B * 64);
+    int side_rc = DR_OK;
+    std::string side_err;
+    std::thread side([&] {
+        drh::parallel_for(B, [&](size_t i) {
+            drh::Bytes msg;
+            if (salt_off) drh::put(msg, salts + salt_off[i], salt_off[i + 1] - salt_off[i]);
+            drh::put(msg, inputs + in_off[i], in_off[i + 1] - in_off[i]);
+            drh::hash_to_field2(su, msg.data(), msg.size(), us.data() + 64 * i);
+        });
+        side_rc = dr_bsn_encode_to_curve_batch(actx, us.data(), B, in_pts.data());
+        if (side_rc != DR_OK) side_err = dr_last_error();
+    });
+    struct Joiner {
+        std::thread& t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{side};
     const size_t n_te = 4 * B, n_g1 = 7 * B + 4;
     TRY(ctx->io_a.reserve(n_te * 32));
     TRY(ctx->io_b.reserve(n_te * 64));
@@ -1797,17 +1837,14 @@ int dr_ringvrf_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_rin
     HIP_TRY(hipMemcpyAsync(g1_le.data(), g1_std.p, 7 * B * 96, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(flags.data(), d_ok, (n_te + 7 * B) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    side.join();
+    if (side_rc != DR_OK) return fail(side_rc, side_err.empty() ? "encode_to_curve failed" : side_err);
     for (size_t i = 0; i < n_te + 7 * B; i++) if (!flags[i]) return DR_OK;                  // malformed / invalid point: ok = 0
-    std::vector<uint8_t> us(B * 64), in_pts(B * 64);
-    drh::parallel_for(B, [&](size_t i) {
-        drh::Bytes msg;
-        if (salt_off) drh::put(msg, salts + salt_off[i], salt_off[i + 1] - salt_off[i]);
-        drh::put(msg, inputs + in_off[i], in_off[i + 1] - in_off[i]);
-        drh::hash_to_field2(su, msg.data(), msg.size(), us.data() + 64 * i);
-    });
-    TRY(dr_bsn_encode_to_curve_batch(ctx, us.data(), B, in_pts.data()));
 
-    // ---- 3. Pedersen part: challenges, then ONE (5B+2)-point MSM that must vanish
+    // ---- 3. Pedersen part (helper thread, second stream): challenges, then ONE (5B+2)-point MSM that must vanish
+    int ped_ok = 0;
+    side = std::thread([&] {
+      side_rc = [&]() -> int {
     std::vector<uint8_t> cs(B * 32);
     drh::parallel_for(B, [&](size_t i) {
         const uint8_t* pr = proofs + 784 * i;
@@ -1860,11 +1897,15 @@ int dr_ringvrf_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_rin
         std::memcpy(pts.data() + 320 * B, su.generator, 64);           drh::store_le32(gs, sc.data() + 160 * B);
         std::memcpy(pts.data() + 320 * B + 64, su.blinding_base, 64);  drh::store_le32(bs, sc.data() + 160 * B + 32);
         uint8_t sum[64];
-        TRY(dr_bsn_msm(ctx, pts.data(), sc.data(), 5 * B + 2, sum));
+        TRY(dr_bsn_msm(actx, pts.data(), sc.data(), 5 * B + 2, sum));
         uint8_t ident[64] = {0};
         ident[32] = 1;
-        if (std::memcmp(sum, ident, 64) != 0) return DR_OK;
+        ped_ok = std::memcmp(sum, ident, 64) == 0 ? 1 : 0;
     }
+    return DR_OK;
+      }();
+      if (side_rc != DR_OK) side_err = dr_last_error();
+    });
 
     // ---- 4. ring proofs: transcript replay + verifier scalar pass per proof, random linear combination of all claims
     drh::RingVerifierDomain dm;
@@ -1958,7 +1999,9 @@ int dr_ringvrf_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_rin
     }
     int pok = 0;
     TRY(dr_pairing_check(pair_g1, vk->g2, 2, &pok));
-    *ok = pok;
+    side.join();
+    if (side_rc != DR_OK) return fail(side_rc, side_err.empty() ? "Pedersen part failed" : side_err);
+    *ok = pok && ped_ok;
     return DR_OK;
 }
 
