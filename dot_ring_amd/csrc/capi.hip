@@ -239,6 +239,12 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     }
     const size_t windows = batch * (size_t)pl.W;                   // digit rows
     const size_t bsets = single ? batch * groups : windows;        // bucket sets
+    // few bucket sets of moderate size (a single MSM over a window table): the reduction is a latency chain of
+    // 2L additions + a log2(H)-bit double-and-add + the fold of H/L partial sums; L = 4 makes it ~40 % shorter
+    if (single && pl.L == 16 && pl.H >= 256 && pl.H <= 4096 && bsets * (size_t)(pl.H / 16) < ((size_t)1 << 17)) {
+        pl.L = 4;
+        pl.T = pl.H / 4;
+    }
     const size_t nbuckets = bsets * pl.H;
     const size_t ndigits = windows * n;
     if (nbuckets >= (1ull << 32) || ndigits >= (1ull << 32))
