@@ -163,6 +163,7 @@ int pick_window(size_t n) {
 }
 
 uint32_t g_chunk_len = 16;   // buckets per lane in k_g1_reduce_chunks (DOTRING_MSM_CHUNK)
+bool g_chain_wave = true;    // one wave per proof for the witness accumulator chain (DOTRING_CHAIN_WAVE=0: one lane per proof)
 bool g_reduce_levels = true; // level-wise bucket reduction for many bucket sets (DOTRING_MSM_LEVELS=0 disables)
 
 struct MsmPlan {
@@ -545,6 +546,7 @@ int dr_ctx_create(int device_id, dr_ctx** out) {
         if (v == 8 || v == 16 || v == 32 || v == 64 || v == 128) g_chunk_len = (uint32_t)v;
     }
     if (const char* lv = std::getenv("DOTRING_MSM_LEVELS")) g_reduce_levels = std::atoi(lv) != 0;
+    if (const char* cw = std::getenv("DOTRING_CHAIN_WAVE")) g_chain_wave = std::atoi(cw) != 0;
     int rc = bsn_consts_init(ctx->stream);
     if (rc != DR_OK) {
         (void)hipStreamDestroy(ctx->stream);
@@ -1364,9 +1366,14 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
         HIP_TRY(hipMemcpyAsync(p->zk.p, zk_rows, batch * 12 * 32, hipMemcpyHostToDevice, st));
     }
     TRY(launch(ctx, "k_ring_chain", [&] {
-        hipLaunchKernelGGL(dr::k_ring_chain, dim3(div_up(batch, 64)), dim3(64), 0, st, p->ring_pts_mont.as<uint32_t>(), p->idx.as<uint32_t>(),
-                           p->blind.as<uint32_t>(), rc, (uint32_t)batch, p->chain_ext.as<uint32_t>(), p->prefix.as<uint32_t>(),
-                           p->chain_aff.as<uint32_t>(), p->cnt.as<uint32_t>());
+        if (g_chain_wave)
+            hipLaunchKernelGGL(dr::k_ring_chain_wave, dim3((unsigned)batch), dim3(64), 0, st, p->ring_pts_mont.as<uint32_t>(), p->idx.as<uint32_t>(),
+                               p->blind.as<uint32_t>(), rc, (uint32_t)batch, p->chain_ext.as<uint32_t>(), p->chain_aff.as<uint32_t>(),
+                               p->cnt.as<uint32_t>());
+        else
+            hipLaunchKernelGGL(dr::k_ring_chain, dim3(div_up(batch, 64)), dim3(64), 0, st, p->ring_pts_mont.as<uint32_t>(), p->idx.as<uint32_t>(),
+                               p->blind.as<uint32_t>(), rc, (uint32_t)batch, p->chain_ext.as<uint32_t>(), p->prefix.as<uint32_t>(),
+                               p->chain_aff.as<uint32_t>(), p->cnt.as<uint32_t>());
     }));
     TRY(launch(ctx, "k_ring_columns", [&] {
         hipLaunchKernelGGL(dr::k_ring_relations, dim3(div_up(batch, 64)), dim3(64), 0, st, p->chain_aff.as<uint32_t>(), p->cnt.as<uint32_t>(),

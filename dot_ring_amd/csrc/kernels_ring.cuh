@@ -180,6 +180,116 @@ __global__ void k_ring_chain(const uint32_t* __restrict__ ring_pts_mont /* N*16:
     }
 }
 
+// The same chain with one WAVE per proof: lane l owns blinding bits 4l..4l+3.  Local sums of the selected bit points,
+// an inclusive scan across the wave (6 shuffle steps), then every lane walks its own <= 4 additions from
+// seed + PK_k + (sum of all lower lanes) — 16 dependent additions instead of ~128, and one Fermat inversion per lane
+// (lock-step, so it costs the time of one) to normalise the lane's own values.  Same outputs as k_ring_chain.
+DR_DEV TePoint te_shfl_up(const TePoint& p, unsigned delta) {
+    TePoint o;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        o.x.l[t] = __shfl_up(p.x.l[t], delta, 64);
+        o.y.l[t] = __shfl_up(p.y.l[t], delta, 64);
+        o.z.l[t] = __shfl_up(p.z.l[t], delta, 64);
+        o.t.l[t] = __shfl_up(p.t.l[t], delta, 64);
+    }
+    return o;
+}
+__global__ __launch_bounds__(64) void k_ring_chain_wave(const uint32_t* __restrict__ ring_pts_mont, const uint32_t* __restrict__ producer_idx,
+                                                        const uint32_t* __restrict__ blinding, RingConsts rc, uint32_t batch,
+                                                        uint32_t* __restrict__ chain_ext /* B*256*32 scratch */,
+                                                        uint32_t* __restrict__ chain_aff /* B*256*16 */, uint32_t* __restrict__ cnt_out) {
+    const uint32_t pid = blockIdx.x, lane = threadIdx.x;
+    if (pid >= batch) return;
+    uint32_t* ext = chain_ext + (size_t)pid * RING_CHAIN * 32;
+    uint32_t* aff = chain_aff + (size_t)pid * RING_CHAIN * 16;
+    auto put = [&](uint32_t idx, const TePoint& p) {
+        gstore_fr(ext + idx * 32, p.x); gstore_fr(ext + idx * 32 + 8, p.y);
+        gstore_fr(ext + idx * 32 + 16, p.z); gstore_fr(ext + idx * 32 + 24, p.t);
+    };
+    auto ring_point = [&](uint32_t row) {
+        TePoint p;
+        p.x = gload_fr(ring_pts_mont + (size_t)row * 16);
+        p.y = gload_fr(ring_pts_mont + (size_t)row * 16 + 8);
+        p.z = Fr::one();
+        p.t = mul(p.x, p.y);
+        return p;
+    };
+    uint32_t t[8];
+    {
+        Fr tt = gload_fr(blinding + (size_t)pid * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = tt.l[j];
+    }
+    t[7] &= 0x1fffffffu;                                   // bits 0..252 only (k_ring_chain's loop bound)
+    const uint32_t j0 = lane * 4;
+    const uint32_t mine = (t[j0 >> 5] >> (j0 & 31)) & 0xfu;    // this lane's four bits
+    // number of set bits below j0 -> chain index of this lane's first value
+    uint32_t below = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        uint32_t lo = w * 32;
+        if (j0 >= lo + 32) below += __popc(t[w]);
+        else if (j0 > lo) below += __popc(t[w] & ((1u << (j0 - lo)) - 1));
+    }
+    uint32_t total_bits = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) total_bits += __popc(t[w]);
+    // 1. local sum of the selected bit points
+    TePoint loc = te_identity();
+#pragma unroll 1
+    for (uint32_t b = 0; b < 4; b++)
+        if ((mine >> b) & 1) loc = te_add(loc, ring_point(rc.max_ring + j0 + b));
+    // 2. inclusive scan across the wave
+    TePoint inc = loc;
+#pragma unroll 1
+    for (unsigned d = 1; d < 64; d <<= 1) {
+        TePoint o = te_shfl_up(inc, d);
+        if (lane >= d) inc = te_add(inc, o);
+    }
+    TePoint exc = te_shfl_up(inc, 1);                      // sum over all lower lanes
+    if (lane == 0) exc = te_identity();
+    // 3. seed, seed + PK_k, then this lane's own values
+    TePoint seed;
+    seed.x = from_arg(rc.seed_x); seed.y = from_arg(rc.seed_y); seed.z = Fr::one(); seed.t = mul(seed.x, seed.y);
+    TePoint base = te_add(seed, ring_point(producer_idx[pid]));
+    uint32_t idx[6];
+    int nv = 0;
+    if (lane == 0) { put(0, seed); put(1, base); idx[nv++] = 0; idx[nv++] = 1; }
+    TePoint cur = te_add(base, exc);
+    uint32_t pos = 2 + below;
+#pragma unroll 1
+    for (uint32_t b = 0; b < 4; b++)
+        if ((mine >> b) & 1) {
+            cur = te_add(cur, ring_point(rc.max_ring + j0 + b));
+            put(pos, cur);
+            idx[nv++] = pos++;
+        }
+    const uint32_t cnt = 2 + total_bits;
+    if (lane == 63) {                                      // cur = the final accumulator value on the last lane
+        put(cnt, te_add(cur, te_cneg(seed, true)));        // relation = result - seed
+        idx[nv++] = cnt;
+        cnt_out[pid] = cnt;
+    }
+    // 4. normalise this lane's values with one inversion
+    Fr pre[6];
+    Fr run = Fr::one();
+#pragma unroll 1
+    for (int i = 0; i < nv; i++) {
+        pre[i] = run;
+        run = mul(run, gload_fr(ext + idx[i] * 32 + 16));
+    }
+    Fr inv_run = inv(run);                                 // lock-step across the wave (inv(1) on idle lanes)
+#pragma unroll 1
+    for (int i = nv - 1; i >= 0; i--) {
+        const uint32_t* e = ext + idx[i] * 32;
+        Fr zi = mul(inv_run, pre[i]);
+        inv_run = mul(inv_run, gload_fr(e + 16));
+        gstore_fr(aff + idx[i] * 16, mul(gload_fr(e), zi));
+        gstore_fr(aff + idx[i] * 16 + 8, mul(gload_fr(e + 8), zi));
+    }
+}
+
 // One lane per (proof, row): the four witness columns in transcript order  b, accip, accx, accy  (standard form).
 // Rows [0, n-4] follow columns.py:111-146; the last three rows are the hidden rows (zk != NULL) or zero.
 __global__ void k_ring_columns(const uint32_t* __restrict__ producer_idx, const uint32_t* __restrict__ blinding,
