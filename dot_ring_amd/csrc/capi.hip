@@ -424,8 +424,21 @@ int msm_to_bytes(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars
     return msm_batch_results_to_bytes(ctx, batch, out_be_xy, is_inf);
 }
 
-// batch > 1: results were left in ctx->result (XYZZ); convert to affine on the device and emit BE records
+// batch > 1: results were left in ctx->result (XYZZ).  The affine conversion is one 381-bit field inversion per
+// result: on the GPU a 570-product Fermat chain (0.85 ms of pure latency per call, whatever the batch).  Measured
+// alternative (DOTRING_AFFINE_ON_HOST=1): download XYZZ and invert on the worker threads (binary Euclid) — 3.5 ms less
+// GPU time but 3.7 ms more wall time per 1024 proofs, so the kernel stays the default.
 int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, int* is_inf) {
+    static const bool on_host = std::getenv("DOTRING_AFFINE_ON_HOST") && std::atoi(std::getenv("DOTRING_AFFINE_ON_HOST")) != 0;
+    if (on_host) {
+        static_assert(sizeof(drh::G1) == 192, "XYZZ layout");
+        std::vector<drh::G1> res(batch);
+        HIP_TRY(hipMemcpyAsync(res.data(), ctx->result.p, batch * 192, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->prof) TRY(prof_collect(ctx));
+        drh::parallel_for(batch, [&](size_t b) { g1_result_to_bytes(res[b], out_be_xy + 96 * b, is_inf ? is_inf + b : nullptr); });
+        return DR_OK;
+    }
     TRY(ctx->io_c.reserve(batch * 96));
     TRY(launch(ctx, "k_g1_results_affine", [&] {
         hipLaunchKernelGGL(dr::k_g1_results_affine, dim3(div_up(batch, 64)), dim3(64), 0, ctx->stream, ctx->result.as<uint32_t>(),
