@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1541,6 +1542,27 @@ int dr_host_hash(int kind, const uint8_t* data, size_t len, uint8_t* out, size_t
 }
 
 namespace {
+// DOTRING_TRACE=1: wall-clock phase breakdown of the native batch calls on stderr
+struct PhaseTrace {
+    bool on;
+    const char* what;
+    std::chrono::steady_clock::time_point t0, last;
+    std::string line;
+    explicit PhaseTrace(const char* w) : on(std::getenv("DOTRING_TRACE") != nullptr), what(w) { t0 = last = std::chrono::steady_clock::now(); }
+    void mark(const char* name) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        char buf[64];
+        std::snprintf(buf, sizeof buf, " %s=%.2f", name, std::chrono::duration<double, std::milli>(now - last).count());
+        line += buf;
+        last = now;
+    }
+    ~PhaseTrace() {
+        if (!on) return;
+        std::fprintf(stderr, "[dotring] %s total=%.2f ms |%s\n", what,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), line.c_str());
+    }
+};
 int load_suite(const dr_vrf_suite* s, drh::VrfSuite& out) {
     if (!s || !s->suite_id || s->suite_id_len == 0 || s->suite_id_len > 200) return fail(DR_ERR_INVALID, "bad VRF suite");
     out.suite_id.assign(s->suite_id, s->suite_id + s->suite_id_len);
@@ -1578,6 +1600,7 @@ int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t 
     dr_ctx* ctx = p->ctx;
     const drh::Mod256& mn = drh::mod_n();
     const size_t B = batch;
+    PhaseTrace tr_("prove_batch");
 
     // 1. hash_to_field(salt || alpha), secrets mod n
     std::vector<uint8_t> us(B * 64), xs(B * 32);
@@ -1590,10 +1613,13 @@ int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t 
         mn.reduce_bytes(secret_scalars + 32 * i, 32, false, x);
         drh::store_le32(x, xs.data() + 32 * i);
     });
+    tr_.mark("h2f");
     // 2. I_i = encode_to_curve, O_i = x_i * I_i
     std::vector<uint8_t> inputs(B * 64), outs(B * 64);
     TRY(dr_bsn_encode_to_curve_batch(ctx, us.data(), B, inputs.data()));
+    tr_.mark("encode");
     TRY(dr_bsn_scalar_mul_batch(ctx, inputs.data(), xs.data(), B, outs.data()));
+    tr_.mark("x*I");
     // 3. transcripts, blinding factors
     std::vector<drh::Bytes> tr(B);
     std::vector<uint8_t> blind(B * 32), gb_pts(B * 128), sc(B * 64);
@@ -1621,6 +1647,7 @@ int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t 
         std::memcpy(sc.data() + 64 * i + 32, blind.data() + 32 * i, 32);
     });
     for (size_t i = 0; i < B; i++) if (bad[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
+    tr_.mark("blinding");
     // 4.-6. the rest of the Pedersen part needs nothing from the ring proof and the ring proof needs only the blinding
     // factors: it runs on a second stream (own context: scratch + stream) from a helper thread while this thread drives
     // the ring phases.  Its kernels are latency-bound (16..64 waves) and hide under the chip-filling MSMs.
@@ -1711,7 +1738,9 @@ int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t 
     }
     std::vector<uint8_t> relation(B * 64), wit(B * 4 * 96), cq(B * 96), evals(B * 256), opens(B * 192);
     std::vector<int> wit_inf(B * 4), cq_inf(B), open_inf(B * 2);
+    tr_.mark("spawn+zk");
     TRY(dr_ring_prove_witness(p, B, producer_index, blind.data(), zk_random48 ? zk.data() : nullptr, relation.data(), wit.data(), wit_inf.data()));
+    tr_.mark("witness");
     drh::FsTranscript base;
     base.sh.update(fs_prefix, fs_prefix_len);
     std::vector<drh::FsTranscript> fs(B, base);
@@ -1723,20 +1752,26 @@ int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t 
         fs[i].absorb_labeled("committed_cols", ser, sizeof ser);
         fs[i].challenges("constraints_aggregation", 7, alphas7.data() + 224 * i);
     });
+    tr_.mark("fs1");
     TRY(dr_ring_prove_quotient(p, B, alphas7.data(), cq.data(), cq_inf.data()));
+    tr_.mark("quotient");
     drh::parallel_for(B, [&](size_t i) {
         uint8_t ser[96];
         drh::g1_serialized(cq.data() + 96 * i, cq_inf[i], ser);
         fs[i].absorb_labeled("quotient", ser, 96);
         fs[i].challenges("evaluation_point", 1, zetas.data() + 32 * i);
     });
+    tr_.mark("fs2");
     TRY(dr_ring_prove_evals(p, B, zetas.data(), evals.data()));
+    tr_.mark("evals");
     drh::parallel_for(B, [&](size_t i) {
         fs[i].absorb_labeled("register_evaluations", evals.data() + 256 * i, 224);
         fs[i].absorb_labeled("shifted_linearization_evaluation", evals.data() + 256 * i + 224, 32);
         fs[i].challenges("kzg_aggregation", 8, nus.data() + 256 * i);
     });
+    tr_.mark("fs3");
     TRY(dr_ring_prove_openings(p, B, nus.data(), opens.data(), open_inf.data()));
+    tr_.mark("openings");
     // 8. payload: 4 compressed commitments, 7 evaluations, C_q, l(zeta*omega), 2 opening proofs  (proof_payload.py:68-117)
     std::vector<int> rc(B, DR_OK);
     drh::parallel_for(B, [&](size_t i) {
@@ -1758,7 +1793,9 @@ int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t 
         }
     });
     for (size_t i = 0; i < B; i++) if (rc[i] != DR_OK) return rc[i];
+    tr_.mark("payload");
     if (ped_thread.joinable()) ped_thread.join();
+    tr_.mark("join");
     if (ped_rc != DR_OK) return fail(ped_rc, ped_err.empty() ? "Pedersen part failed" : ped_err);
     return DR_OK;
 }
