@@ -273,7 +273,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     // sorted by one workgroup each, entirely in LDS; a few huge sets (one 2^20-point MSM) use global atomics.
     const size_t per_set_scalars = single ? (n + groups - 1) / groups : n;
     const size_t per_set_digits = single ? per_set_scalars * (size_t)pl.W : n;
-    const bool lds_sort = pl.H <= dr::SORT_MAX_H && bsets >= 64 && per_set_digits <= 262144 && bsets * per_set_digits < (1ull << 32);
+    const bool lds_sort = pl.H <= dr::SORT_MAX_H && bsets >= 64 && per_set_digits <= (1u << 20) && bsets * per_set_digits < (1ull << 32);
     if (lds_sort) {
         dr::SortSetParams sp;
         sp.n = (uint32_t)n; sp.batch = (uint32_t)batch; sp.H = pl.H; sp.groups = groups; sp.single = single ? 1 : 0;
