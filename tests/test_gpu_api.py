@@ -285,3 +285,47 @@ def test_native_batch_verify_rejects_what_the_python_path_rejects(ctx, monkeypat
     other_root = d.RingRoot.from_ring(other)
     assert not native(raw, als, ads, other, other_root)
     assert isinstance(proofs[0], RingVRF) and proofs[0].verify(als[0], ads[0], ring, root)
+
+
+_KNOB_SCRIPT = r"""
+import hashlib, sys
+import dot_ring_amd as d
+cv = d.Bandersnatch
+sks = [(4000 + i).to_bytes(32, "little") for i in range(300)]
+from dot_ring_amd.curve import scalar_mul_batch
+keys = [p.point_to_string() for p in scalar_mul_batch([cv.point_type.generator_point()] * 300, [int.from_bytes(s, "little") for s in sks])]
+params = d.RingProofParams.from_ring_size(300, test_vectors=True)
+ring = d.Ring(keys, params)
+root = d.RingRoot.from_ring(ring, params)
+n = 5
+proofs = d.RingVRF[cv].prove_batch([b"k%d" % i for i in range(n)], [b"ad"] * n, sks[:n], keys[:n], ring, root)
+assert d.RingVRF[cv].batch_verify(proofs, [b"k%d" % i for i in range(n)], [b"ad"] * n, ring, root)
+print("DIGEST", hashlib.sha256(root.encode() + b"".join(p.encode() for p in proofs)).hexdigest())
+"""
+
+
+def test_tuning_knobs_do_not_change_the_bytes(ctx):
+    """Each knob selects another kernel / orchestration path for the same mathematics: deterministic proofs
+    (test_vectors=True, ring 300 -> N = 1024) must hash to the same digest under every setting.  Child processes,
+    one at a time (the knobs are read when a context is created)."""
+    import os
+    import subprocess
+    import sys
+
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variants = [
+        {},
+        {"DOTRING_NATIVE_HOST": "0"},
+        {"DOTRING_PROVE_OVERLAP": "0", "DOTRING_CHAIN_WAVE": "0", "DOTRING_MSM_LEVELS": "0", "DOTRING_WITNESS_BY_PARTS": "0"},
+        {"DOTRING_SRS_WINDOW": "9", "DOTRING_PS_WINDOW": "8", "DOTRING_MSM_CHUNK": "8", "DOTRING_AFFINE_ON_HOST": "1", "DOTRING_HOST_THREADS": "3"},
+        {"DOTRING_SRS_WINDOW": "0", "DOTRING_NATIVE_HOST": "0", "DOTRING_PROVE_PIPELINE": "2"},
+    ]
+    digests = []
+    for extra in variants:
+        env = {k: v for k, v in os.environ.items() if not k.startswith("DOTRING_")}
+        env.update(extra)
+        env["PYTHONPATH"] = root_dir + os.pathsep + env.get("PYTHONPATH", "")
+        out = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT], cwd=root_dir, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (extra, out.stderr[-2000:])
+        digests.append([ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert len(set(digests)) == 1, list(zip(variants, digests))
