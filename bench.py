@@ -34,6 +34,7 @@ G1_BE = bytes.fromhex(
     "08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1"
 )
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+VALU_PEAK_GADD_S = 1024 * 2.4e9 / 4 * 64 / 6800 / 1e9      # ~5.78 G mixed additions/s (see roofline.valu)
 ALG_BYTES_PER_PAIR = 128       # 96 B affine base + 32 B scalar per (base, scalar) pair
 MSM_KERNELS = ("k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_sort_sets", "k_size_sort", "k_g1_accumulate", "k_g1_reduce_chunks",
                "k_g1_reduce_windows", "k_g1_horner", "k_g1_results_affine")
@@ -260,6 +261,9 @@ def main() -> int:
                    "sample": f"{m} proofs (prove only) of the same workload through oracle/ (Python orchestration + oracle/c "
                              f"kernels for NTT and G1 Pippenger), {cpu_s:.1f} s"}
 
+        # bucket additions of the dense MSMs in the timed region: pairs x windows of the SRS table (non-zero digit rate ~1)
+        table_windows = -(-256 // int(os.environ.get("DOTRING_SRS_WINDOW", "12") or 12))
+        dense_adds = float(batch) * pairs_per_proof * table_windows * args.steps
         total = batch * world * args.steps
         value = total / elapsed
         avg_acc_s = (acc_ms / max(1, acc_launches)) / 1e3
@@ -301,7 +305,13 @@ def main() -> int:
                        "sharding": "proofs sharded per rank, no collective" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_g1_accumulate", "avg_kernel_ms": avg_acc_s * 1e3,
-                         "launches_per_step": acc_launches / max(1, args.steps), "algorithmic_bytes_per_launch": alg_bytes_launch},
+                         "launches_per_step": acc_launches / max(1, args.steps), "algorithmic_bytes_per_launch": alg_bytes_launch,
+                         # the kernel is integer-VALU bound, so the informative ceiling is the VALU issue rate: mixed
+                         # additions/s against 1024 SIMDs x 2.4 GHz / 4 cycles x 64 lanes / ~6800 instructions per
+                         # XYZZ mixed addition (10 Montgomery products of 649 instructions + ~310 add/sub/select)
+                         "valu": {"achieved_gadd_s": dense_adds / (acc_ms / 1e3) / 1e9 if acc_ms else None, "peak_gadd_s": VALU_PEAK_GADD_S,
+                                  "frac": dense_adds / (acc_ms / 1e3) / 1e9 / VALU_PEAK_GADD_S if acc_ms else None,
+                                  "note": "dense bucket additions only (7N pairs x windows per proof); by-parts and verify-side additions not counted"}},
             "cpu_baseline": cpu,
             "parity_ok": parity_ok,
             "prove_only_proofs_per_s": batch * args.steps / prove_s if prove_s else None,
