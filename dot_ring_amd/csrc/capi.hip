@@ -1585,10 +1585,10 @@ int dr_hash_to_field_batch(const dr_vrf_suite* suite, const uint8_t* msgs, const
 
 // The whole batch in one call: Pedersen VRF part (pedersen/vrf.py:86-126) then the ring proof
 // (proof_builder.py:38-315) — GPU phases through the entry points above, the hashing between them on worker threads.
-int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t batch, const uint8_t* alphas, const uint64_t* alpha_off,
-                           const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
-                           const uint8_t* secret_scalars, const uint32_t* producer_index, const uint8_t* fs_prefix, size_t fs_prefix_len,
-                           const uint8_t* zk_random48, uint8_t* out_proofs, uint8_t* out_aux) {
+static int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_t batch, const uint8_t* alphas, const uint64_t* alpha_off,
+                                    const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
+                                    const uint8_t* secret_scalars, const uint32_t* producer_index, const uint8_t* fs_prefix, size_t fs_prefix_len,
+                                    const uint8_t* zk_random48, uint8_t* out_proofs, uint8_t* out_aux) {
     if (!p || !alpha_off || !ad_off || !secret_scalars || !producer_index || !fs_prefix || !out_proofs) return fail(DR_ERR_INVALID, "null argument");
     if (batch == 0) return DR_OK;
     if (batch > 4096) return fail(DR_ERR_INVALID, "batch must be at most 4096 per call");
@@ -1803,9 +1803,24 @@ int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t 
 // RingVRF.batch_verify over encoded proofs (vrf/ring/vrf.py:239-283, pedersen/vrf.py:171-242, ring_proof/verify.py:51-324,
 // pcs/kzg.py:304-338): decode + validate every point on the GPU, replay the transcripts on worker threads, fold all
 // claims into one Bandersnatch MSM (5B+2 points, must be the identity) and two G1 MSMs + one pairing equation.
-int dr_ringvrf_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_ring_verifier_key* vk, size_t batch, const uint8_t* proofs,
-                            const uint8_t* inputs, const uint64_t* in_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts,
-                            const uint64_t* salt_off, const uint8_t seed32[32], int* ok) {
+// C++ exceptions (allocation failures of the host-side staging vectors, thread creation) must not cross the C ABI
+int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t batch, const uint8_t* alphas, const uint64_t* alpha_off,
+                           const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
+                           const uint8_t* secret_scalars, const uint32_t* producer_index, const uint8_t* fs_prefix, size_t fs_prefix_len,
+                           const uint8_t* zk_random48, uint8_t* out_proofs, uint8_t* out_aux) {
+    try {
+        return ringvrf_prove_batch_impl(p, suite, batch, alphas, alpha_off, ads, ad_off, salts, salt_off, secret_scalars, producer_index, fs_prefix,
+                                        fs_prefix_len, zk_random48, out_proofs, out_aux);
+    } catch (const std::bad_alloc&) {
+        return fail(DR_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_DEVICE, std::string("native prover: ") + e.what());
+    }
+}
+
+static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_ring_verifier_key* vk, size_t batch, const uint8_t* proofs,
+                                     const uint8_t* inputs, const uint64_t* in_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts,
+                                     const uint64_t* salt_off, const uint8_t seed32[32], int* ok) {
     TRY(use_ctx(ctx));
     if (!vk || !proofs || !in_off || !ad_off || !seed32 || !ok || !vk->fs_prefix) return fail(DR_ERR_INVALID, "null argument");
     *ok = 0;
@@ -2066,6 +2081,18 @@ int dr_ringvrf_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_rin
     if (side_rc != DR_OK) return fail(side_rc, side_err.empty() ? "Pedersen part failed" : side_err);
     *ok = pok && ped_ok;
     return DR_OK;
+}
+
+int dr_ringvrf_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_ring_verifier_key* vk, size_t batch, const uint8_t* proofs,
+                            const uint8_t* inputs, const uint64_t* in_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts,
+                            const uint64_t* salt_off, const uint8_t seed32[32], int* ok) {
+    try {
+        return ringvrf_verify_batch_impl(ctx, suite, vk, batch, proofs, inputs, in_off, ads, ad_off, salts, salt_off, seed32, ok);
+    } catch (const std::bad_alloc&) {
+        return fail(DR_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_DEVICE, std::string("native verifier: ") + e.what());
+    }
 }
 
 }  // extern "C"
