@@ -90,6 +90,7 @@ _PROTOTYPES.update({
     "dr_ringvrf_verify_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), POINTER(RingVerifierKeyStruct), c_size_t, c_char_p, c_char_p,
                                         POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64),
                                         c_char_p, POINTER(c_int)]),
+    "dr_bsn_decode_points": (c_int, [c_void_p, c_char_p, c_size_t, c_char_p, c_char_p]),
     "dr_pairing_selfcheck": (c_int, [c_char_p, c_char_p, c_size_t, POINTER(c_int)]),
     "dr_host_hash": (c_int, [c_int, c_char_p, c_size_t, c_char_p, c_size_t]),
     "dr_hash_to_field_batch": (c_int, [POINTER(VrfSuiteStruct), c_char_p, POINTER(ctypes.c_uint64), c_size_t, c_char_p]),
@@ -404,6 +405,15 @@ class Context:
         _check(lib().dr_ringvrf_verify_batch(self.handle, byref(suite), byref(vk), batch, proofs, i_blob, i_off, d_blob, d_off, s_blob, s_off,
                                              seed32, byref(ok)))
         return bool(ok.value)
+
+    def bsn_decode_points(self, enc: bytes):
+        """dec_point for len(enc)/32 compressed points on the GPU -> (affine x||y bytes, validity flags)."""
+        if len(enc) % 32:
+            raise ValueError("compressed points are 32 bytes each")
+        count = len(enc) // 32
+        out, ok = ctypes.create_string_buffer(max(1, 64 * count)), ctypes.create_string_buffer(max(1, count))
+        _check(lib().dr_bsn_decode_points(self.handle, enc, count, out, ok))
+        return out.raw[: 64 * count], ok.raw[:count]
 
     def srs_powers(self, base_be_xy: bytes, tau: int, count: int) -> Srs:
         """bases[i] = tau^i * base (known-tau SRS for tests/benchmarks beyond the shipped file), generated on the GPU."""

@@ -744,6 +744,28 @@ int dr_bsn_msm(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars, size_
     return DR_OK;
 }
 
+int dr_bsn_decode_points(dr_ctx* ctx, const uint8_t* enc, size_t n, uint8_t* out_xy, uint8_t* ok) {
+    TRY(use_ctx(ctx));
+    if (n == 0) return DR_OK;
+    if (!enc || !out_xy || !ok) return fail(DR_ERR_INVALID, "null buffer");
+    if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "batch too large");
+    TRY(ctx->io_a.reserve(n * 32));
+    TRY(ctx->io_b.reserve(n * 64));
+    TRY(ctx->io_c.reserve(n * 4));
+    HIP_TRY(hipMemcpyAsync(ctx->io_a.p, enc, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    TRY(launch(ctx, "k_bsn_decode_points", [&] {
+        hipLaunchKernelGGL(dr::k_bsn_decode_points, dim3(div_up(n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream, ctx->io_a.as<uint32_t>(),
+                           ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>(), (uint32_t)n);
+    }));
+    std::vector<uint32_t> flags(n);
+    HIP_TRY(hipMemcpyAsync(out_xy, ctx->io_b.p, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(flags.data(), ctx->io_c.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) TRY(prof_collect(ctx));
+    for (size_t i = 0; i < n; i++) ok[i] = flags[i] ? 1 : 0;
+    return DR_OK;
+}
+
 int dr_bsn_encode_to_curve_batch(dr_ctx* ctx, const uint8_t* u_pairs, size_t n, uint8_t* out_xy) {
     TRY(use_ctx(ctx));
     if (n == 0) return DR_OK;

@@ -34,15 +34,20 @@ def enc_point(point) -> bytes:
 
 
 def dec_points(cv, values) -> list:
-    """Decode + subgroup-validate several points with two kernel launches in total; raises like dec_point."""
-    pts = []
+    """Decode + subgroup-validate several points in ONE kernel launch (dr_bsn_decode_points); raises like dec_point."""
+    from .. import runtime
+
+    values = [bytes(v) for v in values]
     for value in values:
         if len(value) != point_len(cv):
             raise ValueError(f"point must be exactly {point_len(cv)} bytes")
-        pts.append(cv.point_type.string_to_point(value))
-    if not all(valid_points(pts)):
+    if not values:
+        return []
+    raw, ok = runtime.context().bsn_decode_points(b"".join(values))
+    if not all(ok):
         raise ValueError("point is not a valid nonidentity subgroup point")
-    return pts
+    frm, mk = int.from_bytes, cv.point_type._trusted
+    return [mk(frm(raw[i : i + 32], "little"), frm(raw[i + 32 : i + 64], "little")) for i in range(0, len(raw), 64)]
 
 
 def dec_point(cv, value: bytes):

@@ -46,22 +46,17 @@ class Ring:
         self.nm_points = tuple(points)
 
     def _decode_keys(self, keys):
-        """Decode + subgroup-check all keys with two kernel launches; invalid / identity keys -> None."""
+        """Decode + subgroup-check all keys in one kernel launch; invalid / identity keys -> None."""
         cv = self.params.cv
-        pts, slots = [], []
-        for i, key in enumerate(keys):
-            try:
-                if len(key) != point_len(cv):
-                    raise ValueError("bad length")
-                pts.append(cv.point_type.string_to_point(key))
-                slots.append(i)
-            except ValueError:
-                pass
-        ok = valid_points(pts)
+        slots = [i for i, key in enumerate(keys) if len(key) == point_len(cv)]
         out = [None] * len(keys)
-        for slot, pt, good in zip(slots, pts, ok):
-            if good and not pt.is_identity():
-                out[slot] = (pt.x, pt.y)
+        if not slots:
+            return out
+        raw, ok = runtime.context().bsn_decode_points(b"".join(bytes(keys[i]) for i in slots))
+        frm = int.from_bytes
+        for j, slot in enumerate(slots):
+            if ok[j]:
+                out[slot] = (frm(raw[64 * j : 64 * j + 32], "little"), frm(raw[64 * j + 32 : 64 * j + 64], "little"))
         return out
 
     @classmethod

@@ -6,7 +6,7 @@ from dataclasses import dataclass
 from ..curve import msm_groups, scalar_mul_batch
 from .base import VRF
 from .codec import dec_point, dec_scalar, dec_scalar_mod, enc_point, enc_scalar, point_len, scalar_len
-from .primitives import CHALLENGE_LEN, DomSep, VrfIo, challenge, nonce, point_to_hash, vrf_transcript
+from .primitives import CHALLENGE_LEN, DomSep, VrfIo, challenge, nonce, point_to_hash, vrf_transcript, vrf_transcript_scalars
 
 
 @dataclass
@@ -43,11 +43,15 @@ class TinyVRF(VRF):
         inputs = cv.point_type.encode_to_curve_batch(alphas, salts)
         firsts = scalar_mul_batch([gen] * count + inputs, xs + xs)            # pk_i, O_i
         pks, outs = firsts[:count], firsts[count:]
-        transcripts, merged_in = [], []
+        # transcripts + delinearisation scalars on the host, then ONE grouped launch for the merged inputs of all proofs
+        # (vrf_transcript would launch once per proof): merged.input_i = 1*G + z_i*I_i
+        transcripts, pts, zs_all = [], [], []
         for i in range(count):
-            t, merged = vrf_transcript(cv, DomSep.TINY_VRF, [VrfIo(gen, pks[i]), VrfIo(inputs[i], outs[i])], additional_data[i])
+            t, zs = vrf_transcript_scalars(cv, DomSep.TINY_VRF, [VrfIo(gen, pks[i]), VrfIo(inputs[i], outs[i])], additional_data[i])
             transcripts.append(t)
-            merged_in.append(merged.input)
+            pts += [gen, inputs[i]]
+            zs_all += zs
+        merged_in = msm_groups(pts, zs_all, 2)
         ks = [nonce(cv, x, t) for x, t in zip(xs, transcripts)]
         rs = scalar_mul_batch(merged_in, ks)
         order = cv.curve.params.subgroup_order

@@ -93,6 +93,11 @@ DR_API int dr_bsn_msm_groups(dr_ctx *ctx, const uint8_t *pts_xy, const uint8_t *
  * hash_to_field, which stays on the host.  u_pairs: n*2 canonical field elements (32-byte LE). */
 DR_API int dr_bsn_encode_to_curve_batch(dr_ctx *ctx, const uint8_t *u_pairs, size_t n, uint8_t *out_xy);
 
+/* dec_point for n compressed points (dot_ring/vrf/codec.py:39-45, curve/point.py:150-214, curve/curve.py:56-67):
+ * decompression (y < p, x^2 = (1-y^2)/(a-d y^2), the sign bit picks the larger root) and validation (not the
+ * identity, prime-order subgroup) on the GPU.  ok[i] = 1 for valid points; out_xy[i] is meaningful only then. */
+DR_API int dr_bsn_decode_points(dr_ctx *ctx, const uint8_t *enc /* n*32 */, size_t n, uint8_t *out_xy /* n*64 */, uint8_t *ok /* n */);
+
 /* square root in the Bandersnatch base field; DR_ERR_NOTSQUARE if none exists. Host-side, no ctx. */
 DR_API int dr_fr_sqrt(const uint8_t in[32], uint8_t out[32]);
 

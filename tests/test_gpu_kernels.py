@@ -226,3 +226,28 @@ def test_ntt_matches_oracle(ctx, log2n):
         assert fwd[32 * n * b : 32 * n * (b + 1)] == coracle.ntt_raw(data[32 * n * b : 32 * n * (b + 1)], n, omega)
     back = ctx.ntt(fwd, log2n, pow(omega, -1, P), pow(n, -1, P))
     assert back == data
+
+
+def test_bsn_decode_points_matches_oracle(ctx):
+    """dr_bsn_decode_points (decompression + subgroup check on the GPU) against the oracle's dec_point on valid keys,
+    random strings (about half are not x-coordinates of anything, most of the rest have a torsion component),
+    the identity, the order-2 point, non-canonical y and both sign bits."""
+    rng = random.Random(2024)
+    encs = [bsn.enc_point(coracle.te_mul(bsn.G, rng.randrange(1, bsn.N))) for _ in range(70)]
+    encs += [bytes(rng.randrange(256) for _ in range(32)) for _ in range(120)]
+    encs += [(1).to_bytes(32, "little"), (bsn.P - 1).to_bytes(32, "little"), (bsn.P + 3).to_bytes(32, "little"),
+             (0).to_bytes(32, "little"), bytes(31) + b"\x80"]
+    encs += [e[:31] + bytes([e[31] ^ 0x80]) for e in encs[:10]]          # the other root: valid too (it is -P)
+    raw, ok = ctx.bsn_decode_points(b"".join(encs))
+    n_valid = 0
+    for i, e in enumerate(encs):
+        try:
+            want = bsn.dec_point(e)
+        except ValueError:
+            want = None
+        assert bool(ok[i]) == (want is not None), (i, e.hex())
+        if want is not None:
+            n_valid += 1
+            assert (int.from_bytes(raw[64 * i : 64 * i + 32], "little"), int.from_bytes(raw[64 * i + 32 : 64 * i + 64], "little")) == want
+    assert n_valid >= 80
+    assert ctx.bsn_decode_points(b"") == (b"", b"")
