@@ -242,7 +242,7 @@ def main() -> int:
             tv_params = d.RingProofParams.from_ring_size(args.ring_size, test_vectors=True, pcs=pcs)
             tv_ring = d.Ring(keys, tv_params)
             tv_root = d.RingRoot.from_ring(tv_ring, tv_params)
-            m = args.cpu_proofs
+            m = args.cpu_proofs if world == 1 else min(2, args.cpu_proofs)     # N > 1: parity check only, no CPU timing
             gpu_proofs = vrf.prove_batch(alphas[:m], ads[:m], sks[:m], pks[:m], tv_ring, tv_root)
             o_srs = None
             if big:
@@ -257,7 +257,7 @@ def main() -> int:
             cpu_proofs = [oring.ring_vrf_prove(o_ring, o_root, alphas[i], ads[i], signer_sk) for i in range(m)]
             cpu_s = time.perf_counter() - t1
             parity_ok = parity_ok and [p.encode() for p in gpu_proofs] == cpu_proofs
-            cpu = {"value": m / cpu_s, "unit": "proofs/s", "cores": 1, "kind": "port",
+            cpu = None if world > 1 else {"value": m / cpu_s, "unit": "proofs/s", "cores": 1, "kind": "port",
                    "sample": f"{m} proofs (prove only) of the same workload through oracle/ (Python orchestration + oracle/c "
                              f"kernels for NTT and G1 Pippenger), {cpu_s:.1f} s"}
 
@@ -278,7 +278,7 @@ def main() -> int:
             except Exception:
                 traffic = None
         g1 = None
-        if args.msm_log2n > 0:
+        if args.msm_log2n > 0 and world == 1:
             g1 = g1_msm_measurement(ctx, args.msm_log2n, 10, 17, True)
             parity_ok = parity_ok and g1.get("parity_closed_form", True) and g1.get("parity_sample", True)
             if args.msm_log2n > 16:             # BASELINE configs[2] names 2^16 as well
