@@ -124,7 +124,7 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--ring-size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
-    ap.add_argument("--cpu-proofs", type=int, default=6, help="proofs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-proofs", type=int, default=16, help="proofs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--msm-log2n", type=int, default=20, help="secondary G1 MSM size (0 = skip)")
     args = ap.parse_args()
 
