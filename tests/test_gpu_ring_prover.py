@@ -196,3 +196,57 @@ def test_msm_skewed_scalars_stay_correct(ctx, srs_bytes):
         assert ctx.g1_msm(tab, ks) == want_be
     srs.close()
     tab.close()
+
+
+def test_full_size_batch_round_trip_and_properties(ctx):
+    """BASELINE configs[3] at full size (ring 1024, 1024 proofs, random hidden rows) through size-independent
+    properties: every proof verifies, the batch verifies, proofs are pairwise distinct although inputs repeat
+    (hidden rows are random), any single corrupted proof is caught, and the deterministic parts (Pedersen 192 bytes)
+    of two runs agree."""
+    import dot_ring_amd as d
+
+    keys = _keys(1024, b"full")
+    sk = (424242).to_bytes(32, "little")
+    pk = d.Bandersnatch.public_key_from_secret(sk)
+    keys[77] = pk
+    ring = d.Ring(keys)
+    root = d.RingRoot.from_ring(ring)
+    vrf = d.RingVRF[d.Bandersnatch]
+    n = 1024
+    als = [b"in-%d" % (i % 500) for i in range(n)]
+    ads = [b"ad-%d" % (i % 3) for i in range(n)]
+    a = vrf.prove_batch(als, ads, [sk] * n, [pk] * n, ring, root)
+    b = vrf.prove_batch(als, ads, [sk] * n, [pk] * n, ring, root)
+    ea, eb = [p.encode() for p in a], [p.encode() for p in b]
+    assert all(len(e) == 784 for e in ea)
+    assert [e[:192] for e in ea] == [e[:192] for e in eb]            # Pedersen part is deterministic
+    assert len({e[192:] for e in ea + eb}) == 2 * n                  # ring part is blinded by fresh randomness
+    assert vrf.batch_verify(a, als, ads, ring, root)
+    assert a[500].verify(als[500], ads[500], ring, root)
+    mixed = a[:512] + b[512:]
+    assert vrf.batch_verify(mixed, als, ads, ring, root)             # proofs of different runs are interchangeable
+    bad = list(a)
+    raw = bytearray(ea[901])
+    raw[400] ^= 1                                                    # one evaluation of one proof
+    bad[901] = vrf.decode(bytes(raw))
+    assert not vrf.batch_verify(bad, als, ads, ring, root)
+    assert not vrf.batch_verify(a, als[1:] + als[:1], ads, ring, root)
+
+
+def test_g1_msm_linearity_at_2p18(ctx):
+    """MSM(a) + MSM(b) = MSM(a + b) and MSM(c * a) = c * MSM(a) over 2^18 synthetic bases (no oracle needed)."""
+    import bench
+    from dot_ring_amd import _native
+
+    n = 1 << 18
+    srs = ctx.srs_synthetic(bench.G1_BE, n, first=3).precompute(14)
+    va, ra = bench.seeded_scalars(n, b"lin-a")
+    vb, rb = bench.seeded_scalars(n, b"lin-b")
+    r = coracle.FR_P
+    rab = b"".join(((x + y) % r).to_bytes(32, "little") for x, y in zip(va, vb))
+    pa, pb, pab = ctx.g1_msm(srs, ra), ctx.g1_msm(srs, rb), ctx.g1_msm(srs, rab)
+    assert _native.g1_sum([pa, pb]) == pab
+    c = 0x1234567
+    rc = b"".join((c * x % r).to_bytes(32, "little") for x in va)
+    assert ctx.g1_msm(srs, rc) == ctx.g1_msm_points(pa, c.to_bytes(32, "little"))
+    srs.close()
