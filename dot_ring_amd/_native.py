@@ -92,6 +92,10 @@ _PROTOTYPES.update({
                                         c_char_p, POINTER(c_int)]),
     "dr_bsn_decode_points": (c_int, [c_void_p, c_char_p, c_size_t, c_char_p, c_char_p]),
     "dr_pairing_selfcheck": (c_int, [c_char_p, c_char_p, c_size_t, POINTER(c_int)]),
+    "dr_pedersen_prove_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_size_t, c_char_p, POINTER(ctypes.c_uint64), c_char_p,
+                                        POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p, c_char_p, c_char_p]),
+    "dr_pedersen_verify_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_size_t, c_char_p, c_char_p, POINTER(ctypes.c_uint64), c_char_p,
+                                         POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), POINTER(c_int)]),
     "dr_host_hash": (c_int, [c_int, c_char_p, c_size_t, c_char_p, c_size_t]),
     "dr_hash_to_field_batch": (c_int, [POINTER(VrfSuiteStruct), c_char_p, POINTER(ctypes.c_uint64), c_size_t, c_char_p]),
     "dr_ringvrf_prove_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_size_t, c_char_p, POINTER(ctypes.c_uint64), c_char_p,
@@ -99,6 +103,7 @@ _PROTOTYPES.update({
                                        c_char_p, c_size_t, c_char_p, c_char_p, c_char_p]),
 })
 RINGVRF_AUX_BYTES = 960
+PEDERSEN_AUX_BYTES = 288
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)
 
 
@@ -414,6 +419,27 @@ class Context:
         out, ok = ctypes.create_string_buffer(max(1, 64 * count)), ctypes.create_string_buffer(max(1, count))
         _check(lib().dr_bsn_decode_points(self.handle, enc, count, out, ok))
         return out.raw[: 64 * count], ok.raw[:count]
+
+    def pedersen_prove_batch(self, suite: "VrfSuiteStruct", alphas, ads, salts, secret_scalars: bytes):
+        """dr_pedersen_prove_batch -> (batch * 192 proof bytes, batch * 288 auxiliary bytes)."""
+        batch = len(alphas)
+        a_blob, a_off = _ragged(alphas)
+        d_blob, d_off = _ragged(ads)
+        s_blob, s_off = (None, None) if not salts or not any(salts) else _ragged(salts)
+        out, aux = ctypes.create_string_buffer(max(1, 192 * batch)), ctypes.create_string_buffer(max(1, PEDERSEN_AUX_BYTES * batch))
+        _check(lib().dr_pedersen_prove_batch(self.handle, byref(suite), batch, a_blob, a_off, d_blob, d_off, s_blob, s_off, secret_scalars, out, aux))
+        return out.raw[: 192 * batch], aux.raw[: PEDERSEN_AUX_BYTES * batch]
+
+    def pedersen_verify_batch(self, suite: "VrfSuiteStruct", proofs: bytes, inputs, ads, salts) -> bool:
+        batch = len(inputs)
+        if len(proofs) != 192 * batch:
+            raise ValueError("proofs must be 192 bytes each")
+        i_blob, i_off = _ragged(inputs)
+        d_blob, d_off = _ragged(ads)
+        s_blob, s_off = (None, None) if not salts or not any(salts) else _ragged(salts)
+        ok = c_int(0)
+        _check(lib().dr_pedersen_verify_batch(self.handle, byref(suite), batch, proofs, i_blob, i_off, d_blob, d_off, s_blob, s_off, byref(ok)))
+        return bool(ok.value)
 
     def srs_powers(self, base_be_xy: bytes, tau: int, count: int) -> Srs:
         """bases[i] = tau^i * base (known-tau SRS for tests/benchmarks beyond the shipped file), generated on the GPU."""

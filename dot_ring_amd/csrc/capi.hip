@@ -1607,78 +1607,72 @@ int dr_hash_to_field_batch(const dr_vrf_suite* suite, const uint8_t* msgs, const
 
 // The whole batch in one call: Pedersen VRF part (pedersen/vrf.py:86-126) then the ring proof
 // (proof_builder.py:38-315) — GPU phases through the entry points above, the hashing between them on worker threads.
-static int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_t batch, const uint8_t* alphas, const uint64_t* alpha_off,
-                                    const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
-                                    const uint8_t* secret_scalars, const uint32_t* producer_index, const uint8_t* fs_prefix, size_t fs_prefix_len,
-                                    const uint8_t* zk_random48, uint8_t* out_proofs, uint8_t* out_aux) {
-    if (!p || !alpha_off || !ad_off || !secret_scalars || !producer_index || !fs_prefix || !out_proofs) return fail(DR_ERR_INVALID, "null argument");
-    if (batch == 0) return DR_OK;
-    if (batch > 4096) return fail(DR_ERR_INVALID, "batch must be at most 4096 per call");
-    drh::VrfSuite su;
-    TRY(load_suite(suite, su));
-    for (size_t i = 0; i < batch; i++)
-        if (alpha_off[i + 1] < alpha_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
-            return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
-    dr_ctx* ctx = p->ctx;
-    const drh::Mod256& mn = drh::mod_n();
-    const size_t B = batch;
-    PhaseTrace tr_("prove_batch");
+// Pedersen VRF prover for a batch (pedersen/vrf.py:86-126): head() = hash-to-curve, outputs, transcripts and blinding
+// factors (what the ring proof needs); tail() = blinded keys, nonces, R / O_k, challenge, responses and the 192 encoded
+// bytes.  The two halves may run on different contexts (streams) of the same GPU.
+struct PedersenBatch {
+    const drh::VrfSuite& su;
+    size_t B;
+    std::vector<uint8_t> us, xs, inputs, outs, blind, gb_pts, sc, ybar, ks, kbs, pts3, sc3, third;
+    std::vector<drh::Bytes> tr;
+    PedersenBatch(const drh::VrfSuite& s, size_t b) : su(s), B(b) {}
 
-    // 1. hash_to_field(salt || alpha), secrets mod n
-    std::vector<uint8_t> us(B * 64), xs(B * 32);
-    drh::parallel_for(B, [&](size_t i) {
-        drh::Bytes msg;
-        if (salt_off) drh::put(msg, salts + salt_off[i], salt_off[i + 1] - salt_off[i]);
-        drh::put(msg, alphas + alpha_off[i], alpha_off[i + 1] - alpha_off[i]);
-        drh::hash_to_field2(su, msg.data(), msg.size(), us.data() + 64 * i);
-        uint64_t x[4];
-        mn.reduce_bytes(secret_scalars + 32 * i, 32, false, x);
-        drh::store_le32(x, xs.data() + 32 * i);
-    });
-    tr_.mark("h2f");
-    // 2. I_i = encode_to_curve, O_i = x_i * I_i
-    std::vector<uint8_t> inputs(B * 64), outs(B * 64);
-    TRY(dr_bsn_encode_to_curve_batch(ctx, us.data(), B, inputs.data()));
-    tr_.mark("encode");
-    TRY(dr_bsn_scalar_mul_batch(ctx, inputs.data(), xs.data(), B, outs.data()));
-    tr_.mark("x*I");
-    // 3. transcripts, blinding factors
-    std::vector<drh::Bytes> tr(B);
-    std::vector<uint8_t> blind(B * 32), gb_pts(B * 128), sc(B * 64);
-    std::vector<int> bad(B, 0);
-    drh::parallel_for(B, [&](size_t i) {
-        drh::Bytes& t = tr[i];
-        t = su.suite_id;
-        drh::put8(t, 0x02);                                    // PEDERSEN_VRF
-        drh::put_le64(t, 1);                                   // one (input, output) pair
-        uint8_t enc[32];
-        drh::enc_te_point(inputs.data() + 64 * i, enc); drh::put(t, enc, 32);
-        drh::enc_te_point(outs.data() + 64 * i, enc); drh::put(t, enc, 32);
-        size_t adl = ad_off[i + 1] - ad_off[i];
-        drh::put_le64(t, adl);
-        drh::put(t, ads + ad_off[i], adl);
-        drh::Bytes tb = t;
-        drh::put8(tb, 0x12);                                   // PEDERSEN_BLINDING
-        uint64_t x[4], b[4];
-        drh::load_le32(xs.data() + 32 * i, x);
-        if (!drh::vrf_nonce(su, tb, x, b)) bad[i] = 1;
-        drh::store_le32(b, blind.data() + 32 * i);
-        std::memcpy(gb_pts.data() + 128 * i, su.generator, 64);
-        std::memcpy(gb_pts.data() + 128 * i + 64, su.blinding_base, 64);
-        std::memcpy(sc.data() + 64 * i, xs.data() + 32 * i, 32);
-        std::memcpy(sc.data() + 64 * i + 32, blind.data() + 32 * i, 32);
-    });
-    for (size_t i = 0; i < B; i++) if (bad[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
-    tr_.mark("blinding");
-    // 4.-6. the rest of the Pedersen part needs nothing from the ring proof and the ring proof needs only the blinding
-    // factors: it runs on a second stream (own context: scratch + stream) from a helper thread while this thread drives
-    // the ring phases.  Its kernels are latency-bound (16..64 waves) and hide under the chip-filling MSMs.
-    if (!p->aux_ctx) TRY(dr_ctx_create(ctx->device, &p->aux_ctx));
-    dr_ctx* actx = p->aux_ctx;
-    std::vector<uint8_t> ybar(B * 64), ks(B * 32), kbs(B * 32), pts3(2 * B * 128), sc3(2 * B * 64), third(2 * B * 64);
-    int ped_rc = DR_OK;
-    std::string ped_err;
-    auto pedersen_tail = [&]() -> int {
+    int head(dr_ctx* ctx, const uint8_t* alphas, const uint64_t* alpha_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts,
+             const uint64_t* salt_off, const uint8_t* secret_scalars, PhaseTrace& tr_) {
+        const drh::Mod256& mn = drh::mod_n();
+        // 1. hash_to_field(salt || alpha), secrets mod n
+        us.resize(B * 64); xs.resize(B * 32);
+        drh::parallel_for(B, [&](size_t i) {
+            drh::Bytes msg;
+            if (salt_off) drh::put(msg, salts + salt_off[i], salt_off[i + 1] - salt_off[i]);
+            drh::put(msg, alphas + alpha_off[i], alpha_off[i + 1] - alpha_off[i]);
+            drh::hash_to_field2(su, msg.data(), msg.size(), us.data() + 64 * i);
+            uint64_t x[4];
+            mn.reduce_bytes(secret_scalars + 32 * i, 32, false, x);
+            drh::store_le32(x, xs.data() + 32 * i);
+        });
+        tr_.mark("h2f");
+        // 2. I_i = encode_to_curve, O_i = x_i * I_i
+        inputs.resize(B * 64); outs.resize(B * 64);
+        TRY(dr_bsn_encode_to_curve_batch(ctx, us.data(), B, inputs.data()));
+        tr_.mark("encode");
+        TRY(dr_bsn_scalar_mul_batch(ctx, inputs.data(), xs.data(), B, outs.data()));
+        tr_.mark("x*I");
+        // 3. transcripts, blinding factors
+        tr.assign(B, drh::Bytes());
+        blind.resize(B * 32); gb_pts.resize(B * 128); sc.resize(B * 64);
+        std::vector<int> bad(B, 0);
+        drh::parallel_for(B, [&](size_t i) {
+            drh::Bytes& t = tr[i];
+            t = su.suite_id;
+            drh::put8(t, 0x02);                                    // PEDERSEN_VRF
+            drh::put_le64(t, 1);                                   // one (input, output) pair
+            uint8_t enc[32];
+            drh::enc_te_point(inputs.data() + 64 * i, enc); drh::put(t, enc, 32);
+            drh::enc_te_point(outs.data() + 64 * i, enc); drh::put(t, enc, 32);
+            size_t adl = ad_off[i + 1] - ad_off[i];
+            drh::put_le64(t, adl);
+            drh::put(t, ads + ad_off[i], adl);
+            drh::Bytes tb = t;
+            drh::put8(tb, 0x12);                                   // PEDERSEN_BLINDING
+            uint64_t x[4], b[4];
+            drh::load_le32(xs.data() + 32 * i, x);
+            if (!drh::vrf_nonce(su, tb, x, b)) bad[i] = 1;
+            drh::store_le32(b, blind.data() + 32 * i);
+            std::memcpy(gb_pts.data() + 128 * i, su.generator, 64);
+            std::memcpy(gb_pts.data() + 128 * i + 64, su.blinding_base, 64);
+            std::memcpy(sc.data() + 64 * i, xs.data() + 32 * i, 32);
+            std::memcpy(sc.data() + 64 * i + 32, blind.data() + 32 * i, 32);
+        });
+        for (size_t i = 0; i < B; i++) if (bad[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
+        tr_.mark("blinding");
+        return DR_OK;
+    }
+
+    // out_proofs: 192 bytes per proof at `stride`; out_aux (nullable): O, Y_bar, R, O_k affine (4*64) + blinding (32) at aux_stride
+    int tail(dr_ctx* actx, uint8_t* out_proofs, size_t stride, uint8_t* out_aux, size_t aux_stride) {
+        const drh::Mod256& mn = drh::mod_n();
+        ybar.resize(B * 64); ks.resize(B * 32); kbs.resize(B * 32); pts3.resize(2 * B * 128); sc3.resize(2 * B * 64); third.resize(2 * B * 64);
         // 4. blinded public keys  Y_bar_i = x_i*G + b_i*B
         TRY(dr_bsn_msm_groups(actx, gb_pts.data(), sc.data(), B, 2, ybar.data()));
         // 5. nonces
@@ -1705,9 +1699,9 @@ static int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite
         });
         for (size_t i = 0; i < B; i++) if (bad2[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
         TRY(dr_bsn_msm_groups(actx, pts3.data(), sc3.data(), 2 * B, 2, third.data()));
-        // 6. challenge, responses, Pedersen part of the proof
+        // 6. challenge, responses, the 192 encoded bytes
         drh::parallel_for(B, [&](size_t i) {
-            uint8_t* out = out_proofs + 784 * i;
+            uint8_t* out = out_proofs + stride * i;
             drh::enc_te_point(outs.data() + 64 * i, out);
             drh::enc_te_point(ybar.data() + 64 * i, out + 32);
             drh::enc_te_point(third.data() + 64 * i, out + 64);
@@ -1723,7 +1717,7 @@ static int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite
             drh::store_le32(s, out + 128);
             drh::store_le32(sb, out + 160);
             if (out_aux) {
-                uint8_t* a = out_aux + DR_RINGVRF_AUX_BYTES * i;
+                uint8_t* a = out_aux + aux_stride * i;
                 std::memcpy(a, outs.data() + 64 * i, 64);
                 std::memcpy(a + 64, ybar.data() + 64 * i, 64);
                 std::memcpy(a + 128, third.data() + 64 * i, 64);
@@ -1732,16 +1726,44 @@ static int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite
             }
         });
         return DR_OK;
-    };
+    }
+};
+
+static int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_t batch, const uint8_t* alphas, const uint64_t* alpha_off,
+                                    const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
+                                    const uint8_t* secret_scalars, const uint32_t* producer_index, const uint8_t* fs_prefix, size_t fs_prefix_len,
+                                    const uint8_t* zk_random48, uint8_t* out_proofs, uint8_t* out_aux) {
+    if (!p || !alpha_off || !ad_off || !secret_scalars || !producer_index || !fs_prefix || !out_proofs) return fail(DR_ERR_INVALID, "null argument");
+    if (batch == 0) return DR_OK;
+    if (batch > 4096) return fail(DR_ERR_INVALID, "batch must be at most 4096 per call");
+    drh::VrfSuite su;
+    TRY(load_suite(suite, su));
+    for (size_t i = 0; i < batch; i++)
+        if (alpha_off[i + 1] < alpha_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
+            return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
+    dr_ctx* ctx = p->ctx;
+    const size_t B = batch;
+    PhaseTrace tr_("prove_batch");
+
+    PedersenBatch ped(su, B);
+    TRY(ped.head(ctx, alphas, alpha_off, ads, ad_off, salts, salt_off, secret_scalars, tr_));
+    std::vector<uint8_t>& blind = ped.blind;
+    // 4.-6. the rest of the Pedersen part needs nothing from the ring proof and the ring proof needs only the blinding
+    // factors: it runs on a second stream (own context: scratch + stream) from a helper thread while this thread drives
+    // the ring phases.  Its kernels are latency-bound (16..64 waves) and hide under the chip-filling MSMs.
+    if (!p->aux_ctx) TRY(dr_ctx_create(ctx->device, &p->aux_ctx));
+    dr_ctx* actx = p->aux_ctx;
+    int ped_rc = DR_OK;
+    std::string ped_err;
     const bool overlap = std::getenv("DOTRING_PROVE_OVERLAP") == nullptr || std::atoi(std::getenv("DOTRING_PROVE_OVERLAP")) != 0;
     std::thread ped_thread;
     if (overlap) {
         ped_thread = std::thread([&] {
-            ped_rc = pedersen_tail();
+            ped_rc = ped.tail(actx, out_proofs, 784, out_aux, DR_RINGVRF_AUX_BYTES);
             if (ped_rc != DR_OK) ped_err = dr_last_error();
         });
     } else {
-        TRY(pedersen_tail());
+        TRY(ped.tail(ctx, out_proofs, 784, out_aux, DR_RINGVRF_AUX_BYTES));
     }
     struct Joiner {          // every exit path below must wait for the helper before the buffers it uses go away
         std::thread& t;
@@ -1838,6 +1860,73 @@ int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t 
     } catch (const std::exception& e) {
         return fail(DR_ERR_DEVICE, std::string("native prover: ") + e.what());
     }
+}
+
+// Pedersen VRF batch verification core (pedersen/vrf.py:171-242) on decoded points: challenges, weights from one
+// transcript over all (c, s, s_b), then ONE (5B+2)-point MSM that must be the identity.  proofs: 192 bytes per proof at
+// `stride`; te_xy: the four decoded points of each proof (O, Y_bar, R, O_k affine); in_pts: encode_to_curve of the inputs.
+static int pedersen_verify_core(dr_ctx* actx, const drh::VrfSuite& su, size_t B, const uint8_t* proofs, size_t stride,
+                                const std::vector<uint8_t>& te_xy, const std::vector<uint8_t>& in_pts, const uint8_t* ads,
+                                const uint64_t* ad_off, int& ped_ok) {
+    const drh::Mod256& mn = drh::mod_n();
+    std::vector<uint8_t> cs(B * 32);
+    drh::parallel_for(B, [&](size_t i) {
+        const uint8_t* pr = proofs + stride * i;
+        drh::Bytes t = su.suite_id;
+        drh::put8(t, 0x02);
+        drh::put_le64(t, 1);
+        uint8_t enc[32];
+        drh::enc_te_point(in_pts.data() + 64 * i, enc);
+        drh::put(t, enc, 32);
+        drh::put(t, pr, 32);                                   // output point, as encoded in the proof
+        size_t adl = ad_off[i + 1] - ad_off[i];
+        drh::put_le64(t, adl);
+        drh::put(t, ads + ad_off[i], adl);
+        drh::put(t, pr + 32, 32);                              // blinded public key
+        uint64_t c[4];
+        drh::vrf_challenge(su, t, pr + 64, 2, c);              // R, O_k
+        drh::store_le32(c, cs.data() + 32 * i);
+    });
+    {
+        drh::Bytes absorbed = su.suite_id;
+        drh::put8(absorbed, 0x50);                             // BATCH_VERIFY
+        for (size_t i = 0; i < B; i++) {
+            drh::put(absorbed, cs.data() + 32 * i, 32);
+            drh::put(absorbed, proofs + stride * i + 128, 64);    // s, s_b
+        }
+        std::vector<uint8_t> weights(32 * B);
+        drh::vrf_squeeze(su.xof, absorbed.data(), absorbed.size(), weights.data(), weights.size());
+        std::vector<uint8_t> pts((5 * B + 2) * 64), sc((5 * B + 2) * 32);
+        std::vector<uint64_t> gen_part(B * 4), blind_part(B * 4);
+        drh::parallel_for(B, [&](size_t i) {
+            const uint8_t* pr = proofs + stride * i;
+            uint64_t w_io[4], w_cm[4], c[4], s[4], sb[4], t[4];
+            mn.reduce_bytes(weights.data() + 32 * i, 16, false, w_io);
+            mn.reduce_bytes(weights.data() + 32 * i + 16, 16, false, w_cm);
+            drh::load_le32(cs.data() + 32 * i, c);
+            drh::load_le32(pr + 128, s);
+            drh::load_le32(pr + 160, sb);
+            uint8_t* p = pts.data() + 320 * i;
+            uint8_t* k = sc.data() + 160 * i;
+            std::memcpy(p, te_xy.data() + 64 * (4 * i + 3), 64);       drh::store_le32(w_io, k);                       // O_k
+            std::memcpy(p + 64, te_xy.data() + 64 * (4 * i), 64);      mn.mul(w_io, c, t); drh::store_le32(t, k + 32);  // output
+            std::memcpy(p + 128, in_pts.data() + 64 * i, 64);          mn.mul(w_io, s, t); mn.neg(t, t); drh::store_le32(t, k + 64);   // input
+            std::memcpy(p + 192, te_xy.data() + 64 * (4 * i + 2), 64); drh::store_le32(w_cm, k + 96);                  // R
+            std::memcpy(p + 256, te_xy.data() + 64 * (4 * i + 1), 64); mn.mul(w_cm, c, t); drh::store_le32(t, k + 128); // Y_bar
+            mn.mul(w_cm, s, &gen_part[4 * i]);
+            mn.mul(w_cm, sb, &blind_part[4 * i]);
+        });
+        uint64_t gs[4] = {0, 0, 0, 0}, bs[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < B; i++) { mn.sub(gs, &gen_part[4 * i], gs); mn.sub(bs, &blind_part[4 * i], bs); }
+        std::memcpy(pts.data() + 320 * B, su.generator, 64);           drh::store_le32(gs, sc.data() + 160 * B);
+        std::memcpy(pts.data() + 320 * B + 64, su.blinding_base, 64);  drh::store_le32(bs, sc.data() + 160 * B + 32);
+        uint8_t sum[64];
+        TRY(dr_bsn_msm(actx, pts.data(), sc.data(), 5 * B + 2, sum));
+        uint8_t ident[64] = {0};
+        ident[32] = 1;
+        ped_ok = std::memcmp(sum, ident, 64) == 0 ? 1 : 0;
+    }
+    return DR_OK;
 }
 
 static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_ring_verifier_key* vk, size_t batch, const uint8_t* proofs,
@@ -1944,66 +2033,7 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
     // ---- 3. Pedersen part (helper thread, second stream): challenges, then ONE (5B+2)-point MSM that must vanish
     int ped_ok = 0;
     side = std::thread([&] {
-      side_rc = [&]() -> int {
-    std::vector<uint8_t> cs(B * 32);
-    drh::parallel_for(B, [&](size_t i) {
-        const uint8_t* pr = proofs + 784 * i;
-        drh::Bytes t = su.suite_id;
-        drh::put8(t, 0x02);
-        drh::put_le64(t, 1);
-        uint8_t enc[32];
-        drh::enc_te_point(in_pts.data() + 64 * i, enc);
-        drh::put(t, enc, 32);
-        drh::put(t, pr, 32);                                   // output point, as encoded in the proof
-        size_t adl = ad_off[i + 1] - ad_off[i];
-        drh::put_le64(t, adl);
-        drh::put(t, ads + ad_off[i], adl);
-        drh::put(t, pr + 32, 32);                              // blinded public key
-        uint64_t c[4];
-        drh::vrf_challenge(su, t, pr + 64, 2, c);              // R, O_k
-        drh::store_le32(c, cs.data() + 32 * i);
-    });
-    {
-        drh::Bytes absorbed = su.suite_id;
-        drh::put8(absorbed, 0x50);                             // BATCH_VERIFY
-        for (size_t i = 0; i < B; i++) {
-            drh::put(absorbed, cs.data() + 32 * i, 32);
-            drh::put(absorbed, proofs + 784 * i + 128, 64);    // s, s_b
-        }
-        std::vector<uint8_t> weights(32 * B);
-        drh::vrf_squeeze(su.xof, absorbed.data(), absorbed.size(), weights.data(), weights.size());
-        std::vector<uint8_t> pts((5 * B + 2) * 64), sc((5 * B + 2) * 32);
-        std::vector<uint64_t> gen_part(B * 4), blind_part(B * 4);
-        drh::parallel_for(B, [&](size_t i) {
-            const uint8_t* pr = proofs + 784 * i;
-            uint64_t w_io[4], w_cm[4], c[4], s[4], sb[4], t[4];
-            mn.reduce_bytes(weights.data() + 32 * i, 16, false, w_io);
-            mn.reduce_bytes(weights.data() + 32 * i + 16, 16, false, w_cm);
-            drh::load_le32(cs.data() + 32 * i, c);
-            drh::load_le32(pr + 128, s);
-            drh::load_le32(pr + 160, sb);
-            uint8_t* p = pts.data() + 320 * i;
-            uint8_t* k = sc.data() + 160 * i;
-            std::memcpy(p, te_xy.data() + 64 * (4 * i + 3), 64);       drh::store_le32(w_io, k);                       // O_k
-            std::memcpy(p + 64, te_xy.data() + 64 * (4 * i), 64);      mn.mul(w_io, c, t); drh::store_le32(t, k + 32);  // output
-            std::memcpy(p + 128, in_pts.data() + 64 * i, 64);          mn.mul(w_io, s, t); mn.neg(t, t); drh::store_le32(t, k + 64);   // input
-            std::memcpy(p + 192, te_xy.data() + 64 * (4 * i + 2), 64); drh::store_le32(w_cm, k + 96);                  // R
-            std::memcpy(p + 256, te_xy.data() + 64 * (4 * i + 1), 64); mn.mul(w_cm, c, t); drh::store_le32(t, k + 128); // Y_bar
-            mn.mul(w_cm, s, &gen_part[4 * i]);
-            mn.mul(w_cm, sb, &blind_part[4 * i]);
-        });
-        uint64_t gs[4] = {0, 0, 0, 0}, bs[4] = {0, 0, 0, 0};
-        for (size_t i = 0; i < B; i++) { mn.sub(gs, &gen_part[4 * i], gs); mn.sub(bs, &blind_part[4 * i], bs); }
-        std::memcpy(pts.data() + 320 * B, su.generator, 64);           drh::store_le32(gs, sc.data() + 160 * B);
-        std::memcpy(pts.data() + 320 * B + 64, su.blinding_base, 64);  drh::store_le32(bs, sc.data() + 160 * B + 32);
-        uint8_t sum[64];
-        TRY(dr_bsn_msm(actx, pts.data(), sc.data(), 5 * B + 2, sum));
-        uint8_t ident[64] = {0};
-        ident[32] = 1;
-        ped_ok = std::memcmp(sum, ident, 64) == 0 ? 1 : 0;
-    }
-    return DR_OK;
-      }();
+    side_rc = pedersen_verify_core(actx, su, B, proofs, 784, te_xy, in_pts, ads, ad_off, ped_ok);
       if (side_rc != DR_OK) side_err = dr_last_error();
     });
 
@@ -2110,6 +2140,78 @@ int dr_ringvrf_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_rin
                             const uint64_t* salt_off, const uint8_t seed32[32], int* ok) {
     try {
         return ringvrf_verify_batch_impl(ctx, suite, vk, batch, proofs, inputs, in_off, ads, ad_off, salts, salt_off, seed32, ok);
+    } catch (const std::bad_alloc&) {
+        return fail(DR_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_DEVICE, std::string("native verifier: ") + e.what());
+    }
+}
+
+// PedersenVRF.prove for a batch (pedersen/vrf.py:86-126): 192 bytes per proof; same code as the Pedersen part of
+// dr_ringvrf_prove_batch.  out_aux (nullable): per proof O, Y_bar, R, O_k affine (4*64) and the blinding factor (32).
+int dr_pedersen_prove_batch(dr_ctx* ctx, const dr_vrf_suite* suite, size_t batch, const uint8_t* alphas, const uint64_t* alpha_off,
+                            const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
+                            const uint8_t* secret_scalars, uint8_t* out_proofs, uint8_t* out_aux) {
+    try {
+        TRY(use_ctx(ctx));
+        if (!alpha_off || !ad_off || !secret_scalars || !out_proofs) return fail(DR_ERR_INVALID, "null argument");
+        if (batch == 0) return DR_OK;
+        if (batch > 65536) return fail(DR_ERR_INVALID, "batch must be at most 65536 per call");
+        drh::VrfSuite su;
+        TRY(load_suite(suite, su));
+        for (size_t i = 0; i < batch; i++)
+            if (alpha_off[i + 1] < alpha_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
+                return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
+        PhaseTrace tr_("pedersen_prove_batch");
+        PedersenBatch ped(su, batch);
+        TRY(ped.head(ctx, alphas, alpha_off, ads, ad_off, salts, salt_off, secret_scalars, tr_));
+        TRY(ped.tail(ctx, out_proofs, 192, out_aux, DR_PEDERSEN_AUX_BYTES));
+        tr_.mark("tail");
+        return DR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(DR_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_DEVICE, std::string("native prover: ") + e.what());
+    }
+}
+
+// PedersenVRF.batch_verify (pedersen/vrf.py:171-242) over ENCODED proofs (192 bytes each): point decoding + subgroup
+// checks and hash-to-curve on the GPU, challenges on worker threads, one (5B+2)-point MSM.  *ok = 1 iff all verify.
+int dr_pedersen_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, size_t batch, const uint8_t* proofs, const uint8_t* inputs,
+                             const uint64_t* in_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
+                             int* ok) {
+    try {
+        TRY(use_ctx(ctx));
+        if (!proofs || !in_off || !ad_off || !ok) return fail(DR_ERR_INVALID, "null argument");
+        *ok = 0;
+        if (batch == 0) { *ok = 1; return DR_OK; }
+        if (batch > 65536) return fail(DR_ERR_INVALID, "batch must be at most 65536 per call");
+        drh::VrfSuite su;
+        TRY(load_suite(suite, su));
+        const size_t B = batch;
+        const drh::Mod256& mn = drh::mod_n();
+        for (size_t i = 0; i < B; i++)
+            if (in_off[i + 1] < in_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
+                return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
+        std::vector<uint8_t> te_enc(B * 128), te_xy(B * 256), flags(B * 4), us(B * 64), in_pts(B * 64);
+        for (size_t i = 0; i < B; i++) {
+            std::memcpy(te_enc.data() + 128 * i, proofs + 192 * i, 128);
+            uint64_t v[4];
+            for (int k = 0; k < 2; k++) { drh::load_le32(proofs + 192 * i + 128 + 32 * k, v); if (drh::Mod256::geq(v, mn.m)) return DR_OK; }   // dec_scalar
+        }
+        TRY(dr_bsn_decode_points(ctx, te_enc.data(), 4 * B, te_xy.data(), flags.data()));
+        for (size_t i = 0; i < 4 * B; i++) if (!flags[i]) return DR_OK;
+        drh::parallel_for(B, [&](size_t i) {
+            drh::Bytes msg;
+            if (salt_off) drh::put(msg, salts + salt_off[i], salt_off[i + 1] - salt_off[i]);
+            drh::put(msg, inputs + in_off[i], in_off[i + 1] - in_off[i]);
+            drh::hash_to_field2(su, msg.data(), msg.size(), us.data() + 64 * i);
+        });
+        TRY(dr_bsn_encode_to_curve_batch(ctx, us.data(), B, in_pts.data()));
+        int ped_ok = 0;
+        TRY(pedersen_verify_core(ctx, su, B, proofs, 192, te_xy, in_pts, ads, ad_off, ped_ok));
+        *ok = ped_ok;
+        return DR_OK;
     } catch (const std::bad_alloc&) {
         return fail(DR_ERR_NOMEM, "out of host memory");
     } catch (const std::exception& e) {

@@ -1,8 +1,10 @@
 """Pedersen VRF (dot_ring/vrf/pedersen/vrf.py:32-243).  Envelope: gamma || Y_bar || R || O_k || s || s_b."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
+from .. import _native, runtime
 from ..curve import msm_groups, scalar_mul_batch
 from .base import VRF
 from .codec import dec_points, dec_scalar, dec_scalar_mod, enc_point, enc_scalar, point_len, scalar_len
@@ -99,11 +101,44 @@ class PedersenVRF(VRF):
         return proofs
 
     @classmethod
-    def prove_batch(cls, alphas, secret_keys, additional_data, salts=None) -> list:
-        """Additive API: element i equals prove(alphas[i], secret_keys[i], additional_data[i])."""
-        from ..pipeline import drive
+    def _suite_struct(cls):
+        sp = cls.cv.curve.params
+        le = lambda v: int(v).to_bytes(32, "little")
+        gen, bb = sp.generator, sp.auxiliary_points.blinding_base
+        return _native.vrf_suite(sp.suite_id, sp.xof, le(gen[0]) + le(gen[1]), le(bb[0]) + le(bb[1]))
 
-        return drive(cls._prove_gen(alphas, secret_keys, additional_data, salts))
+    @classmethod
+    def prove_batch(cls, alphas, secret_keys, additional_data, salts=None) -> list:
+        """Additive API: element i equals prove(alphas[i], secret_keys[i], additional_data[i]).
+        Default: one dr_pedersen_prove_batch call (transcripts on the library's worker threads);
+        DOTRING_NATIVE_HOST=0 keeps the Python orchestration over the same kernels."""
+        count = len(alphas)
+        if not (len(secret_keys) == len(additional_data) == count) or (salts is not None and len(salts) != count):
+            raise ValueError("batch arguments must have equal lengths")
+        if count == 0:
+            return []
+        if os.environ.get("DOTRING_NATIVE_HOST", "1") == "0" or not cls.cv.curve.params.auxiliary_points.blinding_base:
+            from ..pipeline import drive
+
+            return drive(cls._prove_gen(alphas, secret_keys, additional_data, salts))
+        cv = cls.cv
+        order = cv.curve.params.subgroup_order
+        le = lambda v: int(v).to_bytes(32, "little")
+        sks = b"".join(bytes(sk) if len(sk) == 32 else le(int.from_bytes(sk, "little") % order) for sk in secret_keys)
+        ctx = runtime.context()
+        suite = cls._suite_struct()
+        out, frm, mk = [], int.from_bytes, cv.point_type._trusted
+        step, ab = 65536, _native.PEDERSEN_AUX_BYTES
+        for lo in range(0, count, step):
+            hi = min(count, lo + step)
+            raw, aux = ctx.pedersen_prove_batch(suite, [bytes(a) for a in alphas[lo:hi]], [bytes(a) for a in additional_data[lo:hi]],
+                                                salts[lo:hi] if salts else None, sks[32 * lo : 32 * hi])
+            for i in range(hi - lo):
+                a, r = aux[ab * i : ab * i + ab], raw[192 * i : 192 * i + 192]
+                pts = [mk(frm(a[64 * k : 64 * k + 32], "little"), frm(a[64 * k + 32 : 64 * k + 64], "little")) for k in range(4)]
+                out.append(cls(output_point=pts[0], blinded_pk=pts[1], result_point=pts[2], ok=pts[3], s=frm(r[128:160], "little"),
+                               sb=frm(r[160:192], "little"), _blinding_factor=frm(a[256:288], "little")))
+        return out
 
     @classmethod
     def prove(cls, alpha: bytes, secret_key: bytes, additional_data: bytes, salt: bytes = b"") -> "PedersenVRF":
@@ -144,6 +179,19 @@ class PedersenVRF(VRF):
         cv = cls.cv
         if salts is None:
             salts = [b""] * len(proofs)
+        if os.environ.get("DOTRING_NATIVE_HOST", "1") != "0" and cv.curve.params.auxiliary_points.blinding_base:
+            try:
+                if not (len(proofs) == len(inputs) == len(additional_data) == len(salts)):
+                    return False
+                blobs = [p.encode() for p in proofs]
+                if any(len(b) != 192 for b in blobs):
+                    return False
+                ins, adl, sl = [bytes(x) for x in inputs], [bytes(x) for x in additional_data], [bytes(x) for x in salts]
+            except (AttributeError, TypeError, ValueError):
+                return False
+            ctx, suite, step = runtime.context(), cls._suite_struct(), 65536
+            return all(ctx.pedersen_verify_batch(suite, b"".join(blobs[lo : lo + step]), ins[lo : lo + step], adl[lo : lo + step], sl[lo : lo + step])
+                       for lo in range(0, len(blobs), step))
         order = cv.curve.params.subgroup_order
         items, coeff_bytes = [], bytearray()
         try:

@@ -233,6 +233,18 @@ DR_API int dr_ringvrf_prove_batch(dr_ring_prover *p, const dr_vrf_suite *suite, 
                                   uint8_t *out_aux);
 
 
+/* PedersenVRF.prove / batch_verify for a batch (dot_ring/vrf/pedersen/vrf.py:86-126, 171-242): the Pedersen halves of the
+ * two Ring-VRF calls on their own.  Proofs are 192 bytes (gamma || Y_bar || R || O_k || s || s_b).  out_aux (nullable,
+ * batch * DR_PEDERSEN_AUX_BYTES): O, Y_bar, R, O_k affine (4*64) and the blinding factor (32).  The verifier decodes and
+ * subgroup-checks the proof points on the GPU; *ok = 1 iff every proof verifies (malformed input: *ok = 0, DR_OK). */
+#define DR_PEDERSEN_AUX_BYTES 288
+DR_API int dr_pedersen_prove_batch(dr_ctx *ctx, const dr_vrf_suite *suite, size_t batch, const uint8_t *alphas, const uint64_t *alpha_off,
+                                   const uint8_t *ads, const uint64_t *ad_off, const uint8_t *salts, const uint64_t *salt_off,
+                                   const uint8_t *secret_scalars, uint8_t *out_proofs, uint8_t *out_aux);
+DR_API int dr_pedersen_verify_batch(dr_ctx *ctx, const dr_vrf_suite *suite, size_t batch, const uint8_t *proofs, const uint8_t *inputs,
+                                    const uint64_t *in_off, const uint8_t *ads, const uint64_t *ad_off, const uint8_t *salts,
+                                    const uint64_t *salt_off, int *ok);
+
 /* What a verifier knows about one ring (RingRoot + RingProofParams + SRS verifier part). */
 typedef struct dr_ring_verifier_key {
     unsigned log2n;                      /* domain size N = 2^log2n */
