@@ -96,6 +96,8 @@ _PROTOTYPES.update({
                                         POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p, c_char_p, c_char_p]),
     "dr_pedersen_verify_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_size_t, c_char_p, c_char_p, POINTER(ctypes.c_uint64), c_char_p,
                                          POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), POINTER(c_int)]),
+    "dr_ietf_prove_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_int, c_size_t, c_char_p, POINTER(ctypes.c_uint64), c_char_p,
+                                    POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p, c_char_p, c_char_p]),
     "dr_host_hash": (c_int, [c_int, c_char_p, c_size_t, c_char_p, c_size_t]),
     "dr_hash_to_field_batch": (c_int, [POINTER(VrfSuiteStruct), c_char_p, POINTER(ctypes.c_uint64), c_size_t, c_char_p]),
     "dr_ringvrf_prove_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_size_t, c_char_p, POINTER(ctypes.c_uint64), c_char_p,
@@ -429,6 +431,17 @@ class Context:
         out, aux = ctypes.create_string_buffer(max(1, 192 * batch)), ctypes.create_string_buffer(max(1, PEDERSEN_AUX_BYTES * batch))
         _check(lib().dr_pedersen_prove_batch(self.handle, byref(suite), batch, a_blob, a_off, d_blob, d_off, s_blob, s_off, secret_scalars, out, aux))
         return out.raw[: 192 * batch], aux.raw[: PEDERSEN_AUX_BYTES * batch]
+
+    def ietf_prove_batch(self, suite: "VrfSuiteStruct", thin: bool, alphas, ads, salts, secret_scalars: bytes):
+        """dr_ietf_prove_batch -> (batch * (96 if thin else 80) proof bytes, batch * 128 bytes: O and R affine)."""
+        batch, plen = len(alphas), 96 if thin else 80
+        a_blob, a_off = _ragged(alphas)
+        d_blob, d_off = _ragged(ads)
+        s_blob, s_off = (None, None) if not salts or not any(salts) else _ragged(salts)
+        out, aux = ctypes.create_string_buffer(max(1, plen * batch)), ctypes.create_string_buffer(max(1, 128 * batch))
+        _check(lib().dr_ietf_prove_batch(self.handle, byref(suite), 1 if thin else 0, batch, a_blob, a_off, d_blob, d_off, s_blob, s_off,
+                                         secret_scalars, out, aux))
+        return out.raw[: plen * batch], aux.raw[: 128 * batch]
 
     def pedersen_verify_batch(self, suite: "VrfSuiteStruct", proofs: bytes, inputs, ads, salts) -> bool:
         batch = len(inputs)

@@ -2219,4 +2219,114 @@ int dr_pedersen_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, size_t batc
     }
 }
 
+// TinyVRF.prove / ThinVRF.prove for a batch (vrf/ietf/tiny.py:53-70, thin.py): I = encode_to_curve, pk = x G, O = x I;
+// transcript over the two (input, output) pairs (G, pk), (I, O); delinearised input M = G + z I; k = nonce; R = k M;
+// c = challenge(R); s = k + c x.  Tiny proof = O || c (16) || s (80 bytes), Thin proof = O || R || s (96 bytes).
+int dr_ietf_prove_batch(dr_ctx* ctx, const dr_vrf_suite* suite, int thin, size_t batch, const uint8_t* alphas, const uint64_t* alpha_off,
+                        const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
+                        const uint8_t* secret_scalars, uint8_t* out_proofs, uint8_t* out_aux) {
+    try {
+        TRY(use_ctx(ctx));
+        if (!alpha_off || !ad_off || !secret_scalars || !out_proofs) return fail(DR_ERR_INVALID, "null argument");
+        if (batch == 0) return DR_OK;
+        if (batch > 65536) return fail(DR_ERR_INVALID, "batch must be at most 65536 per call");
+        drh::VrfSuite su;
+        TRY(load_suite(suite, su));
+        const size_t B = batch, plen = thin ? 96 : 80;
+        const drh::Mod256& mn = drh::mod_n();
+        for (size_t i = 0; i < B; i++)
+            if (alpha_off[i + 1] < alpha_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
+                return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
+        std::vector<uint8_t> us(B * 64), xs(B * 32), inputs(B * 64);
+        drh::parallel_for(B, [&](size_t i) {
+            drh::Bytes msg;
+            if (salt_off) drh::put(msg, salts + salt_off[i], salt_off[i + 1] - salt_off[i]);
+            drh::put(msg, alphas + alpha_off[i], alpha_off[i + 1] - alpha_off[i]);
+            drh::hash_to_field2(su, msg.data(), msg.size(), us.data() + 64 * i);
+            uint64_t x[4];
+            mn.reduce_bytes(secret_scalars + 32 * i, 32, false, x);
+            drh::store_le32(x, xs.data() + 32 * i);
+        });
+        TRY(dr_bsn_encode_to_curve_batch(ctx, us.data(), B, inputs.data()));
+        // pk_i = x_i G and O_i = x_i I_i in one launch
+        std::vector<uint8_t> pts(2 * B * 64), sc(2 * B * 32), firsts(2 * B * 64);
+        for (size_t i = 0; i < B; i++) {
+            std::memcpy(pts.data() + 64 * i, su.generator, 64);
+            std::memcpy(pts.data() + 64 * (B + i), inputs.data() + 64 * i, 64);
+            std::memcpy(sc.data() + 32 * i, xs.data() + 32 * i, 32);
+            std::memcpy(sc.data() + 32 * (B + i), xs.data() + 32 * i, 32);
+        }
+        TRY(dr_bsn_scalar_mul_batch(ctx, pts.data(), sc.data(), 2 * B, firsts.data()));
+        const uint8_t* pks = firsts.data();
+        const uint8_t* outs = firsts.data() + 64 * B;
+        // transcripts, delinearisation scalar z, nonces
+        std::vector<drh::Bytes> tr(B);
+        std::vector<uint8_t> gpts(B * 128), gsc(B * 64), ks(B * 32);
+        std::vector<int> bad(B, 0);
+        uint8_t enc_g[32];
+        drh::enc_te_point(su.generator, enc_g);
+        drh::parallel_for(B, [&](size_t i) {
+            drh::Bytes& t = tr[i];
+            t = su.suite_id;
+            drh::put8(t, thin ? 0x01 : 0x00);                      // THIN_VRF / TINY_VRF
+            drh::put_le64(t, 2);
+            uint8_t enc[32];
+            drh::put(t, enc_g, 32);
+            drh::enc_te_point(pks + 64 * i, enc); drh::put(t, enc, 32);
+            drh::enc_te_point(inputs.data() + 64 * i, enc); drh::put(t, enc, 32);
+            drh::enc_te_point(outs + 64 * i, enc); drh::put(t, enc, 32);
+            size_t adl = ad_off[i + 1] - ad_off[i];
+            drh::put_le64(t, adl);
+            drh::put(t, ads + ad_off[i], adl);
+            drh::Bytes d = t;
+            drh::put8(d, 0x30);                                    // DELINEARIZE
+            uint8_t raw[16];
+            drh::vrf_squeeze(su.xof, d.data(), d.size(), raw, 16);
+            uint64_t z[4], x[4], k[4], one[4] = {1, 0, 0, 0};
+            mn.reduce_bytes(raw, 16, false, z);
+            std::memcpy(gpts.data() + 128 * i, su.generator, 64);
+            std::memcpy(gpts.data() + 128 * i + 64, inputs.data() + 64 * i, 64);
+            drh::store_le32(one, gsc.data() + 64 * i);
+            drh::store_le32(z, gsc.data() + 64 * i + 32);
+            drh::load_le32(xs.data() + 32 * i, x);
+            if (!drh::vrf_nonce(su, t, x, k)) bad[i] = 1;
+            drh::store_le32(k, ks.data() + 32 * i);
+        });
+        for (size_t i = 0; i < B; i++) if (bad[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
+        std::vector<uint8_t> merged(B * 64), rs(B * 64);
+        TRY(dr_bsn_msm_groups(ctx, gpts.data(), gsc.data(), B, 2, merged.data()));
+        TRY(dr_bsn_scalar_mul_batch(ctx, merged.data(), ks.data(), B, rs.data()));
+        drh::parallel_for(B, [&](size_t i) {
+            uint8_t* out = out_proofs + plen * i;
+            uint8_t enc_r[32];
+            drh::enc_te_point(outs + 64 * i, out);
+            drh::enc_te_point(rs.data() + 64 * i, enc_r);
+            uint64_t c[4], x[4], k[4], s[4];
+            drh::vrf_challenge(su, tr[i], enc_r, 1, c);
+            drh::load_le32(xs.data() + 32 * i, x);
+            drh::load_le32(ks.data() + 32 * i, k);
+            mn.mul(c, x, s);
+            mn.add(s, k, s);
+            if (out_aux) {
+                std::memcpy(out_aux + 128 * i, outs + 64 * i, 64);
+                std::memcpy(out_aux + 128 * i + 64, rs.data() + 64 * i, 64);
+            }
+            if (thin) {
+                std::memcpy(out + 32, enc_r, 32);
+                drh::store_le32(s, out + 64);
+            } else {
+                uint8_t cb[32];
+                drh::store_le32(c, cb);
+                std::memcpy(out + 32, cb, 16);
+                drh::store_le32(s, out + 48);
+            }
+        });
+        return DR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(DR_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_DEVICE, std::string("native prover: ") + e.what());
+    }
+}
+
 }  // extern "C"

@@ -1,8 +1,10 @@
 """Tiny VRF (dot_ring/vrf/ietf/tiny.py:26-88).  Envelope: gamma || c(16) || s."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
+from .. import _native, runtime
 from ..curve import msm_groups, scalar_mul_batch
 from .base import VRF
 from .codec import dec_point, dec_scalar, dec_scalar_mod, enc_point, enc_scalar, point_len, scalar_len
@@ -37,6 +39,28 @@ class TinyVRF(VRF):
         """Additive API: element i equals prove(alphas[i], secret_keys[i], additional_data[i])."""
         cv = cls.cv
         count = len(alphas)
+        if count and os.environ.get("DOTRING_NATIVE_HOST", "1") != "0":
+            # one dr_ietf_prove_batch call: transcripts on the library's worker threads, four kernel launches in all
+            if not (len(secret_keys) == len(additional_data) == count) or (salts is not None and len(salts) != count):
+                raise ValueError("batch arguments must have equal lengths")
+            sp = cv.curve.params
+            order = sp.subgroup_order
+            le = lambda v: int(v).to_bytes(32, "little")
+            gen = sp.generator
+            bb = sp.auxiliary_points.blinding_base or gen
+            suite = _native.vrf_suite(sp.suite_id, sp.xof, le(gen[0]) + le(gen[1]), le(bb[0]) + le(bb[1]))
+            sks = b"".join(bytes(sk) if len(sk) == 32 else le(int.from_bytes(sk, "little") % order) for sk in secret_keys)
+            out, frm, mk, plen = [], int.from_bytes, cv.point_type._trusted, 80
+            ctx = runtime.context()
+            for lo in range(0, count, 65536):
+                hi = min(count, lo + 65536)
+                blob, aux = ctx.ietf_prove_batch(suite, False, [bytes(a) for a in alphas[lo:hi]], [bytes(a) for a in additional_data[lo:hi]],
+                                                 salts[lo:hi] if salts else None, sks[32 * lo : 32 * hi])
+                for k in range(hi - lo):
+                    raw, a = blob[plen * k : plen * k + plen], aux[128 * k : 128 * k + 128]
+                    o = mk(frm(a[0:32], "little"), frm(a[32:64], "little"))
+                    out.append(cls(o, frm(raw[32:48], "little"), frm(raw[48:80], "little")))
+            return out
         salts = salts or [b""] * count
         gen = cv.point_type.generator_point()
         xs = [dec_scalar_mod(cv, sk) for sk in secret_keys]

@@ -245,6 +245,12 @@ DR_API int dr_pedersen_verify_batch(dr_ctx *ctx, const dr_vrf_suite *suite, size
                                     const uint64_t *in_off, const uint8_t *ads, const uint64_t *ad_off, const uint8_t *salts,
                                     const uint64_t *salt_off, int *ok);
 
+/* TinyVRF.prove (thin = 0: 80-byte proofs O || c || s, dot_ring/vrf/ietf/tiny.py:35-70) or ThinVRF.prove (thin = 1: 96-byte
+ * proofs O || R || s) for a batch; arguments as for dr_pedersen_prove_batch.  out_aux (nullable, batch * 128): O and R affine. */
+DR_API int dr_ietf_prove_batch(dr_ctx *ctx, const dr_vrf_suite *suite, int thin, size_t batch, const uint8_t *alphas,
+                               const uint64_t *alpha_off, const uint8_t *ads, const uint64_t *ad_off, const uint8_t *salts,
+                               const uint64_t *salt_off, const uint8_t *secret_scalars, uint8_t *out_proofs, uint8_t *out_aux);
+
 /* What a verifier knows about one ring (RingRoot + RingProofParams + SRS verifier part). */
 typedef struct dr_ring_verifier_key {
     unsigned log2n;                      /* domain size N = 2^log2n */
