@@ -3,6 +3,7 @@ reference's own known-answer vectors — same assertions as /root/reference/test
 tests/test_ring_vrf/test_ring_vrf.py, tests/test_dot_ring_vectors.py, byte for byte."""
 import json
 import os
+import random
 
 import pytest
 
@@ -329,3 +330,47 @@ def test_tuning_knobs_do_not_change_the_bytes(ctx):
         assert out.returncode == 0, (extra, out.stderr[-2000:])
         digests.append([ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
     assert len(set(digests)) == 1, list(zip(variants, digests))
+
+
+@pytest.mark.parametrize("suite", ["sha512", "shake128"])
+def test_native_orchestration_equals_python_orchestration(ctx, suite, monkeypatch):
+    """Differential test of the two host layers over the same kernels: ragged inputs (empty, 1 byte, multi-block
+    alphas / ads / salts), both suites, all four schemes; the native batch calls must return the bytes of the Python
+    orchestration (which the KATs pin)."""
+    import dot_ring_amd as d
+
+    cv = {"sha512": d.Bandersnatch, "shake128": d.Bandersnatch_SHAKE128}[suite]
+    rng = random.Random(suite)
+    n = 23
+    blob = lambda hi: bytes(rng.randrange(256) for _ in range(rng.choice([0, 1, 31, 32, 33, 127, 128, 129, hi])))
+    als, ads, salts = [blob(700) for _ in range(n)], [blob(300) for _ in range(n)], [blob(40) for _ in range(n)]
+    als[0], ads[0], salts[0] = b"", b"", b""
+    sks = [rng.randrange(1, 1 << 250).to_bytes(32, "little") for _ in range(n)]
+
+    def both(fn):
+        monkeypatch.setenv("DOTRING_NATIVE_HOST", "1")
+        a = fn()
+        monkeypatch.setenv("DOTRING_NATIVE_HOST", "0")
+        b = fn()
+        monkeypatch.delenv("DOTRING_NATIVE_HOST")
+        return a, b
+
+    for scheme in (d.TinyVRF, d.ThinVRF, d.PedersenVRF):
+        vrf = scheme[cv]
+        a, b = both(lambda: [p.encode() for p in vrf.prove_batch(als, sks, ads, salts)])
+        assert a == b, scheme.__name__
+    ped = d.PedersenVRF[cv]
+    proofs = ped.prove_batch(als, sks, ads, salts)
+    a, b = both(lambda: (ped.batch_verify(proofs, als, ads, salts), ped.batch_verify(proofs, als[1:] + als[:1], ads, salts),
+                         ped.batch_verify(proofs, als, ads, salts[1:] + salts[:1])))
+    assert a == b == (True, False, False)
+    keys = [cv.public_key_from_secret(sk) for sk in sks]
+    params = d.RingProofParams.from_ring_size(n, test_vectors=True, cv=cv)
+    ring = d.Ring(keys, params)
+    root = d.RingRoot.from_ring(ring, params)
+    rv = d.RingVRF[cv]
+    a, b = both(lambda: [p.encode() for p in rv.prove_batch(als, ads, sks, keys, ring, root)])
+    assert a == b
+    rp = rv.prove_batch(als, ads, sks, keys, ring, root)
+    a, b = both(lambda: (rv.batch_verify(rp, als, ads, ring, root), rv.batch_verify(rp, als, ads[1:] + ads[:1], ring, root)))
+    assert a == b == (True, False)
