@@ -44,6 +44,7 @@ _PROTOTYPES = {
     "dr_fr_sqrt": (c_int, [c_char_p, c_void_p]),
     "dr_srs_load": (c_int, [c_void_p, c_char_p, c_size_t, POINTER(c_void_p)]),
     "dr_srs_synthetic": (c_int, [c_void_p, c_char_p, c_uint, c_size_t, POINTER(c_void_p)]),
+    "dr_srs_precompute_comb": (c_int, [c_void_p, c_void_p]),
     "dr_srs_powers": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, POINTER(c_void_p)]),
     "dr_g2_mul": (c_int, [c_char_p, c_char_p, c_char_p]),
     "dr_srs_precompute": (c_int, [c_void_p, c_void_p, c_int]),
@@ -239,6 +240,11 @@ class Srs:
     def precompute(self, window_bits: int) -> "Srs":
         """Build (or with 0 drop) the fixed-base window table in HBM."""
         _check(lib().dr_srs_precompute(self.ctx.handle, self.handle, window_bits))
+        return self
+
+    def precompute_comb(self) -> "Srs":
+        """Comb table over the window table (see dr_srs_precompute_comb); MemoryError if it does not fit."""
+        _check(lib().dr_srs_precompute_comb(self.ctx.handle, self.handle))
         return self
 
     def download(self, offset: int, count: int) -> bytes:

@@ -93,6 +93,9 @@ struct dr_srs {
     // optional fixed-base window table: table[w][i] = 2^(start_w) * base[i]; all windows share one bucket set
     uint32_t* d_table = nullptr;
     dr::WindowTable table_wt{};
+    // optional comb table over the window table: comb[j][w][d-1] = d * table[w][j], every digit magnitude precomputed
+    uint32_t* d_comb = nullptr;
+    uint32_t comb_h = 0;
     // derived bases for summation-by-parts commitments, keyed by log2(domain size): PS_j = sum_{i<=j} L_i(tau) G
     std::map<unsigned, dr_srs*> lagrange_prefix;
 };
@@ -164,6 +167,7 @@ int pick_window(size_t n) {
 }
 
 uint32_t g_chunk_len = 16;   // buckets per lane in k_g1_reduce_chunks (DOTRING_MSM_CHUNK)
+bool g_use_comb = true;      // use comb tables when an SRS has one (DOTRING_MSM_COMB=0: bucket method)
 bool g_chain_wave = true;    // one wave per proof for the witness accumulator chain (DOTRING_CHAIN_WAVE=0: one lane per proof)
 bool g_reduce_levels = true; // level-wise bucket reduction for many bucket sets (DOTRING_MSM_LEVELS=0 disables)
 
@@ -215,6 +219,8 @@ struct MsmTable {
     const uint32_t* table = nullptr;
     dr::WindowTable wt{};
     uint32_t stride = 0, offset = 0;
+    const uint32_t* comb = nullptr;      // comb[j][w][d-1], see k_g1_comb_msm
+    uint32_t comb_h = 0;
 };
 
 int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch,
@@ -223,6 +229,25 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     if (n == 0 || batch == 0) return DR_OK;
     if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "MSM size must be below 2^31");
     const bool single = tbl != nullptr && tbl->table != nullptr;
+    // comb table + many MSMs: a plain sum of looked-up points per MSM, nothing to sort or reduce
+    if (single && tbl->comb && batch >= 32 && g_use_comb) {
+        TRY(ctx->result.reserve(batch * 192));
+        // threads per MSM: enough waves to fill 1024 SIMDs x 3 resident waves, at most 4 waves (one block)
+        unsigned waves = (unsigned)std::max<size_t>(1, std::min<size_t>(4, (3072 + batch / 2) / batch));
+        while (waves > 1 && (size_t)waves * 64 > n) waves--;
+        const unsigned threads = waves * 64;
+        const size_t lds = (size_t)tbl->wt.W * threads * 2;
+        TRY(ctx->partial.reserve(batch * threads * 192));
+        TRY(launch(ctx, "k_g1_comb_msm", [&] {
+            hipLaunchKernelGGL(dr::k_g1_comb_msm, dim3((unsigned)batch), dim3(threads), lds, ctx->stream, d_scalars, (uint32_t)n, tbl->wt, tbl->comb,
+                               tbl->comb_h, tbl->offset, ctx->partial.as<uint32_t>());
+        }));
+        TRY(launch(ctx, "k_g1_reduce_windows", [&] {
+            hipLaunchKernelGGL(dr::k_g1_reduce_windows, dim3((unsigned)batch), dim3(dr::RW_BLOCK), 0, ctx->stream, ctx->partial.as<uint32_t>(), threads,
+                               ctx->result.as<uint32_t>());
+        }));
+        return DR_OK;
+    }
     MsmPlan pl = make_plan(n, g_force_c);
     if (single) {
         pl.wt = tbl->wt;
@@ -406,6 +431,8 @@ MsmTable srs_table(const dr_srs* srs, size_t offset) {
         t.wt = srs->table_wt;
         t.stride = (uint32_t)srs->count;
         t.offset = (uint32_t)offset;
+        t.comb = srs->d_comb;
+        t.comb_h = srs->comb_h;
     }
     return t;
 }
@@ -561,6 +588,7 @@ int dr_ctx_create(int device_id, dr_ctx** out) {
     }
     if (const char* lv = std::getenv("DOTRING_MSM_LEVELS")) g_reduce_levels = std::atoi(lv) != 0;
     if (const char* cw = std::getenv("DOTRING_CHAIN_WAVE")) g_chain_wave = std::atoi(cw) != 0;
+    if (const char* cb = std::getenv("DOTRING_MSM_COMB")) g_use_comb = std::atoi(cb) != 0;
     int rc = bsn_consts_init(ctx->stream);
     if (rc != DR_OK) {
         (void)hipStreamDestroy(ctx->stream);
@@ -938,6 +966,7 @@ int dr_srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits) {
     TRY(use_ctx(ctx));
     if (!srs) return fail(DR_ERR_INVALID, "null argument");
     if (srs->device != ctx->device) return fail(DR_ERR_INVALID, "SRS lives on another device");
+    if (srs->d_comb) { (void)hipFree(srs->d_comb); srs->d_comb = nullptr; srs->comb_h = 0; }     // derived from the window table
     if (window_bits == 0) {
         if (srs->d_table) (void)hipFree(srs->d_table);
         srs->d_table = nullptr;
@@ -961,9 +990,49 @@ int dr_srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits) {
     return DR_OK;
 }
 
+int dr_srs_precompute_comb(dr_ctx* ctx, dr_srs* srs) {
+    TRY(use_ctx(ctx));
+    if (!srs) return fail(DR_ERR_INVALID, "null argument");
+    if (srs->device != ctx->device) return fail(DR_ERR_INVALID, "SRS lives on another device");
+    if (!srs->d_table) return fail(DR_ERR_INVALID, "dr_srs_precompute must come first");
+    if (srs->d_comb) return DR_OK;
+    const dr::WindowTable& wt = srs->table_wt;
+    if (wt.cmax > 14) return fail(DR_ERR_INVALID, "comb tables need window_bits <= 14");
+    const uint32_t Hc = 1u << (wt.cmax - 1);
+    const size_t rows = (size_t)srs->count * wt.W;
+    const size_t bytes = rows * Hc * (size_t)dr::COMB_STRIDE * 4;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (bytes + ((size_t)8 << 30) > free_b) return fail(DR_ERR_NOMEM, "comb table of " + std::to_string(bytes >> 20) + " MiB does not fit");
+    uint32_t* comb = nullptr;
+    if (hipMalloc((void**)&comb, bytes) != hipSuccess) return fail(DR_ERR_NOMEM, "comb table allocation failed");
+    // rows per launch bounded by 4 GiB of staging (XYZZ + prefix product per entry)
+    const size_t per_row = (size_t)Hc * (192 + 48);
+    const size_t chunk = std::max<size_t>(128, std::min<size_t>(rows, ((size_t)4 << 30) / per_row) / 128 * 128);
+    uint32_t *tx = nullptr, *tp = nullptr;
+    hipError_t e = hipMalloc((void**)&tx, chunk * Hc * 192);
+    if (e == hipSuccess) e = hipMalloc((void**)&tp, chunk * Hc * 48);
+    for (size_t lo = 0; e == hipSuccess && lo < rows; lo += chunk) {
+        const uint32_t cnt = (uint32_t)std::min(chunk, rows - lo);
+        hipLaunchKernelGGL(dr::k_g1_comb_build, dim3(div_up(cnt, 128)), dim3(128), 0, ctx->stream, srs->d_table, (uint32_t)srs->count, wt, Hc, lo, cnt,
+                           comb, tx, tp);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (tx) (void)hipFree(tx);
+    if (tp) (void)hipFree(tp);
+    if (e != hipSuccess) {
+        (void)hipFree(comb);
+        return fail(e == hipErrorOutOfMemory ? DR_ERR_NOMEM : DR_ERR_DEVICE, std::string("comb table: ") + hipGetErrorString(e));
+    }
+    srs->d_comb = comb;
+    srs->comb_h = Hc;
+    return DR_OK;
+}
+
 void dr_srs_destroy(dr_srs* srs) {
     if (!srs) return;
     (void)hipSetDevice(srs->device);
+    if (srs->d_comb) (void)hipFree(srs->d_comb);
     for (auto& it : srs->lagrange_prefix) dr_srs_destroy(it.second);
     srs->lagrange_prefix.clear();
     if (srs->d_table) (void)hipFree(srs->d_table);
@@ -1265,6 +1334,10 @@ int lagrange_prefix_srs(dr_ctx* ctx, const dr_srs* srs_c, unsigned log2n, const 
     if (const char* e = std::getenv("DOTRING_PS_WINDOW")) { int v = std::atoi(e); if (v >= 7 && v <= 16) ps_bits = v; }
     rc = dr_srs_precompute(ctx, ps, ps_bits);
     if (rc != DR_OK) { dr_srs_destroy(ps); return rc; }
+    // the by-parts scalars are sparse: in the comb kernel a wave skips a slot only when all 64 lanes have a zero digit,
+    // while the bucket method never sees zero digits at all — DOTRING_PS_COMB=1 builds the comb table anyway
+    if (srs->d_comb && ps_bits <= 14 && std::getenv("DOTRING_PS_COMB") && std::atoi(std::getenv("DOTRING_PS_COMB")) != 0)
+        (void)dr_srs_precompute_comb(ctx, ps);
     srs->lagrange_prefix[log2n] = ps;
     *out = ps;
     return DR_OK;

@@ -119,6 +119,14 @@ DR_API int dr_g2_mul(const uint8_t g2_be[192], const uint8_t scalar_le[32], uint
  * 6145-point SRS at c = 12, 1.6 GB for 2^20 bases at c = 16) and makes every later MSM over this SRS use ONE bucket
  * set per MSM: a single bucket reduction instead of W and no window combination.  Results are unchanged. */
 DR_API int dr_srs_precompute(dr_ctx *ctx, dr_srs *srs, int window_bits);
+/* Comb table on top of the window table (window_bits <= 14): comb[i][w][d-1] = d * 2^(start_w) * base[i] for every
+ * digit magnitude d <= 2^(window_bits-1) — count * W * 2^(window_bits-1) * 128 bytes (one cache line per entry: 35 GB for
+ * the shipped SRS at 12 bits; MI355X has 288 GB).  Batched MSMs (>= 32 scalar vectors) over this SRS then skip bucket
+ * sorting and bucket reduction altogether: each MSM is the sum of its n*W selected entries.  DR_ERR_NOMEM when it does
+ * not fit (the window table keeps working).  Results are unchanged.  Measured on MI355X: the looked-up entries come
+ * from HBM instead of L2 / Infinity Cache and the additions run at 4.4-4.6 G/s instead of 5.3 G/s, which costs more
+ * than the sort and reduction it saves — opt-in (DOTRING_SRS_COMB=1 in the Python layer). */
+DR_API int dr_srs_precompute_comb(dr_ctx *ctx, dr_srs *srs);
 /* copy `count` bases starting at `offset` back to the host as BE x||y records */
 DR_API int dr_srs_download(dr_ctx *ctx, const dr_srs *srs, size_t offset, size_t count, uint8_t *out_be_xy);
 DR_API void dr_srs_destroy(dr_srs *srs);

@@ -186,6 +186,26 @@ def test_g1_msm_many_bucket_sets_level_reduction(ctx, srs_bytes, bits, batch):
     tabled.close()
 
 
+@pytest.mark.parametrize("bits,n,batch", [(9, 700, 40), (12, 300, 70), (10, 64, 4100), (8, 1, 33)])
+def test_g1_msm_comb_table_matches_plain(ctx, srs_bytes, bits, n, batch):
+    """dr_srs_precompute_comb: batched MSMs as sums of looked-up multiples (k_g1_comb_msm) — identical results to the
+    bucket method, incl. zero vectors, scalars >= r, offsets into the SRS and every block shape (1..4 waves per MSM)."""
+    rng = random.Random(bits * 1000 + n)
+    plain = ctx.srs_load(srs_bytes[: 96 * (n + 5)])
+    comb = ctx.srs_load(srs_bytes[: 96 * (n + 5)]).precompute(bits).precompute_comb()
+    vecs = [b"".join(rng.randrange(coracle.FR_P).to_bytes(32, "little") for _ in range(n)) for _ in range(6)]
+    vecs.append(bytes(32 * n))
+    vecs.append(b"".join(v.to_bytes(32, "little") for v in ([1, coracle.FR_P - 1, (1 << 256) - 1, 2**255, coracle.FR_P] * n)[:n]))
+    ks = b"".join(vecs[i % len(vecs)] for i in range(batch))
+    got = ctx.g1_msm_batch(comb, ks, n)
+    want = [_oracle_msm_be(srs_bytes, v, n) for v in vecs]
+    for i in range(batch):
+        assert got[i] == want[i % len(vecs)], i
+    assert ctx.g1_msm_batch(plain, ks[: 32 * n * 3], n) == got[:3]
+    plain.close()
+    comb.close()
+
+
 @pytest.mark.parametrize("bits", [7, 12, 16])
 def test_g1_msm_fixed_base_table_matches_plain(ctx, srs_bytes, bits):
     """dr_srs_precompute: one bucket set per MSM over the window table — identical results, single and batched."""

@@ -40,11 +40,11 @@ def main(ring_size, batch, reps=2):
         ctx.prof_enable(False)
         names = ["k_bsn_scalar_mul", "k_ring_chain", "k_ring_columns", "k_ntt_local", "k_ntt_strided", "k_ring_pad", "k_ring_constraints",
                  "k_ring_quotient", "k_ring_eval", "k_ring_linpoly", "k_ring_aggpoly", "k_syndiv", "k_bsn_encode_to_curve", "k_bsn_msm_groups", "k_g1_sort_sets", "k_size_sort", "k_g1_digits", "k_scan", "k_g1_scatter",
-                 "k_g1_accumulate", "k_g1_reduce_chunks", "k_g1_reduce_windows", "k_g1_horner", "k_g1_results_affine"]
+                 "k_g1_accumulate", "k_g1_comb_msm", "k_g1_reduce_chunks", "k_g1_reduce_windows", "k_g1_horner", "k_g1_results_affine"]
         parts = {k: ctx.prof_get(k)[0] for k in names}
         gpu_ms = sum(parts.values())
         print(f"batch {batch}: {dt * 1e3:.1f} ms -> {batch / dt:.1f} proofs/s ; GPU kernels {gpu_ms:.1f} ms | " +
-              " ".join(f"{k[2:]}={v:.1f}" for k, v in parts.items() if v > 0.05), flush=True)
+              " ".join(f"{k[2:]}={v:.1f}" + (f"(x{ctx.prof_get(k)[1]})" if k in ("k_g1_comb_msm", "k_g1_accumulate") else "") for k, v in parts.items() if v > 0.05), flush=True)
     t = time.perf_counter()
     ok = proofs[0].verify(alphas[0], ads[0], ring, root)
     print(f"verify: {ok} in {(time.perf_counter() - t) * 1e3:.1f} ms; batch_verify(8): ", end="")
