@@ -169,6 +169,7 @@ int pick_window(size_t n) {
 uint32_t g_chunk_len = 16;   // buckets per lane in k_g1_reduce_chunks (DOTRING_MSM_CHUNK)
 bool g_use_comb = true;      // use comb tables when an SRS has one (DOTRING_MSM_COMB=0: bucket method)
 bool g_chain_wave = true;    // one wave per proof for the witness accumulator chain (DOTRING_CHAIN_WAVE=0: one lane per proof)
+size_t g_level_threshold = (size_t)1 << 18;   // chunk lanes from which the level-wise reduction is used (DOTRING_MSM_LEVEL_LANES)
 bool g_reduce_levels = true; // level-wise bucket reduction for many bucket sets (DOTRING_MSM_LEVELS=0 disables)
 
 struct MsmPlan {
@@ -342,7 +343,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     }));
     // many bucket sets (batched prover): level-wise reduction, 2 additions per entry and no scalar multiplications;
     // few sets (single MSMs): chunk sums + double-and-add, whose latency is one short chain
-    const bool leveled = g_reduce_levels && pl.L == 16 && pl.H >= 256 && bsets * (size_t)(pl.H / 16) >= ((size_t)1 << 18);
+    const bool leveled = g_reduce_levels && pl.L == 16 && pl.H >= 256 && bsets * (size_t)(pl.H / 16) >= g_level_threshold;
     if (leveled) {
         // level outputs live in ctx->partial: [S | C] per level, sizes sets * H/16, sets * H/256, ...
         size_t total = 0;
@@ -360,7 +361,10 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
             uint32_t* out_s = base + off * 48;
             uint32_t* out_c = base + (off + cnt) * 48;
             TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
-                hipLaunchKernelGGL(dr::k_g1_reduce_level, dim3(div_up(cnt, 128)), dim3(128), 0, st, in_s, in_c, bsets, n, 16u, level, out_s, out_c);
+                if (in_c)
+                    hipLaunchKernelGGL(dr::k_g1_reduce_level<true>, dim3(div_up(cnt, 128)), dim3(128), 0, st, in_s, in_c, bsets, n, 16u, level, out_s, out_c);
+                else
+                    hipLaunchKernelGGL(dr::k_g1_reduce_level<false>, dim3(div_up(cnt, 128)), dim3(128), 0, st, in_s, in_c, bsets, n, 16u, level, out_s, out_c);
             }));
             in_s = out_s; in_c = out_c;
             off += 2 * cnt;
@@ -587,6 +591,7 @@ int dr_ctx_create(int device_id, dr_ctx** out) {
         if (v == 8 || v == 16 || v == 32 || v == 64 || v == 128) g_chunk_len = (uint32_t)v;
     }
     if (const char* lv = std::getenv("DOTRING_MSM_LEVELS")) g_reduce_levels = std::atoi(lv) != 0;
+    if (const char* ll = std::getenv("DOTRING_MSM_LEVEL_LANES")) g_level_threshold = (size_t)std::max(1L, std::atol(ll));
     if (const char* cw = std::getenv("DOTRING_CHAIN_WAVE")) g_chain_wave = std::atoi(cw) != 0;
     if (const char* cb = std::getenv("DOTRING_MSM_COMB")) g_use_comb = std::atoi(cb) != 0;
     int rc = bsn_consts_init(ctx->stream);

@@ -577,7 +577,10 @@ __global__ __launch_bounds__(RW_BLOCK) void k_g1_reduce_windows(const uint32_t* 
 // 3.25 per bucket for the chunk + double-and-add form above) and shrinks the set by L; corrections are carried along as
 // C (scaled by L^(level-1)), so the value of a set is  L^K * W_K - sum C_K  with W_K the direct running sum over the
 // last <= 16 entries.  Latency is a few serial levels: only worth it when the first level alone fills the chip.
-__global__ __launch_bounds__(128) void k_g1_reduce_level(const uint32_t* __restrict__ in_s, const uint32_t* __restrict__ in_c /* null at level 1 */,
+// Both kernels are scratch-free: ONE inlined addition per loop (operands muxed), the scaling doublings in a second
+// loop with one inlined doubling.
+template <bool HAS_C>
+__global__ __launch_bounds__(128) void k_g1_reduce_level(const uint32_t* __restrict__ in_s, const uint32_t* __restrict__ in_c /* unused at level 1 */,
                                                          size_t sets, uint32_t n_in, uint32_t L, int level,
                                                          uint32_t* __restrict__ out_s, uint32_t* __restrict__ out_c) {
     const uint32_t T = n_in / L;
@@ -585,35 +588,68 @@ __global__ __launch_bounds__(128) void k_g1_reduce_level(const uint32_t* __restr
     if (gid >= sets * T) return;
     size_t set = gid / T;
     uint32_t s = (uint32_t)(gid % T) * L;
-    G1Xyzz run = g1_inf(), q = g1_inf(), c = g1_inf();
+    if constexpr (!HAS_C) {
+        // level 1 (94 % of the work): two accumulators only — q += run; run += B_i
+        G1Xyzz run = g1_inf(), q = g1_inf();
 #pragma unroll 1
-    for (uint32_t i = 0; i < L; i++) {
-        size_t idx = set * n_in + s + i;
-        q = g1_add(q, run);
-        run = g1_add(run, load_xyzz(in_s, idx));
-        if (in_c) c = g1_add(c, load_xyzz(in_c, idx));
+        for (uint32_t step = 0; step < 2 * L; step++) {
+            const bool first = (step & 1) == 0;
+            G1Xyzz b = first ? run : load_xyzz(in_s, set * n_in + s + (step >> 1));
+            G1Xyzz r = g1_add_inl(first ? q : run, b);
+            if (first) q = r; else run = r;
+        }
+        store_xyzz(out_s, gid, run);
+        store_xyzz(out_c, gid, q);
+        return;
+    } else {
+        G1Xyzz run = g1_inf(), q = g1_inf(), c = g1_inf();
+        // per entry: q += run; run += S_i; c += C_i; after the loop one more step: c += L^(level-1) q
+        const uint32_t steps = L * 3;
+#pragma unroll 1
+        for (uint32_t step = 0; step <= steps; step++) {
+            if (step == steps) {
+#pragma unroll 1
+                for (int k = 0; k < 4 * (level - 1); k++) q = g1_dbl_inl(q);
+            }
+            const uint32_t i = step / 3, ph = step == steps ? 3u : step % 3;
+            const size_t idx = set * n_in + s + (i < L ? i : 0);
+            G1Xyzz a, b;
+            if (ph == 0) { a = q; b = run; }
+            else if (ph == 1) { a = run; b = load_xyzz(in_s, idx); }
+            else if (ph == 2) { a = c; b = load_xyzz(in_c, idx); }
+            else { a = c; b = q; }
+            G1Xyzz r = g1_add_inl(a, b);
+            if (ph == 0) q = r; else if (ph == 1) run = r; else c = r;
+        }
+        store_xyzz(out_s, gid, run);
+        store_xyzz(out_c, gid, c);
     }
-#pragma unroll 1
-    for (int k = 0; k < 4 * (level - 1); k++) q = g1_dbl(q);          // L = 16: scale by L^(level-1)
-    store_xyzz(out_s, gid, run);
-    store_xyzz(out_c, gid, in_c ? g1_add(c, q) : q);
 }
 // one lane per set: direct running sum over the last n <= 16 entries, then value = L^levels * W - sum C
-__global__ void k_g1_reduce_final(const uint32_t* __restrict__ in_s, const uint32_t* __restrict__ in_c, size_t sets, uint32_t n, int levels,
+__global__ __launch_bounds__(64) void k_g1_reduce_final(const uint32_t* __restrict__ in_s, const uint32_t* __restrict__ in_c, size_t sets, uint32_t n, int levels,
                                   uint32_t* __restrict__ winsum) {
     size_t set = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (set >= sets) return;
     G1Xyzz run = g1_inf(), w = g1_inf(), c = g1_inf();
+    const uint32_t steps = 3 * n;
 #pragma unroll 1
-    for (int j = (int)n - 1; j >= 0; j--) {
-        run = g1_add(run, load_xyzz(in_s, set * n + j));
-        w = g1_add(w, run);
-        c = g1_add(c, load_xyzz(in_c, set * n + j));
+    for (uint32_t step = 0; step <= steps; step++) {
+        if (step == steps) {
+#pragma unroll 1
+            for (int k = 0; k < 4 * levels; k++) w = g1_dbl_inl(w);
+            c.y = neg(c.y);
+        }
+        const uint32_t ph = step == steps ? 3u : step % 3;
+        const size_t idx = set * n + (n - 1 - (step < steps ? step / 3 : 0));
+        G1Xyzz a, b;
+        if (ph == 0) { a = run; b = load_xyzz(in_s, idx); }
+        else if (ph == 1) { a = w; b = run; }
+        else if (ph == 2) { a = c; b = load_xyzz(in_c, idx); }
+        else { a = w; b = c; }
+        G1Xyzz r = g1_add_inl(a, b);
+        if (ph == 0) run = r; else if (ph == 1 || ph == 3) w = r; else c = r;
     }
-#pragma unroll 1
-    for (int k = 0; k < 4 * levels; k++) w = g1_dbl(w);
-    c.y = neg(c.y);
-    store_xyzz(winsum, set, g1_add(w, c));
+    store_xyzz(winsum, set, w);
 }
 
 // ---- 6. (batch > 1) combine the W window sums of each MSM on the device: Horner over windows, width[w] doublings each.
