@@ -522,6 +522,9 @@ __global__ __launch_bounds__(256) void k_g1_accumulate(const uint32_t* __restric
 
 // ---- 5. bucket reduction.  Window value = sum_j (j+1) * B_j.  Chunk [s, s+L): running sums give
 //        sum_j (j-s+1) B_j and A = sum_j B_j; the chunk contributes that plus s*A (double-and-add, s < H).
+// Scratch-free (an out-of-line g1_add passes operands through scratch, and a kernel that reserves scratch loses
+// resident waves): one inlined addition per loop with muxed operands, at most two live accumulators per phase — the
+// chunk's running-sum result waits in `partial` while s*A is built.
 __global__ __launch_bounds__(128) void k_g1_reduce_chunks(const uint32_t* __restrict__ buckets, size_t windows,
                                                           uint32_t H, uint32_t L, uint32_t* __restrict__ partial) {
     const uint32_t T = H / L;
@@ -529,24 +532,31 @@ __global__ __launch_bounds__(128) void k_g1_reduce_chunks(const uint32_t* __rest
     if (gid >= windows * T) return;
     size_t win = gid / T;
     uint32_t ch = (uint32_t)(gid % T), s = ch * L;
-    G1Xyzz run = g1_inf(), sum = g1_inf();
+    G1Xyzz run = g1_inf();
+    {
+        G1Xyzz sum = g1_inf();
 #pragma unroll 1
-    for (int j = (int)L - 1; j >= 0; j--) {
-        G1Xyzz bk = load_xyzz(buckets, win * H + s + j);
-        run = g1_add(run, bk);
-        sum = g1_add(sum, run);
-    }
-    if (s != 0 && !run.is_inf()) {
-        G1Xyzz t = g1_inf();
-        int top = 31 - __clz(s);
-#pragma unroll 1
-        for (int bit = top; bit >= 0; bit--) {
-            t = g1_dbl(t);
-            if ((s >> bit) & 1) t = g1_add(t, run);
+        for (uint32_t step = 0; step < 2 * L; step++) {          // run += B_j ; sum += run, j = L-1 .. 0
+            const bool first = (step & 1) == 0;
+            G1Xyzz b = first ? load_xyzz(buckets, win * H + s + (L - 1 - (step >> 1))) : run;
+            G1Xyzz r = g1_add_inl(first ? run : sum, b);
+            if (first) run = r; else sum = r;
         }
-        sum = g1_add(sum, t);
+        store_xyzz(partial, gid, sum);
     }
-    store_xyzz(partial, gid, sum);
+    if (s == 0 || run.is_inf()) return;
+    // sum += s * run: double-and-add over the bits of s, then the stored running-sum result as one more addition
+    G1Xyzz t = g1_inf();
+    const int top = 31 - __clz(s);
+#pragma unroll 1
+    for (int step = 2 * top + 1; step >= -1; step--) {
+        if (step >= 0 && (step & 1)) { t = g1_dbl_inl(t); continue; }
+        const bool last = step < 0;
+        if (!last && !((s >> (step >> 1)) & 1)) continue;
+        G1Xyzz b = last ? load_xyzz(partial, gid) : run;
+        t = g1_add_inl(t, b);
+    }
+    store_xyzz(partial, gid, t);
 }
 
 // one workgroup per window: lanes stride over the T chunk results, then an LDS tree folds the workgroup.
