@@ -91,6 +91,7 @@ _PROTOTYPES.update({
     "dr_ringvrf_verify_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), POINTER(RingVerifierKeyStruct), c_size_t, c_char_p, c_char_p,
                                         POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64),
                                         c_char_p, POINTER(c_int)]),
+    "dr_g1_decompress_batch": (c_int, [c_void_p, c_char_p, c_size_t, c_char_p, c_char_p]),
     "dr_bsn_decode_points": (c_int, [c_void_p, c_char_p, c_size_t, c_char_p, c_char_p]),
     "dr_pairing_selfcheck": (c_int, [c_char_p, c_char_p, c_size_t, POINTER(c_int)]),
     "dr_pedersen_prove_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_size_t, c_char_p, POINTER(ctypes.c_uint64), c_char_p,
@@ -418,6 +419,18 @@ class Context:
         _check(lib().dr_ringvrf_verify_batch(self.handle, byref(suite), byref(vk), batch, proofs, i_blob, i_off, d_blob, d_off, s_blob, s_off,
                                              seed32, byref(ok)))
         return bool(ok.value)
+
+    def g1_decompress_batch(self, enc: bytes):
+        """KZG.decompress_g1 for len(enc)/48 encodings on the GPU -> (list of 96-byte records or None for infinity, flags)."""
+        if len(enc) % 48:
+            raise ValueError("compressed G1 points are 48 bytes each")
+        count = len(enc) // 48
+        out, ok = ctypes.create_string_buffer(max(1, 96 * count)), ctypes.create_string_buffer(max(1, count))
+        _check(lib().dr_g1_decompress_batch(self.handle, enc, count, out, ok))
+        raw = out.raw
+        zero = bytes(96)
+        pts = [None if raw[96 * i : 96 * i + 96] == zero else raw[96 * i : 96 * i + 96] for i in range(count)]
+        return pts, ok.raw[:count]
 
     def bsn_decode_points(self, enc: bytes):
         """dec_point for len(enc)/32 compressed points on the GPU -> (affine x||y bytes, validity flags)."""

@@ -1228,6 +1228,41 @@ int dr_g1_decompress(const uint8_t in[48], uint8_t out_xy[96], int* is_inf) {
     return DR_OK;
 }
 
+// KZG.decompress_g1 for n points in one launch (zcash 48-byte encodings -> BE x||y records; ok[i] = 0 for malformed
+// encodings, infinity decodes to an all-zero record with ok = 1)
+int dr_g1_decompress_batch(dr_ctx* ctx, const uint8_t* enc, size_t n, uint8_t* out_be_xy, uint8_t* ok) {
+    TRY(use_ctx(ctx));
+    if (n == 0) return DR_OK;
+    if (!enc || !out_be_xy || !ok) return fail(DR_ERR_INVALID, "null buffer");
+    if (n >= (1ull << 28)) return fail(DR_ERR_INVALID, "batch too large");
+    TRY(ctx->vfy_in.reserve(n * 48));
+    TRY(ctx->vfy_bases.reserve(n * 96));
+    TRY(ctx->vfy_std.reserve(n * 96));
+    TRY(ctx->io_c.reserve(n * 4));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->vfy_in.p, enc, n * 48, hipMemcpyHostToDevice, st));
+    TRY(launch(ctx, "k_g1_decompress", [&] {
+        hipLaunchKernelGGL(dr::k_g1_decompress, dim3(div_up(n, 64)), dim3(64), 0, st, ctx->vfy_in.as<uint8_t>(), ctx->vfy_bases.as<uint32_t>(),
+                           ctx->io_c.as<uint32_t>(), (uint32_t)n);
+        hipLaunchKernelGGL(dr::k_g1_bases_from_mont, dim3(div_up(n, 256)), dim3(256), 0, st, ctx->vfy_bases.as<uint32_t>(), ctx->vfy_std.as<uint32_t>(),
+                           (uint32_t)n);
+    }));
+    std::vector<uint8_t> le(n * 96);
+    std::vector<uint32_t> flags(n);
+    HIP_TRY(hipMemcpyAsync(le.data(), ctx->vfy_std.p, n * 96, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(flags.data(), ctx->io_c.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ctx->prof) TRY(prof_collect(ctx));
+    for (size_t i = 0; i < n; i++) {
+        ok[i] = flags[i] ? 1 : 0;
+        for (int j = 0; j < 48; j++) {
+            out_be_xy[96 * i + j] = le[96 * i + 47 - j];
+            out_be_xy[96 * i + 48 + j] = le[96 * i + 95 - j];
+        }
+    }
+    return DR_OK;
+}
+
 int dr_g1_serialize_check(const uint8_t xy[96]) {
     std::vector<uint8_t> le;
     return g1_be_to_le_limbs(xy, 1, le, true);

@@ -7,10 +7,18 @@ from ..curve import CurveVariant
 class VRF:
     cv = None
 
+    _specialised: dict = {}
+
     def __class_getitem__(cls, curve_variant):
         if not isinstance(curve_variant, CurveVariant):
             return cls
-        return type(f"{cls.__name__}[{curve_variant.name}]", (cls,), {"cv": curve_variant})
+        # one class object per (scheme, curve): dataclass equality compares classes, and per-class memos stay alive
+        key = (cls, curve_variant.name)
+        hit = VRF._specialised.get(key)
+        if hit is None or hit.cv is not curve_variant:
+            hit = type(f"{cls.__name__}[{curve_variant.name}]", (cls,), {"cv": curve_variant})
+            VRF._specialised[key] = hit
+        return hit
 
     @classmethod
     def prove(cls, *args, **kwargs):

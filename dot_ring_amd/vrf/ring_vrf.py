@@ -305,6 +305,47 @@ class RingVRF(VRF):
             raise ValueError(f"trailing bytes in ring proof payload: {len(data) - off}")
         return cls(pedersen_proof, *fields)
 
+    @classmethod
+    def decode_batch(cls, proofs) -> list:
+        """decode() for many 784-byte proofs with two kernel launches in total: the 4B Bandersnatch points are decompressed
+        and subgroup-checked by dr_bsn_decode_points, the 7B G1 points by dr_g1_decompress_batch; scalars are checked
+        for canonicity on the host.  Raises ValueError like decode() if any proof is malformed."""
+        blobs = [bytes(p) for p in proofs]
+        expected = cls.proof_len()
+        for b in blobs:
+            if len(b) != expected:
+                raise ValueError(f"invalid Ring VRF proof length: Ring VRF proof must be exactly {expected} bytes, got {len(b)}")
+        if not blobs:
+            return []
+        if expected != 784:
+            return [cls.decode(b) for b in blobs]
+        cv = cls.cv
+        ctx = runtime.context()
+        order, prime = cv.curve.params.subgroup_order, RingProofParams(cv=cv).prime
+        te_raw, te_ok = ctx.bsn_decode_points(b"".join(b[:128] for b in blobs))
+        if not all(te_ok):
+            raise ValueError("Invalid point in proof")
+        g1_pts, g1_ok = ctx.g1_decompress_batch(b"".join(b[192:384] + b[608:656] + b[688:784] for b in blobs))
+        if not all(g1_ok):
+            raise ValueError("invalid BLS12-381 G1 encoding")
+        frm, mk = int.from_bytes, cv.point_type._trusted
+        out = []
+        for i, b in enumerate(blobs):
+            pts = [mk(frm(te_raw[256 * i + 64 * k : 256 * i + 64 * k + 32], "little"), frm(te_raw[256 * i + 64 * k + 32 : 256 * i + 64 * k + 64], "little"))
+                   for k in range(4)]
+            s, sb = frm(b[128:160], "little"), frm(b[160:192], "little")
+            if s >= order or sb >= order:
+                raise ValueError("scalar is not canonical")
+            ped = PedersenVRF[cv](output_point=pts[0], blinded_pk=pts[1], result_point=pts[2], ok=pts[3], s=s, sb=sb)
+            evals = [frm(b[384 + 32 * k : 416 + 32 * k], "little") for k in range(7)]
+            lzw = frm(b[656:688], "little")
+            if any(v >= prime for v in evals) or lzw >= prime:
+                raise ValueError("scalar is not canonical")
+            g = g1_pts[7 * i : 7 * i + 7]
+            cols = [Column(nm, [], _commitment=g[k], _has_commitment=True) for k, nm in enumerate(("c_b", "c_accip", "c_accx", "c_accy"))]
+            out.append(cls(ped, *cols, *evals, Column("c_q", [], _commitment=g[4], _has_commitment=True), lzw, g[5], g[6]))
+        return out
+
     # -- proving
     @classmethod
     def _prove_gen(cls, alphas, additional_data, secret_keys, producer_keys, ring, root, salts, slot=0):

@@ -160,7 +160,10 @@ DR_API int dr_pairing_selfcheck(const uint8_t *g1_be_xy, const uint8_t *g2_be, s
 /* zcash encodings, host-side */
 DR_API int dr_g1_compress(const uint8_t xy[96], int is_inf, uint8_t out[48]);
 DR_API int dr_g1_decompress(const uint8_t in[48], uint8_t out_xy[96], int *is_inf);   /* on-curve check, no subgroup check (as blst P1_Affine(bytes)) */
-DR_API int dr_g1_serialize_check(const uint8_t xy[96]);                              /* DR_OK iff on curve or infinity */
+DR_API int dr_g1_serialize_check(const uint8_t xy[96]);
+/* dr_g1_decompress for n encodings in one kernel launch: out = n BE x||y records (all zero for infinity), ok[i] = 0 for
+ * malformed encodings (compression flag missing, x >= p, x not on the curve, non-canonical infinity). */
+DR_API int dr_g1_decompress_batch(dr_ctx *ctx, const uint8_t *enc /* n*48 */, size_t n, uint8_t *out_be_xy /* n*96 */, uint8_t *ok /* n */);                              /* DR_OK iff on curve or infinity */
 
 /* ---- seam C: NTT over Fr ------------------------------------------------------------------------
  * Replaces BlsScalarNTTPlan.transform / transform_scaled (dot_ring/ring_proof/polynomial/ntt.pyx:104-163,

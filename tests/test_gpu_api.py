@@ -375,3 +375,30 @@ def test_native_orchestration_equals_python_orchestration(ctx, suite, monkeypatc
     rp = rv.prove_batch(als, ads, sks, keys, ring, root)
     a, b = both(lambda: (rv.batch_verify(rp, als, ads, ring, root), rv.batch_verify(rp, als, ads[1:] + ads[:1], ring, root)))
     assert a == b == (True, False)
+
+
+def test_ring_decode_batch_equals_decode(ctx):
+    """RingVRF.decode_batch (two launches for all points) against decode() per proof, incl. malformed inputs."""
+    import dot_ring_amd as d
+
+    cv = d.Bandersnatch
+    vrf = d.RingVRF[cv]
+    sks = [(7000 + i).to_bytes(32, "little") for i in range(9)]
+    keys = [cv.public_key_from_secret(sk) for sk in sks]
+    ring = d.Ring(keys)
+    root = d.RingRoot.from_ring(ring)
+    als = [b"x%d" % i for i in range(9)]
+    raw = [p.encode() for p in vrf.prove_batch(als, als, sks, keys, ring, root)]
+    dec = vrf.decode_batch(raw)
+    assert [p.encode() for p in dec] == raw
+    assert dec == [vrf.decode(b) for b in raw]
+    assert vrf.batch_verify(dec, als, als, ring, root)
+    assert vrf.decode_batch([]) == []
+    for mod in (lambda b: b[:-1], lambda b: b[:130] + b"\xff" * 30 + b[160:], lambda b: bytes([b[0] ^ 1]) + b[1:],
+                lambda b: b[:192] + bytes([b[192] & 0x7F]) + b[193:], lambda b: b[:400] + b"\xff" * 16 + b[416:]):
+        bad = list(raw)
+        bad[4] = mod(raw[4])
+        with pytest.raises(ValueError):
+            vrf.decode_batch(bad)
+        with pytest.raises(ValueError):
+            vrf.decode(bad[4])
