@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -676,9 +677,16 @@ int dr_bsn_scalar_mul_batch_dev(dr_ctx* ctx, const void* d_pts, const void* d_sc
     TRY(use_ctx(ctx));
     if (n == 0) return DR_OK;
     if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "batch too large");
+    // 4-bit windows (64 KiB of LDS per wave, 2 waves per CU) while the launch is latency-bound; 2-bit windows
+    // (16 KiB, 10 waves per CU) once there are more waves than the 4-bit kernel can keep resident
+    static const long w2_from = std::getenv("DOTRING_BSN_W2_FROM") ? std::atol(std::getenv("DOTRING_BSN_W2_FROM")) : 32768;
     TRY(launch(ctx, "k_bsn_scalar_mul", [&] {
-        hipLaunchKernelGGL(dr::k_bsn_scalar_mul, dim3(div_up(n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
-                           (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t*)d_out, (uint32_t)n);
+        if (w2_from > 0 && n >= (size_t)w2_from)
+            hipLaunchKernelGGL(dr::k_bsn_scalar_mul_w2, dim3(div_up(n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
+                               (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t*)d_out, (uint32_t)n);
+        else
+            hipLaunchKernelGGL(dr::k_bsn_scalar_mul, dim3(div_up(n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
+                               (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t*)d_out, (uint32_t)n);
     }));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->prof) TRY(prof_collect(ctx));
@@ -686,10 +694,14 @@ int dr_bsn_scalar_mul_batch_dev(dr_ctx* ctx, const void* d_pts, const void* d_sc
 }
 
 static int check_fr_elems(const uint8_t* p, size_t count, const char* what) {
-    for (size_t i = 0; i < count; i++) {
-        drh::Fr t;
-        if (!drh::Fr::load_le(t, p + 32 * i)) return fail(DR_ERR_INVALID, std::string(what) + " coordinate is not a canonical field element");
-    }
+    // canonical = below p as a little-endian integer; a plain limb comparison, on worker threads for large batches
+    std::atomic<bool> bad{false};
+    drh::parallel_for(count, [&](size_t i) {
+        uint64_t v[4];
+        drh::load_le32(p + 32 * i, v);
+        if (drh::Fr::geq_p(v)) bad.store(true, std::memory_order_relaxed);
+    });
+    if (bad.load()) return fail(DR_ERR_INVALID, std::string(what) + " coordinate is not a canonical field element");
     return DR_OK;
 }
 

@@ -271,3 +271,24 @@ def test_bsn_decode_points_matches_oracle(ctx):
             assert (int.from_bytes(raw[64 * i : 64 * i + 32], "little"), int.from_bytes(raw[64 * i + 32 : 64 * i + 64], "little")) == want
     assert n_valid >= 80
     assert ctx.bsn_decode_points(b"") == (b"", b"")
+
+
+def test_bsn_scalar_mul_large_batch_two_bit_window_kernel(ctx):
+    """From 32768 scalar multiplications per launch the 2-bit-window kernel (k_bsn_scalar_mul_w2, 16 KiB of LDS per wave)
+    takes over: same results as the 4-bit kernel on the same inputs and as the oracle on a sample, incl. edge scalars."""
+    rng = random.Random(77)
+    n = 40000
+    base = [coracle.te_mul(bsn.G, rng.randrange(1, bsn.N)) for _ in range(50)]
+    ks_small = [rng.randrange(bsn.N) for _ in range(50)]
+    edge = [0, 1, 2, 3, bsn.N - 1, bsn.N - 2, bsn.N, (1 << 253) - 1, (1 << 256) - 1, 1 << 252, 0x5555555555555555555555555555555555555555555555555555555555555555 % (1 << 253),
+            0xAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA]
+    ks_small[: len(edge)] = edge
+    pts = coracle.te_pack(base) * (n // 50)
+    ks = b"".join(k.to_bytes(32, "little") for k in ks_small) * (n // 50)
+    got = ctx.bsn_scalar_mul_batch(pts, ks)
+    want = coracle.te_mul_batch_raw(coracle.te_pack(base), b"".join((k % (1 << 256)).to_bytes(32, "little") for k in ks_small), 50, glv=True)
+    assert got[: 64 * 50] == bytes(want)
+    assert got[64 * 50 * 3 : 64 * 50 * 4] == bytes(want)
+    assert got[-64 * 50 :] == bytes(want)
+    small = ctx.bsn_scalar_mul_batch(pts[: 64 * 50], ks[: 32 * 50])            # 4-bit kernel
+    assert small == got[: 64 * 50]
