@@ -696,11 +696,13 @@ int dr_bsn_scalar_mul_batch_dev(dr_ctx* ctx, const void* d_pts, const void* d_sc
 static int check_fr_elems(const uint8_t* p, size_t count, const char* what) {
     // canonical = below p as a little-endian integer; a plain limb comparison, on worker threads for large batches
     std::atomic<bool> bad{false};
-    drh::parallel_for(count, [&](size_t i) {
+    auto check = [&](size_t i) {
         uint64_t v[4];
         drh::load_le32(p + 32 * i, v);
         if (drh::Fr::geq_p(v)) bad.store(true, std::memory_order_relaxed);
-    });
+    };
+    if (count >= 65536) drh::parallel_for(count, check);        // below that, starting threads costs more than the loop
+    else for (size_t i = 0; i < count; i++) check(i);
     if (bad.load()) return fail(DR_ERR_INVALID, std::string(what) + " coordinate is not a canonical field element");
     return DR_OK;
 }
