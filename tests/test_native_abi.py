@@ -79,3 +79,18 @@ def test_host_g1_codecs_and_sum():
     assert got == kzg.serialize(want)
     assert _native.g1_sum([kzg.serialize(pts[0]), kzg.serialize(neg0)]) is None
     assert _native.g1_sum([]) is None
+
+
+def test_plain_c_consumer_of_the_abi(tmp_path):
+    """The boundary is a C ABI: a C99 program includes include/dotring_hip.h, dlopens the library and calls host-side
+    entry points (hashing, field square root, G1 compression) — no Python, no C++, no GPU."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "abi_smoke"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "abi_smoke.c"),
+                    "-ldl", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe), os.path.join(root, "dot_ring_amd", "libdotring_hip.so")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "abi ok" in out.stdout
