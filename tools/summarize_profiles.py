@@ -21,6 +21,22 @@ if stats:
 def short(name):
     return name.split("(")[0]
 
+
+# the --stats summary averages every launch of the process, set-up included (one 60 ms launch builds the by-parts
+# bases); the bench line's figure is the timed region only.  From the kernel trace: the last steps * 6 accumulate launches
+# (profile_round.sh profiles 2 timed steps; 4 prove-side + 2 verify-side launches per step).
+trace = glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True)
+if trace:
+    rows = [r for r in csv.DictReader(open(trace[0])) if "k_g1_accumulate" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    timed = rows[-12:]
+    if timed:
+        dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in timed]
+        with open(f"profiles/{tag}_{workload}_accumulate_timed_region.json", "w") as f:
+            json.dump({"_note": "k_g1_accumulate launches of the 2 timed steps of the rocprofv3 --kernel-trace run (set-up and warm-up "
+                                "launches excluded); compare with roofline.avg_kernel_ms of the bench line",
+                       "launches": len(dur), "avg_ms": sum(dur) / len(dur), "per_launch_ms": [round(x, 3) for x in dur]}, f, indent=1)
+
 sums = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(int))
 for path in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
