@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -99,6 +100,7 @@ struct dr_srs {
     uint32_t comb_h = 0;
     // derived bases for summation-by-parts commitments, keyed by log2(domain size): PS_j = sum_{i<=j} L_i(tau) G
     std::map<unsigned, dr_srs*> lagrange_prefix;
+    std::mutex derive_mutex;             // provers for the same SRS may be created from different threads
 };
 
 namespace {
@@ -1359,6 +1361,7 @@ dr::FrArg arg_of(const drh::Fr& v) { return dr::to_arg(v); }
 // One batched MSM (N MSMs of N points) over the monomial SRS; cached in srs->lagrange_prefix.
 int lagrange_prefix_srs(dr_ctx* ctx, const dr_srs* srs_c, unsigned log2n, const drh::Fr& omega_n, const dr_srs** out) {
     dr_srs* srs = const_cast<dr_srs*>(srs_c);
+    std::lock_guard<std::mutex> lock(srs->derive_mutex);
     auto hit = srs->lagrange_prefix.find(log2n);
     if (hit != srs->lagrange_prefix.end()) { *out = hit->second; return DR_OK; }
     const uint32_t n = 1u << log2n;
