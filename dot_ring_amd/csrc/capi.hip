@@ -85,6 +85,7 @@ struct dr_ctx {
     Scratch scalars, digits, counts, offsets, cursor, tiles, sorted, buckets, partial, winsum, result, io_a, io_b, io_c, perm, cells, cell_off;
     Scratch vfy_bases, vfy_in, vfy_std;      // dr_ringvrf_verify_batch: decompressed G1 points stay resident between its steps
     dr_ctx* aux = nullptr;                   // second stream for the latency-bound Bandersnatch side of the batch verifier
+    dr_ctx* aux2 = nullptr;                  // third stream: the verifier's two G1 MSMs run side by side
     dr::TwiddleCache twiddles;
 };
 
@@ -610,6 +611,7 @@ int dr_ctx_create(int device_id, dr_ctx** out) {
 void dr_ctx_destroy(dr_ctx* ctx) {
     if (!ctx) return;
     if (ctx->aux) { dr_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
+    if (ctx->aux2) { dr_ctx_destroy(ctx->aux2); ctx->aux2 = nullptr; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (Scratch* s : {&ctx->scalars, &ctx->digits, &ctx->counts, &ctx->offsets, &ctx->cursor, &ctx->tiles, &ctx->sorted,
@@ -2246,10 +2248,29 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
     TRY(ctx->scalars.reserve(n_g1 * 32));
     uint8_t pair_g1[2 * 96];
     int pair_inf[2] = {0, 0};
+    // the two MSMs are independent and each is a short latency chain (sort, accumulate, reduce, fold): the rhs runs on
+    // a third stream from a helper thread while this thread does the lhs
+    if (!ctx->aux2) TRY(dr_ctx_create(ctx->device, &ctx->aux2));
+    dr_ctx* bctx = ctx->aux2;
+    int rhs_rc = DR_OK;
+    std::string rhs_err;
+    std::thread rhs_thread([&] {
+        rhs_rc = [&]() -> int {
+            TRY(use_ctx(bctx));
+            TRY(bctx->scalars.reserve(n_g1 * 32));
+            HIP_TRY(hipMemcpyAsync(bctx->scalars.p, rhs_full.data(), n_g1 * 32, hipMemcpyHostToDevice, bctx->stream));
+            return msm_to_bytes(bctx, g1_bases.as<uint32_t>(), bctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1 + 96, pair_inf + 1);
+        }();
+        if (rhs_rc != DR_OK) rhs_err = dr_last_error();
+    });
+    struct RhsJoiner {
+        std::thread& t;
+        ~RhsJoiner() { if (t.joinable()) t.join(); }
+    } rhs_joiner{rhs_thread};
     HIP_TRY(hipMemcpyAsync(ctx->scalars.p, lhs_sc.data(), n_g1 * 32, hipMemcpyHostToDevice, st));
     TRY(msm_to_bytes(ctx, g1_bases.as<uint32_t>(), ctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1, pair_inf));
-    HIP_TRY(hipMemcpyAsync(ctx->scalars.p, rhs_full.data(), n_g1 * 32, hipMemcpyHostToDevice, st));
-    TRY(msm_to_bytes(ctx, g1_bases.as<uint32_t>(), ctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1 + 96, pair_inf + 1));
+    rhs_thread.join();
+    if (rhs_rc != DR_OK) return fail(rhs_rc, rhs_err.empty() ? "rhs MSM failed" : rhs_err);
     const int inf_r = pair_inf[1];
     // (a vanishing rhs can only come from r1 = r2 = 0 or infinity openings: the pairing equation then demands lhs = O)
     if (!inf_r) {                                                                 // e(lhs, G2[0]) * e(-rhs, G2[1]) == 1
