@@ -7,9 +7,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -86,6 +88,7 @@ struct dr_ctx {
     Scratch vfy_bases, vfy_in, vfy_std;      // dr_ringvrf_verify_batch: decompressed G1 points stay resident between its steps
     dr_ctx* aux = nullptr;                   // second stream for the latency-bound Bandersnatch side of the batch verifier
     dr_ctx* aux2 = nullptr;                  // third stream: the verifier's two G1 MSMs run side by side
+    std::vector<dr_ctx*> helpers;            // further streams working for this context (a prover's Pedersen stream): profiling only
     dr::TwiddleCache twiddles;
 };
 
@@ -545,6 +548,14 @@ int dr_device_count(void) {
     return n;
 }
 
+// live contexts (a prover unregisters its helper stream from its context only if that context still exists)
+static std::mutex g_live_mutex;
+static std::set<dr_ctx*> g_live_ctx;
+static bool ctx_alive(dr_ctx* c) {
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    return g_live_ctx.count(c) != 0;
+}
+
 namespace {
 // the Elligator / Tonelli-Shanks constants of kernels_bsn.cuh, computed with the host field and copied to the
 // device's constant block once per context
@@ -604,12 +615,20 @@ int dr_ctx_create(int device_id, dr_ctx** out) {
         delete ctx;
         return rc;
     }
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        g_live_ctx.insert(ctx);
+    }
     *out = ctx;
     return DR_OK;
 }
 
 void dr_ctx_destroy(dr_ctx* ctx) {
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lock(g_live_mutex);
+        g_live_ctx.erase(ctx);
+    }
     if (ctx->aux) { dr_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
     if (ctx->aux2) { dr_ctx_destroy(ctx->aux2); ctx->aux2 = nullptr; }
     (void)hipSetDevice(ctx->device);
@@ -658,21 +677,33 @@ int dr_dev_download(dr_ctx* ctx, void* host, const void* dptr, size_t bytes) {
     return DR_OK;
 }
 
+// profiling covers the helper streams of a context too: their kernels belong to the same calls
+static void for_each_stream(dr_ctx* ctx, const std::function<void(dr_ctx*)>& f) {
+    f(ctx);
+    if (ctx->aux) f(ctx->aux);
+    if (ctx->aux2) f(ctx->aux2);
+    for (dr_ctx* h : ctx->helpers) f(h);
+}
 int dr_prof_enable(dr_ctx* ctx, int on) {
     if (!ctx) return fail(DR_ERR_INVALID, "null context");
-    ctx->prof = on != 0;
+    for_each_stream(ctx, [&](dr_ctx* c) { c->prof = on != 0; });
     return DR_OK;
 }
 int dr_prof_reset(dr_ctx* ctx) {
     if (!ctx) return fail(DR_ERR_INVALID, "null context");
-    ctx->prof_data.clear();
+    for_each_stream(ctx, [&](dr_ctx* c) { c->prof_data.clear(); });
     return DR_OK;
 }
 int dr_prof_get(dr_ctx* ctx, const char* name, double* total_ms, int* launches) {
     if (!ctx || !name) return fail(DR_ERR_INVALID, "null argument");
-    auto it = ctx->prof_data.find(name);
-    if (total_ms) *total_ms = it == ctx->prof_data.end() ? 0.0 : it->second.ms;
-    if (launches) *launches = it == ctx->prof_data.end() ? 0 : it->second.launches;
+    double ms = 0.0;
+    int n = 0;
+    for_each_stream(ctx, [&](dr_ctx* c) {
+        auto it = c->prof_data.find(name);
+        if (it != c->prof_data.end()) { ms += it->second.ms; n += it->second.launches; }
+    });
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
     return DR_OK;
 }
 
@@ -1484,7 +1515,13 @@ void dr_ring_prover_destroy(dr_ring_prover* p) {
                        &p->prefix, &p->chain_aff, &p->cnt, &p->relation, &p->rps, &p->cols, &p->wit4, &p->alphas, &p->agg, &p->q, &p->zetas,
                        &p->evals, &p->ks, &p->lin, &p->nus, &p->aggo, &p->chunkv, &p->quot1, &p->quot2, &p->diffs})
         s->release();
-    if (p->aux_ctx) dr_ctx_destroy(p->aux_ctx);
+    if (p->aux_ctx) {
+        if (p->ctx && ctx_alive(p->ctx)) {
+            auto& hs = p->ctx->helpers;
+            hs.erase(std::remove(hs.begin(), hs.end(), p->aux_ctx), hs.end());
+        }
+        dr_ctx_destroy(p->aux_ctx);
+    }
     delete p;
 }
 
@@ -1883,8 +1920,12 @@ static int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite
     // 4.-6. the rest of the Pedersen part needs nothing from the ring proof and the ring proof needs only the blinding
     // factors: it runs on a second stream (own context: scratch + stream) from a helper thread while this thread drives
     // the ring phases.  Its kernels are latency-bound (16..64 waves) and hide under the chip-filling MSMs.
-    if (!p->aux_ctx) TRY(dr_ctx_create(ctx->device, &p->aux_ctx));
+    if (!p->aux_ctx) {
+        TRY(dr_ctx_create(ctx->device, &p->aux_ctx));
+        ctx->helpers.push_back(p->aux_ctx);
+    }
     dr_ctx* actx = p->aux_ctx;
+    actx->prof = ctx->prof;
     int ped_rc = DR_OK;
     std::string ped_err;
     const bool overlap = std::getenv("DOTRING_PROVE_OVERLAP") == nullptr || std::atoi(std::getenv("DOTRING_PROVE_OVERLAP")) != 0;
@@ -2102,6 +2143,7 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
     // hashes the inputs to the curve on a second stream (all three kernels are latency-bound: a few dozen waves)
     if (!ctx->aux) TRY(dr_ctx_create(ctx->device, &ctx->aux));
     dr_ctx* actx = ctx->aux;
+    actx->prof = ctx->prof;
     std::vector<uint8_t> us(B * 64), in_pts(B * 64);
     int side_rc = DR_OK;
     std::string side_err;
@@ -2252,6 +2294,7 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
     // a third stream from a helper thread while this thread does the lhs
     if (!ctx->aux2) TRY(dr_ctx_create(ctx->device, &ctx->aux2));
     dr_ctx* bctx = ctx->aux2;
+    bctx->prof = ctx->prof;
     int rhs_rc = DR_OK;
     std::string rhs_err;
     std::thread rhs_thread([&] {
