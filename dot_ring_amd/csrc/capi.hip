@@ -174,6 +174,7 @@ int pick_window(size_t n) {
 }
 
 uint32_t g_chunk_len = 16;   // buckets per lane in k_g1_reduce_chunks (DOTRING_MSM_CHUNK)
+bool g_bsn_glv = true;       // GLV lane-pair kernels for latency-bound Bandersnatch launches (DOTRING_BSN_GLV=0: plain 64-window kernels)
 bool g_use_comb = true;      // use comb tables when an SRS has one (DOTRING_MSM_COMB=0: bucket method)
 bool g_chain_wave = true;    // one wave per proof for the witness accumulator chain (DOTRING_CHAIN_WAVE=0: one lane per proof)
 size_t g_level_threshold = (size_t)1 << 18;   // chunk lanes from which the level-wise reduction is used (DOTRING_MSM_LEVEL_LANES)
@@ -573,6 +574,13 @@ int bsn_consts_init(hipStream_t st) {
     dr::BsnConsts h;
     auto put = [](uint32_t (&w)[8], const Fr& v) { std::memcpy(w, v.l, 32); };     // Montgomery limbs, same R on host and device
     put(h.mont_b, mont_b); put(h.a_over_b, aob); put(h.inv_b2, inv_b2);
+    static const uint8_t GLV_B_LE[32] = {0xb4, 0x10, 0x25, 0x17, 0x4d, 0x01, 0x0f, 0xee, 0xd6, 0xf4, 0x9a, 0x0d, 0x77, 0x12, 0xa7, 0x2e,
+                                         0x88, 0x1a, 0x51, 0x63, 0x3a, 0x0d, 0xf0, 0x61, 0xa5, 0x26, 0x84, 0x82, 0x8b, 0xf2, 0xc9, 0x52};
+    static const uint8_t GLV_C_LE[32] = {0x3d, 0x0b, 0x65, 0xdf, 0x6c, 0x80, 0x5c, 0x51, 0xe9, 0xf4, 0x36, 0xff, 0xcf, 0xab, 0x56, 0x84,
+                                         0x07, 0xd1, 0x17, 0x6c, 0xfd, 0x6e, 0x7c, 0xa9, 0xc3, 0x57, 0x54, 0x86, 0xcf, 0x24, 0xc6, 0x6c};
+    Fr gb, gc;
+    if (!Fr::load_le(gb, GLV_B_LE) || !Fr::load_le(gc, GLV_C_LE)) return fail(DR_ERR_DEVICE, "bad curve constant");
+    put(h.glv_b, gb); put(h.glv_c, gc);
     Fr c = five.pow(Q, 4);
     for (int j = 0; j < 32; j++) { put(h.c_pow[j], c); c = c.sqr(); }
     if (!(c == Fr::one())) return fail(DR_ERR_DEVICE, "bad Tonelli-Shanks constants");
@@ -609,6 +617,7 @@ int dr_ctx_create(int device_id, dr_ctx** out) {
     if (const char* ll = std::getenv("DOTRING_MSM_LEVEL_LANES")) g_level_threshold = (size_t)std::max(1L, std::atol(ll));
     if (const char* cw = std::getenv("DOTRING_CHAIN_WAVE")) g_chain_wave = std::atoi(cw) != 0;
     if (const char* cb = std::getenv("DOTRING_MSM_COMB")) g_use_comb = std::atoi(cb) != 0;
+    if (const char* gl = std::getenv("DOTRING_BSN_GLV")) g_bsn_glv = std::atoi(gl) != 0;
     int rc = bsn_consts_init(ctx->stream);
     if (rc != DR_OK) {
         (void)hipStreamDestroy(ctx->stream);
@@ -742,11 +751,48 @@ static int check_fr_elems(const uint8_t* p, size_t count, const char* what) {
     return DR_OK;
 }
 
+// scalars -> GLV halves for the lane-pair kernels: 12 words per term (|k1|, |k2|, two sign words, padding)
+static int glv_split_scalars(const uint8_t* scalars, size_t n, std::vector<uint32_t>& out) {
+    out.assign(n * 12, 0);
+    std::atomic<bool> bad{false};
+    auto one = [&](size_t i) {
+        uint64_t k[4];
+        drh::mod_n().reduce_bytes(scalars + 32 * i, 32, false, k);
+        drh::GlvSplit s;
+        if (!drh::glv_decompose(k, s)) { bad.store(true); return; }
+        uint32_t* o = out.data() + 12 * i;
+        o[0] = (uint32_t)s.k1[0]; o[1] = (uint32_t)(s.k1[0] >> 32); o[2] = (uint32_t)s.k1[1]; o[3] = (uint32_t)(s.k1[1] >> 32);
+        o[4] = (uint32_t)s.k2[0]; o[5] = (uint32_t)(s.k2[0] >> 32); o[6] = (uint32_t)s.k2[1]; o[7] = (uint32_t)(s.k2[1] >> 32);
+        o[8] = (uint32_t)s.neg1; o[9] = (uint32_t)s.neg2;
+    };
+    if (n >= 4096) drh::parallel_for(n, one);
+    else for (size_t i = 0; i < n; i++) one(i);
+    if (bad.load()) return fail(DR_ERR_DEVICE, "GLV decomposition out of range");
+    return DR_OK;
+}
+
 int dr_bsn_scalar_mul_batch(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars, size_t n, uint8_t* out_xy) {
     TRY(use_ctx(ctx));
     if (n == 0) return DR_OK;
     if (!pts_xy || !scalars || !out_xy) return fail(DR_ERR_INVALID, "null buffer");
     TRY(check_fr_elems(pts_xy, 2 * n, "point"));
+    if (g_bsn_glv && n < 16384) {       // latency-bound launch: halve the chain with GLV on lane pairs
+        std::vector<uint32_t> split;
+        TRY(glv_split_scalars(scalars, n, split));
+        TRY(ctx->io_a.reserve(n * 64));
+        TRY(ctx->io_b.reserve(n * 48));
+        TRY(ctx->io_c.reserve(n * 64));
+        HIP_TRY(hipMemcpyAsync(ctx->io_a.p, pts_xy, n * 64, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->io_b.p, split.data(), n * 48, hipMemcpyHostToDevice, ctx->stream));
+        TRY(launch(ctx, "k_bsn_scalar_mul", [&] {
+            hipLaunchKernelGGL(dr::k_bsn_scalar_mul_glv, dim3(div_up(2 * n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
+                               ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>(), (uint32_t)n);
+        }));
+        HIP_TRY(hipMemcpyAsync(out_xy, ctx->io_c.p, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->prof) TRY(prof_collect(ctx));
+        return DR_OK;
+    }
     TRY(ctx->io_a.reserve(n * 64));
     TRY(ctx->io_b.reserve(n * 32));
     TRY(ctx->io_c.reserve(n * 64));
@@ -766,6 +812,26 @@ int dr_bsn_msm_groups(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars
     size_t n = groups * m;
     if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "batch too large");
     TRY(check_fr_elems(pts_xy, 2 * n, "point"));
+    if (g_bsn_glv && m <= 32 && n < 16384) {
+        std::vector<uint32_t> split;
+        TRY(glv_split_scalars(scalars, n, split));
+        uint32_t mpad2 = 2;
+        while (mpad2 < 2 * m) mpad2 <<= 1;
+        TRY(ctx->io_a.reserve(n * 64));
+        TRY(ctx->io_b.reserve(n * 48));
+        TRY(ctx->io_c.reserve(groups * 64));
+        HIP_TRY(hipMemcpyAsync(ctx->io_a.p, pts_xy, n * 64, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->io_b.p, split.data(), n * 48, hipMemcpyHostToDevice, ctx->stream));
+        const uint32_t per_block2 = dr::BSN_BLOCK / mpad2;
+        TRY(launch(ctx, "k_bsn_msm_groups", [&] {
+            hipLaunchKernelGGL(dr::k_bsn_msm_groups_glv, dim3(div_up(groups, per_block2)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
+                               ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>(), (uint32_t)groups, (uint32_t)m, mpad2);
+        }));
+        HIP_TRY(hipMemcpyAsync(out_xy, ctx->io_c.p, groups * 64, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->prof) TRY(prof_collect(ctx));
+        return DR_OK;
+    }
     uint32_t mpad = 1;
     while (mpad < m) mpad <<= 1;
     TRY(ctx->io_a.reserve(n * 64));

@@ -156,6 +156,59 @@ inline const Mod256& mod_p() {       // Bandersnatch base field = BLS12-381 scal
     return s;
 }
 
+// ---------------------------------------------------------------- GLV decomposition (dot_ring/curve/glv.py:57-160)
+// k = k1 + k2*lambda (mod n) with |k1|, |k2| < 2^128, from the lattice basis v1 = (a1, b1), v2 = (a2, -a1) the reference
+// finds by extended Euclid on (n, lambda) (det = -n):  c1 = k*a1/n, c2 = k*b1/n (here: floor via 2^256-scaled
+// reciprocals — any c within 1 of the rounded value still gives a valid, slightly longer pair; the result of the scalar
+// multiplication is the same group element), k1 = k - c1*a1 - c2*a2, k2 = c2*a1 - c1*b1.
+struct GlvSplit {
+    uint64_t k1[2], k2[2];
+    int neg1, neg2;
+};
+inline void mul_limbs(const uint64_t* a, int na, const uint64_t* b, int nb, uint64_t* out) {
+    for (int i = 0; i < na + nb; i++) out[i] = 0;
+    for (int i = 0; i < na; i++) {
+        uint64_t c = 0;
+        for (int j = 0; j < nb; j++) { u128 p = (u128)a[i] * b[j] + out[i + j] + c; out[i + j] = (uint64_t)p; c = (uint64_t)(p >> 64); }
+        out[i + nb] = c;
+    }
+}
+inline bool glv_decompose(const uint64_t k[4], GlvSplit& out) {
+    static const uint64_t A1[2] = {0x4b02f94a9789181fULL, 0x555fe2004be6928eULL};
+    static const uint64_t B1[2] = {0xf8e2591a23d61f44ULL, 0x0814b3eee55e8f5dULL};
+    static const uint64_t A2[2] = {0xf1c4b23447ac3e88ULL, 0x102967ddcabd1ebbULL};
+    static const uint64_t G1[3] = {0xdebac77a3f4747c1ULL, 0xf21df5b0541cf632ULL, 0x0000000000000002ULL};   // floor(2^256 a1 / n)
+    static const uint64_t G2[3] = {0x993b75e7547768aaULL, 0x4760f127d8767bdeULL, 0x0000000000000000ULL};   // floor(2^256 b1 / n)
+    uint64_t t7[7], c1[2], c2[2];
+    mul_limbs(k, 4, G1, 3, t7); c1[0] = t7[4]; c1[1] = t7[5]; if (t7[6]) return false;
+    mul_limbs(k, 4, G2, 3, t7); c2[0] = t7[4]; c2[1] = t7[5]; if (t7[6]) return false;
+    uint64_t p1[4], p2[4], s[4], d[4];
+    auto sub4 = [](const uint64_t* a, const uint64_t* b, uint64_t* r) {          // r = a - b, returns borrow
+        uint64_t bw = 0;
+        for (int i = 0; i < 4; i++) { u128 v = (u128)a[i] - b[i] - bw; r[i] = (uint64_t)v; bw = (uint64_t)(v >> 127); }
+        return bw;
+    };
+    auto finish = [](uint64_t* v, uint64_t borrow, uint64_t* mag, int& neg) {     // signed 256-bit -> 128-bit magnitude
+        neg = borrow ? 1 : 0;
+        if (borrow) { uint64_t c = 1; for (int i = 0; i < 4; i++) { u128 t = (u128)(~v[i]) + c; v[i] = (uint64_t)t; c = (uint64_t)(t >> 64); } }
+        mag[0] = v[0]; mag[1] = v[1];
+        return (v[2] | v[3]) == 0;
+    };
+    // k1 = k - (c1*a1 + c2*a2)
+    mul_limbs(c1, 2, A1, 2, p1);
+    mul_limbs(c2, 2, A2, 2, p2);
+    u128 cy = 0;
+    for (int i = 0; i < 4; i++) { cy += (u128)p1[i] + p2[i]; s[i] = (uint64_t)cy; cy >>= 64; }
+    if (cy) return false;
+    uint64_t bw = sub4(k, s, d);
+    if (!finish(d, bw, out.k1, out.neg1)) return false;
+    // k2 = c2*a1 - c1*b1
+    mul_limbs(c2, 2, A1, 2, p1);
+    mul_limbs(c1, 2, B1, 2, p2);
+    bw = sub4(p1, p2, d);
+    return finish(d, bw, out.k2, out.neg2);
+}
+
 // ---------------------------------------------------------------- byte helpers
 using Bytes = std::vector<uint8_t>;
 inline void put(Bytes& b, const void* p, size_t n) { const uint8_t* q = (const uint8_t*)p; b.insert(b.end(), q, q + n); }

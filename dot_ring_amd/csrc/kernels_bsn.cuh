@@ -273,6 +273,7 @@ DR_DEV Fr fr_pow_limbs(const Fr& a, const uint32_t (&e)[8]) {
 struct BsnConsts {
     uint32_t mont_b[8], a_over_b[8], inv_b2[8];
     uint32_t c_pow[32][8];
+    uint32_t glv_b[8], glv_c[8];         // endomorphism coefficients (bandersnatch.py:58-67), Montgomery form
 };
 __device__ BsnConsts g_bsn_consts;
 DR_DEV Fr bsn_const(const uint32_t (&w)[8]) {
@@ -363,6 +364,122 @@ __global__ void k_bsn_encode_to_curve(const uint32_t* __restrict__ us /* n*2*8 s
     r = te_dbl<false>(r);
     r = te_dbl<false>(r);
     te_store_affine(out + (size_t)i * 16, r);
+}
+
+// ---- GLV on lane pairs (dot_ring/curve/glv.py:128-189, specs/bandersnatch.py:177-191) ----------------------------------
+// k*P = k1*P + k2*psi(P) with |k1|, |k2| < 2^128 (split on the host, hostproto.hpp: glv_decompose).  The reference feeds the
+// two half-length scalars to a joint 2-bit window kernel; here the two halves go to two adjacent LANES, each running the
+// same signed 4-bit window core over 33 windows instead of 64, and one shuffle adds them up: the dependent chain — which
+// is what a launch of a few thousand scalar multiplications costs — is half as long, the total work unchanged.
+// psi(x, y) = (f h : g x y : h x y), f = c (1 - y^2), g = b (y^2 + b), h = y^2 - b, returned in extended coordinates.
+DR_DEV TePoint bsn_endomorphism(const Fr& x, const Fr& y) {
+    const Fr b = bsn_const(g_bsn_consts.glv_b), c = bsn_const(g_bsn_consts.glv_c);
+    Fr y2 = sqr(y), xy = mul(x, y);
+    Fr f = mul(c, sub(Fr::one(), y2)), g = mul(b, add(y2, b)), h = sub(y2, b);
+    Fr X = mul(f, h), Y = mul(g, xy), Z = mul(h, xy);
+    if (Z.is_zero()) return te_identity();            // x y = 0: the identity (or 2-/4-torsion, never a subgroup point)
+    TePoint r;
+    r.x = mul(X, Z); r.y = mul(Y, Z); r.z = sqr(Z); r.t = mul(X, Y);
+    return r;
+}
+// the signed 4-bit window core over NW windows (NW*4 scalar bits, k given as ceil(NW/8) words), base in extended coordinates
+template <int NW>
+DR_DEV TePoint bsn_window_core(uint32_t* tab, int lane, const TePoint& P, const uint32_t (&k)[(NW + 7) / 8]) {
+    constexpr int WORDS = (NW + 7) / 8;
+    lds_store_point(tab, 0, lane, P);
+    TePoint Q = te_dbl<true>(P);
+    lds_store_point(tab, 1, lane, Q);
+#pragma unroll 1
+    for (int e = 2; e < BSN_TABLE; e++) {
+        Q = te_add(Q, P);
+        lds_store_point(tab, e, lane, Q);
+    }
+    uint32_t dig[WORDS];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < WORDS; w++) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t v = ((k[w] >> (4 * j)) & 15u) + carry;
+            carry = v >= 8u ? 1u : 0u;
+            packed |= ((v + 8u) & 15u) << (4 * j);
+        }
+        dig[w] = packed;
+    }
+    TePoint acc = te_identity();
+#pragma unroll 1
+    for (int w = NW - 1; w >= 0; w--) {
+#pragma unroll 1
+        for (int j = 0; j < 3; j++) acc = te_dbl<false>(acc);
+        acc = te_dbl<true>(acc);
+        int d = (int)((dig[w >> 3] >> (4 * (w & 7))) & 15u) - 8;
+        int mag = d < 0 ? -d : d;
+        TePoint T = lds_load_point(tab, mag == 0 ? 0 : mag - 1, lane);
+        T = te_cneg(T, d < 0);
+        if (mag == 0) T = te_identity();
+        acc = te_add(acc, T);
+    }
+    return acc;
+}
+DR_DEV TePoint te_shfl_down(const TePoint& p, unsigned delta) {
+    TePoint o;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        o.x.l[t] = __shfl_down(p.x.l[t], delta, 64);
+        o.y.l[t] = __shfl_down(p.y.l[t], delta, 64);
+        o.z.l[t] = __shfl_down(p.z.l[t], delta, 64);
+        o.t.l[t] = __shfl_down(p.t.l[t], delta, 64);
+    }
+    return o;
+}
+// one half of a GLV pair: the lane's base (P or psi(P), negated when its half-scalar is negative) times |k_half|
+// split: per term 12 words — |k1| (4), |k2| (4), neg1, neg2, 2 pad
+DR_DEV TePoint bsn_glv_half(uint32_t* tab, int lane, const uint32_t* __restrict__ pts, const uint32_t* __restrict__ split, size_t term, bool second) {
+    Fr px = to_mont(load_fr_std(pts + term * 16));
+    Fr py = to_mont(load_fr_std(pts + term * 16 + 8));
+    TePoint base;
+    if (second) base = bsn_endomorphism(px, py);
+    else { base.x = px; base.y = py; base.z = Fr::one(); base.t = mul(px, py); }
+    const uint32_t* s = split + term * 12;
+    base = te_cneg(base, s[8 + (second ? 1 : 0)] != 0);
+    uint32_t k[5];
+#pragma unroll
+    for (int j = 0; j < 4; j++) k[j] = s[(second ? 4 : 0) + j];
+    k[4] = 0;
+    return bsn_window_core<33>(tab, lane, base, k);
+}
+// out[i] = k[i] * P[i] from the split scalars; lanes 2i, 2i+1 share one scalar multiplication
+__global__ __launch_bounds__(BSN_BLOCK) void k_bsn_scalar_mul_glv(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ split,
+                                                                  uint32_t* __restrict__ out, uint32_t n) {
+    __shared__ uint32_t tab[BSN_TABLE * BSN_PT_WORDS * BSN_BLOCK];
+    const int lane = threadIdx.x;
+    uint32_t i = (blockIdx.x * BSN_BLOCK + lane) >> 1;
+    const bool live = i < n;
+    if (!live) i = n - 1;
+    TePoint acc = bsn_glv_half(tab, lane, pts, split, i, (lane & 1) != 0);
+    TePoint o = te_shfl_down(acc, 1);
+    acc = te_add(acc, o);
+    if (live && !(lane & 1)) te_store_affine(out + (size_t)i * 16, acc);
+}
+// out[g] = sum_{j<m} k[g*m+j] * P[g*m+j], m <= 32: 2m lanes per group (mpad2 = 2m rounded up to a power of two)
+__global__ __launch_bounds__(BSN_BLOCK) void k_bsn_msm_groups_glv(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ split,
+                                                                  uint32_t* __restrict__ out, uint32_t groups, uint32_t m, uint32_t mpad2) {
+    __shared__ uint32_t tab[BSN_TABLE * BSN_PT_WORDS * BSN_BLOCK];
+    const int lane = threadIdx.x;
+    const uint32_t per_block = BSN_BLOCK / mpad2;
+    const uint32_t g = blockIdx.x * per_block + lane / mpad2;
+    const uint32_t slot = lane % mpad2, j = slot >> 1;
+    const bool live = g < groups && j < m;
+    const size_t term = live ? (size_t)g * m + j : 0;
+    TePoint r = bsn_glv_half(tab, lane, pts, split, term, (slot & 1) != 0);
+    TePoint acc = live ? r : te_identity();
+#pragma unroll 1
+    for (uint32_t s = mpad2 >> 1; s > 0; s >>= 1) {
+        TePoint o = te_shfl_down(acc, s);
+        acc = te_add(acc, o);
+    }
+    if (g < groups && slot == 0) te_store_affine(out + (size_t)g * 16, acc);
 }
 
 // ---- point decoding for verifiers --------------------------------------------------------------------------------
