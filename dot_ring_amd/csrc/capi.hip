@@ -924,7 +924,7 @@ int dr_bsn_encode_to_curve_batch(dr_ctx* ctx, const uint8_t* u_pairs, size_t n, 
     TRY(ctx->io_c.reserve(n * 64));
     HIP_TRY(hipMemcpyAsync(ctx->io_a.p, u_pairs, n * 64, hipMemcpyHostToDevice, ctx->stream));
     TRY(launch(ctx, "k_bsn_encode_to_curve", [&] {
-        hipLaunchKernelGGL(dr::k_bsn_encode_to_curve, dim3(div_up(n, 64)), dim3(64), 0, ctx->stream, ctx->io_a.as<uint32_t>(),
+        hipLaunchKernelGGL(dr::k_bsn_encode_to_curve, dim3(div_up(2 * n, 64)), dim3(64), 0, ctx->stream, ctx->io_a.as<uint32_t>(),
                            ctx->io_c.as<uint32_t>(), (uint32_t)n);
     }));
     HIP_TRY(hipMemcpyAsync(out_xy, ctx->io_c.p, n * 64, hipMemcpyDeviceToHost, ctx->stream));

@@ -352,18 +352,33 @@ DR_DEV TePoint ell2_finish(const EllHalf& h, const Fr& inv_den) {
     return r;
 }
 
-__global__ void k_bsn_encode_to_curve(const uint32_t* __restrict__ us /* n*2*8 std */, uint32_t* __restrict__ out /* n*16 std */, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    EllHalf h0 = ell2_prepare(to_mont(load_fr_std(us + (size_t)i * 16)));
-    EllHalf h1 = ell2_prepare(to_mont(load_fr_std(us + (size_t)i * 16 + 8)));
-    Fr both = inv(mul(h0.den, h1.den));                // den = 1 + Z u^2 is never zero here (tv1 = -1 was mapped to 0)
-    TePoint q0 = ell2_finish(h0, mul(both, h1.den));
-    TePoint q1 = ell2_finish(h1, mul(both, h0.den));
-    TePoint r = te_add(q0, q1);
+// Two lanes per input, one Elligator map each: the two square roots — the long part of the chain — run side by side;
+// the partner's denominator and point cross over by shuffles (lanes 2i and 2i+1 sit in the same wave).
+__global__ __launch_bounds__(64) void k_bsn_encode_to_curve(const uint32_t* __restrict__ us /* n*2*8 std */, uint32_t* __restrict__ out /* n*16 std */,
+                                                            uint32_t n) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = gid >> 1;
+    const uint32_t half = gid & 1u;
+    const bool live = i < n;
+    if (!live) i = n - 1;                                  // keep the pair (and the shuffles) converged
+    EllHalf h = ell2_prepare(to_mont(load_fr_std(us + (size_t)i * 16 + 8 * half)));
+    Fr other;
+#pragma unroll
+    for (int t = 0; t < 8; t++) other.l[t] = __shfl_xor(h.den.l[t], 1, 64);
+    Fr both = inv(mul(h.den, other));                      // den = 1 + Z u^2 is never zero (tv1 = -1 was mapped to 0)
+    TePoint q = ell2_finish(h, mul(both, other));
+    TePoint p;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        p.x.l[t] = __shfl_xor(q.x.l[t], 1, 64);
+        p.y.l[t] = __shfl_xor(q.y.l[t], 1, 64);
+        p.z.l[t] = __shfl_xor(q.z.l[t], 1, 64);
+        p.t.l[t] = __shfl_xor(q.t.l[t], 1, 64);
+    }
+    TePoint r = te_add(q, p);
     r = te_dbl<false>(r);
     r = te_dbl<false>(r);
-    te_store_affine(out + (size_t)i * 16, r);
+    if (live && half == 0) te_store_affine(out + (size_t)i * 16, r);
 }
 
 // ---- GLV on lane pairs (dot_ring/curve/glv.py:128-189, specs/bandersnatch.py:177-191) ----------------------------------
