@@ -902,7 +902,7 @@ int dr_bsn_decode_points(dr_ctx* ctx, const uint8_t* enc, size_t n, uint8_t* out
     TRY(ctx->io_c.reserve(n * 4));
     HIP_TRY(hipMemcpyAsync(ctx->io_a.p, enc, n * 32, hipMemcpyHostToDevice, ctx->stream));
     TRY(launch(ctx, "k_bsn_decode_points", [&] {
-        hipLaunchKernelGGL(dr::k_bsn_decode_points, dim3(div_up(n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream, ctx->io_a.as<uint32_t>(),
+        hipLaunchKernelGGL(dr::k_bsn_decode_points, dim3(div_up(2 * n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream, ctx->io_a.as<uint32_t>(),
                            ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>(), (uint32_t)n);
     }));
     std::vector<uint32_t> flags(n);
@@ -2234,7 +2234,7 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
     HIP_TRY(hipMemcpyAsync(ctx->io_a.p, te_enc.data(), n_te * 32, hipMemcpyHostToDevice, st));
     uint32_t* d_ok = ctx->io_c.as<uint32_t>();
     TRY(launch(ctx, "k_bsn_decode_points", [&] {
-        hipLaunchKernelGGL(dr::k_bsn_decode_points, dim3(div_up(n_te, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, st, ctx->io_a.as<uint32_t>(),
+        hipLaunchKernelGGL(dr::k_bsn_decode_points, dim3(div_up(2 * n_te, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, st, ctx->io_a.as<uint32_t>(),
                            ctx->io_b.as<uint32_t>(), d_ok, (uint32_t)n_te);
     }));
     std::vector<uint8_t> te_xy(n_te * 64);

@@ -507,7 +507,8 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_decode_points(const uint32_t*
                                                                  uint32_t* __restrict__ ok, uint32_t n) {
     __shared__ uint32_t tab[BSN_TABLE * BSN_PT_WORDS * BSN_BLOCK];
     const int lane = threadIdx.x;
-    uint32_t i = blockIdx.x * BSN_BLOCK + lane;
+    uint32_t i = (blockIdx.x * BSN_BLOCK + lane) >> 1;           // two lanes per point: the GLV halves of the subgroup check
+    const bool half = (lane & 1) != 0;
     const bool live = i < n;
     if (!live) i = n - 1;
     Fr ys = load_fr_std(enc + (size_t)i * 8);
@@ -544,10 +545,22 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_decode_points(const uint32_t*
     if (Q.x.is_zero()) { valid = false; Q = P; }    // 4P = O (x = 0 also covers the order-2 point (0,-1), which 4 kills anyway)
     Fr zi = inv(Q.z.is_zero() ? one : Q.z);
     Fr qx = mul(Q.x, zi), qy = mul(Q.y, zi);
-    uint32_t kk[8] = {0xde592de9u, 0x17bdc507u, 0x5712c355u, 0xbfaba540u, 0x81ce5880u, 0x899ad881u, 0x97cd877du, 0x15bc8f5fu};   // 4^-1 mod n
-    TePoint R = bsn_scalar_mul_core(tab, lane, qx, qy, kk);
+    // [4^-1 mod n] Q by GLV on the lane pair (Q = 4P lies in the prime-order subgroup, where psi acts as lambda):
+    // 4^-1 = k1 + k2 lambda with k1 > 0 > k2, both below 2^127
+    TePoint base;
+    uint32_t kh[5];
+    if (!half) {
+        base.x = qx; base.y = qy; base.z = one; base.t = mul(qx, qy);
+        kh[0] = 0xed8e8490u; kh[1] = 0x84857086u; kh[2] = 0xddb6c35fu; kh[3] = 0x2581605du;
+    } else {
+        base = te_cneg(bsn_endomorphism(qx, qy), true);
+        kh[0] = 0x0e93904eu; kh[1] = 0xccca6304u; kh[2] = 0x928eeeb6u; kh[3] = 0x535ab504u;
+    }
+    kh[4] = 0;
+    TePoint R = bsn_window_core<33>(tab, lane, base, kh);
+    R = te_add(R, te_shfl_down(R, 1));
     if (!(R.x == mul(x, R.z)) || !(R.y == mul(y, R.z))) valid = false;
-    if (live) {
+    if (live && !half) {
         store_fr_std(out_xy + (size_t)i * 16, from_mont(x));
         store_fr_std(out_xy + (size_t)i * 16 + 8, from_mont(y));
         ok[i] = valid ? 1u : 0u;
