@@ -1752,7 +1752,9 @@ int dr_ring_prove_openings(dr_ring_prover* p, size_t batch, const uint8_t* nus, 
     TRY(p->aggo.reserve(batch * (size_t)qn * 32));
     const uint32_t nch1 = (qn + dr::SD_CHUNK - 1) / dr::SD_CHUNK, nch2 = (n + dr::SD_CHUNK - 1) / dr::SD_CHUNK;
     TRY(p->chunkv.reserve(batch * (size_t)nch1 * 32));
-    TRY(p->quot1.reserve(batch * (size_t)(qn - 1) * 32));
+    // both quotients of all proofs share ONE batched MSM: [2*batch][3N] scalar vectors, the short second quotient
+    // zero-padded (zero scalars produce no digits) — one sort / accumulate / reduce / affine pipeline instead of two
+    TRY(p->quot1.reserve(2 * batch * (size_t)(qn - 1) * 32));
     TRY(p->quot2.reserve(batch * (size_t)(n - 1) * 32));
     HIP_TRY(hipMemcpyAsync(p->nus.p, nus, batch * 8 * 32, hipMemcpyHostToDevice, st));
     TRY(launch(ctx, "k_ring_aggpoly", [&] {
@@ -1771,15 +1773,18 @@ int dr_ring_prove_openings(dr_ring_prover* p, size_t batch, const uint8_t* nus, 
     };
     TRY(syndiv(p->aggo.as<uint32_t>(), qn, 0, p->quot1.as<uint32_t>(), nch1));
     TRY(syndiv(p->lin.as<uint32_t>(), n, 1, p->quot2.as<uint32_t>(), nch2));
-    std::vector<uint8_t> o1(batch * 96), o2(batch * 96);
-    std::vector<int> i1(batch), i2(batch);
+    TRY(launch(ctx, "k_ring_pad", [&] {
+        hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up(batch * (size_t)(qn - 1), 256)), dim3(256), 0, st, p->quot2.as<uint32_t>(), n - 1,
+                           p->quot1.as<uint32_t>() + batch * (size_t)(qn - 1) * 8, qn - 1, batch);
+    }));
+    std::vector<uint8_t> o(2 * batch * 96);
+    std::vector<int> inf(2 * batch);
     MsmTable t = srs_table(p->srs, 0);
-    TRY(msm_to_bytes(ctx, p->srs->d_bases, p->quot1.as<uint32_t>(), qn - 1, batch, o1.data(), i1.data(), &t));
-    TRY(msm_to_bytes(ctx, p->srs->d_bases, p->quot2.as<uint32_t>(), n - 1, batch, o2.data(), i2.data(), &t));
+    TRY(msm_to_bytes(ctx, p->srs->d_bases, p->quot1.as<uint32_t>(), qn - 1, 2 * batch, o.data(), inf.data(), &t));
     for (size_t b = 0; b < batch; b++) {
-        std::memcpy(out_openings + 192 * b, o1.data() + 96 * b, 96);
-        std::memcpy(out_openings + 192 * b + 96, o2.data() + 96 * b, 96);
-        if (is_inf) { is_inf[2 * b] = i1[b]; is_inf[2 * b + 1] = i2[b]; }
+        std::memcpy(out_openings + 192 * b, o.data() + 96 * b, 96);
+        std::memcpy(out_openings + 192 * b + 96, o.data() + 96 * (batch + b), 96);
+        if (is_inf) { is_inf[2 * b] = inf[b]; is_inf[2 * b + 1] = inf[batch + b]; }
     }
     return DR_OK;
 }
