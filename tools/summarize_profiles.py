@@ -24,12 +24,13 @@ def short(name):
 
 # the --stats summary averages every launch of the process, set-up included (one 60 ms launch builds the by-parts
 # bases); the bench line's figure is the timed region only.  From the kernel trace: the last steps * 6 accumulate launches
-# (profile_round.sh profiles 2 timed steps; 4 prove-side + 2 verify-side launches per step).
+# (profile_round.sh profiles 2 timed steps; launches per step from the bench line).
 trace = glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True)
 if trace:
     rows = [r for r in csv.DictReader(open(trace[0])) if "k_g1_accumulate" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    timed = rows[-12:]
+    per_step = int(round(json.loads(line)["roofline"].get("launches_per_step", 6)))
+    timed = rows[-2 * per_step:]
     if timed:
         dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in timed]
         with open(f"profiles/{tag}_{workload}_accumulate_timed_region.json", "w") as f:
