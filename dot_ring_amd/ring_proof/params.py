@@ -63,6 +63,10 @@ def _domain_for_size(size: int, prime: int, base_root: int, base_size: int):
 
 @dataclass
 class RingProofParams:
+    """Shape of the ring proof: PIOP domain N, the 4N evaluation domain, ring capacity, roots of unity, PCS and suite.
+    Field names, defaults, derived properties and every error text follow the reference (params.py:119-287) — its
+    tests construct this class directly and match on the messages; the checks themselves are organised as a list of
+    (violated?, message) pairs evaluated in the reference's order."""
     domain_size: int = DEFAULT_DOMAIN_SIZE
     max_ring_size: int = DEFAULT_MAX_RING_SIZE
     padding_rows: int = 4
@@ -75,44 +79,48 @@ class RingProofParams:
 
     def __post_init__(self) -> None:
         aux = self.cv.curve.params.auxiliary_points
-        for name in ("blinding_base", "accumulator_base", "padding_point"):
-            if getattr(aux, name) is None:
-                raise ValueError(f"{self.cv.name} ring proofs require auxiliary point {name}")
-        if self.radix_domain_size is None:
-            self.radix_domain_size = self.domain_size * 4
-        radix = self.radix_domain_size
-        if not _is_power_of_two(self.domain_size):
-            raise ValueError(f"domain_size must be a power of two, got {self.domain_size}")
-        if not _is_power_of_two(radix):
-            raise ValueError(f"radix_domain_size must be a power of two, got {radix}")
-        if radix % self.domain_size != 0:
-            raise ValueError(f"domain_size {self.domain_size} must divide radix_domain_size {radix}")
-        if self.domain_size > MAX_PIOP_DOMAIN_SIZE:
-            raise ValueError(f"domain_size {self.domain_size} exceeds supported SRS domain size {MAX_PIOP_DOMAIN_SIZE}")
-        if self.base_root_size % radix != 0 and radix <= self.base_root_size:
-            raise ValueError(f"radix_domain_size {radix} must divide base_root_size {self.base_root_size}")
-        if pow(self.base_root, self.base_root_size, self.prime) != 1 or pow(self.base_root, self.base_root_size // 2, self.prime) == 1:
-            raise ValueError(f"{self.cv.name} ring proofs require a primitive {self.base_root_size}-th root of unity")
-        if radix > self.base_root_size:
-            self.base_root, self.base_root_size = _extend_root_to_size(self.base_root, self.base_root_size, radix, self.prime)
+        missing = [n for n in ("blinding_base", "accumulator_base", "padding_point") if getattr(aux, n) is None]
+        if missing:
+            raise ValueError(f"{self.cv.name} ring proofs require auxiliary point {missing[0]}")
+        n = self.domain_size
+        radix = self.radix_domain_size = 4 * n if self.radix_domain_size is None else self.radix_domain_size
+        p = self.prime
+
+        def primitive_root_ok() -> bool:
+            return pow(self.base_root, self.base_root_size, p) == 1 and pow(self.base_root, self.base_root_size // 2, p) != 1
+
+        for violated, message in (
+            (lambda: not _is_power_of_two(n), f"domain_size must be a power of two, got {n}"),
+            (lambda: not _is_power_of_two(radix), f"radix_domain_size must be a power of two, got {radix}"),
+            (lambda: radix % n != 0, f"domain_size {n} must divide radix_domain_size {radix}"),
+            (lambda: n > MAX_PIOP_DOMAIN_SIZE, f"domain_size {n} exceeds supported SRS domain size {MAX_PIOP_DOMAIN_SIZE}"),
+            (lambda: radix <= self.base_root_size and self.base_root_size % radix != 0,
+             f"radix_domain_size {radix} must divide base_root_size {self.base_root_size}"),
+            (lambda: not primitive_root_ok(), f"{self.cv.name} ring proofs require a primitive {self.base_root_size}-th root of unity"),
+        ):
+            if violated():
+                raise ValueError(message)
+        if radix > self.base_root_size:          # 4N beyond the shipped 2048-th root: take square roots (reference schedule)
+            self.base_root, self.base_root_size = _extend_root_to_size(self.base_root, self.base_root_size, radix, p)
         if self.base_root_size % radix != 0:
             raise ValueError(f"radix_domain_size {radix} must divide base_root_size {self.base_root_size}")
         if self.padding_rows < 1:
             raise ValueError("padding_rows must be >= 1 to preserve accumulator structure")
-        if self.padding_rows >= self.domain_size:
+        if self.padding_rows >= n:
             raise ValueError("padding_rows must be less than domain_size")
         if self.padding_rows != ZK_ROWS + 1:
             raise ValueError(f"padding_rows must be {ZK_ROWS + 1} to match the {ZK_ROWS} hidden rows")
-        max_supported = self.domain_size - self.row_overhead
-        if max_supported <= 0:
+        capacity = n - self.row_overhead
+        if capacity <= 0:
             raise ValueError(
                 "domain_size is too small for the scalar bit decomposition: "
-                f"domain_size={self.domain_size}, scalar_bits={self.scalar_bits}, padding_rows={self.padding_rows}")
-        if self.max_ring_size == DEFAULT_MAX_RING_SIZE and max_supported != DEFAULT_MAX_RING_SIZE:
-            self.max_ring_size = max_supported
-        elif self.max_ring_size > max_supported:
-            raise ValueError(f"max_ring_size {self.max_ring_size} exceeds supported size {max_supported}")
+                f"domain_size={n}, scalar_bits={self.scalar_bits}, padding_rows={self.padding_rows}")
+        if self.max_ring_size == DEFAULT_MAX_RING_SIZE and capacity != DEFAULT_MAX_RING_SIZE:
+            self.max_ring_size = capacity
+        elif self.max_ring_size > capacity:
+            raise ValueError(f"max_ring_size {self.max_ring_size} exceeds supported size {capacity}")
 
+    # ---- derived quantities
     @property
     def prime(self) -> int:
         return self.cv.curve.params.field_modulus
@@ -125,17 +133,20 @@ class RingProofParams:
     def row_overhead(self) -> int:
         return self.scalar_bits + self.padding_rows
 
+    def _root_of_order(self, size: int) -> int:
+        return pow(self.base_root, self.base_root_size // size, self.prime)
+
     @property
     def omega(self) -> int:
-        return pow(self.base_root, self.base_root_size // self.domain_size, self.prime)
+        return self._root_of_order(self.domain_size)
+
+    @property
+    def radix_omega(self) -> int:
+        return self._root_of_order(self.radix_domain_size)
 
     @property
     def domain(self) -> list:
         return list(_domain_for_size(self.domain_size, self.prime, self.base_root, self.base_root_size))
-
-    @property
-    def radix_omega(self) -> int:
-        return pow(self.base_root, self.base_root_size // self.radix_domain_size, self.prime)
 
     @property
     def radix_domain(self) -> list:
@@ -160,12 +171,10 @@ class RingProofParams:
     @classmethod
     def from_ring_size(cls, ring_size: int, padding_rows: int = 4, base_root: int = ROOT_OF_UNITY_2048,
                        base_root_size: int = 2048, test_vectors: bool = False, cv: CurveVariant = Bandersnatch, pcs: type = KZG):
+        """Smallest power-of-two domain with room for `ring_size` keys, the scalar bits and the padding rows."""
         if ring_size <= 0:
             raise ValueError(f"ring_size must be positive, got {ring_size}")
         overhead = cv.curve.params.subgroup_order.bit_length() + padding_rows
-        need = ring_size + overhead
-        domain_size = 1
-        while domain_size < need:
-            domain_size *= 2
+        domain_size = 1 << max(0, (ring_size + overhead - 1).bit_length())
         return cls(domain_size=domain_size, max_ring_size=domain_size - overhead, padding_rows=padding_rows,
                    base_root=base_root, base_root_size=base_root_size, test_vectors=test_vectors, cv=cv, pcs=pcs)

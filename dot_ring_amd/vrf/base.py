@@ -1,39 +1,44 @@
-"""VRF base class: `Scheme[CurveVariant]` specialisation (dot_ring/vrf/vrf.py:10-48)."""
+"""Common base of the four schemes: `Scheme[curve_variant]` yields the scheme bound to one suite
+(reference behaviour: dot_ring/vrf/vrf.py:10-48).  Bound classes are created once per (scheme, suite) and reused, so
+dataclass equality between proofs works and per-class memos survive."""
 from __future__ import annotations
 
 from ..curve import CurveVariant
+
+_BOUND: dict = {}
+
+
+def _unsupported(owner, what: str):
+    name = owner.__name__ if isinstance(owner, type) else type(owner).__name__
+    return NotImplementedError(f"{name} does not implement {what}")
 
 
 class VRF:
     cv = None
 
-    _specialised: dict = {}
-
-    def __class_getitem__(cls, curve_variant):
-        if not isinstance(curve_variant, CurveVariant):
+    def __class_getitem__(cls, variant):
+        if not isinstance(variant, CurveVariant):
             return cls
-        # one class object per (scheme, curve): dataclass equality compares classes, and per-class memos stay alive
-        key = (cls, curve_variant.name)
-        hit = VRF._specialised.get(key)
-        if hit is None or hit.cv is not curve_variant:
-            hit = type(f"{cls.__name__}[{curve_variant.name}]", (cls,), {"cv": curve_variant})
-            VRF._specialised[key] = hit
-        return hit
+        bound = _BOUND.get((cls, variant.name))
+        if bound is None or bound.cv is not variant:
+            bound = _BOUND[(cls, variant.name)] = type(f"{cls.__name__}[{variant.name}]", (cls,), {"cv": variant})
+        return bound
 
+    # the interface every scheme fills in
     @classmethod
     def prove(cls, *args, **kwargs):
-        raise NotImplementedError(f"{cls.__name__} does not implement prove")
+        raise _unsupported(cls, "prove")
 
     def verify(self, *args, **kwargs):
-        raise NotImplementedError(f"{self.__class__.__name__} does not implement verify")
+        raise _unsupported(self, "verify")
 
     def encode(self) -> bytes:
-        raise NotImplementedError(f"{self.__class__.__name__} does not implement encode")
+        raise _unsupported(self, "encode")
 
     @classmethod
     def decode(cls, data: bytes):
-        raise NotImplementedError(f"{cls.__name__} does not implement from_bytes")
+        raise _unsupported(cls, "from_bytes")
 
     @classmethod
     def batch_verify(cls, *args, **kwargs):
-        raise NotImplementedError(f"{cls.__name__} does not implement batch_verify")
+        raise _unsupported(cls, "batch_verify")

@@ -1,32 +1,48 @@
-"""Scalar / point codecs (dot_ring/vrf/codec.py:9-51)."""
+"""Byte codecs of the VRF layer: little-endian scalars of the group order's width, compressed points
+(reference behaviour: dot_ring/vrf/codec.py:9-51 — same function names, lengths and error texts, because the
+reference's tests match on them).  Point decoding is a batch operation here: decompression and the subgroup check of
+any number of points are one kernel launch (dr_bsn_decode_points)."""
 from __future__ import annotations
 
-from ..curve import valid_points
+_U64 = 1 << 64
+
+
+def _order(cv) -> int:
+    return cv.curve.params.subgroup_order
 
 
 def scalar_len(cv) -> int:
-    return (cv.curve.params.subgroup_order.bit_length() + 7) // 8
+    return -(-_order(cv).bit_length() // 8)
 
 
 def point_len(cv) -> int:
     return cv.curve.params.encoding.point_len
 
 
+def enc_64(value: int) -> bytes:
+    if value < 0 or value >= _U64:
+        raise ValueError("value does not fit in uint64")
+    return value.to_bytes(8, "little")
+
+
 def enc_scalar(cv, value: int) -> bytes:
-    return int(value % cv.curve.params.subgroup_order).to_bytes(scalar_len(cv), "little")
-
-
-def dec_scalar(cv, value: bytes) -> int:
-    if len(value) != scalar_len(cv):
-        raise ValueError(f"scalar must be exactly {scalar_len(cv)} bytes")
-    scalar = int.from_bytes(value, "little")
-    if scalar >= cv.curve.params.subgroup_order:
-        raise ValueError("scalar is not canonical")
-    return scalar
+    return (int(value) % _order(cv)).to_bytes(scalar_len(cv), "little")
 
 
 def dec_scalar_mod(cv, value: bytes) -> int:
-    return int.from_bytes(value, "little") % cv.curve.params.subgroup_order
+    """Any length, reduced mod the group order (nonces, challenges, seeds)."""
+    return int.from_bytes(value, "little") % _order(cv)
+
+
+def dec_scalar(cv, value: bytes) -> int:
+    """Exactly scalar_len bytes and canonical (below the group order)."""
+    width = scalar_len(cv)
+    if len(value) != width:
+        raise ValueError(f"scalar must be exactly {width} bytes")
+    k = int.from_bytes(value, "little")
+    if k >= _order(cv):
+        raise ValueError("scalar is not canonical")
+    return k
 
 
 def enc_point(point) -> bytes:
@@ -34,27 +50,26 @@ def enc_point(point) -> bytes:
 
 
 def dec_points(cv, values) -> list:
-    """Decode + subgroup-validate several points in ONE kernel launch (dr_bsn_decode_points); raises like dec_point."""
+    """dec_point for several encodings at once; raises ValueError if ANY of them is malformed, the identity or outside
+    the prime-order subgroup."""
     from .. import runtime
 
-    values = [bytes(v) for v in values]
-    for value in values:
-        if len(value) != point_len(cv):
-            raise ValueError(f"point must be exactly {point_len(cv)} bytes")
-    if not values:
+    width = point_len(cv)
+    blobs = []
+    for v in values:
+        v = bytes(v)
+        if len(v) != width:
+            raise ValueError(f"point must be exactly {width} bytes")
+        blobs.append(v)
+    if not blobs:
         return []
-    raw, ok = runtime.context().bsn_decode_points(b"".join(values))
-    if not all(ok):
+    xy, flags = runtime.context().bsn_decode_points(b"".join(blobs))
+    if 0 in flags:
         raise ValueError("point is not a valid nonidentity subgroup point")
-    frm, mk = int.from_bytes, cv.point_type._trusted
-    return [mk(frm(raw[i : i + 32], "little"), frm(raw[i + 32 : i + 64], "little")) for i in range(0, len(raw), 64)]
+    make, le = cv.point_type._trusted, int.from_bytes
+    return [make(le(xy[o : o + 32], "little"), le(xy[o + 32 : o + 64], "little")) for o in range(0, 64 * len(blobs), 64)]
 
 
 def dec_point(cv, value: bytes):
-    return dec_points(cv, [value])[0]
-
-
-def enc_64(value: int) -> bytes:
-    if not 0 <= value < 1 << 64:
-        raise ValueError("value does not fit in uint64")
-    return value.to_bytes(8, "little")
+    (point,) = dec_points(cv, (value,))
+    return point
