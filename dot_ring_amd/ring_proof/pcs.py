@@ -68,6 +68,29 @@ def _candidate_srs_files(min_g1_count: int):
     return usable
 
 
+def _precompute_tables(dev) -> None:
+    """Fixed-base tables of an SRS in HBM.  Default: 12-bit windows feeding the bucket pipeline.  DOTRING_SRS_COMB=1
+    switches to 14-bit windows plus the comb table of every digit multiple (count * 19 * 8192 entries of 128 B: 122 GB
+    for the shipped 6145 points), which turns the batched MSMs into plain sums of looked-up points.  Measured A/B on one
+    box it is NOT faster (69 ms vs 61 ms of MSM kernels per 1024 proofs; the random 128 B gathers miss L2) and costs
+    10-13 s to build, hence opt-in; it falls back to the default when the table does not fit.  DOTRING_SRS_WINDOW
+    overrides the width (0 = no table at all)."""
+    want_comb = os.environ.get("DOTRING_SRS_COMB", "0") != "0"
+    explicit = os.environ.get("DOTRING_SRS_WINDOW")
+    bits = int(explicit) if explicit is not None else (14 if want_comb else 12)
+    if not bits:
+        return
+    dev.precompute(bits)
+    if want_comb and bits <= 14:
+        try:
+            dev.precompute_comb()
+            return
+        except MemoryError:
+            pass
+        if explicit is None:
+            dev.precompute(12)
+
+
 class SRS:
     """G1 powers (resident in HBM once used) + the two G2 points (pcs/srs.py:42-148)."""
 
@@ -99,16 +122,7 @@ class SRS:
         hit = self._devices.get(id(ctx))
         if hit is None or hit[0] is not ctx:
             dev = ctx.srs_load(self.g1_raw)
-            bits = int(os.environ.get("DOTRING_SRS_WINDOW", "12"))
-            if bits:
-                dev.precompute(bits)
-                # opt-in comb table (every digit multiple precomputed: 35 GB for 6145 points at 12 bits): measured 6 %
-                # slower than the bucket method for the prover, so off by default
-                if bits <= 14 and os.environ.get("DOTRING_SRS_COMB", "0") != "0":
-                    try:
-                        dev.precompute_comb()
-                    except MemoryError:
-                        pass
+            _precompute_tables(dev)
             hit = (ctx, dev)
             self._devices[id(ctx)] = hit
         return hit[1]
@@ -147,14 +161,7 @@ class SRS:
         ctx = runtime.context()
         dev = ctx.srs_powers(base.g1_raw[:96], tau, count)
         self = cls(dev.download(0, count), [base.g2_raw[0], _native.g2_mul(base.g2_raw[0], tau)])
-        bits = int(os.environ.get("DOTRING_SRS_WINDOW", "12"))
-        if bits:
-            dev.precompute(bits)
-            if bits <= 14 and os.environ.get("DOTRING_SRS_COMB", "0") != "0":
-                try:
-                    dev.precompute_comb()
-                except MemoryError:
-                    pass
+        _precompute_tables(dev)
         self._devices[id(ctx)] = (ctx, dev)
         return self
 
