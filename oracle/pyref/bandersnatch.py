@@ -1,18 +1,21 @@
-"""ORACLE (test infrastructure only) — Bandersnatch curve, codecs and hash-to-curve in plain Python ints.
+"""ORACLE (test infrastructure only) — Bandersnatch (and JubJub) curve, codecs and hash-to-curve in plain Python ints.
 
-Restates, for the two Bandersnatch suites only:
+Restates, for the two Bandersnatch suites and the JubJub suite (same base field; `with using(JUBJUB):` swaps the
+module's curve constants — dot_ring/curve/specs/jubjub.py:17-56 — for the duration of a block):
   curve constants / suites          dot_ring/curve/specs/bandersnatch.py:57-144
   affine twisted-Edwards law        dot_ring/curve/twisted_edwards/te_affine_point.py:69-167
   compressed point codec            dot_ring/curve/point.py:150-214, te_affine_point.py:297-316
   subgroup validation (dec_point)   dot_ring/vrf/codec.py:39-45, dot_ring/curve/curve.py:56-67
   hash_to_field / expand_message    dot_ring/curve/curve.py:110-237
   Elligator2 map + Montgomery->TE   dot_ring/curve/twisted_edwards/te_curve.py:48-95, te_affine_point.py:212-295
+  try-and-increment (JubJub)        dot_ring/curve/point.py:252-296
 Scalar multiplications go through the C oracle (oracle/c/oracle.c), which tests check against the
 affine law below.
 """
 from __future__ import annotations
 
 import hashlib
+from contextlib import contextmanager
 from dataclasses import dataclass
 
 from .. import coracle
@@ -37,6 +40,8 @@ class Suite:
     blinding_base: tuple
     accumulator_base: tuple
     padding_point: tuple
+    curve: str = "bandersnatch"    # which constant set `using` installs
+    e2c: str = "ell2"              # "ell2" (Elligator 2, RO) or "tai" (try and increment)
 
     @property
     def dst(self) -> bytes:
@@ -68,6 +73,46 @@ SHAKE128 = Suite(
     (1834402953989431481748983728202937234471322740714585873803966488035889514523,
      52100941849053769665273763352270294131006971127418863694682093199651869272752),
 )
+JUBJUB = Suite(
+    "JubJub",
+    b"JubJub-SHA512-TAI-v1",
+    False,
+    (38206460563694846719174258613922853630278999941532690543235578292520143148532,
+     34254498978062207918041301829525626783549813531091321004550549786528984401675),
+    (48142684311216766702182564801462043940571084233680216669499475549492432046964,
+     34380560660182334518990118617091967209302636551264477863958902286043397647879),
+    (17348704025397475127937572481155408456556065464328870407269802701696798733683,
+     24318278422173803457621119807961883607097742387673491974779969503617097905596),
+    curve="jubjub",
+    e2c="tai",
+)
+
+_CURVES = {
+    "bandersnatch": dict(N=N, COFACTOR=COFACTOR, A=A, D=D, G=G),
+    "jubjub": dict(                                            # specs/jubjub.py:17-29
+        N=0x0E7DB4EA6533AFA906673B0101343B00A6682093CCC81082D0970E5ED6F72CB7,
+        COFACTOR=8,
+        A=-1 % P,
+        D=19257038036680949359750312669786877991949435402254120286184196891950884077233,
+        G=(8076246640662884909881801758704306714034609987455869804520522091855516602923,
+           13262374693698910701929044844600465831413122818447359594527400194675274060458),
+    ),
+}
+_ACTIVE = "bandersnatch"
+
+
+@contextmanager
+def using(suite: Suite):
+    """Install the curve constants of `suite` as this module's N / COFACTOR / A / D / G for the duration of the block."""
+    global _ACTIVE
+    before = _ACTIVE
+    globals().update(_CURVES[suite.curve])
+    _ACTIVE = suite.curve
+    try:
+        yield suite
+    finally:
+        globals().update(_CURVES[before])
+        _ACTIVE = before
 
 
 # ------------------------------------------------------------------ group law (affine)
@@ -113,6 +158,8 @@ def mul(pt, k: int):
     k %= N
     if k == 0 or pt == IDENTITY:
         return IDENTITY
+    if _ACTIVE != "bandersnatch":          # the C oracle's TE kernels are the reference's: a = -5 only
+        return mul_py(pt, k)
     return coracle.te_mul(pt, k, glv=False)
 
 
@@ -175,10 +222,10 @@ def decompress(data: bytes):
 
 
 def in_prime_subgroup(pt) -> bool:
-    """curve.py:56 valid_point — non-identity, on curve, [4]P != O and [4^-1 mod n][4]P == P."""
+    """curve.py:56 valid_point — non-identity, on curve, [h]P != O and [h^-1 mod n][h]P == P."""
     if pt == IDENTITY or not on_curve(pt):
         return False
-    cleared = double(double(pt))
+    cleared = mul_py(pt, COFACTOR)
     if cleared == IDENTITY:
         return False
     return mul(cleared, pow(COFACTOR, -1, N)) == pt
@@ -299,8 +346,43 @@ def _te_double_ref(pt):
     return 2 * x1 * y1 * pow(dx, -1, P) % P, (y1 * y1 - A * x1 * x1) * pow(dy, -1, P) % P
 
 
+def _squeeze(suite: Suite, absorbed: bytes, size: int) -> bytes:
+    # vrf/primitives.py:165 (restated again in vrf.py, which imports this module)
+    if suite.xof:
+        return hashlib.shake_128(absorbed).digest(size)
+    seed = hashlib.sha512(absorbed).digest()
+    out, ctr = b"", 0
+    while len(out) < size:
+        out += hashlib.sha512(seed + ctr.to_bytes(8, "little")).digest()
+        ctr += 1
+    return out[:size]
+
+
+def encode_to_curve_tai(suite: Suite, alpha: bytes, salt: bytes = b""):
+    """point.py:252 — candidate_c = the first 32 squeezed bytes of suite_id || 0x60 || LE64(len data) || data || c, read
+    as a compressed point (255 value bits + the sign bit); the first c whose candidate decompresses, times the
+    cofactor (skipped if that is the identity)."""
+    data = salt + alpha
+    prefix = suite.suite_id + b"\x60" + len(data).to_bytes(8, "little") + data
+    for counter in range(256):
+        cand = bytearray(_squeeze(suite, prefix + bytes([counter]), 32))
+        sign = cand[-1] & 0x80
+        cand[-1] &= 0x7F          # shave = 256 - 255 bits
+        cand[-1] |= sign
+        try:
+            pt = decompress(bytes(cand))
+        except ValueError:
+            continue
+        pt = mul_py(pt, COFACTOR)
+        if pt != IDENTITY:
+            return pt
+    raise ValueError("hash_to_curve_tai failed")
+
+
 def encode_to_curve(suite: Suite, alpha: bytes, salt: bytes = b""):
     """te_affine_point.py:212 _e2c_ell2_ro: two field elements, two maps, add, clear cofactor (2 doublings)."""
+    if suite.e2c == "tai":
+        return encode_to_curve_tai(suite, alpha, salt)
     u0, u1 = hash_to_field(suite, salt + alpha, 2)
     q0 = from_mont(*map_to_curve_ell2(u0))
     q1 = from_mont(*map_to_curve_ell2(u1))

@@ -10,7 +10,7 @@ from oracle import coracle
 from oracle.pyref import bandersnatch as bsn
 from oracle.pyref import kzg, ring, vrf
 
-SUITES = {"sha512": bsn.SHA512, "shake128": bsn.SHAKE128}
+SUITES = {"sha512": bsn.SHA512, "shake128": bsn.SHAKE128, "jubjub": bsn.JUBJUB}
 
 
 def _load(golden_dir, rel):
@@ -129,39 +129,44 @@ def test_keygen_kat():
 
 TINY = [("sha512", "ark-vrf/bandersnatch_sha-512_ell2_tiny.json"), ("sha512", "ark-vrf/bandersnatch_ed_sha512_ell2_ietf.json"),
         ("sha512", "dot-ring/bandersnatch_sha-512_ell2_tiny.json"), ("shake128", "ark-vrf/bandersnatch_shake128_ell2_tiny.json"),
-        ("shake128", "dot-ring/bandersnatch_shake128_ell2_tiny.json")]
+        ("shake128", "dot-ring/bandersnatch_shake128_ell2_tiny.json"), ("jubjub", "ark-vrf/jubjub_sha-512_tai_tiny.json"),
+        ("jubjub", "ark-vrf/jubjub_sha_512_tai_ietf.json"), ("jubjub", "dot-ring/jubjub_sha-512_tai_tiny.json")]
 PEDERSEN = [("sha512", "ark-vrf/bandersnatch_sha-512_ell2_pedersen.json"), ("sha512", "ark-vrf/bandersnatch_ed_sha512_ell2_pedersen.json"),
             ("sha512", "dot-ring/bandersnatch_sha-512_ell2_pedersen.json"), ("shake128", "ark-vrf/bandersnatch_shake128_ell2_pedersen.json"),
-            ("shake128", "dot-ring/bandersnatch_shake128_ell2_pedersen.json")]
+            ("shake128", "dot-ring/bandersnatch_shake128_ell2_pedersen.json"), ("jubjub", "ark-vrf/jubjub_sha-512_tai_pedersen.json"),
+            ("jubjub", "ark-vrf/jubjub_sha512_tai_pedersen.json"), ("jubjub", "dot-ring/jubjub_sha-512_tai_pedersen.json")]
 RING = [("sha512", "ark-vrf/bandersnatch_sha-512_ell2_ring.json"), ("sha512", "ark-vrf/bandersnatch_ed_sha512_ell2_ring.json"),
         ("sha512", "dot-ring/bandersnatch_sha-512_ell2_ring.json"), ("shake128", "ark-vrf/bandersnatch_shake128_ell2_ring.json"),
-        ("shake128", "dot-ring/bandersnatch_shake128_ell2_ring.json")]
+        ("shake128", "dot-ring/bandersnatch_shake128_ell2_ring.json"), ("jubjub", "ark-vrf/jubjub_sha-512_tai_ring.json"),
+        ("jubjub", "dot-ring/jubjub_sha-512_tai_ring.json")]
 
 
 @pytest.mark.parametrize("suite,rel", TINY)
 def test_tiny_vrf_kats(golden_dir, suite, rel):
     s = SUITES[suite]
-    for v in _load(golden_dir, rel):
-        sk, al, ad = (bytes.fromhex(v[k]) for k in ("sk", "alpha", "ad"))
-        assert bsn.public_key_from_secret(sk).hex() == v["pk"]
-        assert bsn.enc_point(bsn.encode_to_curve(s, al)).hex() == v["h"]
-        proof = vrf.tiny_prove(s, al, sk, ad)
-        assert proof.hex() == v["gamma"] + v["proof_c"] + v["proof_s"]
-        assert vrf.tiny_verify(s, proof, bytes.fromhex(v["pk"]), al, ad)
-        assert not vrf.tiny_verify(s, proof, bytes.fromhex(v["pk"]), al + b"x", ad)
-        assert vrf.point_to_hash(s, bsn.decompress(proof[:32])).hex() == v["beta"][:64]
+    with bsn.using(s):
+        for v in _load(golden_dir, rel):
+            sk, al, ad = (bytes.fromhex(v[k]) for k in ("sk", "alpha", "ad"))
+            assert bsn.public_key_from_secret(sk).hex() == v["pk"]
+            assert bsn.enc_point(bsn.encode_to_curve(s, al)).hex() == v["h"]
+            proof = vrf.tiny_prove(s, al, sk, ad)
+            assert proof.hex() == v["gamma"] + v["proof_c"] + v["proof_s"]
+            assert vrf.tiny_verify(s, proof, bytes.fromhex(v["pk"]), al, ad)
+            assert not vrf.tiny_verify(s, proof, bytes.fromhex(v["pk"]), al + b"x", ad)
+            assert vrf.point_to_hash(s, bsn.decompress(proof[:32])).hex() == v["beta"][:64]
 
 
 @pytest.mark.parametrize("suite,rel", PEDERSEN)
 def test_pedersen_vrf_kats(golden_dir, suite, rel):
     s = SUITES[suite]
-    for v in _load(golden_dir, rel):
-        sk, al, ad = (bytes.fromhex(v[k]) for k in ("sk", "alpha", "ad"))
-        proof, blinding = vrf.pedersen_prove(s, al, sk, ad)
-        assert proof.hex() == v["gamma"] + v["proof_pk_com"] + v["proof_r"] + v["proof_ok"] + v["proof_s"] + v["proof_sb"]
-        assert bsn.enc_scalar(blinding).hex() == v["blinding"]
-        assert vrf.pedersen_verify(s, proof, al, ad)
-        assert not vrf.pedersen_verify(s, proof, al, ad + b"x")
+    with bsn.using(s):
+        for v in _load(golden_dir, rel):
+            sk, al, ad = (bytes.fromhex(v[k]) for k in ("sk", "alpha", "ad"))
+            proof, blinding = vrf.pedersen_prove(s, al, sk, ad)
+            assert proof.hex() == v["gamma"] + v["proof_pk_com"] + v["proof_r"] + v["proof_ok"] + v["proof_s"] + v["proof_sb"]
+            assert bsn.enc_scalar(blinding).hex() == v["blinding"]
+            assert vrf.pedersen_verify(s, proof, al, ad)
+            assert not vrf.pedersen_verify(s, proof, al, ad + b"x")
 
 
 @pytest.mark.parametrize("suite,rel", RING)
@@ -169,17 +174,18 @@ def test_ring_vrf_kats_byte_exact(golden_dir, suite, rel):
     """Full 784-byte proofs incl. all ten G1 commitments per vector (the only tests that pin G1 MSM values:
     /root/reference/tests/test_ring_vrf/test_ring_vrf.py:41-45, tests/test_dot_ring_vectors.py:72)."""
     s = SUITES[suite]
-    for v in _load(golden_dir, rel):
-        sk, al, ad = (bytes.fromhex(v[k]) for k in ("sk", "alpha", "ad"))
-        raw = bytes.fromhex(v["ring_pks"])
-        keys = [raw[i : i + 32] for i in range(0, len(raw), 32)]
-        params = ring.Params(test_vectors=True, suite=s)
-        rg = ring.Ring(keys, params)
-        root = ring.RingRoot(rg)
-        assert root.encode().hex() == v["ring_pks_com"]
-        proof = ring.ring_vrf_prove(rg, root, al, ad, sk)
-        assert proof.hex() == (v["gamma"] + v["proof_pk_com"] + v["proof_r"] + v["proof_ok"] + v["proof_s"]
-                               + v["proof_sb"] + v["ring_proof"])
+    with bsn.using(s):
+        for v in _load(golden_dir, rel):
+            sk, al, ad = (bytes.fromhex(v[k]) for k in ("sk", "alpha", "ad"))
+            raw = bytes.fromhex(v["ring_pks"])
+            keys = [raw[i : i + 32] for i in range(0, len(raw), 32)]
+            params = ring.Params(test_vectors=True, suite=s)
+            rg = ring.Ring(keys, params)
+            root = ring.RingRoot(rg)
+            assert root.encode().hex() == v["ring_pks_com"]
+            proof = ring.ring_vrf_prove(rg, root, al, ad, sk)
+            assert proof.hex() == (v["gamma"] + v["proof_pk_com"] + v["proof_r"] + v["proof_ok"] + v["proof_s"]
+                                   + v["proof_sb"] + v["ring_proof"])
 
 
 def test_safrole_selector_commitment_n2048(golden_dir):
