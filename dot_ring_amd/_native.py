@@ -77,7 +77,7 @@ _PROTOTYPES = {
 class VrfSuiteStruct(ctypes.Structure):
     """dr_vrf_suite (include/dotring_hip.h)."""
     _fields_ = [("suite_id", c_char_p), ("suite_id_len", c_size_t), ("xof", c_int),
-                ("generator_xy", ctypes.c_uint8 * 64), ("blinding_base_xy", ctypes.c_uint8 * 64)]
+                ("generator_xy", ctypes.c_uint8 * 64), ("blinding_base_xy", ctypes.c_uint8 * 64), ("curve", c_int)]
 
 
 class RingVerifierKeyStruct(ctypes.Structure):
@@ -93,6 +93,13 @@ _PROTOTYPES.update({
                                         c_char_p, POINTER(c_int)]),
     "dr_g1_decompress_batch": (c_int, [c_void_p, c_char_p, c_size_t, c_char_p, c_char_p]),
     "dr_bsn_decode_points": (c_int, [c_void_p, c_char_p, c_size_t, c_char_p, c_char_p]),
+    "dr_te_scalar_mul_batch": (c_int, [c_void_p, c_int, c_char_p, c_char_p, c_size_t, c_void_p]),
+    "dr_te_msm": (c_int, [c_void_p, c_int, c_char_p, c_char_p, c_size_t, c_void_p]),
+    "dr_te_msm_groups": (c_int, [c_void_p, c_int, c_char_p, c_char_p, c_size_t, c_size_t, c_void_p]),
+    "dr_te_decode_points": (c_int, [c_void_p, c_int, c_char_p, c_size_t, c_char_p, c_char_p]),
+    "dr_encode_to_curve_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_char_p, POINTER(ctypes.c_uint64), c_char_p,
+                                         POINTER(ctypes.c_uint64), c_size_t, c_char_p]),
+    "dr_ring_prover_create_te": (c_int, [c_void_p, c_int, c_void_p, c_uint, c_uint, c_char_p, c_char_p, c_char_p, c_char_p, POINTER(c_void_p)]),
     "dr_pairing_selfcheck": (c_int, [c_char_p, c_char_p, c_size_t, POINTER(c_int)]),
     "dr_pedersen_prove_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_size_t, c_char_p, POINTER(ctypes.c_uint64), c_char_p,
                                         POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p, c_char_p, c_char_p]),
@@ -121,10 +128,13 @@ def _ragged(items):
     return b"".join(items), off
 
 
-def vrf_suite(suite_id: bytes, xof: bool, generator_xy: bytes, blinding_base_xy: bytes) -> VrfSuiteStruct:
+CURVE_BANDERSNATCH, CURVE_JUBJUB = 0, 1
+
+
+def vrf_suite(suite_id: bytes, xof: bool, generator_xy: bytes, blinding_base_xy: bytes, curve: int = CURVE_BANDERSNATCH) -> VrfSuiteStruct:
     s = VrfSuiteStruct()
     s._keep = bytes(suite_id)
-    s.suite_id, s.suite_id_len, s.xof = s._keep, len(s._keep), 1 if xof else 0
+    s.suite_id, s.suite_id_len, s.xof, s.curve = s._keep, len(s._keep), 1 if xof else 0, curve
     ctypes.memmove(s.generator_xy, generator_xy, 64)
     ctypes.memmove(s.blinding_base_xy, blinding_base_xy, 64)
     return s
@@ -262,12 +272,13 @@ class Srs:
 class RingProver:
     """Device-resident batched ring prover for one ring (dr_ring_prover_*)."""
 
-    def __init__(self, ctx: "Context", srs: Srs, log2n: int, max_ring: int, omega_n: int, omega_4n: int, nm_points_xy: bytes, seed_xy: bytes):
+    def __init__(self, ctx: "Context", srs: Srs, log2n: int, max_ring: int, omega_n: int, omega_4n: int, nm_points_xy: bytes, seed_xy: bytes,
+                 curve: int = CURVE_BANDERSNATCH):
         self.ctx, self.srs = ctx, srs
         self.n = 1 << log2n
         self.handle = c_void_p()
-        _check(lib().dr_ring_prover_create(ctx.handle, srs.handle, log2n, max_ring, omega_n.to_bytes(32, "little"),
-                                           omega_4n.to_bytes(32, "little"), nm_points_xy, seed_xy, byref(self.handle)))
+        _check(lib().dr_ring_prover_create_te(ctx.handle, curve, srs.handle, log2n, max_ring, omega_n.to_bytes(32, "little"),
+                                              omega_4n.to_bytes(32, "little"), nm_points_xy, seed_xy, byref(self.handle)))
 
     def close(self) -> None:
         if self.handle:
@@ -363,33 +374,52 @@ class Context:
         return ms.value, cnt.value
 
     # ---- seam A
-    def bsn_scalar_mul_batch(self, pts_xy: bytes, scalars: bytes) -> bytes:
+    # (curve = CURVE_BANDERSNATCH / CURVE_JUBJUB; the default goes through the dr_bsn_* names of the original seam)
+    def bsn_scalar_mul_batch(self, pts_xy: bytes, scalars: bytes, curve: int = CURVE_BANDERSNATCH) -> bytes:
         n = len(scalars) // 32
         if len(scalars) != 32 * n or len(pts_xy) != 64 * n:
             raise ValueError("Points and scalars must have same length")
         out = ctypes.create_string_buffer(max(64 * n, 1))
-        _check(lib().dr_bsn_scalar_mul_batch(self.handle, pts_xy, scalars, n, out))
+        if curve == CURVE_BANDERSNATCH:
+            _check(lib().dr_bsn_scalar_mul_batch(self.handle, pts_xy, scalars, n, out))
+        else:
+            _check(lib().dr_te_scalar_mul_batch(self.handle, curve, pts_xy, scalars, n, out))
         return out.raw[: 64 * n]
 
     def bsn_scalar_mul_batch_dev(self, d_pts: DeviceBuffer, d_scalars: DeviceBuffer, n: int, d_out: DeviceBuffer) -> None:
         _check(lib().dr_bsn_scalar_mul_batch_dev(self.handle, d_pts.ptr, d_scalars.ptr, n, d_out.ptr))
 
-    def bsn_msm(self, pts_xy: bytes, scalars: bytes) -> bytes:
+    def bsn_msm(self, pts_xy: bytes, scalars: bytes, curve: int = CURVE_BANDERSNATCH) -> bytes:
         n = len(scalars) // 32
         if len(scalars) != 32 * n or len(pts_xy) != 64 * n:
             raise ValueError("Points and scalars must have same length")
         out = ctypes.create_string_buffer(64)
-        _check(lib().dr_bsn_msm(self.handle, pts_xy, scalars, n, out))
+        if curve == CURVE_BANDERSNATCH:
+            _check(lib().dr_bsn_msm(self.handle, pts_xy, scalars, n, out))
+        else:
+            _check(lib().dr_te_msm(self.handle, curve, pts_xy, scalars, n, out))
         return out.raw
 
-    def bsn_msm_groups(self, pts_xy: bytes, scalars: bytes, m: int) -> bytes:
+    def bsn_msm_groups(self, pts_xy: bytes, scalars: bytes, m: int, curve: int = CURVE_BANDERSNATCH) -> bytes:
         n = len(scalars) // 32
         if m <= 0 or n % m or len(scalars) != 32 * n or len(pts_xy) != 64 * n:
             raise ValueError("Points and scalars must have same length (a multiple of the group size)")
         groups = n // m
         out = ctypes.create_string_buffer(max(64 * groups, 1))
-        _check(lib().dr_bsn_msm_groups(self.handle, pts_xy, scalars, groups, m, out))
+        if curve == CURVE_BANDERSNATCH:
+            _check(lib().dr_bsn_msm_groups(self.handle, pts_xy, scalars, groups, m, out))
+        else:
+            _check(lib().dr_te_msm_groups(self.handle, curve, pts_xy, scalars, groups, m, out))
         return out.raw[: 64 * groups]
+
+    def encode_to_curve_batch(self, suite: "VrfSuiteStruct", msgs, salts=None) -> bytes:
+        """dr_encode_to_curve_batch: encode_to_curve(salt_i || msg_i) by the suite's own method -> count * 64 bytes x||y."""
+        count = len(msgs)
+        m_blob, m_off = _ragged([bytes(m) for m in msgs])
+        s_blob, s_off = (None, None) if not salts or not any(salts) else _ragged([bytes(x) for x in salts])
+        out = ctypes.create_string_buffer(max(64 * count, 1))
+        _check(lib().dr_encode_to_curve_batch(self.handle, byref(suite), m_blob, m_off, s_blob, s_off, count, out))
+        return out.raw[: 64 * count]
 
     def bsn_encode_to_curve_batch(self, u_pairs: bytes) -> bytes:
         n = len(u_pairs) // 64
@@ -432,13 +462,16 @@ class Context:
         pts = [None if raw[96 * i : 96 * i + 96] == zero else raw[96 * i : 96 * i + 96] for i in range(count)]
         return pts, ok.raw[:count]
 
-    def bsn_decode_points(self, enc: bytes):
+    def bsn_decode_points(self, enc: bytes, curve: int = CURVE_BANDERSNATCH):
         """dec_point for len(enc)/32 compressed points on the GPU -> (affine x||y bytes, validity flags)."""
         if len(enc) % 32:
             raise ValueError("compressed points are 32 bytes each")
         count = len(enc) // 32
         out, ok = ctypes.create_string_buffer(max(1, 64 * count)), ctypes.create_string_buffer(max(1, count))
-        _check(lib().dr_bsn_decode_points(self.handle, enc, count, out, ok))
+        if curve == CURVE_BANDERSNATCH:
+            _check(lib().dr_bsn_decode_points(self.handle, enc, count, out, ok))
+        else:
+            _check(lib().dr_te_decode_points(self.handle, curve, enc, count, out, ok))
         return out.raw[: 64 * count], ok.raw[:count]
 
     def pedersen_prove_batch(self, suite: "VrfSuiteStruct", alphas, ads, salts, secret_scalars: bytes):

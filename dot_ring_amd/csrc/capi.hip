@@ -174,6 +174,12 @@ int pick_window(size_t n) {
 }
 
 uint32_t g_chunk_len = 16;   // buckets per lane in k_g1_reduce_chunks (DOTRING_MSM_CHUNK)
+// launch kernel template K<CV> for the curve id cv (dr::CV_BANDERSNATCH / dr::CV_JUBJUB)
+#define LAUNCH_CV(cv, K, ...)                                                                  \
+    do {                                                                                        \
+        if ((cv) == dr::CV_JUBJUB) hipLaunchKernelGGL((K<dr::CV_JUBJUB>), __VA_ARGS__);         \
+        else hipLaunchKernelGGL((K<dr::CV_BANDERSNATCH>), __VA_ARGS__);                         \
+    } while (0)
 bool g_bsn_glv = true;       // GLV lane-pair kernels for latency-bound Bandersnatch launches (DOTRING_BSN_GLV=0: plain 64-window kernels)
 bool g_use_comb = true;      // use comb tables when an SRS has one (DOTRING_MSM_COMB=0: bucket method)
 bool g_chain_wave = true;    // one wave per proof for the witness accumulator chain (DOTRING_CHAIN_WAVE=0: one lane per proof)
@@ -717,7 +723,7 @@ int dr_prof_get(dr_ctx* ctx, const char* name, double* total_ms, int* launches) 
 }
 
 // ------------------------------------------------------------------------------- seam A
-int dr_bsn_scalar_mul_batch_dev(dr_ctx* ctx, const void* d_pts, const void* d_scalars, size_t n, void* d_out) {
+static int te_scalar_mul_batch_dev(dr_ctx* ctx, int cv, const void* d_pts, const void* d_scalars, size_t n, void* d_out) {
     TRY(use_ctx(ctx));
     if (n == 0) return DR_OK;
     if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "batch too large");
@@ -726,15 +732,19 @@ int dr_bsn_scalar_mul_batch_dev(dr_ctx* ctx, const void* d_pts, const void* d_sc
     static const long w2_from = std::getenv("DOTRING_BSN_W2_FROM") ? std::atol(std::getenv("DOTRING_BSN_W2_FROM")) : 32768;
     TRY(launch(ctx, "k_bsn_scalar_mul", [&] {
         if (w2_from > 0 && n >= (size_t)w2_from)
-            hipLaunchKernelGGL(dr::k_bsn_scalar_mul_w2, dim3(div_up(n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
-                               (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t*)d_out, (uint32_t)n);
+            LAUNCH_CV(cv, dr::k_bsn_scalar_mul_w2, dim3(div_up(n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
+                      (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t*)d_out, (uint32_t)n);
         else
-            hipLaunchKernelGGL(dr::k_bsn_scalar_mul, dim3(div_up(n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
-                               (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t*)d_out, (uint32_t)n);
+            LAUNCH_CV(cv, dr::k_bsn_scalar_mul, dim3(div_up(n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
+                      (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t*)d_out, (uint32_t)n);
     }));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->prof) TRY(prof_collect(ctx));
     return DR_OK;
+}
+static int check_curve(int cv) { return drh::te_curve(cv) ? DR_OK : fail(DR_ERR_INVALID, "unknown curve id"); }
+int dr_bsn_scalar_mul_batch_dev(dr_ctx* ctx, const void* d_pts, const void* d_scalars, size_t n, void* d_out) {
+    return te_scalar_mul_batch_dev(ctx, dr::CV_BANDERSNATCH, d_pts, d_scalars, n, d_out);
 }
 
 static int check_fr_elems(const uint8_t* p, size_t count, const char* what) {
@@ -771,12 +781,13 @@ static int glv_split_scalars(const uint8_t* scalars, size_t n, std::vector<uint3
     return DR_OK;
 }
 
-int dr_bsn_scalar_mul_batch(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars, size_t n, uint8_t* out_xy) {
+static int te_scalar_mul_batch(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_t* scalars, size_t n, uint8_t* out_xy) {
     TRY(use_ctx(ctx));
+    TRY(check_curve(cv));
     if (n == 0) return DR_OK;
     if (!pts_xy || !scalars || !out_xy) return fail(DR_ERR_INVALID, "null buffer");
     TRY(check_fr_elems(pts_xy, 2 * n, "point"));
-    if (g_bsn_glv && n < 16384) {       // latency-bound launch: halve the chain with GLV on lane pairs
+    if (g_bsn_glv && drh::te_curve(cv)->glv && n < 16384) {       // latency-bound launch: halve the chain with GLV on lane pairs
         std::vector<uint32_t> split;
         TRY(glv_split_scalars(scalars, n, split));
         TRY(ctx->io_a.reserve(n * 64));
@@ -798,21 +809,28 @@ int dr_bsn_scalar_mul_batch(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* s
     TRY(ctx->io_c.reserve(n * 64));
     HIP_TRY(hipMemcpyAsync(ctx->io_a.p, pts_xy, n * 64, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->io_b.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    TRY(dr_bsn_scalar_mul_batch_dev(ctx, ctx->io_a.p, ctx->io_b.p, n, ctx->io_c.p));
+    TRY(te_scalar_mul_batch_dev(ctx, cv, ctx->io_a.p, ctx->io_b.p, n, ctx->io_c.p));
     HIP_TRY(hipMemcpyAsync(out_xy, ctx->io_c.p, n * 64, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return DR_OK;
 }
+int dr_bsn_scalar_mul_batch(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars, size_t n, uint8_t* out_xy) {
+    return te_scalar_mul_batch(ctx, dr::CV_BANDERSNATCH, pts_xy, scalars, n, out_xy);
+}
+int dr_te_scalar_mul_batch(dr_ctx* ctx, int curve, const uint8_t* pts_xy, const uint8_t* scalars, size_t n, uint8_t* out_xy) {
+    return te_scalar_mul_batch(ctx, curve, pts_xy, scalars, n, out_xy);
+}
 
-int dr_bsn_msm_groups(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars, size_t groups, size_t m, uint8_t* out_xy) {
+static int te_msm_groups(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_t* scalars, size_t groups, size_t m, uint8_t* out_xy) {
     TRY(use_ctx(ctx));
+    TRY(check_curve(cv));
     if (groups == 0) return DR_OK;
     if (m == 0 || m > 64) return fail(DR_ERR_INVALID, "group size must be in 1..64");
     if (!pts_xy || !scalars || !out_xy) return fail(DR_ERR_INVALID, "null buffer");
     size_t n = groups * m;
     if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "batch too large");
     TRY(check_fr_elems(pts_xy, 2 * n, "point"));
-    if (g_bsn_glv && m <= 32 && n < 16384) {
+    if (g_bsn_glv && drh::te_curve(cv)->glv && m <= 32 && n < 16384) {
         std::vector<uint32_t> split;
         TRY(glv_split_scalars(scalars, n, split));
         uint32_t mpad2 = 2;
@@ -841,18 +859,24 @@ int dr_bsn_msm_groups(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars
     HIP_TRY(hipMemcpyAsync(ctx->io_b.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
     const uint32_t per_block = dr::BSN_BLOCK / mpad;
     TRY(launch(ctx, "k_bsn_msm_groups", [&] {
-        hipLaunchKernelGGL(dr::k_bsn_msm_groups, dim3(div_up(groups, per_block)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
-                           ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>(), (uint32_t)groups,
-                           (uint32_t)m, mpad);
+        LAUNCH_CV(cv, dr::k_bsn_msm_groups, dim3(div_up(groups, per_block)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
+                  ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>(), (uint32_t)groups, (uint32_t)m, mpad);
     }));
     HIP_TRY(hipMemcpyAsync(out_xy, ctx->io_c.p, groups * 64, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->prof) TRY(prof_collect(ctx));
     return DR_OK;
 }
+int dr_bsn_msm_groups(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars, size_t groups, size_t m, uint8_t* out_xy) {
+    return te_msm_groups(ctx, dr::CV_BANDERSNATCH, pts_xy, scalars, groups, m, out_xy);
+}
+int dr_te_msm_groups(dr_ctx* ctx, int curve, const uint8_t* pts_xy, const uint8_t* scalars, size_t groups, size_t m, uint8_t* out_xy) {
+    return te_msm_groups(ctx, curve, pts_xy, scalars, groups, m, out_xy);
+}
 
-int dr_bsn_msm(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars, size_t n, uint8_t out_xy[64]) {
+static int te_msm(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_t* scalars, size_t n, uint8_t out_xy[64]) {
     TRY(use_ctx(ctx));
+    TRY(check_curve(cv));
     if (!out_xy) return fail(DR_ERR_INVALID, "null buffer");
     if (n == 0) {
         std::memset(out_xy, 0, 64);
@@ -861,25 +885,25 @@ int dr_bsn_msm(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars, size_
     }
     // fold 64 terms at a time on the device (one launch); the n/64 partial sums are then added on the host in extended
     // coordinates — a second device pass would pay a full scalar-multiplication latency for scalars that are all 1
-    if (n <= 64) return dr_bsn_msm_groups(ctx, pts_xy, scalars, 1, n, out_xy);
+    if (n <= 64) return te_msm_groups(ctx, cv, pts_xy, scalars, 1, n, out_xy);
     const size_t parts = (n + 63) / 64;
     std::vector<uint8_t> part(parts * 64);
     if (n % 64 == 0) {
-        TRY(dr_bsn_msm_groups(ctx, pts_xy, scalars, parts, 64, part.data()));
+        TRY(te_msm_groups(ctx, cv, pts_xy, scalars, parts, 64, part.data()));
     } else {        // pad the last group with 0 * (0, 1) so that everything is ONE launch
         std::vector<uint8_t> pp(parts * 64 * 64, 0), kk(parts * 64 * 32, 0);
         std::memcpy(pp.data(), pts_xy, n * 64);
         std::memcpy(kk.data(), scalars, n * 32);
         for (size_t i = n; i < parts * 64; i++) pp[64 * i + 32] = 1;
-        TRY(dr_bsn_msm_groups(ctx, pp.data(), kk.data(), parts, 64, part.data()));
+        TRY(te_msm_groups(ctx, cv, pp.data(), kk.data(), parts, 64, part.data()));
     }
     using drh::Fr;
-    static const uint8_t D_LE[32] = {0xe7, 0x58, 0x8d, 0x18, 0xf5, 0xf2, 0x69, 0xb3, 0x92, 0x4f, 0xe5, 0x77, 0x71, 0x67, 0x66, 0xcb,
-                                     0xd8, 0xb6, 0xe3, 0x6b, 0xf8, 0x3b, 0x6e, 0xc6, 0xcb, 0x67, 0xc2, 0x33, 0x26, 0xc1, 0x89, 0x63};
-    Fr d, five = Fr::from_u64(5);
+    uint8_t D_LE[32];
+    drh::store_le32(drh::te_curve(cv)->d, D_LE);
+    Fr d, five = Fr::from_u64(drh::te_curve(cv)->neg_a[0]);        // -a
     if (!Fr::load_le(d, D_LE)) return fail(DR_ERR_DEVICE, "bad curve constant");
     Fr X = Fr::zero(), Y = Fr::one(), Z = Fr::one(), T = Fr::zero();          // identity
-    for (size_t i = 0; i < parts; i++) {                                      // add-2008-hwcd with Z2 = 1, a = -5
+    for (size_t i = 0; i < parts; i++) {                                      // add-2008-hwcd with Z2 = 1
         Fr x2, y2;
         if (!Fr::load_le(x2, part.data() + 64 * i) || !Fr::load_le(y2, part.data() + 64 * i + 32)) return fail(DR_ERR_DEVICE, "kernel result out of range");
         Fr A = X * x2, B = Y * y2, C = T * d * (x2 * y2), D = Z;
@@ -891,9 +915,32 @@ int dr_bsn_msm(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars, size_
     (Y * zi).store_le(out_xy + 32);
     return DR_OK;
 }
+int dr_bsn_msm(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars, size_t n, uint8_t out_xy[64]) {
+    return te_msm(ctx, dr::CV_BANDERSNATCH, pts_xy, scalars, n, out_xy);
+}
+int dr_te_msm(dr_ctx* ctx, int curve, const uint8_t* pts_xy, const uint8_t* scalars, size_t n, uint8_t out_xy[64]) {
+    return te_msm(ctx, curve, pts_xy, scalars, n, out_xy);
+}
 
-int dr_bsn_decode_points(dr_ctx* ctx, const uint8_t* enc, size_t n, uint8_t* out_xy, uint8_t* ok) {
+// launch the point decoder for `n` encodings already at d_enc: Bandersnatch = the GLV lane-pair kernel, JubJub = the
+// generic one; tai = candidates of try-and-increment (output hP, no subgroup test)
+static void launch_decode_points(dr_ctx* ctx, hipStream_t st, int cv, bool tai, const uint32_t* d_enc, uint32_t* d_xy, uint32_t* d_ok, size_t n) {
+    if (tai) {
+        if (cv == dr::CV_JUBJUB)
+            hipLaunchKernelGGL((dr::k_te_decode_points<dr::CV_JUBJUB, true>), dim3(div_up(n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, st, d_enc, d_xy, d_ok, (uint32_t)n);
+        else
+            hipLaunchKernelGGL((dr::k_te_decode_points<dr::CV_BANDERSNATCH, true>), dim3(div_up(n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, st, d_enc, d_xy, d_ok, (uint32_t)n);
+    } else if (cv == dr::CV_JUBJUB) {
+        hipLaunchKernelGGL((dr::k_te_decode_points<dr::CV_JUBJUB, false>), dim3(div_up(n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, st, d_enc, d_xy, d_ok, (uint32_t)n);
+    } else {
+        hipLaunchKernelGGL(dr::k_bsn_decode_points, dim3(div_up(2 * n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, st, d_enc, d_xy, d_ok, (uint32_t)n);
+    }
+    (void)ctx;
+}
+
+static int te_decode_points(dr_ctx* ctx, int cv, bool tai, const uint8_t* enc, size_t n, uint8_t* out_xy, uint8_t* ok) {
     TRY(use_ctx(ctx));
+    TRY(check_curve(cv));
     if (n == 0) return DR_OK;
     if (!enc || !out_xy || !ok) return fail(DR_ERR_INVALID, "null buffer");
     if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "batch too large");
@@ -902,8 +949,7 @@ int dr_bsn_decode_points(dr_ctx* ctx, const uint8_t* enc, size_t n, uint8_t* out
     TRY(ctx->io_c.reserve(n * 4));
     HIP_TRY(hipMemcpyAsync(ctx->io_a.p, enc, n * 32, hipMemcpyHostToDevice, ctx->stream));
     TRY(launch(ctx, "k_bsn_decode_points", [&] {
-        hipLaunchKernelGGL(dr::k_bsn_decode_points, dim3(div_up(2 * n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream, ctx->io_a.as<uint32_t>(),
-                           ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>(), (uint32_t)n);
+        launch_decode_points(ctx, ctx->stream, cv, tai, ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>(), n);
     }));
     std::vector<uint32_t> flags(n);
     HIP_TRY(hipMemcpyAsync(out_xy, ctx->io_b.p, n * 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -912,6 +958,12 @@ int dr_bsn_decode_points(dr_ctx* ctx, const uint8_t* enc, size_t n, uint8_t* out
     if (ctx->prof) TRY(prof_collect(ctx));
     for (size_t i = 0; i < n; i++) ok[i] = flags[i] ? 1 : 0;
     return DR_OK;
+}
+int dr_bsn_decode_points(dr_ctx* ctx, const uint8_t* enc, size_t n, uint8_t* out_xy, uint8_t* ok) {
+    return te_decode_points(ctx, dr::CV_BANDERSNATCH, false, enc, n, out_xy, ok);
+}
+int dr_te_decode_points(dr_ctx* ctx, int curve, const uint8_t* enc, size_t n, uint8_t* out_xy, uint8_t* ok) {
+    return te_decode_points(ctx, curve, false, enc, n, out_xy, ok);
 }
 
 int dr_bsn_encode_to_curve_batch(dr_ctx* ctx, const uint8_t* u_pairs, size_t n, uint8_t* out_xy) {
@@ -1418,6 +1470,7 @@ int dr_ntt(dr_ctx* ctx, uint8_t* data, unsigned log2n, size_t batch, const uint8
 struct dr_ring_prover {
     dr_ctx* ctx = nullptr;
     const dr_srs* srs = nullptr;
+    int curve = dr::CV_BANDERSNATCH;     // which twisted Edwards curve the ring's keys live on
     dr::RingConsts rc{};
     drh::Fr omega_n, omega_4n;          // Montgomery
     const dr_srs* ps_srs = nullptr;      // prefix-summed Lagrange bases of this domain (owned by srs->lagrange_prefix)
@@ -1505,12 +1558,18 @@ extern "C" {
 
 int dr_ring_prover_create(dr_ctx* ctx, const dr_srs* srs, unsigned log2n, uint32_t max_ring, const uint8_t omega_n[32],
                           const uint8_t omega_4n[32], const uint8_t* nm_points_xy, const uint8_t seed_xy[64], dr_ring_prover** out) {
+    return dr_ring_prover_create_te(ctx, dr::CV_BANDERSNATCH, srs, log2n, max_ring, omega_n, omega_4n, nm_points_xy, seed_xy, out);
+}
+
+int dr_ring_prover_create_te(dr_ctx* ctx, int curve, const dr_srs* srs, unsigned log2n, uint32_t max_ring, const uint8_t omega_n[32],
+                             const uint8_t omega_4n[32], const uint8_t* nm_points_xy, const uint8_t seed_xy[64], dr_ring_prover** out) {
     TRY(use_ctx(ctx));
     if (!out || !srs || !omega_n || !omega_4n || !nm_points_xy || !seed_xy) return fail(DR_ERR_INVALID, "null argument");
     *out = nullptr;
+    TRY(check_curve(curve));
     if (log2n < 9 || log2n > 12) return fail(DR_ERR_INVALID, "domain_size must be between 512 and 4096");
     const uint32_t n = 1u << log2n, m = 4 * n;
-    if (max_ring + 253 + 4 > n) return fail(DR_ERR_INVALID, "max_ring_size exceeds supported size");
+    if (max_ring + drh::te_curve(curve)->scalar_bits + 4 > n) return fail(DR_ERR_INVALID, "max_ring_size exceeds supported size");
     if (srs->count < 3 * (size_t)n + 1) return fail(DR_ERR_INVALID, "polynomial degree exceeds SRS size");
     TRY(check_fr_elems(nm_points_xy, 2 * (size_t)n, "ring point"));
     TRY(check_fr_elems(seed_xy, 2, "seed point"));
@@ -1519,6 +1578,7 @@ int dr_ring_prover_create(dr_ctx* ctx, const dr_srs* srs, unsigned log2n, uint32
     std::unique_ptr<dr_ring_prover, void (*)(dr_ring_prover*)> guard(p, [](dr_ring_prover* q) { dr_ring_prover_destroy(q); });
     p->ctx = ctx;
     p->srs = srs;
+    p->curve = curve;
     if (!drh::Fr::load_le(p->omega_n, omega_n) || !drh::Fr::load_le(p->omega_4n, omega_4n))
         return fail(DR_ERR_INVALID, "omega is not a canonical field element");
     if (std::getenv("DOTRING_WITNESS_BY_PARTS") == nullptr || std::atoi(std::getenv("DOTRING_WITNESS_BY_PARTS")) != 0)
@@ -1638,11 +1698,11 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
     }
     TRY(launch(ctx, "k_ring_chain", [&] {
         if (g_chain_wave)
-            hipLaunchKernelGGL(dr::k_ring_chain_wave, dim3((unsigned)batch), dim3(64), 0, st, p->ring_pts_mont.as<uint32_t>(), p->idx.as<uint32_t>(),
+            LAUNCH_CV(p->curve, dr::k_ring_chain_wave, dim3((unsigned)batch), dim3(64), 0, st, p->ring_pts_mont.as<uint32_t>(), p->idx.as<uint32_t>(),
                                p->blind.as<uint32_t>(), rc, (uint32_t)batch, p->chain_ext.as<uint32_t>(), p->chain_aff.as<uint32_t>(),
                                p->cnt.as<uint32_t>());
         else
-            hipLaunchKernelGGL(dr::k_ring_chain, dim3(div_up(batch, 64)), dim3(64), 0, st, p->ring_pts_mont.as<uint32_t>(), p->idx.as<uint32_t>(),
+            LAUNCH_CV(p->curve, dr::k_ring_chain, dim3(div_up(batch, 64)), dim3(64), 0, st, p->ring_pts_mont.as<uint32_t>(), p->idx.as<uint32_t>(),
                                p->blind.as<uint32_t>(), rc, (uint32_t)batch, p->chain_ext.as<uint32_t>(), p->prefix.as<uint32_t>(),
                                p->chain_aff.as<uint32_t>(), p->cnt.as<uint32_t>());
     }));
@@ -1690,7 +1750,7 @@ int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alpha
     }));
     TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch * 4, false));
     TRY(launch(ctx, "k_ring_constraints", [&] {
-        hipLaunchKernelGGL(dr::k_ring_constraints, dim3(div_up(batch * m, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(), p->fixed4.as<uint32_t>(),
+        LAUNCH_CV(p->curve, dr::k_ring_constraints, dim3(div_up(batch * m, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(), p->fixed4.as<uint32_t>(),
                            p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas.as<uint32_t>(), p->rps.as<uint32_t>(), rc,
                            (uint32_t)batch, p->agg.as<uint32_t>());
     }));
@@ -1723,7 +1783,7 @@ int dr_ring_prove_evals(dr_ring_prover* p, size_t batch, const uint8_t* zetas, u
                            p->cols.as<uint32_t>(), 4u, n, p->zetas.as<uint32_t>(), 0, rc, p->evals.as<uint32_t>(), 8u, 0u);
     }));
     TRY(launch(ctx, "k_ring_linpoly", [&] {
-        hipLaunchKernelGGL(dr::k_ring_lin_scalars, dim3(div_up(batch, 64)), dim3(64), 0, st, p->evals.as<uint32_t>(), p->alphas.as<uint32_t>(),
+        LAUNCH_CV(p->curve, dr::k_ring_lin_scalars, dim3(div_up(batch, 64)), dim3(64), 0, st, p->evals.as<uint32_t>(), p->alphas.as<uint32_t>(),
                            p->zetas.as<uint32_t>(), rc, (uint32_t)batch, p->ks.as<uint32_t>());
         hipLaunchKernelGGL(dr::k_ring_linpoly, dim3(div_up(batch * n, 256)), dim3(256), 0, st, p->cols.as<uint32_t>(), p->ks.as<uint32_t>(), n,
                            (uint32_t)batch, p->lin.as<uint32_t>());
@@ -1831,6 +1891,56 @@ int load_suite(const dr_vrf_suite* s, drh::VrfSuite& out) {
     out.xof = s->xof != 0;
     std::memcpy(out.generator, s->generator_xy, 64);
     std::memcpy(out.blinding_base, s->blinding_base_xy, 64);
+    out.cv = drh::te_curve(s->curve);
+    if (!out.cv) return fail(DR_ERR_INVALID, "unknown curve id in VRF suite");
+    return DR_OK;
+}
+
+// encode_to_curve of B messages salt_i || data_i (salts nullable) into affine points.  Elligator 2 suites: hash_to_field
+// on worker threads + one launch.  Try-and-increment suites (dot_ring/curve/point.py:252-296): the candidates of counters
+// [0,4) of every message go through ONE decode launch, the (1/16 of the) messages none of whose candidates decompressed
+// continue with counters [4,12), and so on — the first counter that works is the one the sequential loop would stop at.
+int encode_to_curve_msgs(dr_ctx* ctx, const drh::VrfSuite& su, size_t B, const uint8_t* data, const uint64_t* off, const uint8_t* salts,
+                         const uint64_t* salt_off, uint8_t* out_xy) {
+    if (B == 0) return DR_OK;
+    std::vector<drh::Bytes> msgs(B);
+    auto build = [&](size_t i) {
+        drh::Bytes& m = msgs[i];
+        if (salt_off) drh::put(m, salts + salt_off[i], salt_off[i + 1] - salt_off[i]);
+        drh::put(m, data + off[i], off[i + 1] - off[i]);
+    };
+    if (!su.cv->tai) {
+        std::vector<uint8_t> us(B * 64);
+        drh::parallel_for(B, [&](size_t i) {
+            build(i);
+            drh::hash_to_field2(su, msgs[i].data(), msgs[i].size(), us.data() + 64 * i);
+        });
+        return dr_bsn_encode_to_curve_batch(ctx, us.data(), B, out_xy);
+    }
+    drh::parallel_for(B, build);
+    std::vector<size_t> pending(B);
+    for (size_t i = 0; i < B; i++) pending[i] = i;
+    std::vector<uint8_t> cand, xy, ok;
+    for (unsigned base = 0; !pending.empty();) {
+        if (base >= 256) return fail(DR_ERR_INVALID, "hash_to_curve_tai failed");
+        const unsigned K = std::min<unsigned>(base == 0 ? 4 : 8, 256 - base);
+        const size_t n = pending.size() * K;
+        cand.resize(n * 32); xy.resize(n * 64); ok.resize(n);
+        drh::parallel_for(n, [&](size_t j) {
+            const drh::Bytes& m = msgs[pending[j / K]];
+            drh::tai_candidate(su, m.data(), m.size(), base + (unsigned)(j % K), cand.data() + 32 * j);
+        });
+        TRY(te_decode_points(ctx, su.cv->id, true, cand.data(), n, xy.data(), ok.data()));
+        std::vector<size_t> still;
+        for (size_t q = 0; q < pending.size(); q++) {
+            unsigned k = 0;
+            while (k < K && !ok[q * K + k]) k++;
+            if (k == K) still.push_back(pending[q]);
+            else std::memcpy(out_xy + 64 * pending[q], xy.data() + 64 * (q * K + k), 64);
+        }
+        pending.swap(still);
+        base += K;
+    }
     return DR_OK;
 }
 }  // namespace
@@ -1843,6 +1953,23 @@ int dr_hash_to_field_batch(const dr_vrf_suite* suite, const uint8_t* msgs, const
         if (off[i + 1] < off[i]) return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
     drh::parallel_for(count, [&](size_t i) { drh::hash_to_field2(su, msgs + off[i], off[i + 1] - off[i], out_u_pairs + 64 * i); });
     return DR_OK;
+}
+
+int dr_encode_to_curve_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const uint8_t* msgs, const uint64_t* off, const uint8_t* salts,
+                             const uint64_t* salt_off, size_t count, uint8_t* out_xy) {
+    try {
+        TRY(use_ctx(ctx));
+        drh::VrfSuite su;
+        TRY(load_suite(suite, su));
+        if (count && (!off || !out_xy || (off[count] && !msgs))) return fail(DR_ERR_INVALID, "null buffer");
+        for (size_t i = 0; i < count; i++)
+            if (off[i + 1] < off[i] || (salt_off && salt_off[i + 1] < salt_off[i])) return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
+        return encode_to_curve_msgs(ctx, su, count, msgs, off, salts, salt_off, out_xy);
+    } catch (const std::bad_alloc&) {
+        return fail(DR_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_DEVICE, std::string("encode_to_curve: ") + e.what());
+    }
 }
 
 // The whole batch in one call: Pedersen VRF part (pedersen/vrf.py:86-126) then the ring proof
@@ -1859,24 +1986,20 @@ struct PedersenBatch {
 
     int head(dr_ctx* ctx, const uint8_t* alphas, const uint64_t* alpha_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts,
              const uint64_t* salt_off, const uint8_t* secret_scalars, PhaseTrace& tr_) {
-        const drh::Mod256& mn = drh::mod_n();
-        // 1. hash_to_field(salt || alpha), secrets mod n
-        us.resize(B * 64); xs.resize(B * 32);
-        drh::parallel_for(B, [&](size_t i) {
-            drh::Bytes msg;
-            if (salt_off) drh::put(msg, salts + salt_off[i], salt_off[i + 1] - salt_off[i]);
-            drh::put(msg, alphas + alpha_off[i], alpha_off[i + 1] - alpha_off[i]);
-            drh::hash_to_field2(su, msg.data(), msg.size(), us.data() + 64 * i);
+        const drh::Mod256& mn = su.cv->n;
+        const int cv = su.cv->id;
+        // 1. secrets mod n
+        xs.resize(B * 32);
+        for (size_t i = 0; i < B; i++) {
             uint64_t x[4];
             mn.reduce_bytes(secret_scalars + 32 * i, 32, false, x);
             drh::store_le32(x, xs.data() + 32 * i);
-        });
-        tr_.mark("h2f");
-        // 2. I_i = encode_to_curve, O_i = x_i * I_i
+        }
+        // 2. I_i = encode_to_curve(salt || alpha), O_i = x_i * I_i
         inputs.resize(B * 64); outs.resize(B * 64);
-        TRY(dr_bsn_encode_to_curve_batch(ctx, us.data(), B, inputs.data()));
+        TRY(encode_to_curve_msgs(ctx, su, B, alphas, alpha_off, salts, salt_off, inputs.data()));
         tr_.mark("encode");
-        TRY(dr_bsn_scalar_mul_batch(ctx, inputs.data(), xs.data(), B, outs.data()));
+        TRY(te_scalar_mul_batch(ctx, cv, inputs.data(), xs.data(), B, outs.data()));
         tr_.mark("x*I");
         // 3. transcripts, blinding factors
         tr.assign(B, drh::Bytes());
@@ -1911,10 +2034,11 @@ struct PedersenBatch {
 
     // out_proofs: 192 bytes per proof at `stride`; out_aux (nullable): O, Y_bar, R, O_k affine (4*64) + blinding (32) at aux_stride
     int tail(dr_ctx* actx, uint8_t* out_proofs, size_t stride, uint8_t* out_aux, size_t aux_stride) {
-        const drh::Mod256& mn = drh::mod_n();
+        const drh::Mod256& mn = su.cv->n;
+        const int cv = su.cv->id;
         ybar.resize(B * 64); ks.resize(B * 32); kbs.resize(B * 32); pts3.resize(2 * B * 128); sc3.resize(2 * B * 64); third.resize(2 * B * 64);
         // 4. blinded public keys  Y_bar_i = x_i*G + b_i*B
-        TRY(dr_bsn_msm_groups(actx, gb_pts.data(), sc.data(), B, 2, ybar.data()));
+        TRY(te_msm_groups(actx, cv, gb_pts.data(), sc.data(), B, 2, ybar.data()));
         // 5. nonces
         std::vector<int> bad2(B, 0);
         drh::parallel_for(B, [&](size_t i) {
@@ -1938,7 +2062,7 @@ struct PedersenBatch {
             std::memset(sc3.data() + 64 * (B + i) + 32, 0, 32);
         });
         for (size_t i = 0; i < B; i++) if (bad2[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
-        TRY(dr_bsn_msm_groups(actx, pts3.data(), sc3.data(), 2 * B, 2, third.data()));
+        TRY(te_msm_groups(actx, cv, pts3.data(), sc3.data(), 2 * B, 2, third.data()));
         // 6. challenge, responses, the 192 encoded bytes
         drh::parallel_for(B, [&](size_t i) {
             uint8_t* out = out_proofs + stride * i;
@@ -1978,6 +2102,7 @@ static int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite
     if (batch > 4096) return fail(DR_ERR_INVALID, "batch must be at most 4096 per call");
     drh::VrfSuite su;
     TRY(load_suite(suite, su));
+    if (su.cv->id != p->curve) return fail(DR_ERR_INVALID, "VRF suite and ring prover are on different curves");
     for (size_t i = 0; i < batch; i++)
         if (alpha_off[i + 1] < alpha_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
             return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
@@ -2112,7 +2237,7 @@ int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t 
 static int pedersen_verify_core(dr_ctx* actx, const drh::VrfSuite& su, size_t B, const uint8_t* proofs, size_t stride,
                                 const std::vector<uint8_t>& te_xy, const std::vector<uint8_t>& in_pts, const uint8_t* ads,
                                 const uint64_t* ad_off, int& ped_ok) {
-    const drh::Mod256& mn = drh::mod_n();
+    const drh::Mod256& mn = su.cv->n;
     std::vector<uint8_t> cs(B * 32);
     drh::parallel_for(B, [&](size_t i) {
         const uint8_t* pr = proofs + stride * i;
@@ -2165,7 +2290,7 @@ static int pedersen_verify_core(dr_ctx* actx, const drh::VrfSuite& su, size_t B,
         std::memcpy(pts.data() + 320 * B, su.generator, 64);           drh::store_le32(gs, sc.data() + 160 * B);
         std::memcpy(pts.data() + 320 * B + 64, su.blinding_base, 64);  drh::store_le32(bs, sc.data() + 160 * B + 32);
         uint8_t sum[64];
-        TRY(dr_bsn_msm(actx, pts.data(), sc.data(), 5 * B + 2, sum));
+        TRY(te_msm(actx, su.cv->id, pts.data(), sc.data(), 5 * B + 2, sum));
         uint8_t ident[64] = {0};
         ident[32] = 1;
         ped_ok = std::memcmp(sum, ident, 64) == 0 ? 1 : 0;
@@ -2188,7 +2313,7 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
         if (in_off[i + 1] < in_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
             return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
     const size_t B = batch;
-    const drh::Mod256& mn = drh::mod_n();
+    const drh::Mod256& mn = su.cv->n;
     const drh::Mod256& mp = drh::mod_p();
     hipStream_t st = ctx->stream;
 
@@ -2215,17 +2340,11 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
     if (!ctx->aux) TRY(dr_ctx_create(ctx->device, &ctx->aux));
     dr_ctx* actx = ctx->aux;
     actx->prof = ctx->prof;
-    std::vector<uint8_t> us(B * 64), in_pts(B * 64);
+    std::vector<uint8_t> in_pts(B * 64);
     int side_rc = DR_OK;
     std::string side_err;
     std::thread side([&] {
-        drh::parallel_for(B, [&](size_t i) {
-            drh::Bytes msg;
-            if (salt_off) drh::put(msg, salts + salt_off[i], salt_off[i + 1] - salt_off[i]);
-            drh::put(msg, inputs + in_off[i], in_off[i + 1] - in_off[i]);
-            drh::hash_to_field2(su, msg.data(), msg.size(), us.data() + 64 * i);
-        });
-        side_rc = dr_bsn_encode_to_curve_batch(actx, us.data(), B, in_pts.data());
+        side_rc = encode_to_curve_msgs(actx, su, B, inputs, in_off, salts, salt_off, in_pts.data());
         if (side_rc != DR_OK) side_err = dr_last_error();
     });
     struct Joiner {
@@ -2239,8 +2358,7 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
     HIP_TRY(hipMemcpyAsync(ctx->io_a.p, te_enc.data(), n_te * 32, hipMemcpyHostToDevice, st));
     uint32_t* d_ok = ctx->io_c.as<uint32_t>();
     TRY(launch(ctx, "k_bsn_decode_points", [&] {
-        hipLaunchKernelGGL(dr::k_bsn_decode_points, dim3(div_up(2 * n_te, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, st, ctx->io_a.as<uint32_t>(),
-                           ctx->io_b.as<uint32_t>(), d_ok, (uint32_t)n_te);
+        launch_decode_points(ctx, st, su.cv->id, false, ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), d_ok, n_te);
     }));
     std::vector<uint8_t> te_xy(n_te * 64);
     std::vector<uint32_t> flags(n_te + n_g1);
@@ -2313,9 +2431,9 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
         t.absorb_labeled("register_evaluations", pl + 192, 224);
         t.absorb_labeled("shifted_linearization_evaluation", pl + 464, 32);
         t.challenges("kzg_aggregation", 8, nus);
-        drh::te_add_affine(vk->seed_xy, relation, result_seed);
+        drh::te_add_affine(*su.cv, vk->seed_xy, relation, result_seed);
         drh::RingClaimScalars cl;
-        if (!drh::ring_verifier_terms(dm, al, nus, zeta, pl + 192, pl + 464, result_seed, cl)) { bad[i] = 1; return; }
+        if (!drh::ring_verifier_terms(*su.cv, dm, al, nus, zeta, pl + 192, pl + 464, result_seed, cl)) { bad[i] = 1; return; }
         // verifier randomness: two non-zero coefficients per proof
         uint64_t r[2][4];
         for (int k = 0; k < 2; k++) {
@@ -2454,25 +2572,19 @@ int dr_pedersen_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, size_t batc
         drh::VrfSuite su;
         TRY(load_suite(suite, su));
         const size_t B = batch;
-        const drh::Mod256& mn = drh::mod_n();
+        const drh::Mod256& mn = su.cv->n;
         for (size_t i = 0; i < B; i++)
             if (in_off[i + 1] < in_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
                 return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
-        std::vector<uint8_t> te_enc(B * 128), te_xy(B * 256), flags(B * 4), us(B * 64), in_pts(B * 64);
+        std::vector<uint8_t> te_enc(B * 128), te_xy(B * 256), flags(B * 4), in_pts(B * 64);
         for (size_t i = 0; i < B; i++) {
             std::memcpy(te_enc.data() + 128 * i, proofs + 192 * i, 128);
             uint64_t v[4];
             for (int k = 0; k < 2; k++) { drh::load_le32(proofs + 192 * i + 128 + 32 * k, v); if (drh::Mod256::geq(v, mn.m)) return DR_OK; }   // dec_scalar
         }
-        TRY(dr_bsn_decode_points(ctx, te_enc.data(), 4 * B, te_xy.data(), flags.data()));
+        TRY(te_decode_points(ctx, su.cv->id, false, te_enc.data(), 4 * B, te_xy.data(), flags.data()));
         for (size_t i = 0; i < 4 * B; i++) if (!flags[i]) return DR_OK;
-        drh::parallel_for(B, [&](size_t i) {
-            drh::Bytes msg;
-            if (salt_off) drh::put(msg, salts + salt_off[i], salt_off[i + 1] - salt_off[i]);
-            drh::put(msg, inputs + in_off[i], in_off[i + 1] - in_off[i]);
-            drh::hash_to_field2(su, msg.data(), msg.size(), us.data() + 64 * i);
-        });
-        TRY(dr_bsn_encode_to_curve_batch(ctx, us.data(), B, in_pts.data()));
+        TRY(encode_to_curve_msgs(ctx, su, B, inputs, in_off, salts, salt_off, in_pts.data()));
         int ped_ok = 0;
         TRY(pedersen_verify_core(ctx, su, B, proofs, 192, te_xy, in_pts, ads, ad_off, ped_ok));
         *ok = ped_ok;
@@ -2498,21 +2610,18 @@ int dr_ietf_prove_batch(dr_ctx* ctx, const dr_vrf_suite* suite, int thin, size_t
         drh::VrfSuite su;
         TRY(load_suite(suite, su));
         const size_t B = batch, plen = thin ? 96 : 80;
-        const drh::Mod256& mn = drh::mod_n();
+        const drh::Mod256& mn = su.cv->n;
+        const int cv = su.cv->id;
         for (size_t i = 0; i < B; i++)
             if (alpha_off[i + 1] < alpha_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
                 return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
-        std::vector<uint8_t> us(B * 64), xs(B * 32), inputs(B * 64);
-        drh::parallel_for(B, [&](size_t i) {
-            drh::Bytes msg;
-            if (salt_off) drh::put(msg, salts + salt_off[i], salt_off[i + 1] - salt_off[i]);
-            drh::put(msg, alphas + alpha_off[i], alpha_off[i + 1] - alpha_off[i]);
-            drh::hash_to_field2(su, msg.data(), msg.size(), us.data() + 64 * i);
+        std::vector<uint8_t> xs(B * 32), inputs(B * 64);
+        for (size_t i = 0; i < B; i++) {
             uint64_t x[4];
             mn.reduce_bytes(secret_scalars + 32 * i, 32, false, x);
             drh::store_le32(x, xs.data() + 32 * i);
-        });
-        TRY(dr_bsn_encode_to_curve_batch(ctx, us.data(), B, inputs.data()));
+        }
+        TRY(encode_to_curve_msgs(ctx, su, B, alphas, alpha_off, salts, salt_off, inputs.data()));
         // pk_i = x_i G and O_i = x_i I_i in one launch
         std::vector<uint8_t> pts(2 * B * 64), sc(2 * B * 32), firsts(2 * B * 64);
         for (size_t i = 0; i < B; i++) {
@@ -2521,7 +2630,7 @@ int dr_ietf_prove_batch(dr_ctx* ctx, const dr_vrf_suite* suite, int thin, size_t
             std::memcpy(sc.data() + 32 * i, xs.data() + 32 * i, 32);
             std::memcpy(sc.data() + 32 * (B + i), xs.data() + 32 * i, 32);
         }
-        TRY(dr_bsn_scalar_mul_batch(ctx, pts.data(), sc.data(), 2 * B, firsts.data()));
+        TRY(te_scalar_mul_batch(ctx, cv, pts.data(), sc.data(), 2 * B, firsts.data()));
         const uint8_t* pks = firsts.data();
         const uint8_t* outs = firsts.data() + 64 * B;
         // transcripts, delinearisation scalar z, nonces
@@ -2559,8 +2668,8 @@ int dr_ietf_prove_batch(dr_ctx* ctx, const dr_vrf_suite* suite, int thin, size_t
         });
         for (size_t i = 0; i < B; i++) if (bad[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
         std::vector<uint8_t> merged(B * 64), rs(B * 64);
-        TRY(dr_bsn_msm_groups(ctx, gpts.data(), gsc.data(), B, 2, merged.data()));
-        TRY(dr_bsn_scalar_mul_batch(ctx, merged.data(), ks.data(), B, rs.data()));
+        TRY(te_msm_groups(ctx, cv, gpts.data(), gsc.data(), B, 2, merged.data()));
+        TRY(te_scalar_mul_batch(ctx, cv, merged.data(), ks.data(), B, rs.data()));
         drh::parallel_for(B, [&](size_t i) {
             uint8_t* out = out_proofs + plen * i;
             uint8_t enc_r[32];

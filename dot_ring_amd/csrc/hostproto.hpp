@@ -156,6 +156,31 @@ inline const Mod256& mod_p() {       // Bandersnatch base field = BLS12-381 scal
     return s;
 }
 
+// The twisted Edwards curves over that field the library serves (ids as DR_CURVE_* in dotring_hip.h and CV_* in
+// curve.cuh): Bandersnatch (specs/bandersnatch.py:57-72) and JubJub (specs/jubjub.py:17-29).
+struct TeCurveHost {
+    int id;
+    Mod256 n;                 // prime-order subgroup
+    uint64_t d[4];            // curve coefficient d, standard form
+    uint64_t neg_a[4];        // -a as a small integer: 5 or 1
+    unsigned scalar_bits;     // bit length of n
+    bool glv;                 // has the endomorphism the lane-pair kernels use
+    bool tai;                 // hash-to-curve by try-and-increment (otherwise Elligator 2)
+};
+inline const TeCurveHost* te_curve(int id) {
+    static const TeCurveHost curves[2] = {
+        [] { TeCurveHost c{}; c.id = 0; c.n = mod_n();
+             const uint64_t d[4] = {0xb369f2f5188d58e7ULL, 0xcb66677177e54f92ULL, 0xc66e3bf86be3b6d8ULL, 0x6389c12633c267cbULL};
+             std::memcpy(c.d, d, 32); c.neg_a[0] = 5; c.scalar_bits = 253; c.glv = true; c.tai = false; return c; }(),
+        [] { TeCurveHost c{}; c.id = 1;
+             const uint64_t n[4] = {0xd0970e5ed6f72cb7ULL, 0xa6682093ccc81082ULL, 0x06673b0101343b00ULL, 0x0e7db4ea6533afa9ULL};
+             c.n.init(n);
+             const uint64_t d[4] = {0x01065fd6d6343eb1ULL, 0x292d7f6d37579d26ULL, 0xf5fd9207e6bd7fd4ULL, 0x2a9318e74bfa2b48ULL};
+             std::memcpy(c.d, d, 32); c.neg_a[0] = 1; c.scalar_bits = 252; c.glv = false; c.tai = true; return c; }(),
+    };
+    return id == 0 || id == 1 ? &curves[id] : nullptr;
+}
+
 // ---------------------------------------------------------------- GLV decomposition (dot_ring/curve/glv.py:57-160)
 // k = k1 + k2*lambda (mod n) with |k1|, |k2| < 2^128, from the lattice basis v1 = (a1, b1), v2 = (a2, -a1) the reference
 // finds by extended Euclid on (n, lambda) (det = -n):  c1 = k*a1/n, c2 = k*b1/n (here: floor via 2^256-scaled
@@ -226,13 +251,14 @@ inline void enc_te_point(const uint8_t xy[64], uint8_t out[32]) {
     if (gt) out[31] |= 0x80;
 }
 
-// affine twisted-Edwards addition on Bandersnatch (a = -5): the verifier's seed + relation (ring/vrf.py:239-283)
-inline void te_add_affine(const uint8_t p1[64], const uint8_t p2[64], uint8_t out[64]) {
-    static const uint64_t D[4] = {0xb369f2f5188d58e7ULL, 0xcb66677177e54f92ULL, 0xc66e3bf86be3b6d8ULL, 0x6389c12633c267cbULL};
+// affine twisted-Edwards addition: the verifier's seed + relation (ring/vrf.py:239-283)
+inline void te_add_affine(const TeCurveHost& cv, const uint8_t p1[64], const uint8_t p2[64], uint8_t out[64]) {
+    const uint64_t* D = cv.d;
+    const uint64_t* five = cv.neg_a;        // -a (5 on Bandersnatch)
     const Mod256& f = mod_p();
-    uint64_t x1[4], y1[4], x2[4], y2[4], a[4], b[4], c[4], e[4], t[4], one[4], five[4];
+    uint64_t x1[4], y1[4], x2[4], y2[4], a[4], b[4], c[4], e[4], t[4], one[4];
     load_le32(p1, x1); load_le32(p1 + 32, y1); load_le32(p2, x2); load_le32(p2 + 32, y2);
-    f.set_u64(1, one); f.set_u64(5, five);
+    f.set_u64(1, one);
     f.mul(x1, x2, a);                       // x1 x2
     f.mul(y1, y2, b);                       // y1 y2
     f.mul(a, b, c); f.mul(c, D, c);         // d x1 x2 y1 y2
@@ -252,6 +278,7 @@ struct VrfSuite {
     Bytes suite_id;
     bool xof;                 // SHAKE128 suite; otherwise SHA-512 counter mode
     uint8_t generator[64], blinding_base[64];
+    const TeCurveHost* cv = te_curve(0);
 };
 // squeeze `size` bytes of the stream defined by everything absorbed
 inline void vrf_squeeze(bool xof, const uint8_t* absorbed, size_t len, uint8_t* out, size_t size) {
@@ -280,9 +307,9 @@ inline bool vrf_nonce(const VrfSuite& su, const Bytes& transcript, const uint64_
     t = transcript;
     put8(t, 0x11);                                   // NONCE
     put(t, exp, 64);
-    vrf_squeeze(su.xof, t.data(), t.size(), raw, 48);   // ceil((253 + 128) / 8)
-    mod_n().reduce_bytes(raw, 48, false, out);
-    return !mod_n().is_zero(out);
+    vrf_squeeze(su.xof, t.data(), t.size(), raw, 48);   // ceil((scalar_bits + 128) / 8) = 48 for 253 and for 252 bits
+    su.cv->n.reduce_bytes(raw, 48, false, out);
+    return !su.cv->n.is_zero(out);
 }
 // primitives.py:82-88: 128-bit challenge over the given compressed points
 inline void vrf_challenge(const VrfSuite& su, const Bytes& transcript, const uint8_t* enc_points, size_t count, uint64_t out[4]) {
@@ -291,7 +318,18 @@ inline void vrf_challenge(const VrfSuite& su, const Bytes& transcript, const uin
     put(t, enc_points, 32 * count);
     uint8_t raw[16];
     vrf_squeeze(su.xof, t.data(), t.size(), raw, 16);
-    mod_n().reduce_bytes(raw, 16, false, out);
+    su.cv->n.reduce_bytes(raw, 16, false, out);
+}
+
+// try-and-increment hash-to-curve, host half (dot_ring/curve/point.py:252-296): candidate `counter` of a message is the
+// first 32 squeezed bytes of suite_id || 0x60 || LE64(len) || data || counter — read by the device as a compressed point
+inline void tai_candidate(const VrfSuite& su, const uint8_t* data, size_t len, unsigned counter, uint8_t out[32]) {
+    Bytes t = su.suite_id;
+    put8(t, 0x60);                                   // HASH_TO_CURVE
+    put_le64(t, len);
+    put(t, data, len);
+    put8(t, (uint8_t)counter);
+    vrf_squeeze(su.xof, t.data(), t.size(), out, 32);
 }
 
 // curve.py:110-185 hash_to_field(msg, 2): two field elements, 32-byte little-endian each
@@ -400,15 +438,16 @@ struct RingClaimScalars {      // what one proof contributes to the folded pairi
 };
 // alphas[7], nus[8], zeta, evals[7] (px py s b accip accx accy), l_zw: 32-byte LE canonical values; result_seed = seed + relation.
 // false when zeta lies in the domain (verify.py raises there).
-inline bool ring_verifier_terms(const RingVerifierDomain& dm, const uint8_t* alphas, const uint8_t* nus, const uint8_t* zeta_le,
+inline bool ring_verifier_terms(const TeCurveHost& cv, const RingVerifierDomain& dm, const uint8_t* alphas, const uint8_t* nus, const uint8_t* zeta_le,
                                 const uint8_t* evals, const uint8_t* l_zw_le, const uint8_t result_seed[64], RingClaimScalars& out) {
     const Mod256& f = mod_p();
-    uint64_t al[7][4], ev[7][4], zeta[4], lzw[4], rsx[4], rsy[4], one[4], five[4];
+    uint64_t al[7][4], ev[7][4], zeta[4], lzw[4], rsx[4], rsy[4], one[4];
+    const uint64_t* five = cv.neg_a;        // -a of the curve
     for (int i = 0; i < 7; i++) { load_le32(alphas + 32 * i, al[i]); load_le32(evals + 32 * i, ev[i]); }
     for (int i = 0; i < 8; i++) load_le32(nus + 32 * i, out.nus[i]);
     load_le32(zeta_le, zeta); load_le32(l_zw_le, lzw);
     load_le32(result_seed, rsx); load_le32(result_seed + 32, rsy);
-    f.set_u64(1, one); f.set_u64(5, five);
+    f.set_u64(1, one);
     const uint64_t *pxz = ev[0], *pyz = ev[1], *sz = ev[2], *bz = ev[3], *ipz = ev[4], *axz = ev[5], *ayz = ev[6];
     uint64_t z1[4], d4[4], zn1[4], t[4], u[4];
     f.sub(zeta, one, z1);
@@ -458,7 +497,7 @@ inline bool ring_verifier_terms(const RingVerifierDomain& dm, const uint8_t* alp
     uint64_t agg[4] = {0, 0, 0, 0};
     for (int i = 0; i < 7; i++) { f.mul(out.nus[i], ev[i], t); f.add(agg, t, agg); }
     f.mul(out.nus[7], qz, t); f.add(agg, t, agg);
-    // fx = b (ay py + a ax px) + (1-b),  fy = b (ax py - px ay) + (1-b),  a = -5
+    // fx = b (ay py + a ax px) + (1-b),  fy = b (ax py - px ay) + (1-b)
     uint64_t fx[4], fy[4];
     f.mul(ayz, pyz, t); f.mul(axz, pxz, u); f.mul(u, five, u); f.sub(t, u, t); f.mul(bz, t, t); f.add(t, one_b, fx);
     f.mul(axz, pyz, t); f.mul(pxz, ayz, u); f.sub(t, u, t); f.mul(bz, t, t); f.add(t, one_b, fy);

@@ -52,31 +52,37 @@ DR_DEV void store_fr_std(uint32_t* p, const Fr& v) {
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-// k mod n for a 256-bit k: n > 2^252, so at most 15 conditional subtractions (exactly: floor(2^256/n) = 8)
+// k mod n for a 256-bit k by conditional subtractions: floor(2^256 / n) = 8 for Bandersnatch (n > 2^252), 17 for JubJub
+// (n > 2^251)
+template <int CV = CV_BANDERSNATCH>
 DR_DEV void reduce_mod_order(uint32_t (&k)[8]) {
-    constexpr uint32_t ORD[8] = {0x2876e7e1u, 0x74fd06b5u, 0x74190471u, 0xff8f8700u,
-                                 0x02687600u, 0x0cce7602u, 0xca675f52u, 0x1cfb69d4u};
+    constexpr uint32_t ORD_B[8] = {0x2876e7e1u, 0x74fd06b5u, 0x74190471u, 0xff8f8700u,
+                                   0x02687600u, 0x0cce7602u, 0xca675f52u, 0x1cfb69d4u};
+    constexpr uint32_t ORD_J[8] = {0xd6f72cb7u, 0xd0970e5eu, 0xccc81082u, 0xa6682093u,
+                                   0x01343b00u, 0x06673b01u, 0x6533afa9u, 0x0e7db4eau};
+    constexpr int ROUNDS = CV == CV_JUBJUB ? 18 : 9;
 #pragma unroll 1
-    for (int it = 0; it < 9; it++) {
+    for (int it = 0; it < ROUNDS; it++) {
         uint32_t d[8], borrow = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) d[i] = subb(k[i], ORD[i], borrow);
+        for (int i = 0; i < 8; i++) d[i] = subb(k[i], CV == CV_JUBJUB ? ORD_J[i] : ORD_B[i], borrow);
 #pragma unroll
         for (int i = 0; i < 8; i++) k[i] = borrow ? k[i] : d[i];
     }
 }
 
 // scalar multiplication core shared by the batch and the grouped-MSM kernels: returns k*P (extended coords)
+template <int CV = CV_BANDERSNATCH>
 DR_DEV TePoint bsn_scalar_mul_core(uint32_t* tab, int lane, const Fr& px, const Fr& py, uint32_t (&k)[8]) {
     TePoint P;
     P.x = px; P.y = py; P.z = Fr::one(); P.t = mul(px, py);
     // table 1P..8P
     lds_store_point(tab, 0, lane, P);
-    TePoint Q = te_dbl<true>(P);
+    TePoint Q = te_dbl<true, CV>(P);
     lds_store_point(tab, 1, lane, Q);
 #pragma unroll 1
     for (int e = 2; e < BSN_TABLE; e++) {
-        Q = te_add(Q, P);
+        Q = te_add<CV>(Q, P);
         lds_store_point(tab, e, lane, Q);
     }
     // signed recoding, LSB first: nibble + carry in [0,16]; >= 8 -> minus 16 with carry
@@ -99,14 +105,14 @@ DR_DEV TePoint bsn_scalar_mul_core(uint32_t* tab, int lane, const Fr& px, const 
 #pragma unroll 1
     for (int w = 63; w >= 0; w--) {
 #pragma unroll 1
-        for (int j = 0; j < 3; j++) acc = te_dbl<false>(acc);   // rolled: keeps the loop body inside the I-cache
-        acc = te_dbl<true>(acc);
+        for (int j = 0; j < 3; j++) acc = te_dbl<false, CV>(acc);   // rolled: keeps the loop body inside the I-cache
+        acc = te_dbl<true, CV>(acc);
         int d = (int)((dig[w >> 3] >> (4 * (w & 7))) & 15u) - 8;
         int mag = d < 0 ? -d : d;
         TePoint T = lds_load_point(tab, mag == 0 ? 0 : mag - 1, lane);
         T = te_cneg(T, d < 0);
         if (mag == 0) T = te_identity();
-        acc = te_add(acc, T);
+        acc = te_add<CV>(acc, T);
     }
     return acc;
 }
@@ -118,6 +124,7 @@ DR_DEV void te_store_affine(uint32_t* out, const TePoint& acc) {
 }
 
 // out[i] = k[i] * P[i].  pts: n x 16 u32 (x||y, standard form LE), ks: n x 8 u32, out: n x 16 u32.
+template <int CV>
 __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_scalar_mul(const uint32_t* __restrict__ pts,
                                                               const uint32_t* __restrict__ ks,
                                                               uint32_t* __restrict__ out, uint32_t n) {
@@ -134,8 +141,8 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_scalar_mul(const uint32_t* __
 #pragma unroll
         for (int j = 0; j < 8; j++) k[j] = kk.l[j];
     }
-    reduce_mod_order(k);
-    TePoint acc = bsn_scalar_mul_core(tab, lane, px, py, k);
+    reduce_mod_order<CV>(k);
+    TePoint acc = bsn_scalar_mul_core<CV>(tab, lane, px, py, k);
     if (live) te_store_affine(out + (size_t)i * 16, acc);
 }
 
@@ -145,6 +152,7 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_scalar_mul(const uint32_t* __
 // from ~32 k scalar multiplications per launch this one is ~3x faster; below that the shorter chain of the 4-bit
 // kernel wins (both are latency-bound there).
 constexpr int BSN2_TABLE = 2;
+template <int CV>
 __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_scalar_mul_w2(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ ks,
                                                                  uint32_t* __restrict__ out, uint32_t n) {
     __shared__ uint32_t tab[BSN2_TABLE * BSN_PT_WORDS * BSN_BLOCK];
@@ -163,9 +171,9 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_scalar_mul_w2(const uint32_t*
 #pragma unroll
         for (int j = 0; j < 8; j++) k[j] = kk.l[j];
     }
-    reduce_mod_order(k);
+    reduce_mod_order<CV>(k);
     lds_store_point(tab, 0, lane, P);
-    lds_store_point(tab, 1, lane, te_dbl<true>(P));
+    lds_store_point(tab, 1, lane, te_dbl<true, CV>(P));
     // signed recoding, LSB first: pair + carry in [0,4]; >= 2 -> minus 4 with carry; digits stored as (d + 2) in 2 bits.
     // k < n < 2^253: the top pairs are 0, so the final carry is absorbed (bits 252..253 -> at most 1 + carry = 2 -> d = -2,
     // carry into pair 127 which is 0 -> 1).
@@ -185,14 +193,14 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_scalar_mul_w2(const uint32_t*
     TePoint acc = te_identity();
 #pragma unroll 1
     for (int w = 127; w >= 0; w--) {
-        acc = te_dbl<false>(acc);
-        acc = te_dbl<true>(acc);
+        acc = te_dbl<false, CV>(acc);
+        acc = te_dbl<true, CV>(acc);
         int d = (int)((dig[w >> 4] >> (2 * (w & 15))) & 3u) - 2;
         int mag = d < 0 ? -d : d;
         TePoint T = lds_load_point(tab, mag == 2 ? 1 : 0, lane);
         T = te_cneg(T, d < 0);
         if (mag == 0) T = te_identity();
-        acc = te_add(acc, T);
+        acc = te_add<CV>(acc, T);
     }
     if (live) te_store_affine(out + (size_t)i * 16, acc);
 }
@@ -200,6 +208,7 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_scalar_mul_w2(const uint32_t*
 // out[g] = sum_{j<m} k[g*m+j] * P[g*m+j]: the lanes of a group (m a power-of-two-padded width <= 64) each do
 // one scalar multiplication, then the group is folded with wave shuffles.  Covers msm-2/3/4 of the sigma
 // protocols (bandersnatch_te.pyx:557,669) and, with one group, small Pippenger inputs (:257).
+template <int CV>
 __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_msm_groups(const uint32_t* __restrict__ pts,
                                                               const uint32_t* __restrict__ ks,
                                                               uint32_t* __restrict__ out, uint32_t groups,
@@ -221,8 +230,8 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_msm_groups(const uint32_t* __
 #pragma unroll
         for (int t = 0; t < 8; t++) k[t] = kk.l[t];
     }
-    reduce_mod_order(k);
-    TePoint r = bsn_scalar_mul_core(tab, lane, px, py, k);
+    reduce_mod_order<CV>(k);
+    TePoint r = bsn_scalar_mul_core<CV>(tab, lane, px, py, k);
     if (live) acc = r;
     // fold within the group: lane j += lane j+s
 #pragma unroll 1
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_msm_groups(const uint32_t* __
             o.z.l[t] = __shfl_down(acc.z.l[t], s, 64);
             o.t.l[t] = __shfl_down(acc.t.l[t], s, 64);
         }
-        acc = te_add(acc, o);
+        acc = te_add<CV>(acc, o);
     }
     if (g < groups && j == 0) te_store_affine(out + (size_t)g * 16, acc);
 }
@@ -561,6 +570,78 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_decode_points(const uint32_t*
     R = te_add(R, te_shfl_down(R, 1));
     if (!(R.x == mul(x, R.z)) || !(R.y == mul(y, R.z))) valid = false;
     if (live && !half) {
+        store_fr_std(out_xy + (size_t)i * 16, from_mont(x));
+        store_fr_std(out_xy + (size_t)i * 16 + 8, from_mont(y));
+        ok[i] = valid ? 1u : 0u;
+    }
+}
+
+// The same decoding for a curve without an endomorphism (JubJub, cofactor 8): one lane per point, Q = hP by log2(h)
+// doublings, then [h^-1 mod n] Q through the plain 64-window core.  TAI = true is the device half of try-and-increment
+// hash-to-curve (dot_ring/curve/point.py:252-296): the candidate only has to decompress; the output is hP and ok says
+// "decompressed and hP is not the identity".
+template <int CV, bool TAI>
+__global__ __launch_bounds__(BSN_BLOCK) void k_te_decode_points(const uint32_t* __restrict__ enc /* n*8 */, uint32_t* __restrict__ out_xy /* n*16 std */,
+                                                                uint32_t* __restrict__ ok, uint32_t n) {
+    __shared__ uint32_t tab[BSN_TABLE * BSN_PT_WORDS * BSN_BLOCK];
+    const int lane = threadIdx.x;
+    uint32_t i = blockIdx.x * BSN_BLOCK + lane;
+    const bool live = i < n;
+    if (!live) i = n - 1;
+    Fr ys = load_fr_std(enc + (size_t)i * 8);
+    const bool sign = (ys.l[7] >> 31) != 0;
+    ys.l[7] &= 0x7fffffffu;
+    bool valid = true;
+    {   // y < p
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) (void)subb(ys.l[j], FrParams::P[j], borrow);
+        valid = borrow != 0;
+    }
+    if (!valid) ys = Fr::zero();
+    const Fr one = Fr::one();
+    Fr y = to_mont(ys);
+    Fr y2 = sqr(y);
+    Fr den = sub(te_mul_a<CV>(one), mul(te_d_mont<CV>(), y2));
+    if (den.is_zero()) { valid = false; den = one; }
+    Fr x2 = mul(sub(one, y2), inv(den));
+    Fr x;
+    if (!fr_sqrt(x2, x)) { valid = false; x = one; }
+    {
+        Fr xs = from_mont(x), nxs = from_mont(neg(x));
+        bool x_larger = false;
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+            if (xs.l[j] != nxs.l[j]) { x_larger = xs.l[j] > nxs.l[j]; break; }
+        }
+        if (x_larger != sign) x = neg(x);
+    }
+    TePoint P;
+    P.x = x; P.y = y; P.z = one; P.t = mul(x, y);
+    constexpr int LOG2_H = CV == CV_JUBJUB ? 3 : 2;
+    TePoint Q = P;
+#pragma unroll 1
+    for (int j = 0; j < LOG2_H; j++) Q = te_dbl<true, CV>(Q);
+    if (Q.x.is_zero()) { valid = false; Q = P; }    // hP = O (x = 0 also covers the order-2 point (0,-1), which h kills anyway)
+    Fr zi = inv(Q.z.is_zero() ? one : Q.z);
+    Fr qx = mul(Q.x, zi), qy = mul(Q.y, zi);
+    if (TAI) {
+        if (live) {
+            store_fr_std(out_xy + (size_t)i * 16, from_mont(qx));
+            store_fr_std(out_xy + (size_t)i * 16 + 8, from_mont(qy));
+            ok[i] = valid ? 1u : 0u;
+        }
+        return;
+    }
+    // h^-1 mod n
+    constexpr uint32_t HINV_B[8] = {0xde592de9u, 0x17bdc507u, 0x5712c355u, 0xbfaba540u, 0x81ce5880u, 0x899ad881u, 0x97cd877du, 0x15bc8f5fu};
+    constexpr uint32_t HINV_J[8] = {0xdadee597u, 0x5a12e1cbu, 0x79990210u, 0x14cd0412u, 0x20268760u, 0x20cce760u, 0x4ca675f5u, 0x01cfb69du};
+    uint32_t k[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) k[j] = CV == CV_JUBJUB ? HINV_J[j] : HINV_B[j];
+    TePoint R = bsn_scalar_mul_core<CV>(tab, lane, qx, qy, k);
+    if (!(R.x == mul(x, R.z)) || !(R.y == mul(y, R.z))) valid = false;
+    if (live) {
         store_fr_std(out_xy + (size_t)i * 16, from_mont(x));
         store_fr_std(out_xy + (size_t)i * 16 + 8, from_mont(y));
         ok[i] = valid ? 1u : 0u;

@@ -117,6 +117,7 @@ struct RingConsts {
 // for the producer key and one per set bit of the blinding factor).  They are produced in extended coordinates,
 // normalised together with ONE inversion (Montgomery's trick) and written as affine Montgomery pairs;
 // entry [cnt] is the relation point (last value minus the seed).  cnt_out[proof] = number of accumulator values.
+template <int CV>
 __global__ void k_ring_chain(const uint32_t* __restrict__ ring_pts_mont /* N*16: x,y Montgomery */,
                              const uint32_t* __restrict__ producer_idx, const uint32_t* __restrict__ blinding /* B*8 */,
                              RingConsts rc, uint32_t batch,
@@ -144,7 +145,7 @@ __global__ void k_ring_chain(const uint32_t* __restrict__ ring_pts_mont /* N*16:
     TePoint seed = acc;
     uint32_t cnt = 0;
     put(cnt++, acc);
-    acc = te_add(acc, ring_point(producer_idx[pid]));
+    acc = te_add<CV>(acc, ring_point(producer_idx[pid]));
     put(cnt++, acc);
     uint32_t t[8];
     {
@@ -155,12 +156,12 @@ __global__ void k_ring_chain(const uint32_t* __restrict__ ring_pts_mont /* N*16:
 #pragma unroll 1
     for (uint32_t j = 0; j < 253; j++) {
         if ((t[j >> 5] >> (j & 31)) & 1) {
-            acc = te_add(acc, ring_point(rc.max_ring + j));
+            acc = te_add<CV>(acc, ring_point(rc.max_ring + j));
             put(cnt++, acc);
         }
     }
     cnt_out[pid] = cnt;
-    put(cnt, te_add(acc, te_cneg(seed, true)));           // relation = result - seed
+    put(cnt, te_add<CV>(acc, te_cneg(seed, true)));           // relation = result - seed
     const uint32_t total = cnt + 1;
     // batch inversion of the Z coordinates
     Fr run = Fr::one();
@@ -195,6 +196,7 @@ DR_DEV TePoint te_shfl_up(const TePoint& p, unsigned delta) {
     }
     return o;
 }
+template <int CV>
 __global__ __launch_bounds__(64) void k_ring_chain_wave(const uint32_t* __restrict__ ring_pts_mont, const uint32_t* __restrict__ producer_idx,
                                                         const uint32_t* __restrict__ blinding, RingConsts rc, uint32_t batch,
                                                         uint32_t* __restrict__ chain_ext /* B*256*32 scratch */,
@@ -239,35 +241,35 @@ __global__ __launch_bounds__(64) void k_ring_chain_wave(const uint32_t* __restri
     TePoint loc = te_identity();
 #pragma unroll 1
     for (uint32_t b = 0; b < 4; b++)
-        if ((mine >> b) & 1) loc = te_add(loc, ring_point(rc.max_ring + j0 + b));
+        if ((mine >> b) & 1) loc = te_add<CV>(loc, ring_point(rc.max_ring + j0 + b));
     // 2. inclusive scan across the wave
     TePoint inc = loc;
 #pragma unroll 1
     for (unsigned d = 1; d < 64; d <<= 1) {
         TePoint o = te_shfl_up(inc, d);
-        if (lane >= d) inc = te_add(inc, o);
+        if (lane >= d) inc = te_add<CV>(inc, o);
     }
     TePoint exc = te_shfl_up(inc, 1);                      // sum over all lower lanes
     if (lane == 0) exc = te_identity();
     // 3. seed, seed + PK_k, then this lane's own values
     TePoint seed;
     seed.x = from_arg(rc.seed_x); seed.y = from_arg(rc.seed_y); seed.z = Fr::one(); seed.t = mul(seed.x, seed.y);
-    TePoint base = te_add(seed, ring_point(producer_idx[pid]));
+    TePoint base = te_add<CV>(seed, ring_point(producer_idx[pid]));
     uint32_t idx[6];
     int nv = 0;
     if (lane == 0) { put(0, seed); put(1, base); idx[nv++] = 0; idx[nv++] = 1; }
-    TePoint cur = te_add(base, exc);
+    TePoint cur = te_add<CV>(base, exc);
     uint32_t pos = 2 + below;
 #pragma unroll 1
     for (uint32_t b = 0; b < 4; b++)
         if ((mine >> b) & 1) {
-            cur = te_add(cur, ring_point(rc.max_ring + j0 + b));
+            cur = te_add<CV>(cur, ring_point(rc.max_ring + j0 + b));
             put(pos, cur);
             idx[nv++] = pos++;
         }
     const uint32_t cnt = 2 + total_bits;
     if (lane == 63) {                                      // cur = the final accumulator value on the last lane
-        put(cnt, te_add(cur, te_cneg(seed, true)));        // relation = result - seed
+        put(cnt, te_add<CV>(cur, te_cneg(seed, true)));        // relation = result - seed
         idx[nv++] = cnt;
         cnt_out[pid] = cnt;
     }
@@ -361,6 +363,7 @@ __global__ void k_ring_relations(const uint32_t* __restrict__ chain_aff, const u
 // ---- K7: the seven constraints, fused with the alpha aggregation ------------------------------------------------
 // One lane per (proof, point of the 4N domain).  Reads the four witness columns at i and at i + 4 (the w_N shift),
 // the per-ring tables at i, and writes sum_k alpha_k * c_k(i)   (constraints.py:83-151, proof_builder.py:175-180).
+template <int CV>
 __global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __restrict__ wit4 /* [B][4][m][8] std: b, accip, accx, accy */,
                                                           const uint32_t* __restrict__ fixed4 /* [3][m][8] mont: px, py, s */,
                                                           const uint32_t* __restrict__ lag4 /* [2][m][8] mont: L0, Llast */,
@@ -389,8 +392,8 @@ __global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __rest
     Fr x1y1 = mul(x1, y1), x2y2 = mul(x2, y2), x1x2 = mul(x1, x2), y1y2 = mul(y1, y2);
     // c1 = (accip' - accip - b*s) * nl
     Fr acc = mul(ld_std(al + 0 * 8), mul(sub(sub(ip_n, ip), mul(b, s)), nl));
-    // c2 = (b*(x3*(y1y2 + a x1x2) - (x1y1 + x2y2)) + (1-b)(x3 - x1)) * nl ,  a = -5
-    Fr t2 = sub(mul(x3, add(y1y2, te_mul_a(x1x2))), add(x1y1, x2y2));
+    // c2 = (b*(x3*(y1y2 + a x1x2) - (x1y1 + x2y2)) + (1-b)(x3 - x1)) * nl ,  a = the curve coefficient
+    Fr t2 = sub(mul(x3, add(y1y2, te_mul_a<CV>(x1x2))), add(x1y1, x2y2));
     Fr c2 = mul(add(mul(b, t2), mul(omb, sub(x3, x1))), nl);
     acc = add(acc, mul(ld_std(al + 1 * 8), c2));
     // c3 = (b*(y3*(x1y2 - x2y1) - (x1y1 - x2y2)) + (1-b)(y3 - y1)) * nl
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(EV_BLOCK) void k_ring_eval(const uint32_t* __restri
 }
 
 // linearisation scalars per proof (proof_builder.py:253-286): k0 = a0*term, k1 = a1*fx*term, k2 = a2*fy*term
+template <int CV>
 __global__ void k_ring_lin_scalars(const uint32_t* __restrict__ evals /* [B][8][8] std: px,py,s,b,accip,accx,accy,(l) */,
                                    const uint32_t* __restrict__ alphas, const uint32_t* __restrict__ zetas, RingConsts rc,
                                    uint32_t batch, uint32_t* __restrict__ ks /* [B][3][8] mont */) {
@@ -486,7 +490,7 @@ __global__ void k_ring_lin_scalars(const uint32_t* __restrict__ evals /* [B][8][
     Fr pxz = ld_std(e), pyz = ld_std(e + 8), bz = ld_std(e + 3 * 8), axz = ld_std(e + 5 * 8), ayz = ld_std(e + 6 * 8);
     Fr term = sub(ld_std(zetas + (size_t)pid * 8), from_arg(rc.last_x));
     Fr omb = sub(Fr::one(), bz);
-    Fr fx = mul(add(mul(bz, add(mul(ayz, pyz), te_mul_a(mul(axz, pxz)))), omb), term);
+    Fr fx = mul(add(mul(bz, add(mul(ayz, pyz), te_mul_a<CV>(mul(axz, pxz)))), omb), term);
     Fr fy = mul(add(mul(bz, sub(mul(axz, pyz), mul(pxz, ayz))), omb), term);
     const uint32_t* al = alphas + (size_t)pid * 7 * 8;
     gstore_fr(ks + ((size_t)pid * 3 + 0) * 8, mul(ld_std(al), term));

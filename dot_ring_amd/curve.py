@@ -1,7 +1,8 @@
-"""Bandersnatch curve layer of the API mirror: suites, points, codecs, hash-to-curve.
+"""Curve layer of the API mirror: the Bandersnatch suites (and JubJub), points, codecs, hash-to-curve.
 
 Mirrors (names, argument meaning, error behaviour) the parts of the reference the Ring-VRF path touches:
   dot_ring/curve/specs/bandersnatch.py:57-306   suites, BandersnatchPoint.__mul__/msm, CurveVariant objects
+  dot_ring/curve/specs/jubjub.py:17-66          JubJub: same field, a = -1, cofactor 8, try-and-increment
   dot_ring/curve/point.py:150-214               compressed codec
   dot_ring/curve/twisted_edwards/*              affine law, Elligator2 encode_to_curve
   dot_ring/curve/curve.py:56-67,110-237,384-401 valid_point, hash_to_field, key derivation
@@ -55,6 +56,8 @@ class SuiteParams:
         19188667384257783945677642223292697773471335439753913231509108946878080696678,
     )
     encoding: Encoding = Encoding()
+    curve_id: int = _native.CURVE_BANDERSNATCH      # DR_CURVE_* of include/dotring_hip.h
+    e2c: str = "ell2"                               # "ell2" (Elligator 2, RO) or "tai" (try and increment)
 
     @property
     def h2c_dst(self) -> bytes:
@@ -96,13 +99,11 @@ class BandersnatchCurve:
         return bool(valid_points([point])[0])
 
 
-def _on_curve(x: int, y: int) -> bool:
-    return (_A * x * x + y * y) % _P == (1 + _D * x * x % _P * y * y) % _P
-
-
 class BandersnatchPoint:
-    """Affine point; `curve` is bound per suite by the subclasses below."""
+    """Affine twisted Edwards point; `curve` and the coefficient shortcuts are bound per suite by the subclasses below
+    (the class keeps its Bandersnatch name: that is what the reference's callers import)."""
     curve: BandersnatchCurve
+    _A, _D, _N, _H, _CV = _A, _D, _N, 4, _native.CURVE_BANDERSNATCH
     __slots__ = ("x", "y")
 
     def __init__(self, x: int, y: int):
@@ -110,8 +111,12 @@ class BandersnatchPoint:
         if (x, y) != (0, 1):
             if not (0 <= x < _P and 0 <= y < _P):
                 raise ValueError("Invalid point coordinates")
-            if not _on_curve(x, y):
+            if not self._on_curve(x, y):
                 raise ValueError("Point is not on the curve")
+
+    @classmethod
+    def _on_curve(cls, x: int, y: int) -> bool:
+        return (cls._A * x * x + y * y) % _P == (1 + cls._D * x * x % _P * y * y) % _P
 
     @classmethod
     def _trusted(cls, x: int, y: int):
@@ -126,7 +131,7 @@ class BandersnatchPoint:
         return isinstance(other, BandersnatchPoint) and self.x == other.x and self.y == other.y
 
     def __hash__(self):
-        return (self.x + self.y) % _N
+        return (self.x + self.y) % self._N
 
     def __repr__(self):
         return f"{type(self).__name__}({self.x}, {self.y})"
@@ -143,7 +148,7 @@ class BandersnatchPoint:
         return self.x == 0 and self.y == 1
 
     def is_on_curve(self) -> bool:
-        return _on_curve(self.x, self.y)
+        return self._on_curve(self.x, self.y)
 
     # -- group law: single additions are host big-int code, as in te_affine_point.py:69-167
     def __add__(self, other):
@@ -156,17 +161,18 @@ class BandersnatchPoint:
         if self == other:
             return self.double()
         x1, y1, x2, y2 = self.x, self.y, other.x, other.y
-        t = _D * x1 % _P * x2 % _P * y1 % _P * y2 % _P
-        return type(self)((x1 * y2 + x2 * y1) * pow(1 + t, -1, _P) % _P, (y1 * y2 - _A * x1 * x2) * pow(1 - t, -1, _P) % _P)
+        a, d = self._A, self._D
+        t = d * x1 % _P * x2 % _P * y1 % _P * y2 % _P
+        return type(self)((x1 * y2 + x2 * y1) * pow(1 + t, -1, _P) % _P, (y1 * y2 - a * x1 * x2) * pow(1 - t, -1, _P) % _P)
 
     def double(self):
-        x1, y1 = self.x, self.y
+        x1, y1, a = self.x, self.y, self._A
         if y1 == 0:
             return self.identity()
-        dx, dy = (_A * x1 * x1 + y1 * y1) % _P, (2 - _A * x1 * x1 - y1 * y1) % _P
+        dx, dy = (a * x1 * x1 + y1 * y1) % _P, (2 - a * x1 * x1 - y1 * y1) % _P
         if dx == 0 or dy == 0:
             return self.identity()
-        return type(self)(2 * x1 * y1 * pow(dx, -1, _P) % _P, (y1 * y1 - _A * x1 * x1) * pow(dy, -1, _P) % _P)
+        return type(self)(2 * x1 * y1 * pow(dx, -1, _P) % _P, (y1 * y1 - a * x1 * x1) * pow(dy, -1, _P) % _P)
 
     def __neg__(self):
         return type(self)(-self.x % _P, self.y)
@@ -186,7 +192,7 @@ class BandersnatchPoint:
             raise ValueError("Points and scalars must have same length")
         if not points:
             return cls.identity()
-        raw = runtime.context().bsn_msm(pack_points(points), pack_scalars(scalars))
+        raw = runtime.context().bsn_msm(pack_points(points), pack_scalars(scalars, cls._N), cls._CV)
         return cls(int.from_bytes(raw[:32], "little"), int.from_bytes(raw[32:], "little"))
 
     # -- codec (point.py:150-214)
@@ -206,7 +212,7 @@ class BandersnatchPoint:
         y = int.from_bytes(raw, "little")
         if y >= _P:
             raise ValueError("Invalid point encoding")
-        den = (_A - _D * y * y) % _P
+        den = (cls._A - cls._D * y * y) % _P
         if den == 0:
             raise ValueError("Invalid point encoding")
         try:
@@ -218,7 +224,20 @@ class BandersnatchPoint:
 
     # -- hash to curve (te_affine_point.py:212-295, te_curve.py:48-95)
     @classmethod
+    def _suite_struct(cls):
+        """dr_vrf_suite of this point type's suite (cached on the class)."""
+        st = cls.__dict__.get("_suite_cache")
+        if st is None:
+            sp = cls.curve.params
+            le = lambda pt: pt[0].to_bytes(32, "little") + pt[1].to_bytes(32, "little")  # noqa: E731
+            st = _native.vrf_suite(sp.suite_id, sp.xof, le(sp.generator), le(sp.auxiliary_points.blinding_base), sp.curve_id)
+            cls._suite_cache = st
+        return st
+
+    @classmethod
     def encode_to_curve(cls, alpha_string: bytes, salt: bytes = b""):
+        if cls.curve.params.e2c == "tai":          # point.py:252-296, through the batch entry point (hashing native, sqrt on the GPU)
+            return cls.encode_to_curve_batch([alpha_string], [salt])[0]
         u0, u1 = cls.curve.hash_to_field(salt + alpha_string, 2)
         r = cls.map_to_curve(u0) + cls.map_to_curve(u1)
         return r.double().double()
@@ -238,7 +257,12 @@ class BandersnatchPoint:
 
     @classmethod
     def encode_to_curve_batch(cls, alpha_strings, salts=None):
-        """encode_to_curve for many inputs: hash_to_field on the host, Elligator2 + cofactor clearing on the GPU."""
+        """encode_to_curve for many inputs: hash_to_field on the host, Elligator2 + cofactor clearing on the GPU; for a
+        try-and-increment suite the candidates are hashed natively and decompressed + cofactor-cleared on the GPU."""
+        if cls.curve.params.e2c == "tai":
+            if not alpha_strings:
+                return []
+            return unpack_points(cls, runtime.context().encode_to_curve_batch(cls._suite_struct(), list(alpha_strings), salts))
         return cls.encode_to_curve_from_field(cls.hash_to_field_pairs(alpha_strings, salts))
 
     @classmethod
@@ -271,8 +295,8 @@ def pack_points(points) -> bytes:
     return b"".join(p.x.to_bytes(32, "little") + p.y.to_bytes(32, "little") for p in points)
 
 
-def pack_scalars(scalars) -> bytes:
-    return b"".join((int(s) % _N).to_bytes(32, "little") for s in scalars)
+def pack_scalars(scalars, order: int = _N) -> bytes:
+    return b"".join((int(s) % order).to_bytes(32, "little") for s in scalars)
 
 
 def unpack_points(cls, raw: bytes):
@@ -287,26 +311,29 @@ def scalar_mul_batch(points, scalars):
         raise ValueError("Points and scalars must have same length")
     if not points:
         return []
-    raw = runtime.context().bsn_scalar_mul_batch(pack_points(points), pack_scalars(scalars))
-    return unpack_points(type(points[0]), raw)
+    cls = type(points[0])
+    raw = runtime.context().bsn_scalar_mul_batch(pack_points(points), pack_scalars(scalars, cls._N), cls._CV)
+    return unpack_points(cls, raw)
 
 
 def msm_groups(points, scalars, m: int):
     """[sum_{j<m} k_{g*m+j} * P_{g*m+j}] for consecutive groups of m terms, one launch."""
     if not points:
         return []
-    raw = runtime.context().bsn_msm_groups(pack_points(points), pack_scalars(scalars), m)
-    return unpack_points(type(points[0]), raw)
+    cls = type(points[0])
+    raw = runtime.context().bsn_msm_groups(pack_points(points), pack_scalars(scalars, cls._N), m, cls._CV)
+    return unpack_points(cls, raw)
 
 
 def valid_points(points) -> list[bool]:
-    """curve.py:56 for a whole batch: [4]P != O and [4^-1 mod n][4]P == P, two launches for all points."""
+    """curve.py:56 for a whole batch: [h]P != O and [h^-1 mod n][h]P == P (h the cofactor), one launch for all points."""
     live = [i for i, p in enumerate(points) if not p.is_identity() and p.is_on_curve()]
     out = [False] * len(points)
     if not live:
         return out
-    cleared = scalar_mul_batch_raw([points[i] for i in live], [4] * len(live))
-    back = scalar_mul_batch([c for c in cleared], [pow(4, -1, _N)] * len(live))
+    h, order = type(points[live[0]])._H, type(points[live[0]])._N
+    cleared = scalar_mul_batch_raw([points[i] for i in live], [h] * len(live))
+    back = scalar_mul_batch([c for c in cleared], [pow(h, -1, order)] * len(live))
     for i, c, b in zip(live, cleared, back):
         out[i] = (not c.is_identity()) and b == points[i]
     return out
@@ -315,21 +342,25 @@ def valid_points(points) -> list[bool]:
 def scalar_mul_batch_raw(points, small_scalars):
     """Scalar multiplication WITHOUT reduction mod n for points that may lie outside the prime-order subgroup:
     the kernel reduces scalars mod n, which is only sound on the subgroup, so small cofactor multiples are done
-    with host doublings (4P = two doublings, as te_affine_point.py:235 clear_cofactor)."""
+    with host doublings (4P = two doublings, 8P = three, as te_affine_point.py:235 clear_cofactor)."""
     out = []
     for p, k in zip(points, small_scalars):
-        if k != 4:
+        if k != type(p)._H:
             raise ValueError("only the cofactor multiple is supported here")
-        out.append(p.double().double())
+        for _ in range(k.bit_length() - 1):
+            p = p.double()
+        out.append(p)
     return out
 
 
 # ------------------------------------------------------------------ suites / curve variants
-def _suite(name: str, suite_id: bytes, xof: bool, bb, ab, pp):
+def _suite(name: str, suite_id: bytes, xof: bool, bb, ab, pp, **curve_consts):
     params = SuiteParams(suite_id=suite_id, hash_fn=hashlib.shake_128 if xof else hashlib.sha512,
-                         auxiliary_points=AuxiliaryPoints(bb, ab, pp), xof=xof)
+                         auxiliary_points=AuxiliaryPoints(bb, ab, pp), xof=xof, **curve_consts)
     curve = BandersnatchCurve(params)
-    point_type = type(f"{name}Point", (BandersnatchPoint,), {"curve": curve, "__slots__": ()})
+    point_type = type(f"{name}Point", (BandersnatchPoint,), {
+        "curve": curve, "__slots__": (), "_A": params.a, "_D": params.d, "_N": params.subgroup_order, "_H": params.cofactor,
+        "_CV": params.curve_id})
     return CurveVariant(name, curve, point_type)
 
 
@@ -378,4 +409,22 @@ Bandersnatch_SHAKE128 = _suite(
      37605358688136619817560700742505556266961225274493904038881144193539047100140),
     (1834402953989431481748983728202937234471322740714585873803966488035889514523,
      52100941849053769665273763352270294131006971127418863694682093199651869272752),
+)
+# dot_ring/curve/specs/jubjub.py:17-66 — the other twisted Edwards curve over the BLS12-381 scalar field
+JubJub = _suite(
+    "JubJub", b"JubJub-SHA512-TAI-v1", False,
+    (38206460563694846719174258613922853630278999941532690543235578292520143148532,
+     34254498978062207918041301829525626783549813531091321004550549786528984401675),
+    (48142684311216766702182564801462043940571084233680216669499475549492432046964,
+     34380560660182334518990118617091967209302636551264477863958902286043397647879),
+    (17348704025397475127937572481155408456556065464328870407269802701696798733683,
+     24318278422173803457621119807961883607097742387673491974779969503617097905596),
+    subgroup_order=0x0E7DB4EA6533AFA906673B0101343B00A6682093CCC81082D0970E5ED6F72CB7,
+    cofactor=8,
+    a=-1,
+    d=19257038036680949359750312669786877991949435402254120286184196891950884077233,
+    generator=(8076246640662884909881801758704306714034609987455869804520522091855516602923,
+               13262374693698910701929044844600465831413122818447359594527400194675274060458),
+    curve_id=_native.CURVE_JUBJUB,
+    e2c="tai",
 )

@@ -42,7 +42,7 @@ def get_device_prover(ring, slot: int = 0) -> _native.RingProver:
     pts = b"".join(int(x).to_bytes(32, "little") + int(y).to_bytes(32, "little") for x, y in ring.nm_points)
     seed = params.cv.curve.params.auxiliary_points.accumulator_base
     prover = _native.RingProver(ctx, srs, params.domain_size.bit_length() - 1, params.max_ring_size, params.omega, params.radix_omega,
-                                pts, int(seed[0]).to_bytes(32, "little") + int(seed[1]).to_bytes(32, "little"))
+                                pts, int(seed[0]).to_bytes(32, "little") + int(seed[1]).to_bytes(32, "little"), params.cv.curve.params.curve_id)
     provers[(id(ctx), slot)] = prover
     return prover
 

@@ -63,7 +63,7 @@ def dec_points(cv, values) -> list:
         blobs.append(v)
     if not blobs:
         return []
-    xy, flags = runtime.context().bsn_decode_points(b"".join(blobs))
+    xy, flags = runtime.context().bsn_decode_points(b"".join(blobs), cv.curve.params.curve_id)
     if 0 in flags:
         raise ValueError("point is not a valid nonidentity subgroup point")
     make, le = cv.point_type._trusted, int.from_bytes

@@ -44,7 +44,7 @@ class IetfVRF(VRF):
         le = lambda v: int(v).to_bytes(32, "little")
         gen = sp.generator
         bb = sp.auxiliary_points.blinding_base or gen                      # unused by these two schemes
-        suite = _native.vrf_suite(sp.suite_id, sp.xof, le(gen[0]) + le(gen[1]), le(bb[0]) + le(bb[1]))
+        suite = _native.vrf_suite(sp.suite_id, sp.xof, le(gen[0]) + le(gen[1]), le(bb[0]) + le(bb[1]), sp.curve_id)
         sks = b"".join(bytes(sk) if len(sk) == 32 else le(int.from_bytes(sk, "little") % sp.subgroup_order) for sk in secret_keys)
         plen = 96 if cls.THIN else 80
         ctx, make, frm, out = runtime.context(), cv.point_type._trusted, int.from_bytes, []

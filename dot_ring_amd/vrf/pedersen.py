@@ -66,10 +66,11 @@ class PedersenVRF(VRF):
         gen, bb = cv.point_type.generator_point(), cls._blinding_base()
         order = cv.curve.params.subgroup_order
         xs = [dec_scalar_mod(cv, sk) for sk in secret_keys]
-        us = cv.point_type.hash_to_field_pairs(alphas, salts)
+        tai = cv.curve.params.e2c == "tai"
+        us = None if tai else cv.point_type.hash_to_field_pairs(alphas, salts)
 
         def first():
-            inputs = cv.point_type.encode_to_curve_from_field(us)
+            inputs = cv.point_type.encode_to_curve_batch(alphas, salts) if tai else cv.point_type.encode_to_curve_from_field(us)
             return inputs, scalar_mul_batch(inputs, xs)                                  # I_i, O_i = x_i * I_i
 
         inputs, outs = yield first
@@ -105,7 +106,7 @@ class PedersenVRF(VRF):
         sp = cls.cv.curve.params
         le = lambda v: int(v).to_bytes(32, "little")
         gen, bb = sp.generator, sp.auxiliary_points.blinding_base
-        return _native.vrf_suite(sp.suite_id, sp.xof, le(gen[0]) + le(gen[1]), le(bb[0]) + le(bb[1]))
+        return _native.vrf_suite(sp.suite_id, sp.xof, le(gen[0]) + le(gen[1]), le(bb[0]) + le(bb[1]), sp.curve_id)
 
     @classmethod
     def prove_batch(cls, alphas, secret_keys, additional_data, salts=None) -> list:

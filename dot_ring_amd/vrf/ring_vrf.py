@@ -52,7 +52,7 @@ class Ring:
         out = [None] * len(keys)
         if not slots:
             return out
-        raw, ok = runtime.context().bsn_decode_points(b"".join(bytes(keys[i]) for i in slots))
+        raw, ok = runtime.context().bsn_decode_points(b"".join(bytes(keys[i]) for i in slots), cv.curve.params.curve_id)
         frm = int.from_bytes
         for j, slot in enumerate(slots):
             if ok[j]:
@@ -322,7 +322,7 @@ class RingVRF(VRF):
         cv = cls.cv
         ctx = runtime.context()
         order, prime = cv.curve.params.subgroup_order, RingProofParams(cv=cv).prime
-        te_raw, te_ok = ctx.bsn_decode_points(b"".join(b[:128] for b in blobs))
+        te_raw, te_ok = ctx.bsn_decode_points(b"".join(b[:128] for b in blobs), cv.curve.params.curve_id)
         if not all(te_ok):
             raise ValueError("Invalid point in proof")
         g1_pts, g1_ok = ctx.g1_decompress_batch(b"".join(b[192:384] + b[608:656] + b[688:784] for b in blobs))
@@ -483,7 +483,7 @@ class RingVRF(VRF):
         sp = cls.cv.curve.params
         le = lambda v: int(v).to_bytes(32, "little")
         gen, bb = sp.generator, sp.auxiliary_points.blinding_base
-        return _native.vrf_suite(sp.suite_id, sp.xof, le(gen[0]) + le(gen[1]), le(bb[0]) + le(bb[1]))
+        return _native.vrf_suite(sp.suite_id, sp.xof, le(gen[0]) + le(gen[1]), le(bb[0]) + le(bb[1]), sp.curve_id)
 
     @classmethod
     def _batch_verify_native(cls, proofs, inputs, additional_data, ring: Ring, ring_root: RingRoot) -> bool:

@@ -98,6 +98,16 @@ DR_API int dr_bsn_encode_to_curve_batch(dr_ctx *ctx, const uint8_t *u_pairs, siz
  * identity, prime-order subgroup) on the GPU.  ok[i] = 1 for valid points; out_xy[i] is meaningful only then. */
 DR_API int dr_bsn_decode_points(dr_ctx *ctx, const uint8_t *enc /* n*32 */, size_t n, uint8_t *out_xy /* n*64 */, uint8_t *ok /* n */);
 
+/* The same four operations on any twisted Edwards curve over this base field the library knows:
+ * DR_CURVE_BANDERSNATCH (a = -5, cofactor 4; identical to the dr_bsn_* calls) or DR_CURVE_JUBJUB (a = -1, cofactor 8,
+ * dot_ring/curve/specs/jubjub.py:17-29 — no endomorphism, so the plain 64-window kernels).  The sigma-protocol and
+ * ring entry points below take the curve from dr_vrf_suite.curve. */
+enum { DR_CURVE_BANDERSNATCH = 0, DR_CURVE_JUBJUB = 1 };
+DR_API int dr_te_scalar_mul_batch(dr_ctx *ctx, int curve, const uint8_t *pts_xy, const uint8_t *scalars, size_t n, uint8_t *out_xy);
+DR_API int dr_te_msm(dr_ctx *ctx, int curve, const uint8_t *pts_xy, const uint8_t *scalars, size_t n, uint8_t out_xy[64]);
+DR_API int dr_te_msm_groups(dr_ctx *ctx, int curve, const uint8_t *pts_xy, const uint8_t *scalars, size_t groups, size_t m, uint8_t *out_xy);
+DR_API int dr_te_decode_points(dr_ctx *ctx, int curve, const uint8_t *enc, size_t n, uint8_t *out_xy, uint8_t *ok);
+
 /* square root in the Bandersnatch base field; DR_ERR_NOTSQUARE if none exists. Host-side, no ctx. */
 DR_API int dr_fr_sqrt(const uint8_t in[32], uint8_t out[32]);
 
@@ -194,6 +204,11 @@ typedef struct dr_ring_prover dr_ring_prover;
 DR_API int dr_ring_prover_create(dr_ctx *ctx, const dr_srs *srs, unsigned log2n, uint32_t max_ring, const uint8_t omega_n[32],
                                  const uint8_t omega_4n[32], const uint8_t *nm_points_xy, const uint8_t seed_xy[64],
                                  dr_ring_prover **out);
+/* the same for a ring whose keys live on `curve` (DR_CURVE_*): the constraint system uses that curve's coefficient a and
+ * max_ring + bit length of its group order + 4 must fit the domain */
+DR_API int dr_ring_prover_create_te(dr_ctx *ctx, int curve, const dr_srs *srs, unsigned log2n, uint32_t max_ring,
+                                    const uint8_t omega_n[32], const uint8_t omega_4n[32], const uint8_t *nm_points_xy,
+                                    const uint8_t seed_xy[64], dr_ring_prover **out);
 DR_API void dr_ring_prover_destroy(dr_ring_prover *p);
 DR_API int dr_ring_prover_root(const dr_ring_prover *p, uint8_t out_commitments[3 * 96], int is_inf[3]);
 DR_API int dr_ring_prover_fixed_coeffs(dr_ring_prover *p, uint8_t *out /* 3*N*32: px, py, s coefficients */);
@@ -221,12 +236,19 @@ typedef struct dr_vrf_suite {
     int xof;                        /* 1: SHAKE128 suite, 0: SHA-512 (counter-mode squeeze, expand_message_xmd) */
     uint8_t generator_xy[64];       /* group generator, x||y little-endian */
     uint8_t blinding_base_xy[64];   /* Pedersen blinding base (bandersnatch.py:89-102) */
+    int curve;                      /* DR_CURVE_BANDERSNATCH (Elligator 2 hash-to-curve) or DR_CURVE_JUBJUB (try-and-increment) */
 } dr_vrf_suite;
 
 /* hash_to_field(msg, 2) for `count` messages msgs[off[i]..off[i+1]): out = count * 2 field elements (32-byte LE),
  * the input format of dr_bsn_encode_to_curve_batch. */
 DR_API int dr_hash_to_field_batch(const dr_vrf_suite *suite, const uint8_t *msgs, const uint64_t *off /* count+1 */, size_t count,
                                   uint8_t *out_u_pairs);
+
+/* encode_to_curve(salt_i || msg_i) for `count` messages (salts / salt_off nullable), whichever way the suite's curve hashes:
+ * Elligator 2 (hash_to_field here + dr_bsn_encode_to_curve_batch) or try-and-increment (dot_ring/curve/point.py:252-296:
+ * candidates hashed on worker threads, decompressed and cofactor-cleared on the GPU, several counters per launch). */
+DR_API int dr_encode_to_curve_batch(dr_ctx *ctx, const dr_vrf_suite *suite, const uint8_t *msgs, const uint64_t *off /* count+1 */,
+                                    const uint8_t *salts, const uint64_t *salt_off, size_t count, uint8_t *out_xy /* count*64 */);
 
 /* RingVRF.prove for `batch` (<= 4096) proofs over the prover's ring: out_proofs = batch * 784 bytes
  * (Pedersen 192 || ring payload 592, dot_ring/vrf/ring/vrf.py:51-58).  alphas/ads/salts are concatenated with

@@ -18,15 +18,18 @@ def _load(golden_dir, rel):
 def _cv(name):
     import dot_ring_amd as d
 
-    return {"sha512": d.Bandersnatch, "shake128": d.Bandersnatch_SHAKE128}[name]
+    return {"sha512": d.Bandersnatch, "shake128": d.Bandersnatch_SHAKE128, "jubjub": d.JubJub}[name]
 
 
 TINY = [("sha512", "ark-vrf/bandersnatch_sha-512_ell2_tiny.json"), ("sha512", "ark-vrf/bandersnatch_ed_sha512_ell2_ietf.json"),
-        ("shake128", "ark-vrf/bandersnatch_shake128_ell2_tiny.json"), ("sha512", "dot-ring/bandersnatch_sha-512_ell2_tiny.json")]
+        ("shake128", "ark-vrf/bandersnatch_shake128_ell2_tiny.json"), ("sha512", "dot-ring/bandersnatch_sha-512_ell2_tiny.json"),
+        ("jubjub", "ark-vrf/jubjub_sha-512_tai_tiny.json"), ("jubjub", "dot-ring/jubjub_sha-512_tai_tiny.json")]
 PEDERSEN = [("sha512", "ark-vrf/bandersnatch_sha-512_ell2_pedersen.json"), ("shake128", "ark-vrf/bandersnatch_shake128_ell2_pedersen.json"),
-            ("sha512", "dot-ring/bandersnatch_sha-512_ell2_pedersen.json")]
+            ("sha512", "dot-ring/bandersnatch_sha-512_ell2_pedersen.json"), ("jubjub", "ark-vrf/jubjub_sha-512_tai_pedersen.json"),
+            ("jubjub", "dot-ring/jubjub_sha-512_tai_pedersen.json")]
 RING = [("sha512", "ark-vrf/bandersnatch_ed_sha512_ell2_ring.json"), ("shake128", "ark-vrf/bandersnatch_shake128_ell2_ring.json"),
-        ("sha512", "dot-ring/bandersnatch_sha-512_ell2_ring.json")]
+        ("sha512", "dot-ring/bandersnatch_sha-512_ell2_ring.json"), ("jubjub", "ark-vrf/jubjub_sha-512_tai_ring.json"),
+        ("jubjub", "dot-ring/jubjub_sha-512_tai_ring.json")]
 
 
 def test_keygen_and_h2c_kats(ctx):
@@ -54,6 +57,7 @@ def test_tiny_vrf_vectors(ctx, golden_dir, suite, rel):
     for v in vectors:
         sk, al, ad = (bytes.fromhex(v[k]) for k in ("sk", "alpha", "ad"))
         assert cv.public_key_from_secret(sk).hex() == v["pk"]
+        assert cv.point_type.encode_to_curve(al).point_to_string().hex() == v["h"]
         proof = vrf.prove(al, sk, ad)
         assert proof.encode().hex() == v["gamma"] + v["proof_c"] + v["proof_s"]
         assert proof.verify(bytes.fromhex(v["pk"]), al, ad)
@@ -70,7 +74,8 @@ def test_tiny_vrf_vectors(ctx, golden_dir, suite, rel):
 
 
 THIN = [("sha512", "ark-vrf/bandersnatch_sha-512_ell2_thin.json"), ("shake128", "ark-vrf/bandersnatch_shake128_ell2_thin.json"),
-        ("sha512", "dot-ring/bandersnatch_sha-512_ell2_thin.json")]
+        ("sha512", "dot-ring/bandersnatch_sha-512_ell2_thin.json"), ("jubjub", "ark-vrf/jubjub_sha-512_tai_thin.json"),
+        ("jubjub", "dot-ring/jubjub_sha-512_tai_thin.json")]
 
 
 @pytest.mark.parametrize("suite,rel", THIN)
@@ -334,14 +339,14 @@ def test_tuning_knobs_do_not_change_the_bytes(ctx):
     assert len(set(digests)) == 1, list(zip(variants, digests))
 
 
-@pytest.mark.parametrize("suite", ["sha512", "shake128"])
+@pytest.mark.parametrize("suite", ["sha512", "shake128", "jubjub"])
 def test_native_orchestration_equals_python_orchestration(ctx, suite, monkeypatch):
     """Differential test of the two host layers over the same kernels: ragged inputs (empty, 1 byte, multi-block
     alphas / ads / salts), both suites, all four schemes; the native batch calls must return the bytes of the Python
     orchestration (which the KATs pin)."""
     import dot_ring_amd as d
 
-    cv = {"sha512": d.Bandersnatch, "shake128": d.Bandersnatch_SHAKE128}[suite]
+    cv = _cv(suite)
     rng = random.Random(suite)
     n = 23
     blob = lambda hi: bytes(rng.randrange(256) for _ in range(rng.choice([0, 1, 31, 32, 33, 127, 128, 129, hi])))

@@ -292,3 +292,65 @@ def test_bsn_scalar_mul_large_batch_two_bit_window_kernel(ctx):
     assert got[-64 * 50 :] == bytes(want)
     small = ctx.bsn_scalar_mul_batch(pts[: 64 * 50], ks[: 32 * 50])            # 4-bit kernel
     assert small == got[: 64 * 50]
+
+
+# ------------------------------------------------------------------ seam A on JubJub (a = -1, cofactor 8)
+def _jub_points(rng, count):
+    return [bsn.mul_py(bsn.G, rng.randrange(1, bsn.N)) for _ in range(count)]
+
+
+def test_jubjub_scalar_mul_msm_and_groups_match_oracle(ctx):
+    """dr_te_scalar_mul_batch / dr_te_msm / dr_te_msm_groups with DR_CURVE_JUBJUB against the oracle's affine double-and-add
+    (bandersnatch.py under using(JUBJUB)), incl. the edge scalars 0, 1, n-1, n, 2^256-1 (17 subtractions of n)."""
+    rng = random.Random(4242)
+    with bsn.using(bsn.JUBJUB):
+        order = bsn.N
+        n = 70
+        pts = _jub_points(rng, n)
+        ks = [rng.randrange(1 << 256) for _ in range(n)]
+        ks[:8] = [0, 1, order - 1, order, (1 << 256) - 1, 2, 8, 17 * order - 1]
+        got = coracle.te_unpack(ctx.bsn_scalar_mul_batch(coracle.te_pack(pts), b"".join(k.to_bytes(32, "little") for k in ks), 1))
+        want = [bsn.mul(p, k) for p, k in zip(pts, ks)]
+        assert got == want
+        for m in (1, 5, 64, 70):
+            msm = coracle.te_unpack(ctx.bsn_msm(coracle.te_pack(pts[:m]), coracle.scalars_pack([k % order for k in ks[:m]]), 1))[0]
+            acc = bsn.IDENTITY
+            for w in want[:m]:
+                acc = bsn._te_add_ref(acc, w)
+            assert msm == acc
+        groups = coracle.te_unpack(ctx.bsn_msm_groups(coracle.te_pack(pts[:69]), coracle.scalars_pack([k % order for k in ks[:69]]), 3, 1))
+        assert groups == [bsn._te_add_ref(bsn._te_add_ref(want[3 * g], want[3 * g + 1]), want[3 * g + 2]) for g in range(23)]
+    # the default curve is untouched by the template parameter
+    assert coracle.te_unpack(ctx.bsn_scalar_mul_batch(coracle.te_pack([bsn.G]), (3).to_bytes(32, "little")))[0] == coracle.te_mul(bsn.G, 3)
+
+
+def test_jubjub_decode_points_and_try_and_increment_match_oracle(ctx):
+    """dr_te_decode_points on JubJub (cofactor-8 subgroup check without an endomorphism) and dr_encode_to_curve_batch
+    (try-and-increment: several counters per launch) against the oracle, incl. inputs whose first candidates fail."""
+    import dot_ring_amd as d
+
+    rng = random.Random(99)
+    with bsn.using(bsn.JUBJUB):
+        encs = [bsn.enc_point(p) for p in _jub_points(rng, 40)]
+        encs += [bytes(rng.randrange(256) for _ in range(32)) for _ in range(120)]
+        encs += [(1).to_bytes(32, "little"), (bsn.P - 1).to_bytes(32, "little"), (bsn.P + 3).to_bytes(32, "little"), bytes(32), bytes(31) + b"\x80"]
+        encs += [e[:31] + bytes([e[31] ^ 0x80]) for e in encs[:10]]
+        raw, ok = ctx.bsn_decode_points(b"".join(encs), 1)
+        n_valid = 0
+        for i, e in enumerate(encs):
+            try:
+                want = bsn.dec_point(e)
+            except ValueError:
+                want = None
+            assert bool(ok[i]) == (want is not None), (i, e.hex())
+            if want is not None:
+                n_valid += 1
+                assert coracle.te_unpack(raw[64 * i : 64 * i + 64])[0] == want
+        assert n_valid >= 50
+        msgs = [b"", b"foo"] + [bytes(rng.randrange(256) for _ in range(rng.randrange(0, 200))) for _ in range(60)]
+        salts = [b""] * 32 + [bytes(rng.randrange(256) for _ in range(rng.randrange(0, 40))) for _ in range(30)]
+        got = d.JubJub.point_type.encode_to_curve_batch(msgs, salts)
+        want = [bsn.encode_to_curve(bsn.JUBJUB, m, s) for m, s in zip(msgs, salts)]
+        assert [(p.x, p.y) for p in got] == want
+        assert d.JubJub.point_type.encode_to_curve(b"foo") == got[1]
+        assert d.JubJub.point_type.encode_to_curve_batch([]) == []
