@@ -65,6 +65,9 @@ def dec_points(cv, values) -> list:
         return []
     xy, flags = runtime.context().bsn_decode_points(b"".join(blobs), cv.curve.params.curve_id)
     if 0 in flags:
+        # the reference reports the first bad point: "Invalid point encoding" when it does not decompress
+        # (point.py:176-205), otherwise the subgroup message of dec_point
+        cv.point_type.string_to_point(blobs[bytes(flags).index(0)])
         raise ValueError("point is not a valid nonidentity subgroup point")
     make, le = cv.point_type._trusted, int.from_bytes
     return [make(le(xy[o : o + 32], "little"), le(xy[o + 32 : o + 64], "little")) for o in range(0, 64 * len(blobs), 64)]
