@@ -275,3 +275,34 @@ def test_batch_verify_apis_and_negative_cases(ctx, golden_dir, cvname, prefix):
     wrong_sk = bytes.fromhex(load("tiny")[1]["sk"])
     with pytest.raises(ValueError, match="producer key is not in ring"):
         d.RingVRF[cv].prove(alpha, ad, wrong_sk, cv.public_key_from_secret(wrong_sk), ring, root)
+
+
+# ------------------------------------------------------------------ tests/test_coverage/test_kzg.py (the PCS seam by itself)
+def test_kzg_commit_open_verify_batch_verify(ctx, monkeypatch):
+    from dot_ring_amd.ring_proof.pcs import KZG, Opening
+    from oracle.pyref import kzg as okzg
+
+    assert KZG.commit([1, 2, 3]) is not None and KZG.commit([5]) is not None
+    assert KZG.commit([0, 0, 0]) is None                                   # the point at infinity
+    sparse = [1, 0, 0, 0, 0, 5, 0, 0, 0, 3]
+    assert KZG.compress_g1(KZG.commit(sparse)) == okzg.compress(okzg.commit(sparse))
+    asked = []
+    monkeypatch.setattr(KZG, "ensure_srs_size", classmethod(lambda cls, deg: asked.append(deg)))
+    KZG.commit([1, 2, 3])
+    assert asked == [2]
+    monkeypatch.undo()
+    opening = KZG.open([1, 2, 3], 5)
+    assert isinstance(opening, Opening) and opening.y == 86 and KZG.open([7, 2, 3], 0).y == 7
+    cm = KZG.commit([1, 2, 3])
+    assert KZG.verify(cm, opening.proof, 5, opening.y) is True
+    assert KZG.verify(cm, opening.proof, 5, (opening.y + 1) % (1 << 256)) is False
+    assert KZG.batch_verify([]) is True
+    assert KZG.batch_verify([(cm, opening.proof, 5, opening.y)]) is True
+    claims = []
+    for i in range(3):
+        coeffs, x = [1 + i, 2 + i, 3 + i], 5 + i
+        op = KZG.open(coeffs, x)
+        claims.append((KZG.commit(coeffs), op.proof, x, op.y))
+    assert KZG.batch_verify(claims) is True
+    op = KZG.open([1, 2, 3], 10)
+    assert KZG.batch_verify(claims[:2] + [(cm, op.proof, 10, (op.y + 1000) % (1 << 256))]) is False
