@@ -12,8 +12,8 @@ def seed(*parts):
         h.update(b"\0")
     return h.digest()
 
-def main(ring_size, batch, reps=2):
-    cv = d.Bandersnatch
+def main(ring_size, batch, reps=2, curve="Bandersnatch"):
+    cv = getattr(d, curve)
     vrf = d.RingVRF[cv]
     t0 = time.perf_counter()
     signer_pk, signer_sk = cv.secret_from_seed(seed("signer", 0, 0))
@@ -24,7 +24,7 @@ def main(ring_size, batch, reps=2):
     keys = [p.point_to_string() for p in pts]
     keys[min(3, ring_size - 1)] = signer_pk
     t1 = time.perf_counter()
-    ring = d.Ring(keys)
+    ring = d.Ring(keys, d.RingProofParams.from_ring_size(ring_size, cv=cv))
     root = d.RingRoot.from_ring(ring)
     t2 = time.perf_counter()
     print(f"ring {ring_size}: domain {ring.params.domain_size}; keygen {t1 - t0:.2f}s, Ring+RingRoot {t2 - t1:.3f}s", flush=True)
@@ -61,4 +61,4 @@ def main(ring_size, batch, reps=2):
     pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]))
+    main(int(sys.argv[1]), int(sys.argv[2]), curve=sys.argv[3] if len(sys.argv) > 3 else "Bandersnatch")
