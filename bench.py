@@ -154,6 +154,10 @@ def main() -> int:
         red_device = "cpu" if share else "cuda"
 
     os.environ["DOTRING_DEVICE"] = str(local_rank)
+    if world > 1 and "DOTRING_HOST_THREADS" not in os.environ:
+        # the library's worker threads (hashing between the GPU phases) default to min(16, cores) per process: with one
+        # process per GPU share the host's cores between the ranks instead of oversubscribing them
+        os.environ["DOTRING_HOST_THREADS"] = str(max(2, min(16, len(os.sched_getaffinity(0)) // world)))
     import dot_ring_amd as d
     from dot_ring_amd import runtime
     from dot_ring_amd.ring_proof.pcs import SRS
