@@ -315,7 +315,11 @@ def main() -> int:
                          # XYZZ mixed addition (10 Montgomery products of 649 instructions + ~310 add/sub/select)
                          "valu": {"achieved_gadd_s": dense_adds / (acc_ms / 1e3) / 1e9 if acc_ms else None, "peak_gadd_s": VALU_PEAK_GADD_S,
                                   "frac": dense_adds / (acc_ms / 1e3) / 1e9 / VALU_PEAK_GADD_S if acc_ms else None,
-                                  "note": "dense bucket additions only (7N pairs x windows per proof); by-parts and verify-side additions not counted"}},
+                                  "note": "dense bucket additions only (7N pairs x windows per proof); by-parts and verify-side additions not counted"},
+                         # per-proof unique traffic (11N scalars + 14 NTT passes' data + 784 B out), 3.17 KB per
+                         # domain point = 6.5 MB per proof at N = 2048, over the whole job
+                         "whole_proof": {"algorithmic_bytes_per_proof": 3174 * n_dom, "achieved": 3174 * n_dom * value / 1e9, "unit": "GB/s",
+                                         "frac": 3174 * n_dom * value / 1e9 / (HBM_PEAK_GBS * world)}},
             "cpu_baseline": cpu,
             "parity_ok": parity_ok,
             "prove_only_proofs_per_s": batch * args.steps / prove_s if prove_s else None,
