@@ -250,3 +250,39 @@ def test_g1_msm_linearity_at_2p18(ctx):
     rc = b"".join((c * x % r).to_bytes(32, "little") for x in va)
     assert ctx.g1_msm(srs, rc) == ctx.g1_msm_points(pa, c.to_bytes(32, "little"))
     srs.close()
+
+
+def test_jubjub_device_prover_domain_1024_matches_oracle(ctx):
+    """The curve-templated witness chain / constraint / linearisation kernels with a = -1 at N = 1024 (ring of 300 JubJub
+    keys, 252 blinding bits, capacity 768 + 0): ring root and proofs byte for byte against the oracle, incl. edge
+    blinding factors (1, n - 1, the top bit, alternating bits); then prove_batch + batch_verify end to end."""
+    import dot_ring_amd as d
+    from dot_ring_amd.ring_proof import device_prover
+
+    rng = random.Random(11)
+    cv = d.JubJub
+    with obsn.using(obsn.JUBJUB):
+        n = obsn.N
+        sks = [rng.randrange(1, n) for _ in range(300)]
+        keys = [cv.public_key_from_secret(sk.to_bytes(32, "little")) for sk in sks]
+        assert keys[5] == obsn.enc_point(obsn.mul_py(obsn.G, sks[5]))
+        keys[1] = bytes(32)                                       # undecodable -> padding point
+        params = d.RingProofParams.from_ring_size(300, test_vectors=True, cv=cv)
+        assert (params.domain_size, params.max_ring_size) == (1024, 768)
+        ring = d.Ring(keys, params)
+        root = d.RingRoot.from_ring(ring, params)
+        o_ring = oring.Ring(keys, oring.Params.from_ring_size(300, test_vectors=True, suite=obsn.JUBJUB))
+        o_root = oring.RingRoot(o_ring)
+        assert root.encode() == o_root.encode()
+        blindings = [1, n - 1, 1 << 251, (1 << 251) - 1, 0x5555555555555555555555555555555555555555555555555555555555555555 % n, rng.randrange(n)]
+        producers = [0, 2, 299, 3, 150, 2]
+        got = device_prover.build_ring_proofs_device(ring, root, ring.indices_of([keys[p] for p in producers]), blindings)
+        for payload, p, t in zip(got, producers, blindings):
+            assert _encode_payload(None, payload) == oring.prove_ring(o_ring, o_root, keys[p], t)
+        vrf = d.RingVRF[cv]
+        who = [0, 2, 299, 17]
+        als = [b"jub-%d" % i for i in range(4)]
+        proofs = vrf.prove_batch(als, als, [sks[w].to_bytes(32, "little") for w in who], [keys[w] for w in who], ring, root)
+        assert proofs[2].encode() == oring.ring_vrf_prove(o_ring, o_root, als[2], als[2], sks[299].to_bytes(32, "little"))
+        assert vrf.batch_verify(proofs, als, als, ring, root)
+        assert not vrf.batch_verify(proofs, als[::-1], als, ring, root)
