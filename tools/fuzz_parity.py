@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""One-off large differential run of the Bandersnatch / JubJub kernels against the oracle (beyond the sizes the test suite
+uses): python tools/fuzz_parity.py [scale]   (scale 1 = about two minutes of oracle time).  Exit code 1 on any mismatch."""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dot_ring_amd as d
+from dot_ring_amd import runtime
+from oracle import coracle
+from oracle.pyref import bandersnatch as bsn
+
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+rng = random.Random(20260)
+ctx = runtime.context()
+bad = 0
+
+
+def report(name, n, wrong, t0):
+    global bad
+    bad += wrong
+    print(f"{name}: {n} cases, {wrong} mismatches, {time.perf_counter() - t0:.1f} s", flush=True)
+
+
+# 1. Bandersnatch scalar multiplication (both kernels: GLV lane pairs below 16384 terms, 2-bit windows from 32768)
+for n in (int(3000 * scale), int(40000 * scale)):
+    t0 = time.perf_counter()
+    base = [coracle.te_mul(bsn.G, rng.randrange(1, bsn.N)) for _ in range(200)]
+    pts = [base[rng.randrange(200)] for _ in range(n)]
+    ks = [rng.randrange(1 << 256) for _ in range(n)]
+    got = ctx.bsn_scalar_mul_batch(coracle.te_pack(pts), b"".join(k.to_bytes(32, "little") for k in ks))
+    want = coracle.te_mul_batch_raw(coracle.te_pack(pts), coracle.scalars_pack([k % bsn.N for k in ks]), n, glv=True)
+    report(f"bsn scalar_mul n={n}", n, sum(got[64 * i : 64 * i + 64] != bytes(want[64 * i : 64 * i + 64]) for i in range(n)), t0)
+
+# 2. Bandersnatch point decoding: random strings, valid keys, sign flips
+t0 = time.perf_counter()
+n = int(60000 * scale)
+encs = [bytes(rng.randrange(256) for _ in range(32)) for _ in range(n)]
+for i in range(0, n, 7):
+    encs[i] = bsn.enc_point(coracle.te_mul(bsn.G, rng.randrange(1, bsn.N)))
+raw, ok = ctx.bsn_decode_points(b"".join(encs))
+wrong = 0
+for i, e in enumerate(encs):
+    try:
+        want = bsn.dec_point(e)
+    except ValueError:
+        want = None
+    if bool(ok[i]) != (want is not None) or (want is not None and coracle.te_unpack(raw[64 * i : 64 * i + 64])[0] != want):
+        wrong += 1
+report("bsn decode_points", n, wrong, t0)
+
+# 3. Elligator 2 on both Bandersnatch suites
+for cv, suite in ((d.Bandersnatch, bsn.SHA512), (d.Bandersnatch_SHAKE128, bsn.SHAKE128)):
+    t0 = time.perf_counter()
+    n = int(4000 * scale)
+    msgs = [bytes(rng.randrange(256) for _ in range(rng.randrange(0, 90))) for _ in range(n)]
+    got = cv.point_type.encode_to_curve_batch(msgs)
+    report(f"elligator {cv.name}", n, sum((p.x, p.y) != bsn.encode_to_curve(suite, m) for p, m in zip(got, msgs)), t0)
+
+# 4. JubJub: try-and-increment, decoding, scalar multiplication (the oracle's affine double-and-add is slow: smaller counts)
+with bsn.using(bsn.JUBJUB):
+    t0 = time.perf_counter()
+    n = int(6000 * scale)
+    msgs = [bytes(rng.randrange(256) for _ in range(rng.randrange(0, 90))) for _ in range(n)]
+    got = d.JubJub.point_type.encode_to_curve_batch(msgs)
+    report("jubjub try-and-increment", n, sum((p.x, p.y) != bsn.encode_to_curve(bsn.JUBJUB, m) for p, m in zip(got, msgs)), t0)
+    t0 = time.perf_counter()
+    n = int(1500 * scale)
+    encs = [bytes(rng.randrange(256) for _ in range(32)) for _ in range(n)]
+    for i in range(0, n, 5):
+        encs[i] = bsn.enc_point(bsn.mul_py(bsn.G, rng.randrange(1, bsn.N)))
+    raw, ok = ctx.bsn_decode_points(b"".join(encs), 1)
+    wrong = 0
+    for i, e in enumerate(encs):
+        try:
+            want = bsn.dec_point(e)
+        except ValueError:
+            want = None
+        if bool(ok[i]) != (want is not None) or (want is not None and coracle.te_unpack(raw[64 * i : 64 * i + 64])[0] != want):
+            wrong += 1
+    report("jubjub decode_points", n, wrong, t0)
+    t0 = time.perf_counter()
+    n = int(1500 * scale)
+    base = [bsn.mul_py(bsn.G, rng.randrange(1, bsn.N)) for _ in range(20)]
+    pts = [base[rng.randrange(20)] for _ in range(n)]
+    ks = [rng.randrange(1 << 256) for _ in range(n)]
+    got = coracle.te_unpack(ctx.bsn_scalar_mul_batch(coracle.te_pack(pts), b"".join(k.to_bytes(32, "little") for k in ks), 1))
+    report("jubjub scalar_mul", n, sum(g != bsn.mul(p, k) for g, p, k in zip(got, pts, ks)), t0)
+
+print("FUZZ", "FAILED" if bad else "OK")
+sys.exit(1 if bad else 0)
