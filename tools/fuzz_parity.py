@@ -85,5 +85,32 @@ with bsn.using(bsn.JUBJUB):
     got = coracle.te_unpack(ctx.bsn_scalar_mul_batch(coracle.te_pack(pts), b"".join(k.to_bytes(32, "little") for k in ks), 1))
     report("jubjub scalar_mul", n, sum(g != bsn.mul(p, k) for g, p, k in zip(got, pts, ks)), t0)
 
+# 5. whole Ring-VRF proofs (native batch prover) against the oracle prover: random ring sizes, signers, input lengths
+from oracle.pyref import ring as oring
+
+for cv, suite in ((d.Bandersnatch, bsn.SHA512), (d.Bandersnatch_SHAKE128, bsn.SHAKE128), (d.JubJub, bsn.JUBJUB)):
+    with bsn.using(suite):
+        t0 = time.perf_counter()
+        wrong = total = 0
+        for _ in range(max(1, int(2 * scale))):
+            size = rng.choice([1, 2, 9, 100, 255, 256, 300, 700])
+            sks = [rng.randrange(1, bsn.N).to_bytes(32, "little") for _ in range(size)]
+            keys = [cv.public_key_from_secret(sk) for sk in sks]
+            params = d.RingProofParams.from_ring_size(size, test_vectors=True, cv=cv)
+            ring = d.Ring(keys, params)
+            root = d.RingRoot.from_ring(ring, params)
+            o_ring = oring.Ring(keys, oring.Params.from_ring_size(size, test_vectors=True, suite=suite))
+            o_root = oring.RingRoot(o_ring)
+            wrong += root.encode() != o_root.encode()
+            who = [rng.randrange(size) for _ in range(4)]
+            als = [bytes(rng.randrange(256) for _ in range(rng.randrange(0, 70))) for _ in who]
+            ads = [bytes(rng.randrange(256) for _ in range(rng.randrange(0, 70))) for _ in who]
+            proofs = d.RingVRF[cv].prove_batch(als, ads, [sks[w] for w in who], [keys[w] for w in who], ring, root)
+            for pf, w, al, ad in zip(proofs, who, als, ads):
+                wrong += pf.encode() != oring.ring_vrf_prove(o_ring, o_root, al, ad, sks[w])
+                total += 1
+            wrong += not d.RingVRF[cv].batch_verify(proofs, als, ads, ring, root)
+        report(f"ring proofs {cv.name}", total, wrong, t0)
+
 print("FUZZ", "FAILED" if bad else "OK")
 sys.exit(1 if bad else 0)
