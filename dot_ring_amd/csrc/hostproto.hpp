@@ -9,7 +9,13 @@
 //   point / scalar codecs                    dot_ring/vrf/codec.py:9-45, dot_ring/curve/point.py:150-214
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -33,6 +39,91 @@ inline unsigned host_threads() {
     }();
     return cached;
 }
+// A persistent pool of host_threads() - 1 workers: starting 16 threads costs ~0.35 ms, and one batch goes through a dozen
+// short parallel loops (0.1-0.5 ms of hashing each).  Several threads may run parallel loops at once (the prover's main
+// thread and its Pedersen helper): jobs queue up, every worker drains the oldest one, and the CALLER works on its own job too,
+// so a loop finishes even when no worker is free (or after a fork, when none exists).  DOTRING_HOST_POOL=0 goes back to
+// one std::thread per slice.
+class WorkerPool {
+    struct Job {
+        const std::function<void(size_t)>* f;
+        size_t n, chunk, chunks;
+        std::atomic<size_t> next{0}, done{0};
+        std::mutex m;
+        std::condition_variable cv;
+    };
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::shared_ptr<Job>> jobs_;
+    std::vector<std::thread> workers_;
+    bool stop_ = false;
+
+    static void drain(Job& j) {
+        for (;;) {
+            size_t c = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (c >= j.chunks) return;
+            size_t lo = c * j.chunk, hi = std::min(j.n, lo + j.chunk);
+            for (size_t i = lo; i < hi; i++) (*j.f)(i);
+            if (j.done.fetch_add(1, std::memory_order_acq_rel) + 1 == j.chunks) {
+                std::lock_guard<std::mutex> lk(j.m);
+                j.cv.notify_all();
+            }
+        }
+    }
+    void worker() {
+        for (;;) {
+            std::shared_ptr<Job> j;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || !jobs_.empty(); });
+                if (stop_) return;
+                j = jobs_.front();
+            }
+            drain(*j);
+            std::lock_guard<std::mutex> lk(m_);
+            if (!jobs_.empty() && jobs_.front() == j) jobs_.pop_front();          // all its chunks are taken
+        }
+    }
+
+public:
+    explicit WorkerPool(unsigned workers) {
+        for (unsigned k = 0; k < workers; k++) workers_.emplace_back([this] { worker(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void run(size_t n, unsigned slices, const std::function<void(size_t)>& f) {
+        auto j = std::make_shared<Job>();
+        j->f = &f;
+        j->n = n;
+        j->chunk = (n + slices - 1) / slices;
+        j->chunks = (n + j->chunk - 1) / j->chunk;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            jobs_.push_back(j);
+        }
+        cv_.notify_all();
+        drain(*j);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            auto it = std::find(jobs_.begin(), jobs_.end(), j);
+            if (it != jobs_.end()) jobs_.erase(it);
+        }
+        std::unique_lock<std::mutex> lk(j->m);
+        j->cv.wait(lk, [&] { return j->done.load(std::memory_order_acquire) == j->chunks; });
+    }
+};
+inline WorkerPool* worker_pool() {
+    static const bool enabled = [] { const char* e = std::getenv("DOTRING_HOST_POOL"); return !e || std::atoi(e) != 0; }();
+    if (!enabled || host_threads() <= 1) return nullptr;
+    static WorkerPool pool(host_threads() - 1);
+    return &pool;
+}
 // f(i) for i in [0, n); f must not throw.  Short loops stay on the calling thread.
 template <class F>
 void parallel_for(size_t n, F f) {
@@ -40,6 +131,11 @@ void parallel_for(size_t n, F f) {
     if (t > n / 16) t = (unsigned)(n / 16);
     if (t <= 1) {
         for (size_t i = 0; i < n; i++) f(i);
+        return;
+    }
+    if (WorkerPool* pool = worker_pool()) {
+        const std::function<void(size_t)> fn = [&f](size_t i) { f(i); };
+        pool->run(n, t, fn);
         return;
     }
     std::vector<std::thread> pool;
