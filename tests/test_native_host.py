@@ -48,3 +48,29 @@ def test_pairing_fast_final_exponentiation_matches_reference(srs_bytes):
         ok = ctypes.c_int(0)
         assert lib.dr_pairing_selfcheck(b"".join(a for a, _ in pairs), b"".join(b for _, b in pairs), len(pairs), ctypes.byref(ok)) == 0
         assert ok.value == 1
+
+
+def test_worker_pool_serves_concurrent_callers():
+    """The library's persistent worker pool (hostproto.hpp: WorkerPool) with six threads inside parallel loops at once —
+    the situation of the prover's main thread and its helper threads: every call returns the right bytes, none hangs."""
+    import threading
+
+    import dot_ring_amd as d
+
+    suite = d.Bandersnatch.point_type._suite_struct()
+    rng = random.Random(5)
+    msgs = [bytes(rng.randrange(256) for _ in range(rng.randrange(0, 100))) for _ in range(3000)]
+    want = b"".join(u.to_bytes(32, "little") for m in msgs[:64] for u in obsn.hash_to_field(obsn.SHA512, m, 2))
+    wrong = []
+
+    def work():
+        for _ in range(25):
+            if _native.hash_to_field_batch(suite, msgs)[: 64 * 64] != want:
+                wrong.append(1)
+
+    threads = [threading.Thread(target=work) for _ in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads) and not wrong
