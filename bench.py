@@ -75,6 +75,52 @@ def bench_ring_keys(cv, ring_size: int, sample_index: int):
     return signer_pk, signer_sk, keys
 
 
+def cpu_baseline_all_cores(keys, ring_size: int, signer_sk: bytes, per_worker: int, workers: int, first_proofs):
+    """The oracle prover in `workers` child processes at once (each proves `per_worker` proofs of the benchmark's inputs;
+    worker 0's first proofs are compared with the single-process run).  Children never touch the GPU."""
+    import subprocess
+    import tempfile
+
+    if workers < 0:
+        workers = min(16, len(os.sched_getaffinity(0)))
+    workers = max(1, workers)
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump({"keys": [k.hex() for k in keys], "ring_size": ring_size, "signer_sk": signer_sk.hex(),
+                   "alpha_prefix": b"bench-batch-input".hex(), "ad_prefix": b"bench-batch-ad".hex()}, f)
+        job = f.name
+    env = {k: v for k, v in os.environ.items()}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    procs = []
+    try:
+        for w in range(workers):
+            procs.append(subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", job, str(w * per_worker), str(per_worker)], cwd=ROOT, env=env,
+                                          stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+        for p in procs:
+            if p.stdout.readline().strip() != "READY":
+                raise RuntimeError("oracle worker failed to start")
+        t0 = time.perf_counter()
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        outs = [p.stdout.readline().split() for p in procs]
+        wall = time.perf_counter() - t0
+        for p in procs:
+            p.wait(timeout=60)
+        if any(len(o) != 3 or o[0] != "DONE" for o in outs):
+            raise RuntimeError("oracle worker failed")
+        want = hashlib.sha256(b"".join(first_proofs[:per_worker])).hexdigest()
+        return {"value": workers * per_worker / wall, "unit": "proofs/s", "cores": workers, "kind": "port",
+                "sample": f"{workers} oracle processes x {per_worker} proofs each (prove only), released together, {wall:.1f} s wall",
+                "matches_single_process": outs[0][2] == want}
+    except Exception as exc:          # a baseline that cannot run is reported, not fatal
+        return {"value": None, "unit": "proofs/s", "cores": workers, "kind": "port", "sample": f"failed: {exc}"}
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        os.unlink(job)
+
+
 def g1_msm_measurement(ctx, log2n: int, steps: int, cpu_sample_log2: int, do_cpu: bool):
     """Secondary: G1 MSM at 2^log2n synthetic bases. Returns a dict (rank-local)."""
     n = 1 << log2n
@@ -125,6 +171,7 @@ def main() -> int:
     ap.add_argument("--ring-size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
     ap.add_argument("--cpu-proofs", type=int, default=16, help="proofs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=-1, help="processes of the all-cores CPU baseline (-1 = min(16, cores), 0 = skip)")
     ap.add_argument("--msm-log2n", type=int, default=20, help="secondary G1 MSM size (0 = skip)")
     args = ap.parse_args()
 
@@ -241,7 +288,7 @@ def main() -> int:
         from oracle.pyref import ring as oring
 
         parity_ok = all_ok
-        cpu = None
+        cpu = cpu_all = None
         if args.cpu_proofs > 0:
             tv_params = d.RingProofParams.from_ring_size(args.ring_size, test_vectors=True, pcs=pcs)
             tv_ring = d.Ring(keys, tv_params)
@@ -264,6 +311,10 @@ def main() -> int:
             cpu = None if world > 1 else {"value": m / cpu_s, "unit": "proofs/s", "cores": 1, "kind": "port",
                    "sample": f"{m} proofs (prove only) of the same workload through oracle/ (Python orchestration + oracle/c "
                              f"kernels for NTT and G1 Pippenger), {cpu_s:.1f} s"}
+
+            # the same port on all host cores: one oracle process per core, released together
+            if world == 1 and not big and args.cpu_workers != 0:
+                cpu_all = cpu_baseline_all_cores(keys, args.ring_size, signer_sk, max(2, m // 4), args.cpu_workers, cpu_proofs)
 
         # bucket additions of the dense MSMs in the timed region: pairs x windows of the SRS table (non-zero digit rate ~1)
         table_windows = -(-256 // int(os.environ.get("DOTRING_SRS_WINDOW", "12") or 12))
@@ -321,6 +372,7 @@ def main() -> int:
                          "whole_proof": {"algorithmic_bytes_per_proof": 3174 * n_dom, "achieved": 3174 * n_dom * value / 1e9, "unit": "GB/s",
                                          "frac": 3174 * n_dom * value / 1e9 / (HBM_PEAK_GBS * world)}},
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
             "parity_ok": parity_ok,
             "prove_only_proofs_per_s": batch * args.steps / prove_s if prove_s else None,
             "verify_only_proofs_per_s": batch * args.steps / verify_s if verify_s else None,
