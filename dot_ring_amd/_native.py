@@ -268,6 +268,12 @@ class Srs:
             lib().dr_srs_destroy(self.handle)
             self.handle = c_void_p()
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 class RingProver:
     """Device-resident batched ring prover for one ring (dr_ring_prover_*)."""
@@ -284,6 +290,14 @@ class RingProver:
         if self.handle:
             lib().dr_ring_prover_destroy(self.handle)
             self.handle = c_void_p()
+
+    def __del__(self):
+        # provers are cached on Ring objects: when the ring goes, its tables and per-batch state (hundreds of MB of HBM)
+        # must go too
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @staticmethod
     def _points(raw: bytes, inf, count: int) -> list:

@@ -1473,6 +1473,7 @@ struct dr_ring_prover {
     dr_ctx* ctx = nullptr;
     const dr_srs* srs = nullptr;
     int curve = dr::CV_BANDERSNATCH;     // which twisted Edwards curve the ring's keys live on
+    int device = 0;                      // copy of ctx->device: destroy may run after the context is gone (finalizers)
     dr::RingConsts rc{};
     drh::Fr omega_n, omega_4n;          // Montgomery
     const dr_srs* ps_srs = nullptr;      // prefix-summed Lagrange bases of this domain (owned by srs->lagrange_prefix)
@@ -1579,6 +1580,7 @@ int dr_ring_prover_create_te(dr_ctx* ctx, int curve, const dr_srs* srs, unsigned
     if (!p) return fail(DR_ERR_NOMEM, "out of host memory");
     std::unique_ptr<dr_ring_prover, void (*)(dr_ring_prover*)> guard(p, [](dr_ring_prover* q) { dr_ring_prover_destroy(q); });
     p->ctx = ctx;
+    p->device = ctx->device;
     p->srs = srs;
     p->curve = curve;
     if (!drh::Fr::load_le(p->omega_n, omega_n) || !drh::Fr::load_le(p->omega_4n, omega_4n))
@@ -1638,7 +1640,7 @@ int dr_ring_prover_create_te(dr_ctx* ctx, int curve, const dr_srs* srs, unsigned
 
 void dr_ring_prover_destroy(dr_ring_prover* p) {
     if (!p) return;
-    if (p->ctx) (void)hipSetDevice(p->ctx->device);
+    (void)hipSetDevice(p->device);
     for (Scratch* s : {&p->ring_pts_mont, &p->fixed_coef, &p->fixed4, &p->lag4, &p->not_last, &p->idx, &p->blind, &p->zk, &p->chain_ext,
                        &p->prefix, &p->chain_aff, &p->cnt, &p->relation, &p->rps, &p->cols, &p->wit4, &p->alphas, &p->agg, &p->q, &p->zetas,
                        &p->evals, &p->ks, &p->lin, &p->nus, &p->aggo, &p->chunkv, &p->quot1, &p->quot2, &p->diffs})

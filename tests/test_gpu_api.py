@@ -408,3 +408,39 @@ def test_ring_decode_batch_equals_decode(ctx):
             vrf.decode_batch(bad)
         with pytest.raises(ValueError):
             vrf.decode(bad[4])
+
+
+def test_rings_release_their_device_state(ctx):
+    """A Ring owns a device prover (tables + per-batch state, hundreds of MB of HBM): dropping the ring must free it —
+    fresh rings in a loop keep the card's memory use flat (tools/leak_check.py is the long version)."""
+    import gc
+    import shutil
+    import subprocess
+    import weakref
+
+    import dot_ring_amd as d
+
+    if shutil.which("rocm-smi") is None:
+        pytest.skip("rocm-smi not available")
+
+    def vram_used():
+        out = subprocess.run(["rocm-smi", "--showmeminfo", "vram", "--csv"], capture_output=True, text=True).stdout
+        return next(int(line.split(",")[2]) for line in out.splitlines() if line.startswith("card"))
+
+    cv = d.Bandersnatch
+    sks = [(8100 + i).to_bytes(32, "little") for i in range(12)]
+    keys = [cv.public_key_from_secret(sk) for sk in sks]
+    used, provers = [], []
+    for it in range(7):
+        params = d.RingProofParams.from_ring_size(300)
+        ring = d.Ring(keys, params)
+        root = d.RingRoot.from_ring(ring, params)
+        al = [b"r%d-%d" % (it, i) for i in range(128)]
+        proofs = d.RingVRF[cv].prove_batch(al, al, [sks[i % 12] for i in range(128)], [keys[i % 12] for i in range(128)], ring, root)
+        assert d.RingVRF[cv].batch_verify(proofs, al, al, ring, root)
+        provers.append(weakref.ref(next(iter(ring.__dict__["_device_provers"].values()))))
+        del ring, root, proofs
+        gc.collect()
+        used.append(vram_used())
+    assert all(w() is None for w in provers)
+    assert used[-1] - used[2] < 32 << 20, used
