@@ -1681,7 +1681,14 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
     const uint32_t n = rc.n;
     for (size_t i = 0; i < batch; i++)
         if (producer_index[i] >= rc.max_ring) return fail(DR_ERR_INVALID, "producer key is not in ring");
-    TRY(check_fr_elems(blinding, batch, "blinding factor"));
+    {   // blinding factors are scalars of the ring's curve: their bits select rows max_ring .. max_ring + bits(n) - 1
+        const drh::Mod256& order = drh::te_curve(p->curve)->n;
+        for (size_t i = 0; i < batch; i++) {
+            uint64_t v[4];
+            drh::load_le32(blinding + 32 * i, v);
+            if (drh::Mod256::geq(v, order.m)) return fail(DR_ERR_INVALID, "blinding factor is not a canonical scalar of the curve");
+        }
+    }
     if (zk_rows) TRY(check_fr_elems(zk_rows, batch * 12, "hidden row"));
     p->batch = batch;
     hipStream_t st = ctx->stream;

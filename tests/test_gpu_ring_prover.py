@@ -279,6 +279,9 @@ def test_jubjub_device_prover_domain_1024_matches_oracle(ctx):
         got = device_prover.build_ring_proofs_device(ring, root, ring.indices_of([keys[p] for p in producers]), blindings)
         for payload, p, t in zip(got, producers, blindings):
             assert _encode_payload(None, payload) == oring.prove_ring(o_ring, o_root, keys[p], t)
+        for too_big in (n, (1 << 252) + 5):          # not a scalar of this curve: bit 252 would select a padding row
+            with pytest.raises(ValueError, match="canonical scalar"):
+                device_prover.build_ring_proofs_device(ring, root, [0], [too_big])
         vrf = d.RingVRF[cv]
         who = [0, 2, 299, 17]
         als = [b"jub-%d" % i for i in range(4)]
