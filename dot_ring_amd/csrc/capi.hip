@@ -289,6 +289,11 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         pl.L = 4;
         pl.T = pl.H / 4;
     }
+    // the same for a small MSM over plain bases (the verifier's 2- and 11-point folds): 41 -> 16 dependent additions
+    if (!single && pl.L == 16 && pl.H >= 16 && bsets * (size_t)(pl.H / 16) < ((size_t)1 << 12)) {
+        pl.L = 4;
+        pl.T = pl.H / 4;
+    }
     const size_t nbuckets = bsets * pl.H;
     const size_t ndigits = windows * n;
     if (nbuckets >= (1ull << 32) || ndigits >= (1ull << 32))

@@ -156,10 +156,11 @@ class PedersenVRF(VRF):
     def verify(self, input: bytes, additional_data: bytes, salt: bytes = b"") -> bool:
         cv = self.cv
         _, merged, c = self._challenge(input, additional_data, salt)
-        if cv.point_type.msm([merged.input, merged.output], [self.s, -c]) != self.ok:
-            return False
-        lhs2 = cv.point_type.msm([cv.point_type.generator_point(), self._blinding_base(), self.blinded_pk], [self.s, self.sb, -c])
-        return lhs2 == self.result_point
+        # the two checks  s*I - c*O == O_k  and  s*G + s_b*B - c*Y_bar == R  as ONE launch of two 3-term groups
+        gen = cv.point_type.generator_point()
+        lhs1, lhs2 = msm_groups([merged.input, merged.output, gen, gen, self._blinding_base(), self.blinded_pk],
+                                [self.s, -c, 0, self.s, self.sb, -c], 3)
+        return lhs1 == self.ok and lhs2 == self.result_point
 
     def verify_unblinding(self, public_key: bytes, blinding_factor: int) -> bool:
         from .codec import dec_point
