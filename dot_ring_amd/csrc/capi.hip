@@ -483,7 +483,9 @@ int msm_to_bytes(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars
 // GPU time but 3.7 ms more wall time per 1024 proofs, so the kernel stays the default.
 int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, int* is_inf) {
     static const bool on_host = std::getenv("DOTRING_AFFINE_ON_HOST") && std::atoi(std::getenv("DOTRING_AFFINE_ON_HOST")) != 0;
-    if (on_host) {
+    // a handful of results (a single proof's 4 witness commitments, 2 openings): the kernel's one inversion chain is 0.6 ms of
+    // latency whatever the count, the host inverts in ~15 us each
+    if (on_host || batch <= 16) {
         static_assert(sizeof(drh::G1) == 192, "XYZZ layout");
         std::vector<drh::G1> res(batch);
         HIP_TRY(hipMemcpyAsync(res.data(), ctx->result.p, batch * 192, hipMemcpyDeviceToHost, ctx->stream));
