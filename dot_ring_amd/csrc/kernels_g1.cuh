@@ -563,21 +563,29 @@ __global__ __launch_bounds__(128) void k_g1_reduce_chunks(const uint32_t* __rest
 constexpr int RW_BLOCK = 128;
 __global__ __launch_bounds__(RW_BLOCK) void k_g1_reduce_windows(const uint32_t* __restrict__ partial, uint32_t T,
                                                                 uint32_t* __restrict__ winsum) {
+    // scratch-free like the other reduction kernels: ONE inlined addition serves the strided pass over the T chunk results and
+    // the log2(RW_BLOCK) tree levels (operand picked per step; an infinite operand leaves acc as it is)
     __shared__ uint32_t sm[RW_BLOCK * 48];
     size_t win = blockIdx.x;
     G1Xyzz acc = g1_inf();
+    const int pre = (int)((T + RW_BLOCK - 1) / RW_BLOCK);
+    int s = RW_BLOCK;
 #pragma unroll 1
-    for (uint32_t t = threadIdx.x; t < T; t += RW_BLOCK) acc = g1_add(acc, load_xyzz(partial, win * T + t));
-    store_xyzz(sm, threadIdx.x, acc);
-    __syncthreads();
-#pragma unroll 1
-    for (int s = RW_BLOCK / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            acc = g1_add(acc, load_xyzz(sm, threadIdx.x + s));
+    for (int step = 0; step < pre + 7; step++) {
+        G1Xyzz b = g1_inf();
+        if (step < pre) {
+            const uint32_t t = threadIdx.x + (uint32_t)step * RW_BLOCK;
+            if (t < T) b = load_xyzz(partial, win * T + t);
+        } else {
             store_xyzz(sm, threadIdx.x, acc);
+            __syncthreads();
+            s >>= 1;
+            if ((int)threadIdx.x < s) b = load_xyzz(sm, threadIdx.x + s);
+            __syncthreads();                    // partners are read before anyone overwrites its own slot in the next level
         }
-        __syncthreads();
+        acc = g1_add_inl(acc, b);
     }
+    static_assert(RW_BLOCK == 128, "seven tree levels");
     if (threadIdx.x == 0) store_xyzz(winsum, win, acc);
 }
 
