@@ -522,30 +522,57 @@ __global__ __launch_bounds__(256) void k_g1_accumulate(const uint32_t* __restric
 
 // ---- 5. bucket reduction.  Window value = sum_j (j+1) * B_j.  Chunk [s, s+L): running sums give
 //        sum_j (j-s+1) B_j and A = sum_j B_j; the chunk contributes that plus s*A (double-and-add, s < H).
-// Scratch-free (an out-of-line g1_add passes operands through scratch, and a kernel that reserves scratch loses
-// resident waves): one inlined addition per loop with muxed operands, at most two live accumulators per phase — the
-// chunk's running-sum result waits in `partial` while s*A is built.
-__global__ __launch_bounds__(128) void k_g1_reduce_chunks(const uint32_t* __restrict__ buckets, size_t windows,
-                                                          uint32_t H, uint32_t L, uint32_t* __restrict__ partial) {
+// Register budget: a full XYZZ addition with both operands and the result live is ~185 VGPRs (k_g1_reduce_windows); a
+// second accumulator on top of that spilled 97 dwords per lane to scratch.  So only ONE accumulator lives in registers
+// (`run`, later `t`); the other one (`sum`, later A) is parked in LDS, word-major so that the 64 lanes of a wave hit 64
+// different banks, and comes in as the second operand of the one inlined addition of each loop.
+constexpr int RC_BLOCK = 128;
+DR_DEV void park_put(uint32_t* park, const G1Xyzz& v) {
+    uint32_t* p = park + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        p[(0 + i) * RC_BLOCK] = v.x.l[i];
+        p[(12 + i) * RC_BLOCK] = v.y.l[i];
+        p[(24 + i) * RC_BLOCK] = v.zz.l[i];
+        p[(36 + i) * RC_BLOCK] = v.zzz.l[i];
+    }
+}
+DR_DEV G1Xyzz park_get(const uint32_t* park) {
+    const uint32_t* p = park + threadIdx.x;
+    G1Xyzz v;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        v.x.l[i] = p[(0 + i) * RC_BLOCK];
+        v.y.l[i] = p[(12 + i) * RC_BLOCK];
+        v.zz.l[i] = p[(24 + i) * RC_BLOCK];
+        v.zzz.l[i] = p[(36 + i) * RC_BLOCK];
+    }
+    return v;
+}
+__global__ __launch_bounds__(RC_BLOCK) void k_g1_reduce_chunks(const uint32_t* __restrict__ buckets, size_t windows,
+                                                               uint32_t H, uint32_t L, uint32_t* __restrict__ partial) {
+    __shared__ uint32_t park[48 * RC_BLOCK];                     // 24 KB: one parked XYZZ value per lane (private slots: no barriers)
     const uint32_t T = H / L;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= windows * T) return;
     size_t win = gid / T;
     uint32_t ch = (uint32_t)(gid % T), s = ch * L;
     G1Xyzz run = g1_inf();
-    {
-        G1Xyzz sum = g1_inf();
+    park_put(park, run);                                         // sum = O
 #pragma unroll 1
-        for (uint32_t step = 0; step < 2 * L; step++) {          // run += B_j ; sum += run, j = L-1 .. 0
-            const bool first = (step & 1) == 0;
-            G1Xyzz b = first ? load_xyzz(buckets, win * H + s + (L - 1 - (step >> 1))) : run;
-            G1Xyzz r = g1_add_inl(first ? run : sum, b);
-            if (first) run = r; else sum = r;
-        }
-        store_xyzz(partial, gid, sum);
+    for (uint32_t step = 0; step < 2 * L; step++) {              // run += B_j ; sum += run, j = L-1 .. 0
+        const bool first = (step & 1) == 0;
+        G1Xyzz b = first ? load_xyzz(buckets, win * H + s + (L - 1 - (step >> 1))) : park_get(park);
+        G1Xyzz r = g1_add_inl(run, b);
+        if (first) run = r; else park_put(park, r);
     }
-    if (s == 0 || run.is_inf()) return;
-    // sum += s * run: double-and-add over the bits of s, then the stored running-sum result as one more addition
+    if (s == 0 || run.is_inf()) {
+        store_xyzz(partial, gid, park_get(park));
+        return;
+    }
+    // result = sum + s * run: double-and-add over the bits of s with A = run parked, then the running-sum result
+    store_xyzz(partial, gid, park_get(park));
+    park_put(park, run);
     G1Xyzz t = g1_inf();
     const int top = 31 - __clz(s);
 #pragma unroll 1
@@ -553,7 +580,7 @@ __global__ __launch_bounds__(128) void k_g1_reduce_chunks(const uint32_t* __rest
         if (step >= 0 && (step & 1)) { t = g1_dbl_inl(t); continue; }
         const bool last = step < 0;
         if (!last && !((s >> (step >> 1)) & 1)) continue;
-        G1Xyzz b = last ? load_xyzz(partial, gid) : run;
+        G1Xyzz b = last ? load_xyzz(partial, gid) : park_get(park);
         t = g1_add_inl(t, b);
     }
     store_xyzz(partial, gid, t);
