@@ -634,17 +634,19 @@ __global__ __launch_bounds__(128) void k_g1_reduce_level(const uint32_t* __restr
     size_t set = gid / T;
     uint32_t s = (uint32_t)(gid % T) * L;
     if constexpr (!HAS_C) {
-        // level 1 (94 % of the work): two accumulators only — q += run; run += B_i
-        G1Xyzz run = g1_inf(), q = g1_inf();
+        // level 1 (94 % of the work): two accumulators only — q += run; run += B_i; q waits in LDS (see k_g1_reduce_chunks)
+        __shared__ uint32_t park[48 * RC_BLOCK];
+        G1Xyzz run = g1_inf();
+        park_put(park, run);
 #pragma unroll 1
         for (uint32_t step = 0; step < 2 * L; step++) {
             const bool first = (step & 1) == 0;
-            G1Xyzz b = first ? run : load_xyzz(in_s, set * n_in + s + (step >> 1));
-            G1Xyzz r = g1_add_inl(first ? q : run, b);
-            if (first) q = r; else run = r;
+            G1Xyzz b = first ? park_get(park) : load_xyzz(in_s, set * n_in + s + (step >> 1));
+            G1Xyzz r = g1_add_inl(run, b);
+            if (first) park_put(park, r); else run = r;
         }
         store_xyzz(out_s, gid, run);
-        store_xyzz(out_c, gid, q);
+        store_xyzz(out_c, gid, park_get(park));
         return;
     } else {
         G1Xyzz run = g1_inf(), q = g1_inf(), c = g1_inf();
