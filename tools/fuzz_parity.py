@@ -112,5 +112,29 @@ for cv, suite in ((d.Bandersnatch, bsn.SHA512), (d.Bandersnatch_SHAKE128, bsn.SH
             wrong += not d.RingVRF[cv].batch_verify(proofs, als, ads, ring, root)
         report(f"ring proofs {cv.name}", total, wrong, t0)
 
+# 6. G1 MSMs of random shape (size, batch, plain bases / window tables of several widths, sparse and dense scalars)
+srs_be = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dot_ring_amd", "data", "bls12-381-srs-2-11-uncompressed-zcash.bin"), "rb").read()[8 : 8 + 96 * 6145]
+srs_le = b"".join(srs_be[96 * i : 96 * i + 48][::-1] + srs_be[96 * i + 48 : 96 * i + 96][::-1] for i in range(6145))
+t0 = time.perf_counter()
+wrong = total = 0
+for table in (0, 9, 12, 14):
+    srs = ctx.srs_load(srs_be)
+    if table:
+        srs.precompute(table)
+    for _ in range(max(1, int(3 * scale))):
+        n = rng.choice([1, 2, 3, 17, 64, 65, 300, 2047, 2048, 6145])
+        batch = rng.choice([1, 1, 2, 5, 33])
+        dense = rng.random() < 0.6
+        ks = [[(rng.randrange(coracle.FR_P) if dense or rng.random() < 0.1 else rng.choice([0, 0, 0, 1])) for _ in range(n)] for _ in range(batch)]
+        raw = b"".join(k.to_bytes(32, "little") for row in ks for k in row)
+        got = ctx.g1_msm_batch(srs, raw, n) if batch > 1 else [ctx.g1_msm(srs, raw)]
+        for row, g in zip(ks, got):
+            w = coracle.g1_msm_raw(srs_le[: 96 * n], coracle.scalars_pack(row), n)
+            w_be = None if w == bytes(96) else w[:48][::-1] + w[48:][::-1]
+            wrong += g != w_be
+            total += 1
+    srs.close()
+report("g1 msm shapes", total, wrong, t0)
+
 print("FUZZ", "FAILED" if bad else "OK")
 sys.exit(1 if bad else 0)
