@@ -1762,6 +1762,8 @@ int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alpha
     TRY(p->agg.reserve(batch * (size_t)m * 32));
     TRY(p->q.reserve(batch * (size_t)qn * 32));
     HIP_TRY(hipMemcpyAsync(p->alphas.p, alphas, batch * 7 * 32, hipMemcpyHostToDevice, st));
+    // 7 alphas per proof are read by every point of the 4N domain: convert them to Montgomery form once
+    hipLaunchKernelGGL(dr::k_fr_to_mont, dim3(div_up(batch * 7, 256)), dim3(256), 0, st, p->alphas.as<uint32_t>(), batch * 7);
     TRY(launch(ctx, "k_ring_pad", [&] {
         hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up(batch * 4 * m, 256)), dim3(256), 0, st, p->cols.as<uint32_t>(), n, p->wit4.as<uint32_t>(), m,
                            batch * 4);

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __rest
                                                           const uint32_t* __restrict__ fixed4 /* [3][m][8] mont: px, py, s */,
                                                           const uint32_t* __restrict__ lag4 /* [2][m][8] mont: L0, Llast */,
                                                           const uint32_t* __restrict__ not_last /* [m][8] mont */,
-                                                          const uint32_t* __restrict__ alphas /* [B][7][8] std */,
+                                                          const uint32_t* __restrict__ alphas /* [B][7][8] Montgomery (converted once per batch) */,
                                                           const uint32_t* __restrict__ rps_mont /* [B][16] */,
                                                           RingConsts rc, uint32_t batch, uint32_t* __restrict__ agg /* [B][m][8] std */) {
     const uint32_t m = rc.n * 4;
@@ -390,26 +390,27 @@ __global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __rest
     Fr one = Fr::one();
     Fr omb = sub(one, b);
     Fr x1y1 = mul(x1, y1), x2y2 = mul(x2, y2), x1x2 = mul(x1, x2), y1y2 = mul(y1, y2);
-    // c1 = (accip' - accip - b*s) * nl
-    Fr acc = mul(ld_std(al + 0 * 8), mul(sub(sub(ip_n, ip), mul(b, s)), nl));
+    // c1 = (accip' - accip - b*s) * nl          (the common factor nl of c1..c3 is applied once, after the alphas)
+    Fr acc = mul(gload_fr(al + 0 * 8), sub(sub(ip_n, ip), mul(b, s)));
     // c2 = (b*(x3*(y1y2 + a x1x2) - (x1y1 + x2y2)) + (1-b)(x3 - x1)) * nl ,  a = the curve coefficient
     Fr t2 = sub(mul(x3, add(y1y2, te_mul_a<CV>(x1x2))), add(x1y1, x2y2));
-    Fr c2 = mul(add(mul(b, t2), mul(omb, sub(x3, x1))), nl);
-    acc = add(acc, mul(ld_std(al + 1 * 8), c2));
+    Fr c2 = add(mul(b, t2), mul(omb, sub(x3, x1)));
+    acc = add(acc, mul(gload_fr(al + 1 * 8), c2));
     // c3 = (b*(y3*(x1y2 - x2y1) - (x1y1 - x2y2)) + (1-b)(y3 - y1)) * nl
     Fr t3 = sub(mul(y3, sub(mul(x1, y2), mul(x2, y1))), sub(x1y1, x2y2));
-    Fr c3 = mul(add(mul(b, t3), mul(omb, sub(y3, y1))), nl);
-    acc = add(acc, mul(ld_std(al + 2 * 8), c3));
+    Fr c3 = add(mul(b, t3), mul(omb, sub(y3, y1)));
+    acc = add(acc, mul(gload_fr(al + 2 * 8), c3));
+    acc = mul(acc, nl);
     // c4 = b(1-b)
-    acc = add(acc, mul(ld_std(al + 3 * 8), mul(b, omb)));
+    acc = add(acc, mul(gload_fr(al + 3 * 8), mul(b, omb)));
     // c5/c6 = (acc - seed)*L0 + (acc - (result+seed))*Llast ; c7 = accip*L0 + (accip-1)*Llast
     Fr rx = gload_fr(rps_mont + (size_t)pid * 16), ry = gload_fr(rps_mont + (size_t)pid * 16 + 8);
     Fr c5 = add(mul(sub(x1, from_arg(rc.seed_x)), l0), mul(sub(x1, rx), ln));
     Fr c6 = add(mul(sub(y1, from_arg(rc.seed_y)), l0), mul(sub(y1, ry), ln));
     Fr c7 = add(mul(ip, l0), mul(sub(ip, one), ln));
-    acc = add(acc, mul(ld_std(al + 4 * 8), c5));
-    acc = add(acc, mul(ld_std(al + 5 * 8), c6));
-    acc = add(acc, mul(ld_std(al + 6 * 8), c7));
+    acc = add(acc, mul(gload_fr(al + 4 * 8), c5));
+    acc = add(acc, mul(gload_fr(al + 5 * 8), c6));
+    acc = add(acc, mul(gload_fr(al + 6 * 8), c7));
     st_std(agg + gid * 8, acc);
 }
 
@@ -493,9 +494,9 @@ __global__ void k_ring_lin_scalars(const uint32_t* __restrict__ evals /* [B][8][
     Fr fx = mul(add(mul(bz, add(mul(ayz, pyz), te_mul_a<CV>(mul(axz, pxz)))), omb), term);
     Fr fy = mul(add(mul(bz, sub(mul(axz, pyz), mul(pxz, ayz))), omb), term);
     const uint32_t* al = alphas + (size_t)pid * 7 * 8;
-    gstore_fr(ks + ((size_t)pid * 3 + 0) * 8, mul(ld_std(al), term));
-    gstore_fr(ks + ((size_t)pid * 3 + 1) * 8, mul(ld_std(al + 8), fx));
-    gstore_fr(ks + ((size_t)pid * 3 + 2) * 8, mul(ld_std(al + 16), fy));
+    gstore_fr(ks + ((size_t)pid * 3 + 0) * 8, mul(gload_fr(al), term));          // alphas: Montgomery, see k_ring_constraints
+    gstore_fr(ks + ((size_t)pid * 3 + 1) * 8, mul(gload_fr(al + 8), fx));
+    gstore_fr(ks + ((size_t)pid * 3 + 2) * 8, mul(gload_fr(al + 16), fy));
 }
 // lin[j] = k0*accip[j] + k1*accx[j] + k2*accy[j]
 __global__ void k_ring_linpoly(const uint32_t* __restrict__ cols /* [B][4][n][8] std coefficient columns */,
