@@ -1499,7 +1499,7 @@ struct dr_ring_prover {
 
 namespace {
 
-int ring_ntt(dr_ring_prover* p, uint32_t* d_data, unsigned log2n, size_t batch, bool inverse) {
+int ring_ntt(dr_ring_prover* p, uint32_t* d_data, unsigned log2n, size_t batch, bool inverse, bool in_mont = false, bool out_mont = false) {
     dr_ctx* ctx = p->ctx;
     const drh::Fr& w = log2n == p->rc.log2n ? p->omega_n : p->omega_4n;
     drh::Fr wi = inverse ? w.inv() : w;
@@ -1510,7 +1510,7 @@ int ring_ntt(dr_ring_prover* p, uint32_t* d_data, unsigned log2n, size_t batch, 
         size_t take = std::min<size_t>(batch - done, 65535);
         int rc = dr::ntt_run(ctx->stream, [&](const char* name, auto&& f) { return launch(ctx, name, f); }, ctx->twiddles, ctx->io_b,
                              d_data + done * ((size_t)8 << log2n), log2n, take, wi, inverse ? &scale : nullptr,
-                             [&]() -> int { return DR_OK; });
+                             [&]() -> int { return DR_OK; }, in_mont, out_mont);
         if (rc != DR_OK) return rc == DR_ERR_NOMEM ? fail(rc, "out of device memory in NTT") : fail(rc, "NTT launch failed");
         done += take;
     }
@@ -1768,13 +1768,13 @@ int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alpha
         hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up(batch * 4 * m, 256)), dim3(256), 0, st, p->cols.as<uint32_t>(), n, p->wit4.as<uint32_t>(), m,
                            batch * 4);
     }));
-    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch * 4, false));
+    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch * 4, false, false, true));      // evaluations stay in Montgomery form
     TRY(launch(ctx, "k_ring_constraints", [&] {
         LAUNCH_CV(p->curve, dr::k_ring_constraints, dim3(div_up(batch * m, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(), p->fixed4.as<uint32_t>(),
                            p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas.as<uint32_t>(), p->rps.as<uint32_t>(), rc,
                            (uint32_t)batch, p->agg.as<uint32_t>());
     }));
-    TRY(ring_ntt(p, p->agg.as<uint32_t>(), rc.log2n + 2, batch, true));
+    TRY(ring_ntt(p, p->agg.as<uint32_t>(), rc.log2n + 2, batch, true, true, false));            // the constraint kernel wrote Montgomery form
     TRY(launch(ctx, "k_ring_quotient", [&] {
         hipLaunchKernelGGL(dr::k_ring_quotient, dim3(div_up(batch * qn, 256)), dim3(256), 0, st, p->agg.as<uint32_t>(), rc, (uint32_t)batch,
                            p->q.as<uint32_t>());

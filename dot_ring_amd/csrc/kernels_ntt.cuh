@@ -68,7 +68,7 @@ __global__ void k_ntt_twiddles(uint32_t* tw, uint32_t count, FrArg omega_mont) {
 // where one workgroup owns the whole transform).
 __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_local(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                                          const uint32_t* __restrict__ tw, int k, int S, int final_pass,
-                                                         FrArg out_factor) {
+                                                         FrArg out_factor, int in_mont) {
     __shared__ uint32_t tile[8 * NTT_TILE];
     const size_t n = (size_t)1 << k;
     const int tsize = 1 << S;
@@ -78,7 +78,8 @@ __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_local(const uint32_t* __restr
     for (int i = threadIdx.x; i < tsize; i += NTT_BLOCK) {
         size_t pos = tbase + i;
         size_t rev = (size_t)(__brevll((unsigned long long)pos) >> (64 - k));
-        lds_put(tile, i, to_mont(gload_fr(in + rev * 8)));
+        Fr v = gload_fr(in + rev * 8);
+        lds_put(tile, i, in_mont ? v : to_mont(v));     // in_mont: the producer already wrote Montgomery form
     }
     __syncthreads();
     for (int s = 1; s <= S; s++) {
@@ -161,9 +162,11 @@ inline FrArg to_arg(const drh::Fr& v) {   // raw limbs (whatever form v is in)
     return a;
 }
 
+// in_mont / out_mont: the data is (left) in Montgomery form instead of standard form — producers and consumers inside the
+// prover that work in Montgomery form anyway save the two conversions (one product per element each).
 template <class Launch, class ScratchT, class Sync>
 int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp, uint32_t* d_data, unsigned k, size_t batch,
-            const drh::Fr& omega_mont, const drh::Fr* scale_mont, Sync&& sync) {
+            const drh::Fr& omega_mont, const drh::Fr* scale_mont, Sync&& sync, bool in_mont = false, bool out_mont = false) {
     const size_t n = (size_t)1 << k;
     if (batch > 65535) return DR_ERR_INVALID;
     uint32_t* d_tw = nullptr;
@@ -184,12 +187,16 @@ int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp,
         cache.entries.push_back({k, omega_mont, d_tw});
     }
     // output factor in STANDARD form: Montgomery value * standard factor = standard(value * factor)
-    drh::Fr factor_std = scale_mont ? scale_mont->from_mont() : drh::Fr::one().from_mont();
+    // (Montgomery output: Montgomery value * Montgomery factor = Montgomery(value * factor); without a scale the final
+    // product is skipped altogether)
+    drh::Fr factor_std = out_mont ? (scale_mont ? *scale_mont : drh::Fr::one()) : (scale_mont ? scale_mont->from_mont() : drh::Fr::one().from_mont());
     FrArg fa = to_arg(factor_std);
+    const int do_final = (out_mont && !scale_mont) ? 0 : 1;
+    const int im = in_mont ? 1 : 0;
     const int S = (int)std::min<unsigned>(k, NTT_LOG_TILE);
     if ((int)k == S) {
         int rc = launch("k_ntt_local", [&] {
-            hipLaunchKernelGGL(k_ntt_local, dim3(1, (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_data, d_data, d_tw, (int)k, S, 1, fa);
+            hipLaunchKernelGGL(k_ntt_local, dim3(1, (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_data, d_data, d_tw, (int)k, S, do_final, fa, im);
         });
         if (rc != DR_OK) return rc;
         return sync();
@@ -198,12 +205,12 @@ int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp,
     if (rc != DR_OK) return rc;
     uint32_t* d_tmp = reinterpret_cast<uint32_t*>(tmp.p);
     rc = launch("k_ntt_local", [&] {
-        hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> S), (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_data, d_tmp, d_tw, (int)k, S, 0, fa);
+        hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> S), (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_data, d_tmp, d_tw, (int)k, S, 0, fa, im);
     });
     if (rc != DR_OK) return rc;
     for (int lo = S; lo < (int)k; lo += NTT_MAX_ROW_BITS) {
         int hi = std::min<int>((int)k, lo + NTT_MAX_ROW_BITS);
-        int fin = hi == (int)k;
+        int fin = hi == (int)k ? do_final : 0;
         unsigned blocks = (unsigned)(n >> (hi - lo) >> 6);    // tiles per transform
         rc = launch("k_ntt_strided", [&] {
             hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_tmp, d_tw, (int)k, lo, hi, fin, fa);

@@ -364,13 +364,13 @@ __global__ void k_ring_relations(const uint32_t* __restrict__ chain_aff, const u
 // One lane per (proof, point of the 4N domain).  Reads the four witness columns at i and at i + 4 (the w_N shift),
 // the per-ring tables at i, and writes sum_k alpha_k * c_k(i)   (constraints.py:83-151, proof_builder.py:175-180).
 template <int CV>
-__global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __restrict__ wit4 /* [B][4][m][8] std: b, accip, accx, accy */,
+__global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __restrict__ wit4 /* [B][4][m][8] Montgomery (NTT output): b, accip, accx, accy */,
                                                           const uint32_t* __restrict__ fixed4 /* [3][m][8] mont: px, py, s */,
                                                           const uint32_t* __restrict__ lag4 /* [2][m][8] mont: L0, Llast */,
                                                           const uint32_t* __restrict__ not_last /* [m][8] mont */,
                                                           const uint32_t* __restrict__ alphas /* [B][7][8] Montgomery (converted once per batch) */,
                                                           const uint32_t* __restrict__ rps_mont /* [B][16] */,
-                                                          RingConsts rc, uint32_t batch, uint32_t* __restrict__ agg /* [B][m][8] std */) {
+                                                          RingConsts rc, uint32_t batch, uint32_t* __restrict__ agg /* [B][m][8] Montgomery */) {
     const uint32_t m = rc.n * 4;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)batch * m) return;
@@ -378,10 +378,10 @@ __global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __rest
     uint32_t k = i + 4;
     if (k >= m) k -= m;
     const uint32_t* w = wit4 + (size_t)pid * 4 * m * 8;
-    Fr b = ld_std(w + ((size_t)0 * m + i) * 8);
-    Fr ip = ld_std(w + ((size_t)1 * m + i) * 8), ip_n = ld_std(w + ((size_t)1 * m + k) * 8);
-    Fr x1 = ld_std(w + ((size_t)2 * m + i) * 8), x3 = ld_std(w + ((size_t)2 * m + k) * 8);
-    Fr y1 = ld_std(w + ((size_t)3 * m + i) * 8), y3 = ld_std(w + ((size_t)3 * m + k) * 8);
+    Fr b = gload_fr(w + ((size_t)0 * m + i) * 8);
+    Fr ip = gload_fr(w + ((size_t)1 * m + i) * 8), ip_n = gload_fr(w + ((size_t)1 * m + k) * 8);
+    Fr x1 = gload_fr(w + ((size_t)2 * m + i) * 8), x3 = gload_fr(w + ((size_t)2 * m + k) * 8);
+    Fr y1 = gload_fr(w + ((size_t)3 * m + i) * 8), y3 = gload_fr(w + ((size_t)3 * m + k) * 8);
     Fr x2 = gload_fr(fixed4 + ((size_t)0 * m + i) * 8), y2 = gload_fr(fixed4 + ((size_t)1 * m + i) * 8);
     Fr s = gload_fr(fixed4 + ((size_t)2 * m + i) * 8);
     Fr l0 = gload_fr(lag4 + (size_t)i * 8), ln = gload_fr(lag4 + ((size_t)m + i) * 8);
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __rest
     acc = add(acc, mul(gload_fr(al + 4 * 8), c5));
     acc = add(acc, mul(gload_fr(al + 5 * 8), c6));
     acc = add(acc, mul(gload_fr(al + 6 * 8), c7));
-    st_std(agg + gid * 8, acc);
+    gstore_fr(agg + gid * 8, acc);
 }
 
 // ---- K8: coefficient-space passes ---------------------------------------------------------------------------
