@@ -1837,6 +1837,7 @@ int dr_ring_prove_openings(dr_ring_prover* p, size_t batch, const uint8_t* nus, 
     TRY(p->quot1.reserve(2 * batch * (size_t)(qn - 1) * 32));
     TRY(p->quot2.reserve(batch * (size_t)(n - 1) * 32));
     HIP_TRY(hipMemcpyAsync(p->nus.p, nus, batch * 8 * 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(dr::k_fr_to_mont, dim3(div_up(batch * 8, 256)), dim3(256), 0, st, p->nus.as<uint32_t>(), batch * 8);     // multipliers: Montgomery form
     TRY(launch(ctx, "k_ring_aggpoly", [&] {
         hipLaunchKernelGGL(dr::k_ring_aggpoly, dim3(div_up(batch * qn, 256)), dim3(256), 0, st, p->fixed_coef.as<uint32_t>(), p->cols.as<uint32_t>(),
                            p->q.as<uint32_t>(), p->nus.as<uint32_t>(), n, (uint32_t)batch, p->aggo.as<uint32_t>());

@@ -415,6 +415,10 @@ __global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __rest
 }
 
 // ---- K8: coefficient-space passes ---------------------------------------------------------------------------
+// These kernels combine standard-form coefficient vectors with a few per-proof scalars.  A Montgomery product of a
+// Montgomery-form scalar with a STANDARD-form value is the standard form of the product (x R * c / R = x c), and sums of
+// standard-form values are standard-form: so the scalars (tail, k_i, nu_i, the evaluation point) are kept in Montgomery
+// form and the coefficients are used exactly as they lie in memory — no conversion per coefficient, none per result.
 // quotient: c_agg = tail (cubic) * agg_poly ;  q_j = sum_{i>=1} c_agg[j + i*N],  j < 3N+1
 __global__ void k_ring_quotient(const uint32_t* __restrict__ agg_poly /* [B][4N][8] std */, RingConsts rc, uint32_t batch,
                                 uint32_t* __restrict__ q /* [B][3N+1][8] std */) {
@@ -430,10 +434,10 @@ __global__ void k_ring_quotient(const uint32_t* __restrict__ agg_poly /* [B][4N]
         if (kidx >= m + 3) break;
 #pragma unroll
         for (uint32_t d = 0; d < 4; d++) {
-            if (kidx >= d && kidx - d < m) acc = add(acc, mul(from_arg(rc.tail[d]), ld_std(a + (size_t)(kidx - d) * 8)));
+            if (kidx >= d && kidx - d < m) acc = add(acc, mul(from_arg(rc.tail[d]), gload_fr(a + (size_t)(kidx - d) * 8)));
         }
     }
-    st_std(q + gid * 8, acc);
+    gstore_fr(q + gid * 8, acc);
 }
 
 // Horner evaluation of `npoly` polynomials per proof at that proof's point: one workgroup per (proof, poly).
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(EV_BLOCK) void k_ring_eval(const uint32_t* __restri
     if (lo < len) {
         uint32_t hi = lo + per < len ? lo + per : len;
 #pragma unroll 1
-        for (int j = (int)hi - 1; j >= (int)lo; j--) acc = add(mul(acc, x), ld_std(src + (size_t)j * 8));
+        for (int j = (int)hi - 1; j >= (int)lo; j--) acc = add(mul(acc, x), gload_fr(src + (size_t)j * 8));     // acc in standard form, x Montgomery
         acc = mul(acc, fr_pow_u32(x, lo));
     }
 #pragma unroll
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(EV_BLOCK) void k_ring_eval(const uint32_t* __restri
         Fr r;
 #pragma unroll
         for (int l = 0; l < 8; l++) r.l[l] = red[l * EV_BLOCK];
-        st_std(out + ((size_t)pid * out_stride + out_off + p) * 8, r);
+        gstore_fr(out + ((size_t)pid * out_stride + out_off + p) * 8, r);
     }
 }
 
@@ -505,29 +509,29 @@ __global__ void k_ring_linpoly(const uint32_t* __restrict__ cols /* [B][4][n][8]
     if (gid >= (size_t)batch * n) return;
     uint32_t pid = (uint32_t)(gid / n), j = (uint32_t)(gid % n);
     const uint32_t* c = cols + (size_t)pid * 4 * n * 8;
-    Fr v = mul(gload_fr(ks + ((size_t)pid * 3 + 0) * 8), ld_std(c + ((size_t)1 * n + j) * 8));
-    v = add(v, mul(gload_fr(ks + ((size_t)pid * 3 + 1) * 8), ld_std(c + ((size_t)2 * n + j) * 8)));
-    v = add(v, mul(gload_fr(ks + ((size_t)pid * 3 + 2) * 8), ld_std(c + ((size_t)3 * n + j) * 8)));
-    st_std(lin + gid * 8, v);
+    Fr v = mul(gload_fr(ks + ((size_t)pid * 3 + 0) * 8), gload_fr(c + ((size_t)1 * n + j) * 8));
+    v = add(v, mul(gload_fr(ks + ((size_t)pid * 3 + 1) * 8), gload_fr(c + ((size_t)2 * n + j) * 8)));
+    v = add(v, mul(gload_fr(ks + ((size_t)pid * 3 + 2) * 8), gload_fr(c + ((size_t)3 * n + j) * 8)));
+    gstore_fr(lin + gid * 8, v);
 }
 // aggregated opening polynomial: sum of nu_i * poly_i over (px, py, s, b, accip, accx, accy, q)
 __global__ void k_ring_aggpoly(const uint32_t* __restrict__ fixed /* [3][n][8] std */, const uint32_t* __restrict__ cols,
-                               const uint32_t* __restrict__ q /* [B][3n+1][8] */, const uint32_t* __restrict__ nus /* [B][8][8] std */,
+                               const uint32_t* __restrict__ q /* [B][3n+1][8] */, const uint32_t* __restrict__ nus /* [B][8][8] Montgomery (converted once per batch) */,
                                uint32_t n, uint32_t batch, uint32_t* __restrict__ out /* [B][3n+1][8] */) {
     const uint32_t qn = 3 * n + 1;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)batch * qn) return;
     uint32_t pid = (uint32_t)(gid / qn), j = (uint32_t)(gid % qn);
     const uint32_t* nu = nus + (size_t)pid * 8 * 8;
-    Fr v = mul(ld_std(nu + 7 * 8), ld_std(q + gid * 8));
+    Fr v = mul(gload_fr(nu + 7 * 8), gload_fr(q + gid * 8));
     if (j < n) {
 #pragma unroll 1
-        for (uint32_t p = 0; p < 3; p++) v = add(v, mul(ld_std(nu + p * 8), ld_std(fixed + ((size_t)p * n + j) * 8)));
+        for (uint32_t p = 0; p < 3; p++) v = add(v, mul(gload_fr(nu + p * 8), gload_fr(fixed + ((size_t)p * n + j) * 8)));
         const uint32_t* c = cols + (size_t)pid * 4 * n * 8;
 #pragma unroll 1
-        for (uint32_t p = 0; p < 4; p++) v = add(v, mul(ld_std(nu + (3 + p) * 8), ld_std(c + ((size_t)p * n + j) * 8)));
+        for (uint32_t p = 0; p < 4; p++) v = add(v, mul(gload_fr(nu + (3 + p) * 8), gload_fr(c + ((size_t)p * n + j) * 8)));
     }
-    st_std(out + gid * 8, v);
+    gstore_fr(out + gid * 8, v);
 }
 
 // Synthetic division by (X - x): quotient Q_{i-1} = S_i with S_i = a_i + x*S_{i+1} (suffix Horner values).
@@ -535,7 +539,7 @@ __global__ void k_ring_aggpoly(const uint32_t* __restrict__ fixed /* [3][n][8] s
 // pass 3 replays each chunk with its incoming value and writes the quotient.
 constexpr uint32_t SD_CHUNK = 32;
 __global__ void k_syndiv_local(const uint32_t* __restrict__ poly, uint32_t len, const uint32_t* __restrict__ points, int mul_omega,
-                               RingConsts rc, uint32_t batch, uint32_t* __restrict__ chunk_val /* [B][nchunks][8] mont */) {
+                               RingConsts rc, uint32_t batch, uint32_t* __restrict__ chunk_val /* [B][nchunks][8] std */) {
     const uint32_t nch = (len + SD_CHUNK - 1) / SD_CHUNK;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)batch * nch) return;
@@ -546,7 +550,7 @@ __global__ void k_syndiv_local(const uint32_t* __restrict__ poly, uint32_t len, 
     const uint32_t* a = poly + (size_t)pid * len * 8;
     Fr acc = Fr::zero();
 #pragma unroll 1
-    for (int j = (int)hi - 1; j >= (int)lo; j--) acc = add(mul(acc, x), ld_std(a + (size_t)j * 8));
+    for (int j = (int)hi - 1; j >= (int)lo; j--) acc = add(mul(acc, x), gload_fr(a + (size_t)j * 8));
     gstore_fr(chunk_val + gid * 8, acc);
 }
 __global__ void k_syndiv_link(uint32_t* __restrict__ chunk_val, uint32_t len, const uint32_t* __restrict__ points, int mul_omega,
@@ -584,8 +588,8 @@ __global__ void k_syndiv_write(const uint32_t* __restrict__ poly, uint32_t len, 
     Fr s = gload_fr(chunk_val + gid * 8);
 #pragma unroll 1
     for (int j = (int)hi - 1; j >= (int)lo; j--) {
-        s = add(mul(s, x), ld_std(a + (size_t)j * 8));      // S_j
-        if (j >= 1) st_std(qo + (size_t)(j - 1) * 8, s);
+        s = add(mul(s, x), gload_fr(a + (size_t)j * 8));      // S_j
+        if (j >= 1) gstore_fr(qo + (size_t)(j - 1) * 8, s);
     }
 }
 
