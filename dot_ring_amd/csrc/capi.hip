@@ -1499,7 +1499,8 @@ struct dr_ring_prover {
 
 namespace {
 
-int ring_ntt(dr_ring_prover* p, uint32_t* d_data, unsigned log2n, size_t batch, bool inverse, bool in_mont = false, bool out_mont = false) {
+int ring_ntt(dr_ring_prover* p, uint32_t* d_data, unsigned log2n, size_t batch, bool inverse, bool in_mont = false, bool out_mont = false,
+             const uint32_t* d_src = nullptr, int pad = 0) {
     dr_ctx* ctx = p->ctx;
     const drh::Fr& w = log2n == p->rc.log2n ? p->omega_n : p->omega_4n;
     drh::Fr wi = inverse ? w.inv() : w;
@@ -1510,7 +1511,8 @@ int ring_ntt(dr_ring_prover* p, uint32_t* d_data, unsigned log2n, size_t batch, 
         size_t take = std::min<size_t>(batch - done, 65535);
         int rc = dr::ntt_run(ctx->stream, [&](const char* name, auto&& f) { return launch(ctx, name, f); }, ctx->twiddles, ctx->io_b,
                              d_data + done * ((size_t)8 << log2n), log2n, take, wi, inverse ? &scale : nullptr,
-                             [&]() -> int { return DR_OK; }, in_mont, out_mont);
+                             [&]() -> int { return DR_OK; }, in_mont, out_mont,
+                             d_src ? d_src + done * ((size_t)8 << (log2n - pad)) : nullptr, pad);
         if (rc != DR_OK) return rc == DR_ERR_NOMEM ? fail(rc, "out of device memory in NTT") : fail(rc, "NTT launch failed");
         done += take;
     }
@@ -1764,11 +1766,9 @@ int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alpha
     HIP_TRY(hipMemcpyAsync(p->alphas.p, alphas, batch * 7 * 32, hipMemcpyHostToDevice, st));
     // 7 alphas per proof are read by every point of the 4N domain: convert them to Montgomery form once
     hipLaunchKernelGGL(dr::k_fr_to_mont, dim3(div_up(batch * 7, 256)), dim3(256), 0, st, p->alphas.as<uint32_t>(), batch * 7);
-    TRY(launch(ctx, "k_ring_pad", [&] {
-        hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up(batch * 4 * m, 256)), dim3(256), 0, st, p->cols.as<uint32_t>(), n, p->wit4.as<uint32_t>(), m,
-                           batch * 4);
-    }));
-    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch * 4, false, false, true));      // evaluations stay in Montgomery form
+    // N coefficients per column -> evaluations on the 4N domain: the NTT reads the columns directly (zero padding implied) and
+    // leaves the evaluations in Montgomery form
+    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch * 4, false, false, true, p->cols.as<uint32_t>(), 2));
     TRY(launch(ctx, "k_ring_constraints", [&] {
         LAUNCH_CV(p->curve, dr::k_ring_constraints, dim3(div_up(batch * m, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(), p->fixed4.as<uint32_t>(),
                            p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas.as<uint32_t>(), p->rps.as<uint32_t>(), rc,

@@ -68,21 +68,35 @@ __global__ void k_ntt_twiddles(uint32_t* tw, uint32_t count, FrArg omega_mont) {
 // where one workgroup owns the whole transform).
 __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_local(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
                                                          const uint32_t* __restrict__ tw, int k, int S, int final_pass,
-                                                         FrArg out_factor, int in_mont) {
+                                                         FrArg out_factor, int in_mont, int pad) {
     __shared__ uint32_t tile[8 * NTT_TILE];
     const size_t n = (size_t)1 << k;
     const int tsize = 1 << S;
     const size_t xform = blockIdx.y, tbase = (size_t)blockIdx.x * tsize;
-    const uint32_t* in = src + xform * n * 8;
+    const uint32_t* in = src + xform * (n >> pad) * 8;
     uint32_t* out = dst + xform * n * 8;
-    for (int i = threadIdx.x; i < tsize; i += NTT_BLOCK) {
-        size_t pos = tbase + i;
-        size_t rev = (size_t)(__brevll((unsigned long long)pos) >> (64 - k));
-        Fr v = gload_fr(in + rev * 8);
-        lds_put(tile, i, in_mont ? v : to_mont(v));     // in_mont: the producer already wrote Montgomery form
+    if (pad == 0) {
+        for (int i = threadIdx.x; i < tsize; i += NTT_BLOCK) {
+            size_t pos = tbase + i;
+            size_t rev = (size_t)(__brevll((unsigned long long)pos) >> (64 - k));
+            Fr v = gload_fr(in + rev * 8);
+            lds_put(tile, i, in_mont ? v : to_mont(v));     // in_mont: the producer already wrote Montgomery form
+        }
+    } else {
+        // the input is a polynomial of n / 2^pad coefficients, zero-padded to n: in bit-reversed order only every 2^pad-th
+        // position is non-zero (the low `pad` bits of a position are the top bits of its source index), and the first `pad`
+        // stages — butterflies with a zero lower half and twiddles that never multiply anything but zero — just copy that
+        // value over its group.  So: load n / 2^pad values, replicate, start at stage pad + 1 (no padded copy in HBM either).
+        for (int i = threadIdx.x; i < (tsize >> pad); i += NTT_BLOCK) {
+            size_t grp = (tbase >> pad) + i;
+            size_t rev = (size_t)(__brevll((unsigned long long)grp) >> (64 - (k - pad)));
+            Fr v = gload_fr(in + rev * 8);
+            if (!in_mont) v = to_mont(v);
+            for (int c = 0; c < (1 << pad); c++) lds_put(tile, (i << pad) + c, v);
+        }
     }
     __syncthreads();
-    for (int s = 1; s <= S; s++) {
+    for (int s = 1 + pad; s <= S; s++) {
         const int half = 1 << (s - 1);
         for (int t = threadIdx.x; t < tsize / 2; t += NTT_BLOCK) {
             int j = t & (half - 1);
@@ -166,7 +180,10 @@ inline FrArg to_arg(const drh::Fr& v) {   // raw limbs (whatever form v is in)
 // prover that work in Montgomery form anyway save the two conversions (one product per element each).
 template <class Launch, class ScratchT, class Sync>
 int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp, uint32_t* d_data, unsigned k, size_t batch,
-            const drh::Fr& omega_mont, const drh::Fr* scale_mont, Sync&& sync, bool in_mont = false, bool out_mont = false) {
+            const drh::Fr& omega_mont, const drh::Fr* scale_mont, Sync&& sync, bool in_mont = false, bool out_mont = false,
+            const uint32_t* d_src = nullptr, int pad = 0) {
+    // d_src (optional): the input lives in another buffer, n / 2^pad coefficients per transform (zero-padded to n in effect);
+    // the first pass then writes straight into d_data and no temporary / copy back is needed
     const size_t n = (size_t)1 << k;
     if (batch > 65535) return DR_ERR_INVALID;
     uint32_t* d_tw = nullptr;
@@ -196,16 +213,20 @@ int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp,
     const int S = (int)std::min<unsigned>(k, NTT_LOG_TILE);
     if ((int)k == S) {
         int rc = launch("k_ntt_local", [&] {
-            hipLaunchKernelGGL(k_ntt_local, dim3(1, (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_data, d_data, d_tw, (int)k, S, do_final, fa, im);
+            hipLaunchKernelGGL(k_ntt_local, dim3(1, (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_src ? d_src : d_data, d_data, d_tw, (int)k, S, do_final, fa, im, pad);
         });
         if (rc != DR_OK) return rc;
         return sync();
     }
-    int rc = tmp.reserve(n * batch * 32);
-    if (rc != DR_OK) return rc;
-    uint32_t* d_tmp = reinterpret_cast<uint32_t*>(tmp.p);
+    int rc = DR_OK;
+    uint32_t* d_tmp = d_data;
+    if (!d_src) {
+        rc = tmp.reserve(n * batch * 32);
+        if (rc != DR_OK) return rc;
+        d_tmp = reinterpret_cast<uint32_t*>(tmp.p);
+    }
     rc = launch("k_ntt_local", [&] {
-        hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> S), (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_data, d_tmp, d_tw, (int)k, S, 0, fa, im);
+        hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> S), (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_src ? d_src : d_data, d_tmp, d_tw, (int)k, S, 0, fa, im, pad);
     });
     if (rc != DR_OK) return rc;
     for (int lo = S; lo < (int)k; lo += NTT_MAX_ROW_BITS) {
@@ -217,7 +238,7 @@ int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp,
         });
         if (rc != DR_OK) return rc;
     }
-    if (hipMemcpyAsync(d_data, d_tmp, n * batch * 32, hipMemcpyDeviceToDevice, st) != hipSuccess) return DR_ERR_DEVICE;
+    if (d_tmp != d_data && hipMemcpyAsync(d_data, d_tmp, n * batch * 32, hipMemcpyDeviceToDevice, st) != hipSuccess) return DR_ERR_DEVICE;
     return sync();
 }
 
