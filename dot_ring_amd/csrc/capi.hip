@@ -1774,9 +1774,11 @@ int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alpha
                            p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas.as<uint32_t>(), p->rps.as<uint32_t>(), rc,
                            (uint32_t)batch, p->agg.as<uint32_t>());
     }));
-    TRY(ring_ntt(p, p->agg.as<uint32_t>(), rc.log2n + 2, batch, true, true, false));            // the constraint kernel wrote Montgomery form
+    // the constraint kernel wrote Montgomery form; the coefficients land in the (now free) wit4 buffer: the first pass cannot
+    // run in place, so a separate output saves the temporary and the copy back
+    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch, true, true, false, p->agg.as<uint32_t>(), 0));
     TRY(launch(ctx, "k_ring_quotient", [&] {
-        hipLaunchKernelGGL(dr::k_ring_quotient, dim3(div_up(batch * qn, 256)), dim3(256), 0, st, p->agg.as<uint32_t>(), rc, (uint32_t)batch,
+        hipLaunchKernelGGL(dr::k_ring_quotient, dim3(div_up(batch * qn, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(), rc, (uint32_t)batch,
                            p->q.as<uint32_t>());
     }));
     MsmTable t = srs_table(p->srs, 0);
