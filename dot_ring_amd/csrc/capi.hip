@@ -1710,6 +1710,11 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
     TRY(p->relation.reserve(batch * 64));
     TRY(p->rps.reserve(batch * 64));
     TRY(p->cols.reserve(batch * 4 * (size_t)n * 32));
+    // the columns are built in evaluation form in the wit4 buffer (unused until the quotient phase, which needs 4x this size anyway)
+    // and interpolated from there into `cols`: the inverse NTT's first pass cannot run in place, a separate source saves its
+    // temporary and the copy back
+    TRY(p->wit4.reserve(batch * 4 * (size_t)n * 4 * 32));
+    uint32_t* col_evals = p->wit4.as<uint32_t>();
     HIP_TRY(hipMemcpyAsync(p->idx.p, producer_index, batch * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(p->blind.p, blinding, batch * 32, hipMemcpyHostToDevice, st));
     if (zk_rows) {
@@ -1730,21 +1735,21 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
         hipLaunchKernelGGL(dr::k_ring_relations, dim3(div_up(batch, 64)), dim3(64), 0, st, p->chain_aff.as<uint32_t>(), p->cnt.as<uint32_t>(),
                            (uint32_t)batch, p->relation.as<uint32_t>(), p->rps.as<uint32_t>());
         hipLaunchKernelGGL(dr::k_ring_columns, dim3(div_up(batch * n, 256)), dim3(256), 0, st, p->idx.as<uint32_t>(), p->blind.as<uint32_t>(),
-                           p->chain_aff.as<uint32_t>(), zk_rows ? p->zk.as<uint32_t>() : nullptr, rc, (uint32_t)batch, p->cols.as<uint32_t>());
+                           p->chain_aff.as<uint32_t>(), zk_rows ? p->zk.as<uint32_t>() : nullptr, rc, (uint32_t)batch, col_evals);
     }));
     HIP_TRY(hipMemcpyAsync(out_relation_xy, p->relation.p, batch * 64, hipMemcpyDeviceToHost, st));
     if (p->ps_srs) {
         // commit in evaluation form by summation by parts (sparse scalars), then interpolate for the later phases
         TRY(p->diffs.reserve(batch * 4 * (size_t)n * 32));
         TRY(launch(ctx, "k_ring_diff", [&] {
-            hipLaunchKernelGGL(dr::k_ring_diff, dim3(div_up(batch * 4 * n, 256)), dim3(256), 0, st, p->cols.as<uint32_t>(), n, batch * 4,
+            hipLaunchKernelGGL(dr::k_ring_diff, dim3(div_up(batch * 4 * n, 256)), dim3(256), 0, st, col_evals, n, batch * 4,
                                p->diffs.as<uint32_t>());
         }));
-        TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true));
+        TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true, false, false, col_evals, 0));
         MsmTable t = srs_table(p->ps_srs, 0);
         return msm_to_bytes(ctx, p->ps_srs->d_bases, p->diffs.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t);
     }
-    TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true));
+    TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true, false, false, col_evals, 0));
     MsmTable t = srs_table(p->srs, 0);
     return msm_to_bytes(ctx, p->srs->d_bases, p->cols.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t);
 }
