@@ -236,6 +236,7 @@ struct MsmTable {
     uint32_t stride = 0, offset = 0;
     const uint32_t* comb = nullptr;      // comb[j][w][d-1], see k_g1_comb_msm
     uint32_t comb_h = 0;
+    uint32_t short_from = 0xffffffffu, n_short = 0;   // batched MSM: vectors from this index on are zero beyond n_short (sort hint)
 };
 
 int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch,
@@ -326,6 +327,8 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         sp.n = (uint32_t)n; sp.batch = (uint32_t)batch; sp.H = pl.H; sp.groups = groups; sp.single = single ? 1 : 0;
         sp.tbl_stride = single ? tbl->stride : 0; sp.tbl_offset = single ? tbl->offset : 0;
         sp.capacity = (uint32_t)per_set_digits;
+        sp.short_from = single ? tbl->short_from : 0xffffffffu;
+        sp.n_short = single ? std::min<uint32_t>(tbl->n_short, (uint32_t)n) : 0;
         TRY(ctx->sorted.reserve(bsets * per_set_digits * 4));
         TRY(launch(ctx, "k_g1_sort_sets", [&] {
             hipLaunchKernelGGL(dr::k_g1_sort_sets, dim3((unsigned)bsets), dim3(dr::SORT_BLOCK), 0, st, d_scalars, pl.wt, sp,
@@ -1868,6 +1871,8 @@ int dr_ring_prove_openings(dr_ring_prover* p, size_t batch, const uint8_t* nus, 
     std::vector<uint8_t> o(2 * batch * 96);
     std::vector<int> inf(2 * batch);
     MsmTable t = srs_table(p->srs, 0);
+    t.short_from = (uint32_t)batch;          // the second half of the vectors (quot2) has N - 1 coefficients, the rest is padding
+    t.n_short = n - 1;
     TRY(msm_to_bytes(ctx, p->srs->d_bases, p->quot1.as<uint32_t>(), qn - 1, 2 * batch, o.data(), inf.data(), &t));
     for (size_t b = 0; b < batch; b++) {
         std::memcpy(out_openings + 192 * b, o.data() + 96 * b, 96);

@@ -362,6 +362,7 @@ struct SortSetParams {
     int single;                         // 1: window-table mode (set = MSM x group, all windows), 0: set = (MSM, window)
     uint32_t tbl_stride, tbl_offset;
     uint32_t capacity;                  // entries reserved per set in `sorted`
+    uint32_t short_from, n_short;       // scalar vectors b >= short_from are zero beyond n_short entries: not even read
 };
 
 DR_DEV void load_scalar_mod_r(const uint32_t* __restrict__ scalars, size_t idx, uint32_t (&k)[9]) {
@@ -415,8 +416,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
     if (sp.single) {
         b = set / sp.groups;
         uint32_t g = set % sp.groups;
-        i_lo = (uint32_t)(((uint64_t)g * sp.n + sp.groups - 1) / sp.groups);
-        i_hi = (uint32_t)(((uint64_t)(g + 1) * sp.n + sp.groups - 1) / sp.groups);
+        const uint32_t n_eff = b >= sp.short_from ? sp.n_short : sp.n;
+        i_lo = (uint32_t)(((uint64_t)g * n_eff + sp.groups - 1) / sp.groups);
+        i_hi = (uint32_t)(((uint64_t)(g + 1) * n_eff + sp.groups - 1) / sp.groups);
         w_lo = 0; w_hi = wt.W;
     } else {
         b = set / wt.W;
