@@ -2350,6 +2350,7 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
     const drh::Mod256& mp = drh::mod_p();
     hipStream_t st = ctx->stream;
 
+    PhaseTrace tr_("verify_batch");
     // ---- 1. canonical scalars; gather encoded points
     std::vector<uint8_t> te_enc(B * 4 * 32), g1_enc(B * 7 * 48);
     bool canonical = true;
@@ -2425,6 +2426,7 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
     side.join();
     if (side_rc != DR_OK) return fail(side_rc, side_err.empty() ? "encode_to_curve failed" : side_err);
     for (size_t i = 0; i < n_te + 7 * B; i++) if (!flags[i]) return DR_OK;                  // malformed / invalid point: ok = 0
+    tr_.mark("decode");
 
     // ---- 3. Pedersen part (helper thread, second stream): challenges, then ONE (5B+2)-point MSM that must vanish
     int ped_ok = 0;
@@ -2496,6 +2498,7 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
         mp.mul(r[0], cl.agg_zeta, v); mp.mul(r[1], cl.l_zw, w); mp.add(v, w, fp + 12);
     });
     for (size_t i = 0; i < B; i++) if (bad[i]) return DR_OK;
+    tr_.mark("transcripts");
     {
         uint64_t acc[4][4] = {{0}};
         for (size_t i = 0; i < B; i++)
@@ -2535,6 +2538,7 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
     HIP_TRY(hipMemcpyAsync(ctx->scalars.p, lhs_sc.data(), n_g1 * 32, hipMemcpyHostToDevice, st));
     TRY(msm_to_bytes(ctx, g1_bases.as<uint32_t>(), ctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1, pair_inf));
     rhs_thread.join();
+    tr_.mark("g1 msms");
     if (rhs_rc != DR_OK) return fail(rhs_rc, rhs_err.empty() ? "rhs MSM failed" : rhs_err);
     const int inf_r = pair_inf[1];
     // (a vanishing rhs can only come from r1 = r2 = 0 or infinity openings: the pairing equation then demands lhs = O)
@@ -2545,7 +2549,9 @@ static int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, con
     }
     int pok = 0;
     TRY(dr_pairing_check(pair_g1, vk->g2, 2, &pok));
+    tr_.mark("pairing");
     side.join();
+    tr_.mark("pedersen join");
     if (side_rc != DR_OK) return fail(side_rc, side_err.empty() ? "Pedersen part failed" : side_err);
     *ok = pok && ped_ok;
     return DR_OK;

@@ -226,12 +226,44 @@ struct Mod256 {
             }
         std::memcpy(r, acc, 32);
     }
-    void inv(const uint64_t* a, uint64_t* r) const {                          // a^(m-2); 0 -> 0
+    void inv_fermat(const uint64_t* a, uint64_t* r) const {                   // a^(m-2); 0 -> 0
         uint64_t e[4];
         std::memcpy(e, m, 32);
         uint64_t bw = 2;
         for (int i = 0; i < 4 && bw; i++) { uint64_t old = e[i]; e[i] -= bw; bw = old < bw ? 1 : 0; }
         pow(a, e, r);
+    }
+    // a^-1 mod m for a < m, m an odd prime (0 -> 0): binary extended Euclid on the standard-form value, ~2 us against ~40 us for
+    // the 766 Montgomery products of the Fermat power — the verifier's scalar pass inverts twice per proof
+    void inv(const uint64_t* a, uint64_t* r) const {
+        if (is_zero(a)) { r[0] = r[1] = r[2] = r[3] = 0; return; }
+        uint64_t u[4], v[4], x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+        std::memcpy(u, a, 32);
+        std::memcpy(v, m, 32);
+        auto is_one = [](const uint64_t* t) { return t[0] == 1 && (t[1] | t[2] | t[3]) == 0; };
+        auto shr1 = [](uint64_t* t, uint64_t top) {
+            t[0] = (t[0] >> 1) | (t[1] << 63); t[1] = (t[1] >> 1) | (t[2] << 63); t[2] = (t[2] >> 1) | (t[3] << 63); t[3] = (t[3] >> 1) | (top << 63);
+        };
+        auto halve = [&](uint64_t* x) {                                       // x / 2 mod m
+            uint64_t top = 0;
+            if (x[0] & 1) {
+                u128 c = 0;
+                for (int i = 0; i < 4; i++) { c += (u128)x[i] + m[i]; x[i] = (uint64_t)c; c >>= 64; }
+                top = (uint64_t)c;
+            }
+            shr1(x, top);
+        };
+        auto sub_raw = [](uint64_t* x, const uint64_t* y) {                   // x -= y, x >= y
+            uint64_t bw = 0;
+            for (int i = 0; i < 4; i++) { u128 d = (u128)x[i] - y[i] - bw; x[i] = (uint64_t)d; bw = (uint64_t)(d >> 127); }
+        };
+        while (!is_one(u) && !is_one(v)) {
+            while (!(u[0] & 1)) { shr1(u, 0); halve(x1); }
+            while (!(v[0] & 1)) { shr1(v, 0); halve(x2); }
+            if (geq(u, v)) { sub_raw(u, v); sub(x1, x2, x1); }
+            else { sub_raw(v, u); sub(x2, x1, x2); }
+        }
+        std::memcpy(r, is_one(u) ? x1 : x2, 32);
     }
     void neg(const uint64_t* a, uint64_t* r) const { const uint64_t z[4] = {0, 0, 0, 0}; sub(z, a, r); }
     void set_u64(uint64_t v, uint64_t* r) const { r[0] = v; r[1] = r[2] = r[3] = 0; }
