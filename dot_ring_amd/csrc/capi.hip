@@ -2005,6 +2005,47 @@ int dr_encode_to_curve_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const uint8
     }
 }
 
+// I_i = encode_to_curve(salt_i || alpha_i) and O_i = x_i * I_i for an Elligator suite without a host round trip in between:
+// the Elligator kernel writes the affine inputs to device memory, the GLV lane-pair kernel (scalars split on the host while
+// the first kernel runs) reads them from there; ONE synchronisation and download for both.  Other cases (try-and-increment
+// suites, batches beyond the GLV kernel's range) take the two separate calls.
+int encode_and_mul(dr_ctx* ctx, const drh::VrfSuite& su, size_t B, const uint8_t* data, const uint64_t* off, const uint8_t* salts,
+                   const uint64_t* salt_off, const uint8_t* xs, uint8_t* inputs_xy, uint8_t* outs_xy) {
+    if (su.cv->tai || !su.cv->glv || !g_bsn_glv || B == 0 || B >= 16384) {
+        TRY(encode_to_curve_msgs(ctx, su, B, data, off, salts, salt_off, inputs_xy));
+        return te_scalar_mul_batch(ctx, su.cv->id, inputs_xy, xs, B, outs_xy);
+    }
+    TRY(use_ctx(ctx));
+    std::vector<uint8_t> us(B * 64);
+    drh::parallel_for(B, [&](size_t i) {
+        drh::Bytes m;
+        if (salt_off) drh::put(m, salts + salt_off[i], salt_off[i + 1] - salt_off[i]);
+        drh::put(m, data + off[i], off[i + 1] - off[i]);
+        drh::hash_to_field2(su, m.data(), m.size(), us.data() + 64 * i);
+    });
+    TRY(ctx->io_a.reserve(B * 64));
+    TRY(ctx->io_b.reserve(B * 48));
+    TRY(ctx->io_c.reserve(2 * B * 64));
+    uint32_t* d_in = ctx->io_c.as<uint32_t>();
+    uint32_t* d_out = d_in + B * 16;
+    HIP_TRY(hipMemcpyAsync(ctx->io_a.p, us.data(), B * 64, hipMemcpyHostToDevice, ctx->stream));
+    TRY(launch(ctx, "k_bsn_encode_to_curve", [&] {
+        hipLaunchKernelGGL(dr::k_bsn_encode_to_curve, dim3(div_up(2 * B, 64)), dim3(64), 0, ctx->stream, ctx->io_a.as<uint32_t>(), d_in, (uint32_t)B);
+    }));
+    std::vector<uint32_t> split;
+    TRY(glv_split_scalars(xs, B, split));                  // on the host, while the Elligator kernel runs
+    HIP_TRY(hipMemcpyAsync(ctx->io_b.p, split.data(), B * 48, hipMemcpyHostToDevice, ctx->stream));
+    TRY(launch(ctx, "k_bsn_scalar_mul", [&] {
+        hipLaunchKernelGGL(dr::k_bsn_scalar_mul_glv, dim3(div_up(2 * B, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream, d_in,
+                           ctx->io_b.as<uint32_t>(), d_out, (uint32_t)B);
+    }));
+    HIP_TRY(hipMemcpyAsync(inputs_xy, d_in, B * 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(outs_xy, d_out, B * 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) TRY(prof_collect(ctx));
+    return DR_OK;
+}
+
 // The whole batch in one call: Pedersen VRF part (pedersen/vrf.py:86-126) then the ring proof
 // (proof_builder.py:38-315) — GPU phases through the entry points above, the hashing between them on worker threads.
 // Pedersen VRF prover for a batch (pedersen/vrf.py:86-126): head() = hash-to-curve, outputs, transcripts and blinding
@@ -2030,10 +2071,8 @@ struct PedersenBatch {
         }
         // 2. I_i = encode_to_curve(salt || alpha), O_i = x_i * I_i
         inputs.resize(B * 64); outs.resize(B * 64);
-        TRY(encode_to_curve_msgs(ctx, su, B, alphas, alpha_off, salts, salt_off, inputs.data()));
-        tr_.mark("encode");
-        TRY(te_scalar_mul_batch(ctx, cv, inputs.data(), xs.data(), B, outs.data()));
-        tr_.mark("x*I");
+        TRY(encode_and_mul(ctx, su, B, alphas, alpha_off, salts, salt_off, xs.data(), inputs.data(), outs.data()));
+        tr_.mark("encode+x*I");
         // 3. transcripts, blinding factors
         tr.assign(B, drh::Bytes());
         blind.resize(B * 32); gb_pts.resize(B * 128); sc.resize(B * 64);
