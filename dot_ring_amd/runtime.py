@@ -8,10 +8,13 @@ from __future__ import annotations
 
 import os
 import threading
+import weakref
 
 from . import _native
 
 _local = threading.local()
+_created: list = []                 # weak references to every context handed out by context()
+_created_lock = threading.Lock()
 
 
 def device_index() -> int:
@@ -24,7 +27,17 @@ def context() -> _native.Context:
     if ctx is None:
         ctx = _native.Context(device_index())
         _local.ctx = ctx
+        with _created_lock:
+            _created[:] = [r for r in _created if r() is not None]
+            _created.append(weakref.ref(ctx))
     return ctx
+
+
+def contexts() -> list:
+    """All live contexts created through context() (the calling thread's and those of the prover's helper threads): profiling
+    tools sum their per-kernel timers."""
+    with _created_lock:
+        return [c for c in (r() for r in _created) if c is not None and c.handle]
 
 
 def set_context(ctx: _native.Context | None) -> None:

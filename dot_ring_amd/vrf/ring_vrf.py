@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import os
 import secrets
+import threading
 from dataclasses import dataclass
 from functools import lru_cache
 
@@ -196,6 +197,21 @@ def _public_keys_column_data(nm_points, domain_size, omega, prime, pcs):
     else:
         px_cm, py_cm = pcs.commit(px_c), pcs.commit(py_c)
     return tuple(px_e), tuple(px_c), px_cm, tuple(py_e), tuple(py_c), py_cm
+
+
+_POOL = None
+_POOL_LOCK = threading.Lock()
+
+
+def _helper_pool():
+    """Persistent helper threads of prove_batch (each keeps its own GPU context for the life of the process)."""
+    global _POOL
+    with _POOL_LOCK:
+        if _POOL is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            _POOL = ThreadPoolExecutor(max_workers=3, thread_name_prefix="dotring-prove")
+        return _POOL
 
 
 # ------------------------------------------------------------------ RingVRF (vrf.py:30-305, proof_payload.py)
@@ -425,16 +441,36 @@ class RingVRF(VRF):
         suite = cls._suite_struct()
         indices = ring.indices_of(producer_keys)
         prefix = root.verifier_transcript_prefix_bytes()
-        out = []
-        for lo in range(0, len(alphas), device_prover.MAX_DEVICE_BATCH):
-            hi = min(len(alphas), lo + device_prover.MAX_DEVICE_BATCH)
+        ab = _native.RINGVRF_AUX_BYTES
+
+        def prove_span(lo: int, hi: int) -> list:
+            # runs on the calling thread or on a helper thread: runtime.context() / get_device_prover give each thread its own
+            # stream, scratch and per-ring prover state
             zk = None if ring.params.test_vectors else secrets.token_bytes(48 * 12 * (hi - lo))
             raw, aux = device_prover.get_device_prover(ring, 0).ringvrf_prove_batch(
                 suite, alphas[lo:hi], additional_data[lo:hi], salts[lo:hi] if salts else None,
                 b"".join(bytes(sk) if len(sk) == 32 else le(int.from_bytes(sk, "little") % sp.subgroup_order) for sk in secret_keys[lo:hi]),
                 indices[lo:hi], prefix, zk)
-            ab = _native.RINGVRF_AUX_BYTES
-            out.extend(cls._from_native(raw[784 * i : 784 * i + 784], aux[ab * i : ab * i + ab]) for i in range(hi - lo))
+            return [cls._from_native(raw[784 * i : 784 * i + 784], aux[ab * i : ab * i + ab]) for i in range(hi - lo)]
+
+        # Opt-in (DOTRING_PROVE_PARTS=2; default 1 = one call): large batches as two halves from two threads — while one half is in
+        # its store-bound sort or its latency-bound bucket reduction / affine conversion, the other half's accumulate kernel fills
+        # the machine.  Measured +0.8 % on the bench (+3 % without per-kernel timers: 94.9 -> 92 ms per 1024 proofs), while every
+        # kernel's own duration roughly doubles — per-launch roofline figures are only meaningful with one call at a time.
+        count = len(alphas)
+        parts = max(1, int(os.environ.get("DOTRING_PROVE_PARTS", "1")))
+        spans = []
+        for lo in range(0, count, device_prover.MAX_DEVICE_BATCH * parts):
+            hi = min(count, lo + device_prover.MAX_DEVICE_BATCH * parts)
+            k = parts if hi - lo >= 512 else 1
+            spans.append([(lo + (hi - lo) * j // k, lo + (hi - lo) * (j + 1) // k) for j in range(k)])
+        out = []
+        for group in spans:
+            futures = [_helper_pool().submit(prove_span, a, b) for a, b in group[1:]]
+            first = prove_span(*group[0])
+            out.extend(first)
+            for f in futures:
+                out.extend(f.result())
         return out
 
     @classmethod

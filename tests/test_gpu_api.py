@@ -444,3 +444,29 @@ def test_rings_release_their_device_state(ctx):
         used.append(vram_used())
     assert all(w() is None for w in provers)
     assert used[-1] - used[2] < 32 << 20, used
+
+
+def test_prove_batch_in_two_concurrent_halves_gives_the_same_proofs(ctx, monkeypatch):
+    """DOTRING_PROVE_PARTS=2: batches of 512+ proofs run as two halves on two threads (own context, stream and prover state
+    each); deterministic proofs must come out identical and in order, and the helper thread's context must be visible to the
+    profiling registry."""
+    import dot_ring_amd as d
+    from dot_ring_amd import runtime
+
+    cv = d.Bandersnatch
+    sks = [(9100 + i).to_bytes(32, "little") for i in range(16)]
+    keys = [cv.public_key_from_secret(sk) for sk in sks]
+    params = d.RingProofParams.from_ring_size(16, test_vectors=True)
+    ring = d.Ring(keys, params)
+    root = d.RingRoot.from_ring(ring, params)
+    n = 601
+    al = [b"p%d" % i for i in range(n)]
+    args = (al, al, [sks[i % 16] for i in range(n)], [keys[i % 16] for i in range(n)], ring, root)
+    monkeypatch.setenv("DOTRING_PROVE_PARTS", "1")
+    one = [p.encode() for p in d.RingVRF[cv].prove_batch(*args)]
+    before = len(runtime.contexts())
+    monkeypatch.setenv("DOTRING_PROVE_PARTS", "2")
+    two = [p.encode() for p in d.RingVRF[cv].prove_batch(*args)]
+    assert one == two
+    assert len(runtime.contexts()) >= max(2, before)
+    assert d.RingVRF[cv].batch_verify(d.RingVRF[cv].decode_batch(two), al, al, ring, root)
