@@ -19,10 +19,10 @@
 #include "hostmath.hpp"
 #include "hostpairing.hpp"
 #include "hostproto.hpp"
-#include "kernels_bsn.cuh"
-#include "kernels_g1.cuh"
-#include "kernels_ntt.cuh"
-#include "kernels_ring.cuh"
+#include "kernels_bsn.hip.h"
+#include "kernels_g1.hip.h"
+#include "kernels_ntt.hip.h"
+#include "kernels_ring.hip.h"
 
 namespace {
 
@@ -576,7 +576,7 @@ static bool ctx_alive(dr_ctx* c) {
 }
 
 namespace {
-// the Elligator / Tonelli-Shanks constants of kernels_bsn.cuh, computed with the host field and copied to the
+// the Elligator / Tonelli-Shanks constants of kernels_bsn.hip.h, computed with the host field and copied to the
 // device's constant block once per context
 int bsn_consts_init(hipStream_t st) {
     using drh::Fr;

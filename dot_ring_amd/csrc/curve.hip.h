@@ -7,7 +7,7 @@
 //    mixed add 8M+2S, full add 12M+2S, doubling 6M+4S (EFD "xyzz": madd-2008-s, add-2008-s, dbl-2008-s-1).
 //    The reference reaches this arithmetic through blst (dot_ring/ring_proof/pcs/kzg.py:147-175).
 #pragma once
-#include "field.cuh"
+#include "field.hip.h"
 
 namespace dr {
 

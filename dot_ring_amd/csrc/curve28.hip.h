@@ -1,5 +1,5 @@
 // BLS12-381 G1 in XYZZ coordinates over the unsaturated field of fq28.hip.h — the arithmetic of the MSM's bucket kernels.
-// Same formulas as curve.cuh (EFD madd-2008-s / add-2008-s / dbl-2008-s-1, a = 0); the reference reaches this arithmetic
+// Same formulas as curve.hip.h (EFD madd-2008-s / add-2008-s / dbl-2008-s-1, a = 0); the reference reaches this arithmetic
 // through blst (dot_ring/ring_proof/pcs/kzg.py:147-175).  Limb / value bounds are tracked in the comments: "N" = normal
 // (a product, or carry()'d), "d" = difference of two N values (|limb| < 2^28), see fq28.hip.h.
 #pragma once

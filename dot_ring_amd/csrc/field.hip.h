@@ -20,7 +20,7 @@
 
 #define DR_DEV __device__ __forceinline__
 
-#include "montmul_gen.cuh"
+#include "montmul_gen.hip.h"
 
 namespace dr {
 

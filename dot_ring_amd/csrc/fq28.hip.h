@@ -2,7 +2,7 @@
 //
 // Why (round-2 measurement, tools/ubench_limbs.hip): with saturated 32-bit limbs every partial product of the Montgomery
 // multiplication costs v_mad_u64_u32 + v_addc_co_u32 (the 64-bit accumulator overflows after one product: 288 + 288
-// instructions for Fq, field.cuh).  With 28-bit limbs a 64-bit accumulator absorbs a whole column — 28 products of < 2^58
+// instructions for Fq, field.hip.h).  With 28-bit limbs a 64-bit accumulator absorbs a whole column — 28 products of < 2^58
 // — so a partial product is ONE v_mad_i64_i32 and the carry instructions disappear: 392 multiply-adds per product
 // instead of 576 multiply-add + carry instructions.  The 11 spare bits (R = 2^392 against a 381-bit p) also make
 // additions and subtractions plain limb-wise v_add/v_sub (no carry chain, no conditional subtraction of p).
@@ -13,7 +13,7 @@
 // mul() accepts lazy operands as long as  14 * max|a_i| * max|b_j| + 2^60 < 2^63  (e.g. 2^30 x 2^28, 2^29 x 2^29) and
 // |a|, |b| < 32 p (then |a b| / R < p / 2).  Canonical values (standard 12 x u32 words, < p) exist only in memory.
 #pragma once
-#include "field.cuh"
+#include "field.hip.h"
 #include "montmul28_gen.hip.h"
 
 namespace dr {

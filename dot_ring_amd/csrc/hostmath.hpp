@@ -177,7 +177,7 @@ inline bool fr_sqrt(Fr& out, const Fr& x) {
     }
 }
 
-// ---- G1 in XYZZ coordinates (host copy of the device formulas, curve.cuh)
+// ---- G1 in XYZZ coordinates (host copy of the device formulas, curve.hip.h)
 struct G1 {
     Fq x, y, zz, zzz;
     bool is_inf() const { return zz.is_zero(); }

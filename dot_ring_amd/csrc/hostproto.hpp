@@ -285,7 +285,7 @@ inline const Mod256& mod_p() {       // Bandersnatch base field = BLS12-381 scal
 }
 
 // The twisted Edwards curves over that field the library serves (ids as DR_CURVE_* in dotring_hip.h and CV_* in
-// curve.cuh): Bandersnatch (specs/bandersnatch.py:57-72) and JubJub (specs/jubjub.py:17-29).
+// curve.hip.h): Bandersnatch (specs/bandersnatch.py:57-72) and JubJub (specs/jubjub.py:17-29).
 struct TeCurveHost {
     int id;
     Mod256 n;                 // prime-order subgroup

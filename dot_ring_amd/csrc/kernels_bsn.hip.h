@@ -7,7 +7,7 @@
 // window kernel (dot_ring/curve/native_field/bandersnatch_te.pyx:480-554 via specs/bandersnatch.py:177-191):
 // the output is the canonical affine point, so the different window schedule is invisible in the bytes.
 #pragma once
-#include "curve.cuh"
+#include "curve.hip.h"
 
 namespace dr {
 

@@ -17,7 +17,7 @@
 // Pipeline: k_g1_digits -> scan (3 small kernels) -> k_g1_scatter -> k_g1_accumulate (dominant)
 //           -> k_g1_reduce_chunks -> k_g1_reduce_windows -> [host or k_g1_horner] combine windows.
 #pragma once
-#include "curve.cuh"
+#include "curve.hip.h"
 
 namespace dr {
 

@@ -10,7 +10,7 @@
 // HBM (Montgomery form), cached in the context.  Elements are converted to Montgomery form on the first load
 // and back (fused with the optional scale) on the last store, so a transform moves 2 x 32 B per element per pass.
 #pragma once
-#include "curve.cuh"
+#include "curve.hip.h"
 #include "hostmath.hpp"
 
 namespace dr {

@@ -10,8 +10,8 @@
 // elements — what the NTT and MSM kernels consume); per-ring tables (fixed columns on the 4N domain, Lagrange
 // rows, x - w^(N-4), ring points) are kept in MONTGOMERY form.  Batch-major layouts: [proof][column][index].
 #pragma once
-#include "kernels_bsn.cuh"
-#include "kernels_ntt.cuh"
+#include "kernels_bsn.hip.h"
+#include "kernels_ntt.hip.h"
 
 namespace dr {
 

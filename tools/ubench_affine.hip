@@ -11,7 +11,7 @@
 
 #include <vector>
 
-#include "kernels_g1.cuh"
+#include "kernels_g1.hip.h"
 
 using namespace dr;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)

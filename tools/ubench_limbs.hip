@@ -1,6 +1,6 @@
 // Micro-benchmark behind DESIGN "unsaturated limbs": the bucket walk of k_g1_accumulate (a chain of XYZZ mixed additions
 // over points gathered from a 13 MB table — the prover's window table) with the Fq product as it is today
-// (12 x 32-bit limbs: v_mad_u64_u32 + v_addc_co_u32 per partial product, field.cuh) against 14 x 28-bit signed limbs
+// (12 x 32-bit limbs: v_mad_u64_u32 + v_addc_co_u32 per partial product, field.hip.h) against 14 x 28-bit signed limbs
 // (one v_mad_i64_i32 per partial product, lazy reduction, fq28.hip.h).  Results of the two chains are compared word for word.
 //   build: hipcc --offload-arch=gfx950 -O3 -I dot_ring_amd/csrc tools/ubench_limbs.hip -o tools/ubench_limbs
 //   run:   tools/ubench_limbs [K ...]
@@ -11,7 +11,7 @@
 
 #include <vector>
 
-#include "kernels_g1.cuh"
+#include "kernels_g1.hip.h"
 #include "curve28.hip.h"
 
 using namespace dr;
