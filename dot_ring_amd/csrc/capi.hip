@@ -156,6 +156,35 @@ int prof_collect(dr_ctx* ctx) {
 
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// The device keeps Fq in Montgomery form with R = 2^392 (14 x 28-bit limbs, fq28.hip.h), the host with R = 2^384
+// (6 x 64-bit limbs, hostmath.hpp); both store canonical little-endian words, so crossing the boundary is one Montgomery
+// product per coordinate: device -> host multiplies by 2^-8 (host-Montgomery constant 2^376), host -> device by 2^8 (2^392).
+inline drh::Fq fq_dev_to_host(const drh::Fq& v) {
+    static const drh::Fq k = [] { drh::Fq c = drh::Fq::zero(); c.l[5] = 0x0100000000000000ULL; return c; }();
+    return v * k;
+}
+inline drh::Fq fq_host_to_dev(const drh::Fq& v) {
+    static const drh::Fq k = [] {
+        drh::Fq c;
+        const uint64_t w[6] = {0x19d800000347fcb8ULL, 0x12e00cde6d2002b1ULL, 0x37669f83a2090c72ULL, 0x09b09b42da0f73e0ULL, 0xa7c515d98f1297bbULL, 0x0577a659fcfa012cULL};
+        std::memcpy(c.l, w, sizeof w);
+        return c;
+    }();
+    return v * k;
+}
+inline void g1_dev_to_host(drh::G1* pts, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        pts[i].x = fq_dev_to_host(pts[i].x); pts[i].y = fq_dev_to_host(pts[i].y);
+        pts[i].zz = fq_dev_to_host(pts[i].zz); pts[i].zzz = fq_dev_to_host(pts[i].zzz);
+    }
+}
+inline void g1_host_to_dev(drh::G1* pts, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        pts[i].x = fq_host_to_dev(pts[i].x); pts[i].y = fq_host_to_dev(pts[i].y);
+        pts[i].zz = fq_host_to_dev(pts[i].zz); pts[i].zzz = fq_host_to_dev(pts[i].zzz);
+    }
+}
+
 // ---- window plan for the GPU Pippenger.  Scalars are reduced mod r (< 2^255) on the device and the 256 bits
 // are tiled by W = ceil(256/c) windows of width cmax or cmax-1 (see WindowTable).  Work ~ W*n mixed adds +
 // W*2^(c-1)*(2 full adds) + per-chunk scalar multiplications; a full add costs ~1.4 mixed adds; pick the c
@@ -416,6 +445,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
             std::vector<drh::G1> parts(bsets);
             HIP_TRY(hipMemcpyAsync(parts.data(), ctx->winsum.p, bsets * 192, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            g1_dev_to_host(parts.data(), parts.size());
             for (size_t b = 0; b < batch; b++) {
                 drh::G1 acc = drh::G1::inf();
                 for (uint32_t g = 0; g < groups; g++) acc = drh::g1_add(acc, parts[b * groups + g]);
@@ -423,7 +453,10 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
             }
             if (batch > 1) {      // keep the batched contract: results in ctx->result for the device-side affine pass
                 TRY(ctx->result.reserve(batch * 192));
-                HIP_TRY(hipMemcpyAsync(ctx->result.p, results.data(), batch * 192, hipMemcpyHostToDevice, st));
+                std::vector<drh::G1> up(results);
+                g1_host_to_dev(up.data(), up.size());
+                HIP_TRY(hipMemcpyAsync(ctx->result.p, up.data(), batch * 192, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipStreamSynchronize(st));
             }
         } else {
             TRY(ctx->result.reserve(batch * 192));
@@ -434,6 +467,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         std::vector<drh::G1> ws(pl.W);
         HIP_TRY(hipMemcpyAsync(ws.data(), ctx->winsum.p, (size_t)pl.W * 192, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        g1_dev_to_host(ws.data(), ws.size());
         drh::G1 acc = ws[pl.W - 1];
         for (int w = pl.W - 2; w >= 0; w--) {
             for (int j = 0; j < pl.wt.width[w]; j++) acc = drh::g1_dbl(acc);
@@ -494,6 +528,7 @@ int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, in
         HIP_TRY(hipMemcpyAsync(res.data(), ctx->result.p, batch * 192, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->prof) TRY(prof_collect(ctx));
+        g1_dev_to_host(res.data(), res.size());
         drh::parallel_for(batch, [&](size_t b) { g1_result_to_bytes(res[b], out_be_xy + 96 * b, is_inf ? is_inf + b : nullptr); });
         return DR_OK;
     }

@@ -215,11 +215,11 @@ DR_DEV Fe<FP> inv_fermat(const Fe<FP>& a) {
 // product with R^3 gives a^-1 R.  ~16*N instructions per step: Fr 61 k, Fq 137 k instructions against 116 k / 370 k
 // for the Fermat power — every affine conversion in the latency-bound kernels is an inversion.  0 -> 0.
 template <class FP>
-DR_DEV Fe<FP> inv(const Fe<FP>& a) {
+DR_DEV void inv_words(const uint32_t (&a)[FP::N], uint32_t (&out)[FP::N]) {      // out = a^-1 mod p on plain words (a < p)
     constexpr int N = FP::N;
     uint32_t u[N], v[N], x1[N], x2[N];
 #pragma unroll
-    for (int i = 0; i < N; i++) { u[i] = a.l[i]; v[i] = FP::P[i]; x1[i] = i == 0 ? 1u : 0u; x2[i] = 0u; }
+    for (int i = 0; i < N; i++) { u[i] = a[i]; v[i] = FP::P[i]; x1[i] = i == 0 ? 1u : 0u; x2[i] = 0u; }
     int bits = 32 * N;
     while (bits > 0 && !((FP::P[(bits - 1) >> 5] >> ((bits - 1) & 31)) & 1u)) bits--;      // bit length of p (compile-time)
 #pragma unroll 1
@@ -258,9 +258,15 @@ DR_DEV Fe<FP> inv(const Fe<FP>& a) {
         for (int i = 0; i < N - 1; i++) x1[i] = (x1[i] >> 1) | (x1[i + 1] << 31);
         x1[N - 1] = (x1[N - 1] >> 1) | (carry << 31);
     }
-    Fe<FP> r, r2;
 #pragma unroll
-    for (int i = 0; i < N; i++) { r.l[i] = x2[i]; r2.l[i] = FP::R2[i]; }
+    for (int i = 0; i < N; i++) out[i] = x2[i];
+}
+template <class FP>
+DR_DEV Fe<FP> inv(const Fe<FP>& a) {
+    Fe<FP> r, r2;
+    inv_words<FP>(a.l, r.l);
+#pragma unroll
+    for (int i = 0; i < FP::N; i++) r2.l[i] = FP::R2[i];
     return mul(r, mul(r2, r2));                                  // * R^3 (Montgomery): A^-1 -> a^-1 R
 }
 

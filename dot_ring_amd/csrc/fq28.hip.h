@@ -27,6 +27,12 @@ struct Fq28Params {
     static constexpr uint32_t N0 = 0xffcfffdu;                     // -p^-1 mod 2^28
     static constexpr uint32_t ONE[14] = {0x347fcb8u, 0xd800000u, 0x002b119u, 0x0cde6d2u, 0xc7212e0u, 0x83a2090u, 0x037669fu,
                                          0xda0f73eu, 0x9b09b42u, 0x1297bb0u, 0x515d98fu, 0x012ca7cu, 0x659fcfau, 0x000577au};   // 2^392 mod p
+    static constexpr uint32_t R2[14] = {0x10370edu, 0x6d1c345u, 0xe243d62u, 0xec45c53u, 0x3b1d65au, 0x093317du, 0xb4f36a0u,
+                                        0x5d74088u, 0xc10ea72u, 0x865d118u, 0x7320a75u, 0xfd5cd50u, 0xcc8a759u, 0x000c8d4u};    // R^2 mod p
+    static constexpr uint32_t R3[14] = {0x1f7b890u, 0x294cc4du, 0x9f3af22u, 0xb5ba56cu, 0xcb5c0ccu, 0xc0d975cu, 0xc89a8c5u,
+                                        0x6c968b4u, 0x22672eau, 0x91de8c9u, 0x35652a6u, 0x84977c8u, 0x424bbb9u, 0x00141abu};    // R^3 mod p
+    static constexpr uint32_t FOUR[14] = {0xd1ff2e0u, 0x6000000u, 0x00ac467u, 0x3379b48u, 0x1c84b80u, 0x0e88243u, 0x0dd9a7eu,
+                                          0x683dcf8u, 0x6c26d0bu, 0x4a5eec2u, 0x457663cu, 0x04b29f1u, 0x967f3e8u, 0x0015de9u};  // 4 R mod p (curve b)
     // 2^400 mod p: mul28(x 2^384, K400) = x 2^392 — from the 32-bit-limb Montgomery form (R = 2^384) into this one
     static constexpr uint32_t K400[14] = {0x80e6299u, 0x3500034u, 0xeb12856u, 0xdeb2699u, 0xc988670u, 0x4ef6697u, 0x70983e8u,
                                           0xa4e6fe9u, 0x3e8a053u, 0xecf271eu, 0xc20d323u, 0x6eb6385u, 0x47f1286u, 0x00156dau};
@@ -240,21 +246,44 @@ DR_DEV bool is_zero_mod_p(const Fq28& a) {            // exact; cold paths only
 // Never misses a zero; says "maybe" for 2 of 2^28 non-zero values.
 DR_DEV bool maybe_zero_normal(const Fq28& a) { return a.l[0] == 0 || a.l[0] == (int32_t)Fq28Params::P[0]; }
 
-DR_DEV Fq28 load_fq28(const uint32_t* p) {
-    uint32_t w[12];
+DR_DEV void load_words12(const uint32_t* p, uint32_t (&w)[12]) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     uint4 a = q[0], b = q[1], c = q[2];
     w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
     w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+}
+DR_DEV void store_words12(uint32_t* p, const uint32_t (&w)[12]) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    q[2] = make_uint4(w[8], w[9], w[10], w[11]);
+}
+DR_DEV Fq28 load_fq28(const uint32_t* p) {
+    uint32_t w[12];
+    load_words12(p, w);
     return unpack28(w);
 }
 DR_DEV void store_fq28(uint32_t* p, const Fq28& v) {
     uint32_t w[12];
     canon28(v, w);
-    uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    q[2] = make_uint4(w[8], w[9], w[10], w[11]);
+    store_words12(p, w);
+}
+
+// standard form (canonical words) <-> Montgomery form
+DR_DEV Fq28 to_mont28(const uint32_t (&w)[12]) { return mul(unpack28(w), Fq28::constant<Fq28Params::R2>()); }
+DR_DEV void from_mont28(const Fq28& a, uint32_t (&w)[12]) {
+    Fq28 one_std = Fq28::zero();
+    one_std.l[0] = 1;
+    canon28(mul(a, one_std), w);
+}
+
+// a^-1 (Montgomery in, Montgomery out; 0 -> 0): the branch-free binary extended Euclid of field.hip.h on the canonical
+// words A = aR, which yields A^-1 = a^-1 R^-1, then one product with R^3.
+DR_DEV Fq28 inv(const Fq28& a) {
+    uint32_t w[12], r[12];
+    canon28(a, w);
+    inv_words<FqParams>(w, r);
+    return mul(unpack28(r), Fq28::constant<Fq28Params::R3>());
 }
 
 }  // namespace dr

@@ -3,7 +3,7 @@
 //     GPU lane runs ~50x slower than one host core),
 //   * projective -> affine conversion and byte encodings of single results,
 //   * zcash G1 compression / decompression, Fr square roots for point decoding.
-// 64-bit limbs, Montgomery form with R = 2^(64*N) — the same R as the device's 32-bit-limb layout, so device
+// 64-bit limbs, Montgomery form with R = 2^(64*N) — the same R as the device's 32-bit-limb Fr layout, so device Fr
 // buffers are reinterpreted in place (little-endian limbs).
 #pragma once
 #include <cstdint>

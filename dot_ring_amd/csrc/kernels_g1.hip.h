@@ -17,65 +17,24 @@
 // Pipeline: k_g1_digits -> scan (3 small kernels) -> k_g1_scatter -> k_g1_accumulate (dominant)
 //           -> k_g1_reduce_chunks -> k_g1_reduce_windows -> [host or k_g1_horner] combine windows.
 #pragma once
-#include "curve.hip.h"
+#include "g1.hip.h"
 
 namespace dr {
 
-DR_DEV Fq load_fq(const uint32_t* p) {
-    Fq r;
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    uint4 a = q[0], b = q[1], c = q[2];
-    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
-    return r;
-}
-DR_DEV void store_fq(uint32_t* p, const Fq& v) {
-    uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-    q[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
-}
-DR_DEV G1Affine load_affine(const uint32_t* bases, uint32_t idx) {
-    const uint32_t* p = bases + (size_t)idx * 24;
-    G1Affine a;
-    a.x = load_fq(p);
-    a.y = load_fq(p + 12);
-    return a;
-}
-DR_DEV G1Xyzz load_xyzz(const uint32_t* arr, size_t idx) {
-    const uint32_t* p = arr + idx * 48;
-    G1Xyzz r;
-    r.x = load_fq(p); r.y = load_fq(p + 12); r.zz = load_fq(p + 24); r.zzz = load_fq(p + 36);
-    return r;
-}
-DR_DEV void store_xyzz(uint32_t* arr, size_t idx, const G1Xyzz& v) {
-    uint32_t* p = arr + idx * 48;
-    store_fq(p, v.x); store_fq(p + 12, v.y); store_fq(p + 24, v.zz); store_fq(p + 36, v.zzz);
-}
-
 // standard-form little-endian limbs -> Montgomery, in place (SRS load). (0,0) stays (0,0).
-__global__ void k_g1_bases_to_mont(uint32_t* bases, uint32_t n) {
+__global__ __launch_bounds__(256) void k_g1_bases_to_mont(uint32_t* bases, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t* p = bases + (size_t)i * 24;
-    store_fq(p, to_mont(load_fq(p)));
-    store_fq(p + 12, to_mont(load_fq(p + 12)));
-}
-
-// XYZZ -> affine (Montgomery); infinity -> (0,0)
-DR_DEV G1Affine g1_to_affine_dev(const G1Xyzz& p) {
-    G1Affine a;
-    if (p.is_inf()) { a.x = Fq::zero(); a.y = Fq::zero(); return a; }
-    Fq zi3 = inv(p.zzz);
-    Fq t = mul(p.zz, zi3);
-    a.x = mul(p.x, sqr(t));
-    a.y = mul(p.y, zi3);
-    return a;
+    uint32_t wx[12], wy[12];
+    load_words12(p, wx);
+    load_words12(p + 12, wy);
+    store_fq28(p, to_mont28(wx));
+    store_fq28(p + 12, to_mont28(wy));
 }
 
 // synthetic bases for full-size measurements: bases[i] = (first + i) * seed   (seed affine, Montgomery)
-__global__ void k_g1_synth_bases(uint32_t* bases, uint32_t n, uint32_t first, const uint32_t* seed) {
+__global__ __launch_bounds__(256) void k_g1_synth_bases(uint32_t* bases, uint32_t n, uint32_t first, const uint32_t* seed) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     G1Affine s = load_affine(seed, 0);
@@ -86,15 +45,12 @@ __global__ void k_g1_synth_bases(uint32_t* bases, uint32_t n, uint32_t first, co
         acc = g1_dbl(acc);
         if ((k >> bit) & 1) acc = g1_madd(acc, s);
     }
-    G1Affine a = g1_to_affine_dev(acc);
-    uint32_t* p = bases + (size_t)i * 24;
-    store_fq(p, a.x);
-    store_fq(p + 12, a.y);
+    store_affine(bases, i, g1_to_affine_dev(acc));
 }
 
 // known-tau SRS for domains the shipped file does not cover: bases[i] = scalars[i] * seed with
 // scalars[i] = tau^i (standard form, < r) prepared by the host; one lane per base
-__global__ void k_g1_scalar_bases(uint32_t* bases, uint32_t n, const uint32_t* __restrict__ scalars, const uint32_t* seed) {
+__global__ __launch_bounds__(256) void k_g1_scalar_bases(uint32_t* bases, uint32_t n, const uint32_t* __restrict__ scalars, const uint32_t* seed) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t e[8];
@@ -107,75 +63,86 @@ __global__ void k_g1_scalar_bases(uint32_t* bases, uint32_t n, const uint32_t* _
         acc = g1_dbl(acc);
         if ((e[bit >> 5] >> (bit & 31)) & 1) acc = g1_madd(acc, s);
     }
-    G1Affine a = g1_to_affine_dev(acc);
-    uint32_t* p = bases + (size_t)i * 24;
-    store_fq(p, a.x);
-    store_fq(p + 12, a.y);
+    store_affine(bases, i, g1_to_affine_dev(acc));
 }
 
 // zcash-compressed G1 (48 bytes, big-endian; flag bits: 7 compressed, 6 infinity, 5 "y is the larger root") ->
 // Montgomery affine, the layout the MSM kernels read; (0,0) = infinity.  On-curve by construction, no subgroup
 // check — as blst's P1_Affine(bytes) behind KZG.decompress_g1 (dot_ring/ring_proof/pcs/kzg.py:137-144).
 // ok[i] = 0 for malformed encodings (the point is then written as infinity).
-__global__ void k_g1_decompress(const uint8_t* __restrict__ enc /* n*48 */, uint32_t* __restrict__ bases /* n*24 */, uint32_t* __restrict__ ok, uint32_t n) {
+__global__ __launch_bounds__(256) void k_g1_decompress(const uint8_t* __restrict__ enc /* n*48 */, uint32_t* __restrict__ bases /* n*24 */, uint32_t* __restrict__ ok, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t* p = enc + (size_t)i * 48;
-    Fq xs;
+    uint32_t xs[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) {
         const uint8_t* q = p + 44 - 4 * j;
-        xs.l[j] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+        xs[j] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
     }
-    const uint32_t flags = xs.l[11] >> 29;
-    xs.l[11] &= 0x1fffffffu;
+    const uint32_t flags = xs[11] >> 29;
+    xs[11] &= 0x1fffffffu;
     bool valid = (flags & 4u) != 0;
-    Fq X = Fq::zero(), Y = Fq::zero();
+    G1Affine out;
+    out.x = Fq28::zero(); out.y = Fq28::zero(); out.inf = 1;
+    uint32_t xnz = 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) xnz |= xs[j];
     if (flags & 2u) {
-        if (!xs.is_zero() || (flags & 1u)) valid = false;
+        if (xnz != 0 || (flags & 1u)) valid = false;
     } else {
         uint32_t borrow = 0;
 #pragma unroll
-        for (int j = 0; j < 12; j++) (void)subb(xs.l[j], FqParams::P[j], borrow);
-        if (!borrow) { valid = false; xs = Fq::zero(); }
-        X = to_mont(xs);
-        Fq four = Fq::zero();
-        four.l[0] = 4;
-        Fq rhs = add(mul(sqr(X), X), to_mont(four));
+        for (int j = 0; j < 12; j++) (void)subb(xs[j], FqParams::P[j], borrow);
+        if (!borrow) {
+            valid = false;
+#pragma unroll
+            for (int j = 0; j < 12; j++) xs[j] = 0;
+        }
+        Fq28 X = to_mont28(xs);
+        Fq28 rhs = add(mul(sqr(X), X), Fq28::constant<Fq28Params::FOUR>());      // limbs < 2^29
         // p = 3 mod 4: y = rhs^((p+1)/4)
         constexpr uint32_t E[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
                                     0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};
-        Fq y = Fq::one();
+        Fq28 y = Fq28::one();
 #pragma unroll 1
         for (int b = 378; b >= 0; b--) {                 // (p+1)/4 has 379 bits
             y = sqr(y);
             if ((E[b >> 5] >> (b & 31)) & 1u) y = mul(y, rhs);
         }
-        if (!(sqr(y) == rhs)) valid = false;
-        Fq ny = neg(y);
-        Fq ys = from_mont(y), nys = from_mont(ny);
+        if (!is_zero_mod_p(sub(sqr(y), rhs))) valid = false;
+        // sign: the flag says whether y is the larger of (y, p - y) as standard-form integers
+        uint32_t ys[12], nys[12];
+        from_mont28(y, ys);
+        uint32_t ynz = 0;
+        borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) { nys[j] = subb(FqParams::P[j], ys[j], borrow); ynz |= ys[j]; }
         bool y_larger = false;
 #pragma unroll
         for (int j = 11; j >= 0; j--) {
-            if (ys.l[j] != nys.l[j]) { y_larger = ys.l[j] > nys.l[j]; break; }
+            if (ys[j] != nys[j]) { y_larger = ys[j] > nys[j]; break; }
         }
-        Y = (y_larger != ((flags & 1u) != 0)) ? ny : y;
-        if (!valid) { X = Fq::zero(); Y = Fq::zero(); }
+        if (ynz == 0) y_larger = false;                  // y = 0: -y = 0 as well (not on the curve anyway)
+        out.x = X;
+        out.y = cneg(y, y_larger != ((flags & 1u) != 0));
+        out.inf = valid ? 0u : 1u;
     }
-    uint32_t* o = bases + (size_t)i * 24;
-    store_fq(o, X);
-    store_fq(o + 12, Y);
+    store_affine(bases, i, out);
     ok[i] = valid ? 1u : 0u;
 }
 
 // Montgomery affine -> standard-form little-endian limbs (SRS download)
-__global__ void k_g1_bases_from_mont(const uint32_t* bases, uint32_t* out, uint32_t n) {
+__global__ __launch_bounds__(256) void k_g1_bases_from_mont(const uint32_t* bases, uint32_t* out, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* p = bases + (size_t)i * 24;
     uint32_t* q = out + (size_t)i * 24;
-    store_fq(q, from_mont(load_fq(p)));
-    store_fq(q + 12, from_mont(load_fq(p + 12)));
+    uint32_t w[12];
+    from_mont28(load_fq28(p), w);
+    store_words12(q, w);
+    from_mont28(load_fq28(p + 12), w);
+    store_words12(q + 12, w);
 }
 
 // Window table: the 256 scalar bits are tiled by W windows of width cmax or cmax-1 (wider ones on top), so every
@@ -331,7 +298,7 @@ __global__ void k_g1_scatter(const int32_t* __restrict__ digits, uint32_t n, siz
 }
 
 // fixed-base window table: table[w][i] = 2^(start_w) * base[i]  (affine, Montgomery), one lane per base
-__global__ void k_g1_window_table(const uint32_t* __restrict__ bases, uint32_t n, WindowTable wt, uint32_t* __restrict__ table) {
+__global__ __launch_bounds__(256) void k_g1_window_table(const uint32_t* __restrict__ bases, uint32_t n, WindowTable wt, uint32_t* __restrict__ table) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     G1Affine a = load_affine(bases, i);
@@ -343,9 +310,7 @@ __global__ void k_g1_window_table(const uint32_t* __restrict__ bases, uint32_t n
             for (int j = 0; j < wt.width[w - 1]; j++) cur = g1_dbl(cur);
             a = g1_to_affine_dev(cur);
         }
-        uint32_t* p = table + ((size_t)w * n + i) * 24;
-        store_fq(p, a.x);
-        store_fq(p + 12, a.y);
+        store_affine(table, (size_t)w * n + i, a);
     }
 }
 
@@ -529,31 +494,11 @@ __global__ __launch_bounds__(256) void k_g1_accumulate(const uint32_t* __restric
 // (`run`, later `t`); the other one (`sum`, later A) is parked in LDS, word-major so that the 64 lanes of a wave hit 64
 // different banks, and comes in as the second operand of the one inlined addition of each loop.
 constexpr int RC_BLOCK = 128;
-DR_DEV void park_put(uint32_t* park, const G1Xyzz& v) {
-    uint32_t* p = park + threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        p[(0 + i) * RC_BLOCK] = v.x.l[i];
-        p[(12 + i) * RC_BLOCK] = v.y.l[i];
-        p[(24 + i) * RC_BLOCK] = v.zz.l[i];
-        p[(36 + i) * RC_BLOCK] = v.zzz.l[i];
-    }
-}
-DR_DEV G1Xyzz park_get(const uint32_t* park) {
-    const uint32_t* p = park + threadIdx.x;
-    G1Xyzz v;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        v.x.l[i] = p[(0 + i) * RC_BLOCK];
-        v.y.l[i] = p[(12 + i) * RC_BLOCK];
-        v.zz.l[i] = p[(24 + i) * RC_BLOCK];
-        v.zzz.l[i] = p[(36 + i) * RC_BLOCK];
-    }
-    return v;
-}
+DR_DEV void park_put(uint32_t* park, const G1Xyzz& v) { put_raw(park + threadIdx.x, RC_BLOCK, v); }
+DR_DEV G1Xyzz park_get(const uint32_t* park) { return get_raw(park + threadIdx.x, RC_BLOCK); }
 __global__ __launch_bounds__(RC_BLOCK) void k_g1_reduce_chunks(const uint32_t* __restrict__ buckets, size_t windows,
                                                                uint32_t H, uint32_t L, uint32_t* __restrict__ partial) {
-    __shared__ uint32_t park[48 * RC_BLOCK];                     // 24 KB: one parked XYZZ value per lane (private slots: no barriers)
+    __shared__ uint32_t park[XYZZ_RAW_WORDS * RC_BLOCK];         // 28.5 KB: one parked XYZZ value per lane, raw limbs (private slots: no barriers)
     const uint32_t T = H / L;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= windows * T) return;
@@ -565,10 +510,10 @@ __global__ __launch_bounds__(RC_BLOCK) void k_g1_reduce_chunks(const uint32_t* _
     for (uint32_t step = 0; step < 2 * L; step++) {              // run += B_j ; sum += run, j = L-1 .. 0
         const bool first = (step & 1) == 0;
         G1Xyzz b = first ? load_xyzz(buckets, win * H + s + (L - 1 - (step >> 1))) : park_get(park);
-        G1Xyzz r = g1_add_inl(run, b);
+        G1Xyzz r = g1_add(run, b);
         if (first) run = r; else park_put(park, r);
     }
-    if (s == 0 || run.is_inf()) {
+    if (s == 0 || run.inf) {
         store_xyzz(partial, gid, park_get(park));
         return;
     }
@@ -579,11 +524,11 @@ __global__ __launch_bounds__(RC_BLOCK) void k_g1_reduce_chunks(const uint32_t* _
     const int top = 31 - __clz(s);
 #pragma unroll 1
     for (int step = 2 * top + 1; step >= -1; step--) {
-        if (step >= 0 && (step & 1)) { t = g1_dbl_inl(t); continue; }
+        if (step >= 0 && (step & 1)) { t = g1_dbl(t); continue; }
         const bool last = step < 0;
         if (!last && !((s >> (step >> 1)) & 1)) continue;
         G1Xyzz b = last ? load_xyzz(partial, gid) : park_get(park);
-        t = g1_add_inl(t, b);
+        t = g1_add(t, b);
     }
     store_xyzz(partial, gid, t);
 }
@@ -594,7 +539,7 @@ __global__ __launch_bounds__(RW_BLOCK) void k_g1_reduce_windows(const uint32_t* 
                                                                 uint32_t* __restrict__ winsum) {
     // scratch-free like the other reduction kernels: ONE inlined addition serves the strided pass over the T chunk results and
     // the log2(RW_BLOCK) tree levels (operand picked per step; an infinite operand leaves acc as it is)
-    __shared__ uint32_t sm[RW_BLOCK * 48];
+    __shared__ uint32_t sm[RW_BLOCK * XYZZ_RAW_WORDS];
     size_t win = blockIdx.x;
     G1Xyzz acc = g1_inf();
     const int pre = (int)((T + RW_BLOCK - 1) / RW_BLOCK);
@@ -606,13 +551,13 @@ __global__ __launch_bounds__(RW_BLOCK) void k_g1_reduce_windows(const uint32_t* 
             const uint32_t t = threadIdx.x + (uint32_t)step * RW_BLOCK;
             if (t < T) b = load_xyzz(partial, win * T + t);
         } else {
-            store_xyzz(sm, threadIdx.x, acc);
+            put_raw(sm + threadIdx.x, RW_BLOCK, acc);
             __syncthreads();
             s >>= 1;
-            if ((int)threadIdx.x < s) b = load_xyzz(sm, threadIdx.x + s);
+            if ((int)threadIdx.x < s) b = get_raw(sm + threadIdx.x + s, RW_BLOCK);
             __syncthreads();                    // partners are read before anyone overwrites its own slot in the next level
         }
-        acc = g1_add_inl(acc, b);
+        acc = g1_add(acc, b);
     }
     static_assert(RW_BLOCK == 128, "seven tree levels");
     if (threadIdx.x == 0) store_xyzz(winsum, win, acc);
@@ -637,14 +582,14 @@ __global__ __launch_bounds__(128) void k_g1_reduce_level(const uint32_t* __restr
     uint32_t s = (uint32_t)(gid % T) * L;
     if constexpr (!HAS_C) {
         // level 1 (94 % of the work): two accumulators only — q += run; run += B_i; q waits in LDS (see k_g1_reduce_chunks)
-        __shared__ uint32_t park[48 * RC_BLOCK];
+        __shared__ uint32_t park[XYZZ_RAW_WORDS * RC_BLOCK];
         G1Xyzz run = g1_inf();
         park_put(park, run);
 #pragma unroll 1
         for (uint32_t step = 0; step < 2 * L; step++) {
             const bool first = (step & 1) == 0;
             G1Xyzz b = first ? park_get(park) : load_xyzz(in_s, set * n_in + s + (step >> 1));
-            G1Xyzz r = g1_add_inl(run, b);
+            G1Xyzz r = g1_add(run, b);
             if (first) park_put(park, r); else run = r;
         }
         store_xyzz(out_s, gid, run);
@@ -658,7 +603,7 @@ __global__ __launch_bounds__(128) void k_g1_reduce_level(const uint32_t* __restr
         for (uint32_t step = 0; step <= steps; step++) {
             if (step == steps) {
 #pragma unroll 1
-                for (int k = 0; k < 4 * (level - 1); k++) q = g1_dbl_inl(q);
+                for (int k = 0; k < 4 * (level - 1); k++) q = g1_dbl(q);
             }
             const uint32_t i = step / 3, ph = step == steps ? 3u : step % 3;
             const size_t idx = set * n_in + s + (i < L ? i : 0);
@@ -667,7 +612,7 @@ __global__ __launch_bounds__(128) void k_g1_reduce_level(const uint32_t* __restr
             else if (ph == 1) { a = run; b = load_xyzz(in_s, idx); }
             else if (ph == 2) { a = c; b = load_xyzz(in_c, idx); }
             else { a = c; b = q; }
-            G1Xyzz r = g1_add_inl(a, b);
+            G1Xyzz r = g1_add(a, b);
             if (ph == 0) q = r; else if (ph == 1) run = r; else c = r;
         }
         store_xyzz(out_s, gid, run);
@@ -685,7 +630,7 @@ __global__ __launch_bounds__(64) void k_g1_reduce_final(const uint32_t* __restri
     for (uint32_t step = 0; step <= steps; step++) {
         if (step == steps) {
 #pragma unroll 1
-            for (int k = 0; k < 4 * levels; k++) w = g1_dbl_inl(w);
+            for (int k = 0; k < 4 * levels; k++) w = g1_dbl(w);
             c.y = neg(c.y);
         }
         const uint32_t ph = step == steps ? 3u : step % 3;
@@ -695,14 +640,14 @@ __global__ __launch_bounds__(64) void k_g1_reduce_final(const uint32_t* __restri
         else if (ph == 1) { a = w; b = run; }
         else if (ph == 2) { a = c; b = load_xyzz(in_c, idx); }
         else { a = w; b = c; }
-        G1Xyzz r = g1_add_inl(a, b);
+        G1Xyzz r = g1_add(a, b);
         if (ph == 0) run = r; else if (ph == 1 || ph == 3) w = r; else c = r;
     }
     store_xyzz(winsum, set, w);
 }
 
 // ---- 6. (batch > 1) combine the W window sums of each MSM on the device: Horner over windows, width[w] doublings each.
-__global__ void k_g1_horner(const uint32_t* __restrict__ winsum, uint32_t batch, WindowTable wt, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_g1_horner(const uint32_t* __restrict__ winsum, uint32_t batch, WindowTable wt, uint32_t* __restrict__ out) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     G1Xyzz acc = load_xyzz(winsum, (size_t)b * wt.W + wt.W - 1);
@@ -716,12 +661,15 @@ __global__ void k_g1_horner(const uint32_t* __restrict__ winsum, uint32_t batch,
 }
 
 // batched results: XYZZ (Montgomery) -> affine standard-form little-endian limbs, (0,0) for infinity
-__global__ void k_g1_results_affine(const uint32_t* __restrict__ xyzz, uint32_t count, uint32_t* __restrict__ out /* count*24 */) {
+__global__ __launch_bounds__(256) void k_g1_results_affine(const uint32_t* __restrict__ xyzz, uint32_t count, uint32_t* __restrict__ out /* count*24 */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     G1Affine a = g1_to_affine_dev(load_xyzz(xyzz, i));
-    store_fq(out + (size_t)i * 24, from_mont(a.x));
-    store_fq(out + (size_t)i * 24 + 12, from_mont(a.y));
+    uint32_t w[12] = {0};
+    if (!a.inf) from_mont28(a.x, w);
+    store_words12(out + (size_t)i * 24, w);
+    if (!a.inf) from_mont28(a.y, w);
+    store_words12(out + (size_t)i * 24 + 12, w);
 }
 
 // ---- 7. comb tables: every multiple a digit can select, precomputed --------------------------------------------------
@@ -745,28 +693,29 @@ __global__ __launch_bounds__(128) void k_g1_comb_build(const uint32_t* __restric
     const uint32_t hw = 1u << (wt.width[w] - 1);
     uint32_t* out = comb + row * Hc * COMB_STRIDE;
     const G1Affine B = load_affine(wtable, (size_t)w * count + j);
-    if (B.x.is_zero() && B.y.is_zero()) {
-        for (uint32_t d = 0; d < hw; d++) { store_fq(out + (size_t)d * COMB_STRIDE, B.x); store_fq(out + (size_t)d * COMB_STRIDE + 12, B.y); }
+    if (B.inf) {
+        uint32_t z[12] = {0};
+        for (uint32_t d = 0; d < hw; d++) { store_words12(out + (size_t)d * COMB_STRIDE, z); store_words12(out + (size_t)d * COMB_STRIDE + 12, z); }
         return;
     }
     G1Xyzz acc = g1_from_affine(B);
-    Fq run = Fq::one();
+    Fq28 run = Fq28::one();
 #pragma unroll 1
     for (uint32_t d = 0; d < hw; d++) {
         store_xyzz(tmp_xyzz, (size_t)d * rows + lane, acc);
-        store_fq(tmp_pre + ((size_t)d * rows + lane) * 12, run);
+        store_fq28(tmp_pre + ((size_t)d * rows + lane) * 12, run);
         run = mul(run, acc.zzz);
         acc = g1_madd(acc, B);
     }
-    Fq inv_run = inv(run);
+    Fq28 inv_run = inv(run);
 #pragma unroll 1
     for (int d = (int)hw - 1; d >= 0; d--) {
         G1Xyzz p = load_xyzz(tmp_xyzz, (size_t)d * rows + lane);
-        Fq izzz = mul(inv_run, load_fq(tmp_pre + ((size_t)d * rows + lane) * 12));
+        Fq28 izzz = mul(inv_run, load_fq28(tmp_pre + ((size_t)d * rows + lane) * 12));
         inv_run = mul(inv_run, p.zzz);
-        Fq izz = sqr(mul(p.zz, izzz));
-        store_fq(out + (size_t)d * COMB_STRIDE, mul(p.x, izz));
-        store_fq(out + (size_t)d * COMB_STRIDE + 12, mul(p.y, izzz));
+        Fq28 izz = sqr(mul(p.zz, izzz));
+        store_fq28(out + (size_t)d * COMB_STRIDE, mul(p.x, izz));
+        store_fq28(out + (size_t)d * COMB_STRIDE + 12, mul(p.y, izzz));
     }
 }
 
@@ -775,17 +724,6 @@ __global__ __launch_bounds__(128) void k_g1_comb_build(const uint32_t* __restric
 #ifndef COMB_TOUCH_AHEAD
 #define COMB_TOUCH_AHEAD 1
 #endif
-DR_DEV G1Xyzz xyzz_shfl_down(const G1Xyzz& p, unsigned delta) {
-    G1Xyzz o;
-#pragma unroll
-    for (int t = 0; t < 12; t++) {
-        o.x.l[t] = __shfl_down(p.x.l[t], delta, 64);
-        o.y.l[t] = __shfl_down(p.y.l[t], delta, 64);
-        o.zz.l[t] = __shfl_down(p.zz.l[t], delta, 64);
-        o.zzz.l[t] = __shfl_down(p.zzz.l[t], delta, 64);
-    }
-    return o;
-}
 __global__ __launch_bounds__(256) void k_g1_comb_msm(const uint32_t* __restrict__ scalars /* [batch][n][8] */, uint32_t n, WindowTable wt,
                                                       const uint32_t* __restrict__ comb, uint32_t Hc, uint32_t tbl_offset,
                                                       uint32_t* __restrict__ results /* [batch][T] XYZZ partial sums */) {
@@ -819,10 +757,7 @@ __global__ __launch_bounds__(256) void k_g1_comb_msm(const uint32_t* __restrict_
             }
             if (d != 0) {
                 const uint32_t* e = comb + entry(w, d);
-                G1Affine q;
-                q.x = load_fq(e);
-                q.y = load_fq(e + 12);
-                acc = g1_madd(acc, g1_neg_affine(q, d < 0));
+                acc = g1_madd(acc, g1_neg_affine(load_affine(e, 0), d < 0));
             }
             asm volatile("" ::"v"(t0), "v"(t1));          // keep the touch loads alive until after the addition
         }
