@@ -9,10 +9,20 @@ pairs, signer at index 3; inputs b"bench-batch-input"/b"bench-batch-ad" || LE64(
 RingRoot, the SRS and the per-ring prover tables are resident in HBM before the timed region; inputs of a step
 are 2 short byte strings per proof.  Hidden (ZK) rows are drawn at random as in production (test_vectors=False);
 a parity subset is proved again with test_vectors=True and compared byte-for-byte with the CPU oracle.
-With N ranks every rank proves and verifies its own 1024 proofs (independent units, no collective).
 
-Secondary measurement in the same JSON line ("g1_msm"): one G1 Pippenger MSM over 2^20 synthetic bases
-(configs[2]), the kernel north_star puts the roofline target on.
+The timed region runs with the library's per-kernel timers OFF; the same K steps are then repeated with the timers on
+(HIP events on the streams the kernels are launched on) and that pass supplies `gpu_kernel_ms_per_step` and the
+dominant kernel's average launch duration of `roofline`.
+
+Secondary measurements in the same JSON line (rank 0, one GPU):
+  bsn_scalar_mul     BASELINE configs[1]: 4096 Bandersnatch variable-base scalar multiplications (SURVEY 8(d) config 2 inputs)
+  g1_msm             BASELINE configs[2]: one G1 Pippenger MSM over 2^20 (and 2^16) synthetic bases
+  other_ring_sizes   the metric's other ring sizes: 256 (N = 1024) and 3000 (N = 4096, known-tau SRS: BASELINE configs[4]'s shape)
+  distinct_signers   the headline workload with 1024 different signing keys instead of one
+With N ranks (one per GPU) every rank proves and verifies its own 1024 proofs — independent units, no collective — and the
+base-sharded MSM leg (`g1_msm_sharded`) runs one MSM over bases sharded across the ranks with an RCCL all-gather of the partial
+points (dot_ring_amd/parallel.py, dr_comm_*).  No PyTorch anywhere: the launcher only has to export RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 through torch.distributed.run (one rank per GPU).
 """
@@ -22,6 +32,7 @@ import argparse
 import hashlib
 import json
 import os
+import struct
 import sys
 import time
 
@@ -34,11 +45,16 @@ G1_BE = bytes.fromhex(
     "08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1"
 )
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
-VALU_PEAK_GADD_S = 1024 * 2.4e9 / 4 * 64 / 6800 / 1e9      # ~5.78 G mixed additions/s (see roofline.valu)
+# VALU ceiling of the bucket walk: one XYZZ mixed addition = 8 products (461 instructions each) + 2 squarings (383) over
+# 14 x 28-bit limbs + ~330 add / sub / carry / unpack instructions = ~4780 wave-instructions per 64 additions; 1024 SIMDs
+# x 2.4 GHz at ~4.2 cycles per instruction (profiles/r02_ubench_valu.txt: v_mad_i64_i32 4.2-4.4, VOP2 2.6)
+MADD_INSTRUCTIONS = 8 * 461 + 2 * 383 + 330
+VALU_PEAK_GADD_S = 1024 * 2.4e9 / 4.2 * 64 / MADD_INSTRUCTIONS / 1e9
 ALG_BYTES_PER_PAIR = 128       # 96 B affine base + 32 B scalar per (base, scalar) pair
+ALG_BYTES_PER_SCALAR_MUL = 160  # 64 B point + 32 B scalar + 64 B result
 MSM_KERNELS = ("k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_sort_sets", "k_size_sort", "k_g1_accumulate", "k_g1_reduce_chunks",
                "k_g1_reduce_windows", "k_g1_horner", "k_g1_results_affine")
-RING_KERNELS = ("k_bsn_scalar_mul", "k_bsn_encode_to_curve", "k_bsn_msm_groups", "k_ring_chain", "k_ring_columns", "k_ntt_local",
+RING_KERNELS = ("k_bsn_scalar_mul", "k_bsn_encode_to_curve", "k_bsn_msm_groups", "k_bsn_pippenger", "k_ring_chain", "k_ring_columns", "k_ntt_local",
                 "k_ntt_strided", "k_ring_pad", "k_ring_constraints", "k_ring_quotient", "k_ring_eval", "k_ring_linpoly",
                 "k_ring_aggpoly", "k_syndiv", "k_ring_diff", "k_bsn_decode_points", "k_g1_decompress")
 
@@ -64,15 +80,19 @@ def _seed(*parts) -> bytes:
 
 
 def bench_ring_keys(cv, ring_size: int, sample_index: int):
-    """Signer key pair + ring keys of the reference bench (bench_ring_proof.py:60-77), keys derived on the GPU."""
+    """Signer key pair + ring keys of the reference bench (bench_ring_proof.py:60-77), keys derived on the GPU.
+    Also returns every member's secret key (the distinct-signers variant signs with all of them)."""
     from dot_ring_amd.curve import scalar_mul_batch
     from dot_ring_amd.vrf.primitives import secret_from_seed_scalar
 
     signer_pk, signer_sk = cv.secret_from_seed(_seed("signer", sample_index, 0))
     secrets_ = [secret_from_seed_scalar(cv, _seed("ring-member", sample_index, i)) for i in range(ring_size)]
     keys = [p.point_to_string() for p in scalar_mul_batch([cv.point_type.generator_point()] * ring_size, secrets_)]
-    keys[min(3, ring_size - 1)] = signer_pk
-    return signer_pk, signer_sk, keys
+    member_sks = [int(s).to_bytes(32, "little") for s in secrets_]
+    at = min(3, ring_size - 1)
+    keys[at] = signer_pk
+    member_sks[at] = signer_sk
+    return signer_pk, signer_sk, keys, member_sks
 
 
 def cpu_baseline_all_cores(keys, ring_size: int, signer_sk: bytes, per_worker: int, workers: int, first_proofs):
@@ -109,7 +129,7 @@ def cpu_baseline_all_cores(keys, ring_size: int, signer_sk: bytes, per_worker: i
         if any(len(o) != 3 or o[0] != "DONE" for o in outs):
             raise RuntimeError("oracle worker failed")
         want = hashlib.sha256(b"".join(first_proofs[:per_worker])).hexdigest()
-        return {"value": workers * per_worker / wall, "unit": "proofs/s", "cores": workers, "kind": "port",
+        return {"value": workers * per_worker / wall, "unit": "proofs/s", "cores": workers, "kind": "port", "work": "prove only",
                 "sample": f"{workers} oracle processes x {per_worker} proofs each (prove only), released together, {wall:.1f} s wall",
                 "matches_single_process": outs[0][2] == want}
     except Exception as exc:          # a baseline that cannot run is reported, not fatal
@@ -121,8 +141,9 @@ def cpu_baseline_all_cores(keys, ring_size: int, signer_sk: bytes, per_worker: i
         os.unlink(job)
 
 
+# ------------------------------------------------------------------------------------------------ secondary legs
 def g1_msm_measurement(ctx, log2n: int, steps: int, cpu_sample_log2: int, do_cpu: bool):
-    """Secondary: G1 MSM at 2^log2n synthetic bases. Returns a dict (rank-local)."""
+    """BASELINE configs[2]: G1 MSM at 2^log2n synthetic bases. Returns a dict (rank-local)."""
     n = 1 << log2n
     srs = ctx.srs_synthetic(G1_BE, n, first=1)
     # fixed-base window table in HBM (W * n * 96 B = 1.6 GB at 2^20 with 16-bit windows): one bucket set per MSM
@@ -130,17 +151,23 @@ def g1_msm_measurement(ctx, log2n: int, steps: int, cpu_sample_log2: int, do_cpu
     vals, raw = seeded_scalars(n, b"\0\0\0\0")
     d_scalars = ctx.alloc(32 * n).upload(raw)
     ctx.g1_msm_dev(srs, d_scalars, n)
-    ctx.prof_reset()
-    ctx.prof_enable(True)
     t0 = time.perf_counter()
     result = None
     for _ in range(steps):
         result = ctx.g1_msm_dev(srs, d_scalars, n)
     elapsed = time.perf_counter() - t0
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(min(steps, 5)):
+        ctx.g1_msm_dev(srs, d_scalars, n)
     ctx.prof_enable(False)
     acc_ms, acc_n = ctx.prof_get("k_g1_accumulate")
+    kern = {k: round(ctx.prof_get(k)[0] / max(1, min(steps, 5)), 3) for k in MSM_KERNELS if ctx.prof_get(k)[1]}
+    total_kernel_ms = sum(kern.values())
     out = {"pairs": n, "scalar_muls_per_s": n * steps / elapsed, "ms_per_msm": elapsed / steps * 1e3,
-           "k_g1_accumulate_avg_ms": acc_ms / max(1, acc_n),
+           "k_g1_accumulate_avg_ms": acc_ms / max(1, acc_n), "kernel_ms_per_msm": kern,
+           "non_accumulate_share": 1.0 - kern.get("k_g1_accumulate", 0.0) / (elapsed / steps * 1e3) if elapsed else None,
+           "kernel_ms_sum": round(total_kernel_ms, 3),
            "roofline_frac_hbm": (ALG_BYTES_PER_PAIR * n / (acc_ms / max(1, acc_n) / 1e3) / 1e9) / HBM_PEAK_GBS if acc_ms else None}
     if do_cpu:
         from oracle import coracle
@@ -163,6 +190,179 @@ def g1_msm_measurement(ctx, log2n: int, steps: int, cpu_sample_log2: int, do_cpu
     return out
 
 
+def bsn_scalar_mul_measurement(ctx, cv, n: int, steps: int):
+    """BASELINE configs[1] / SURVEY 8(d) config 2: n variable-base scalar multiplications, P_i = public key of
+    secret_from_seed(sha256("bsn-pt" || LE64(i))), k_i = sha256("bsn-k" || LE64(i)) mod n, all n compared with the oracle."""
+    from dot_ring_amd.curve import pack_points, scalar_mul_batch
+    from dot_ring_amd.vrf.primitives import secret_from_seed_scalar
+    from oracle import coracle
+    from oracle.pyref import bandersnatch as obsn
+
+    secrets_ = [secret_from_seed_scalar(cv, hashlib.sha256(b"bsn-pt" + i.to_bytes(8, "little")).digest()) for i in range(n)]
+    raw_p = pack_points(scalar_mul_batch([cv.point_type.generator_point()] * n, secrets_))
+    ks = [int.from_bytes(hashlib.sha256(b"bsn-k" + i.to_bytes(8, "little")).digest(), "little") % obsn.N for i in range(n)]
+    raw_k = b"".join(k.to_bytes(32, "little") for k in ks)
+    d_p, d_k, d_o = ctx.alloc(64 * n).upload(raw_p), ctx.alloc(32 * n).upload(raw_k), ctx.alloc(64 * n)
+    ctx.bsn_scalar_mul_batch_dev(d_p, d_k, n, d_o)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.bsn_scalar_mul_batch_dev(d_p, d_k, n, d_o)                       # device-resident in and out, one launch + sync
+    wall = (time.perf_counter() - t0) / steps
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(steps):
+        ctx.bsn_scalar_mul_batch_dev(d_p, d_k, n, d_o)
+    ctx.prof_enable(False)
+    k_ms, k_n = ctx.prof_get("k_bsn_scalar_mul")
+    kernel_ms = k_ms / max(1, k_n)
+    got = d_o.download()
+    t1 = time.perf_counter()
+    want = coracle.te_mul_batch_raw(raw_p, raw_k, n, glv=True)
+    cpu_s = time.perf_counter() - t1
+    # the host-buffer entry point (GLV lane pairs below 16384 terms: half the dependent chain), PCIe included
+    t2 = time.perf_counter()
+    for _ in range(steps):
+        host_out = ctx.bsn_scalar_mul_batch(raw_p, raw_k)
+    host_wall = (time.perf_counter() - t2) / steps
+    for b in (d_p, d_k, d_o):
+        b.free()
+    return {"n": n, "scalar_muls_per_s": n / wall, "ms_per_call": wall * 1e3, "kernel_ms": kernel_ms,
+            "scalar_muls_per_s_kernel": n / (kernel_ms / 1e3) if kernel_ms else None,
+            "host_buffers_scalar_muls_per_s": n / host_wall, "host_buffers_ms_per_call": host_wall * 1e3,
+            "roofline_frac_hbm": ALG_BYTES_PER_SCALAR_MUL * n / (kernel_ms / 1e3) / 1e9 / HBM_PEAK_GBS if kernel_ms else None,
+            "algorithmic_bytes_per_scalar_mul": ALG_BYTES_PER_SCALAR_MUL,
+            "cpu_port": {"scalar_muls_per_s": n / cpu_s, "cores": 1, "kind": "port",
+                         "sample": f"all {n} through oracle/c te_mul_batch (GLV + joint 2-bit windows, bandersnatch_te.pyx:480), {cpu_s:.2f} s"},
+            "parity_ok": got == want and host_out == want}
+
+
+class RingWorkload:
+    """ring + root + inputs of one ring size, and the prove_batch + batch_verify step over them"""
+
+    def __init__(self, d, ring_size: int, batch: int, first_index: int = 0):
+        from dot_ring_amd.ring_proof.pcs import SRS
+
+        self.d, self.ring_size, self.batch = d, ring_size, batch
+        self.cv = d.Bandersnatch
+        self.vrf = d.RingVRF[self.cv]
+        self.signer_pk, self.signer_sk, self.keys, self.member_sks = bench_ring_keys(self.cv, ring_size, 0)
+        # domains above 2048 need more SRS points than the shipped file holds (SURVEY R5): known-tau SRS, same on every rank
+        self.big = d.RingProofParams.from_ring_size(ring_size).domain_size > 2048
+        self.tau = int.from_bytes(hashlib.sha256(b"bench-known-tau").digest(), "little") % d.KZG.scalar_modulus
+        self.pcs = d.KZG.with_srs(SRS.synthetic(self.tau, 3 * 4096 + 1)) if self.big else d.KZG
+        self.params = d.RingProofParams.from_ring_size(ring_size, pcs=self.pcs)
+        t = time.perf_counter()
+        self.ring = d.Ring(self.keys, self.params)
+        self.root = d.RingRoot.from_ring(self.ring, self.params)
+        self.ring_root_s = time.perf_counter() - t
+        self.alphas = [b"bench-batch-input" + (first_index + i).to_bytes(8, "little") for i in range(batch)]
+        self.ads = [b"bench-batch-ad" + (first_index + i).to_bytes(8, "little") for i in range(batch)]
+        self.sks, self.pks = [self.signer_sk] * batch, [self.signer_pk] * batch
+        self.prove_s = self.verify_s = 0.0
+
+    def distinct_signers(self):
+        """every proof signed by another ring member (ring_size >= batch)"""
+        self.sks = [self.member_sks[i % self.ring_size] for i in range(self.batch)]
+        self.pks = [self.keys[i % self.ring_size] for i in range(self.batch)]
+
+    def step(self):
+        t = time.perf_counter()
+        proofs = self.vrf.prove_batch(self.alphas, self.ads, self.sks, self.pks, self.ring, self.root)
+        t1 = time.perf_counter()
+        ok = self.vrf.batch_verify(proofs, self.alphas, self.ads, self.ring, self.root)
+        t2 = time.perf_counter()
+        self.prove_s += t1 - t
+        self.verify_s += t2 - t1
+        return proofs, ok
+
+    def run(self, steps: int, warmup: int, barrier=lambda: None):
+        for _ in range(warmup):
+            self.step()
+        self.prove_s = self.verify_s = 0.0
+        barrier()
+        t0 = time.perf_counter()
+        all_ok = True
+        for _ in range(steps):
+            _, ok = self.step()
+            all_ok = all_ok and ok
+        barrier()
+        return time.perf_counter() - t0, all_ok
+
+    def parity(self, m: int, time_it: bool = False):
+        """m deterministic proofs (test_vectors=True) byte-compared with the CPU oracle; returns (ok, cpu proofs, cpu seconds)"""
+        from oracle.pyref import bandersnatch as obsn
+        from oracle.pyref import ring as oring
+
+        d = self.d
+        tv_params = d.RingProofParams.from_ring_size(self.ring_size, test_vectors=True, pcs=self.pcs)
+        tv_ring = d.Ring(self.keys, tv_params)
+        tv_root = d.RingRoot.from_ring(tv_ring, tv_params)
+        gpu_proofs = self.vrf.prove_batch(self.alphas[:m], self.ads[:m], self.sks[:m], self.pks[:m], tv_ring, tv_root)
+        o_srs = None
+        if self.big:
+            from oracle.pyref import kzg as okzg
+
+            o_srs = okzg.SRS.from_tau(self.tau, 3 * 4096 + 1)
+            o_srs.g2_raw = list(self.pcs.srs.g2_raw)
+        o_params = oring.Params.from_ring_size(self.ring_size, test_vectors=True, suite=obsn.SHA512, srs=o_srs)
+        o_ring = oring.Ring(self.keys, o_params)
+        o_root = oring.RingRoot(o_ring)
+        ok = o_root.encode() == tv_root.encode() == self.root.encode()
+        t1 = time.perf_counter()
+        cpu_proofs = [oring.ring_vrf_prove(o_ring, o_root, self.alphas[i], self.ads[i], self.sks[i]) for i in range(m)]
+        cpu_s = time.perf_counter() - t1
+        ok = ok and [p.encode() for p in gpu_proofs] == cpu_proofs
+        ok = ok and self.vrf.batch_verify(gpu_proofs, self.alphas[:m], self.ads[:m], tv_ring, tv_root)
+        return ok, cpu_proofs, cpu_s
+
+
+def ring_size_leg(d, ring_size: int, batch: int, steps: int, parity_proofs: int):
+    w = RingWorkload(d, ring_size, batch)
+    elapsed, all_ok = w.run(steps, 1)
+    ok, _, _ = w.parity(parity_proofs) if parity_proofs else (True, None, 0.0)
+    out = {"ring_size": ring_size, "domain_size": w.ring.params.domain_size, "batch": batch, "steps": steps,
+           "proofs_per_s": batch * steps / elapsed, "prove_only_proofs_per_s": batch * steps / w.prove_s,
+           "verify_only_proofs_per_s": batch * steps / w.verify_s, "parity_ok": bool(ok and all_ok), "parity_proofs": parity_proofs,
+           "ring_root_s": w.ring_root_s, "srs": "known-tau, 12289 points" if w.big else "shipped 2^11 file"}
+    del w
+    return out
+
+
+def sharded_msm_leg(ctx, comm, log2_total: int, steps: int, scaling: str):
+    """One G1 MSM whose 2^log2_total bases are sharded over the ranks (each rank: srs_synthetic(first = lo + 1) for its slice,
+    scalars seeded per rank); closed-form check on every rank, time = max over ranks through the communicator."""
+    from dot_ring_amd import parallel
+    from oracle import coracle
+
+    n = 1 << log2_total
+    lo, hi = parallel.shard_range(n, comm.rank, comm.world)
+    cnt = hi - lo
+    srs = ctx.srs_synthetic(G1_BE, cnt, first=lo + 1)
+    srs.precompute(16 if cnt >= (1 << 18) else 12)
+    vals, raw = seeded_scalars(cnt, b"shard" + comm.rank.to_bytes(4, "little"))
+    d_scalars = ctx.alloc(32 * cnt).upload(raw)
+    local_sum = sum(k * (lo + 1 + i) for i, k in enumerate(vals)) % FR
+    expect = sum(int.from_bytes(b, "little") for b in comm.all_gather(local_sum.to_bytes(32, "little"))) % FR
+    got = parallel.g1_msm_sharded(ctx, comm, srs, d_scalars, cnt)            # warm-up + the checked result
+    want = bytes(coracle.g1_msm_raw(be_to_le_points(G1_BE), expect.to_bytes(32, "little"), 1))
+    ok = got == want[:48][::-1] + want[48:][::-1]
+    ctx.sync()
+    comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        parallel.g1_msm_sharded(ctx, comm, srs, d_scalars, cnt)
+    ctx.sync()
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    stats = [struct.unpack("<dB", b) for b in comm.all_gather(struct.pack("<dB", elapsed, 1 if ok else 0))]
+    elapsed = max(s[0] for s in stats)
+    d_scalars.free()
+    srs.close()
+    return {"sharding": "bases", "scaling": scaling, "pairs_total": n, "pairs_per_rank": cnt, "ranks": comm.world,
+            "collective": type(comm).__name__, "scalar_muls_per_s": n * steps / elapsed, "ms_per_msm": elapsed / steps * 1e3,
+            "parity_closed_form_all_ranks": all(s[1] for s in stats)}
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +373,7 @@ def main() -> int:
     ap.add_argument("--cpu-proofs", type=int, default=16, help="proofs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=-1, help="processes of the all-cores CPU baseline (-1 = min(16, cores), 0 = skip)")
     ap.add_argument("--msm-log2n", type=int, default=20, help="secondary G1 MSM size (0 = skip)")
+    ap.add_argument("--extras", type=int, default=1, help="0 = skip the secondary legs (bsn_scalar_mul, other ring sizes, distinct signers)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -184,92 +385,50 @@ def main() -> int:
             return 2
         args.gpus = world
 
-    dist = torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        # rehearsal on a box with fewer GPUs than ranks (never used by the driver): DOTRING_BENCH_SHARE_GPU=1 puts every
-        # rank on device 0 and swaps RCCL for gloo (RCCL refuses two ranks on one GPU)
-        share = os.environ.get("DOTRING_BENCH_SHARE_GPU") == "1"
-        if share:
-            local_rank = 0
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        red_device = "cpu" if share else "cuda"
-
+    # rehearsal on a box with fewer GPUs than ranks (never used by the driver): DOTRING_BENCH_SHARE_GPU=1 puts every rank on
+    # device 0 and swaps the RCCL all-gather for the TCP one (RCCL refuses two ranks on one GPU)
+    share = os.environ.get("DOTRING_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     os.environ["DOTRING_DEVICE"] = str(local_rank)
     if world > 1 and "DOTRING_HOST_THREADS" not in os.environ:
         # the library's worker threads (hashing between the GPU phases) default to min(16, cores) per process: with one
         # process per GPU share the host's cores between the ranks instead of oversubscribing them
         os.environ["DOTRING_HOST_THREADS"] = str(max(2, min(16, len(os.sched_getaffinity(0)) // world)))
     import dot_ring_amd as d
-    from dot_ring_amd import runtime
-    from dot_ring_amd.ring_proof.pcs import SRS
+    from dot_ring_amd import parallel, runtime
 
     ctx = runtime.context()
-    cv = d.Bandersnatch
-    vrf = d.RingVRF[cv]
+    comm = None
+    if world > 1:
+        comm = parallel.make_comm(ctx, "socket" if share else "rccl")        # RCCL: ncclCommInitRank on this rank's GPU
     batch = args.batch
 
     # ---- setup (untimed): ring, ring root, per-ring prover tables in HBM
     t_setup = time.perf_counter()
-    signer_pk, signer_sk, keys = bench_ring_keys(cv, args.ring_size, 0)
-    # domains above 2048 need more SRS points than the shipped file holds: known-tau SRS, same on every rank
-    big = d.RingProofParams.from_ring_size(args.ring_size).domain_size > 2048
-    tau = int.from_bytes(hashlib.sha256(b"bench-known-tau").digest(), "little") % d.KZG.scalar_modulus
-    pcs = d.KZG.with_srs(SRS.synthetic(tau, 3 * 4096 + 1)) if big else d.KZG
-    params = d.RingProofParams.from_ring_size(args.ring_size, pcs=pcs)
-    t_ring = time.perf_counter()
-    ring = d.Ring(keys, params)
-    root = d.RingRoot.from_ring(ring, params)
-    ring_root_s = time.perf_counter() - t_ring
-    base = rank * batch
-    alphas = [b"bench-batch-input" + (base + i).to_bytes(8, "little") for i in range(batch)]
-    ads = [b"bench-batch-ad" + (base + i).to_bytes(8, "little") for i in range(batch)]
-    sks, pks = [signer_sk] * batch, [signer_pk] * batch
-    vrf.prove_batch(alphas, ads, sks, pks, ring, root)          # builds the device prover tables (also those of prove_batch's helper thread)
+    w = RingWorkload(d, args.ring_size, batch, first_index=rank * batch)
+    w.step()                       # builds the device prover tables (also those of prove_batch's helper thread)
     setup_s = time.perf_counter() - t_setup
 
     def barrier():
-        ctx.sync()
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        for c in runtime.contexts():
+            c.sync()
+        if comm is not None:
+            comm.barrier()
 
-    prove_s = verify_s = 0.0
+    # ---- timed region: per-kernel timers off
+    elapsed, all_ok = w.run(args.steps, args.warmup, barrier)
+    prove_s, verify_s = w.prove_s, w.verify_s
+    if comm is not None:
+        stats = [struct.unpack("<dB", b) for b in comm.all_gather(struct.pack("<dB", elapsed, 1 if all_ok else 0))]
+        elapsed, all_ok = max(s[0] for s in stats), all(s[1] for s in stats)
 
-    def step():
-        nonlocal prove_s, verify_s
-        t = time.perf_counter()
-        proofs = vrf.prove_batch(alphas, ads, sks, pks, ring, root)
-        t1 = time.perf_counter()
-        ok = vrf.batch_verify(proofs, alphas, ads, ring, root)
-        t2 = time.perf_counter()
-        prove_s += t1 - t
-        verify_s += t2 - t1
-        return proofs, ok
-
-    for _ in range(args.warmup):
-        step()
-    prove_s = verify_s = 0.0
-    # per-kernel timers of every context of this process (prove_batch runs its two halves on two threads, each with its own)
+    # ---- the same steps again with the per-kernel timers on (every context of this process: prove_batch's helper threads too)
     all_ctx = runtime.contexts()
     for c in all_ctx:
         c.prof_reset()
         c.prof_enable(True)
-    barrier()
-    t0 = time.perf_counter()
-    all_ok = True
-    proofs = None
-    for _ in range(args.steps):
-        proofs, ok = step()
-        all_ok = all_ok and ok
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_prof, _ = w.run(args.steps, 0, barrier)
     for c in all_ctx:
         c.prof_enable(False)
 
@@ -280,55 +439,41 @@ def main() -> int:
             ms, cnt = ms + m_, cnt + n_
         return ms, cnt
 
-    if dist is not None:
-        t = torch.tensor([elapsed, 0.0 if all_ok else 1.0], dtype=torch.float64, device=red_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, all_ok = float(t[0].item()), float(t[1].item()) == 0.0
-
     kernel_ms = {name: prof_sum(name)[0] / max(1, args.steps) for name in MSM_KERNELS + RING_KERNELS}
     acc_ms, acc_launches = prof_sum("k_g1_accumulate")
 
+    sharded = None
+    if comm is not None and args.msm_log2n > 0:
+        # strong: 2^msm_log2n pairs in total; weak: 2^msm_log2n pairs per rank (rounded up to a power of two of ranks)
+        sharded = [sharded_msm_leg(ctx, comm, args.msm_log2n, 10, "strong")]
+        extra = max(0, (world - 1).bit_length())
+        if extra:
+            sharded.append(sharded_msm_leg(ctx, comm, args.msm_log2n + extra, 5, "weak"))
+
+    rc = 0
     if rank == 0:
-        n_dom = ring.params.domain_size
+        n_dom = w.ring.params.domain_size
         # dense (base, scalar) pairs per proof: quotient 3N+1, two opening quotients 3N + (N-1)  (SURVEY 3.3); the four
         # witness columns (4N) are committed by summation by parts: 4N scalars are read, only ~1.1k bases gathered,
         # so they are priced at the 32 B scalar alone
         pairs_per_proof = 7 * n_dom
         scalar_only_per_proof = 4 * n_dom
-        # ---- parity subset: deterministic proofs (test_vectors=True) byte-compared with the CPU oracle
-        from oracle.pyref import bandersnatch as obsn
-        from oracle.pyref import ring as oring
-
         parity_ok = all_ok
         cpu = cpu_all = None
         if args.cpu_proofs > 0:
-            tv_params = d.RingProofParams.from_ring_size(args.ring_size, test_vectors=True, pcs=pcs)
-            tv_ring = d.Ring(keys, tv_params)
-            tv_root = d.RingRoot.from_ring(tv_ring, tv_params)
             m = args.cpu_proofs if world == 1 else min(2, args.cpu_proofs)     # N > 1: parity check only, no CPU timing
-            gpu_proofs = vrf.prove_batch(alphas[:m], ads[:m], sks[:m], pks[:m], tv_ring, tv_root)
-            o_srs = None
-            if big:
-                from oracle.pyref import kzg as okzg
-                o_srs = okzg.SRS.from_tau(tau, 3 * 4096 + 1)
-                o_srs.g2_raw = list(pcs.srs.g2_raw)
-            o_params = oring.Params.from_ring_size(args.ring_size, test_vectors=True, suite=obsn.SHA512, srs=o_srs)
-            o_ring = oring.Ring(keys, o_params)
-            o_root = oring.RingRoot(o_ring)
-            parity_ok = parity_ok and o_root.encode() == tv_root.encode() == root.encode()
-            t1 = time.perf_counter()
-            cpu_proofs = [oring.ring_vrf_prove(o_ring, o_root, alphas[i], ads[i], signer_sk) for i in range(m)]
-            cpu_s = time.perf_counter() - t1
-            parity_ok = parity_ok and [p.encode() for p in gpu_proofs] == cpu_proofs
-            cpu = None if world > 1 else {"value": m / cpu_s, "unit": "proofs/s", "cores": 1, "kind": "port",
-                   "sample": f"{m} proofs (prove only) of the same workload through oracle/ (Python orchestration + oracle/c "
-                             f"kernels for NTT and G1 Pippenger), {cpu_s:.1f} s"}
-
+            ok, cpu_proofs, cpu_s = w.parity(m)
+            parity_ok = parity_ok and ok
+            cpu = None if world > 1 else {
+                "value": m / cpu_s, "unit": "proofs/s", "cores": 1, "kind": "port", "work": "prove only",
+                "sample": f"{m} proofs of the same workload through oracle/ (Python orchestration + oracle/c kernels for NTT and G1 "
+                          f"Pippenger), {cpu_s:.1f} s.  PROVE ONLY — the GPU figure is prove + verify; the reference's verify adds 0.7 % "
+                          f"to its prove time (3.99 ms vs 534.57 ms, docs/BENCHMARK.md:72-73)"}
             # the same port on all host cores: one oracle process per core, released together
-            if world == 1 and not big and args.cpu_workers != 0:
-                cpu_all = cpu_baseline_all_cores(keys, args.ring_size, signer_sk, max(2, m // 4), args.cpu_workers, cpu_proofs)
+            if world == 1 and not w.big and args.cpu_workers != 0:
+                cpu_all = cpu_baseline_all_cores(w.keys, args.ring_size, w.signer_sk, max(2, m // 4), args.cpu_workers, cpu_proofs)
 
-        # bucket additions of the dense MSMs in the timed region: pairs x windows of the SRS table (non-zero digit rate ~1)
+        # bucket additions of the dense MSMs in the profiled pass: pairs x windows of the SRS table (non-zero digit rate ~1)
         table_windows = -(-256 // int(os.environ.get("DOTRING_SRS_WINDOW", "12") or 12))
         dense_adds = float(batch) * pairs_per_proof * table_windows * args.steps
         total = batch * world * args.steps
@@ -337,21 +482,40 @@ def main() -> int:
         pairs_per_launch = (batch * pairs_per_proof * args.steps + 0.0) / max(1, acc_launches)      # prove-side MSM pairs / launches
         alg_bytes_launch = ALG_BYTES_PER_PAIR * pairs_per_launch + 32.0 * batch * scalar_only_per_proof * args.steps / max(1, acc_launches)
         achieved = alg_bytes_launch / avg_acc_s / 1e9 if avg_acc_s > 0 else 0.0
-        traffic = None
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"ringvrf_ring{args.ring_size}_batch{batch}", {}).get("k_g1_accumulate_bytes_per_launch")
+                rec = json.load(open(tpath))
+                traffic = rec.get(f"ringvrf_ring{args.ring_size}_batch{batch}", {}).get("k_g1_accumulate_bytes_per_launch")
+                traffic_source = rec.get("_source", "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh, "
+                                                    "NOT measured in this run)") if traffic else None
             except Exception:
                 traffic = None
-        g1 = None
-        if args.msm_log2n > 0 and world == 1:
+        g1 = bsn = others = distinct = None
+        if world == 1 and args.msm_log2n > 0:
             g1 = g1_msm_measurement(ctx, args.msm_log2n, 10, 17, True)
             parity_ok = parity_ok and g1.get("parity_closed_form", True) and g1.get("parity_sample", True)
             if args.msm_log2n > 16:             # BASELINE configs[2] names 2^16 as well
                 small = g1_msm_measurement(ctx, 16, 20, 0, True)
                 parity_ok = parity_ok and small.get("parity_closed_form", True)
-                g1["at_2p16"] = {k: small[k] for k in ("pairs", "scalar_muls_per_s", "ms_per_msm", "parity_closed_form")}
+                g1["at_2p16"] = {k: small[k] for k in ("pairs", "scalar_muls_per_s", "ms_per_msm", "parity_closed_form", "kernel_ms_per_msm")}
+        if world == 1 and args.extras:
+            bsn = bsn_scalar_mul_measurement(ctx, d.Bandersnatch, 4096, 20)
+            parity_ok = parity_ok and bsn["parity_ok"]
+            if args.ring_size == 1024 and batch >= 2:
+                # 1024 different signing keys (the reference bench — and the headline — sign every proof with one key)
+                w.distinct_signers()
+                el, ok_d = w.run(2, 1)
+                ok_p, _, _ = w.parity(2)
+                distinct = {"proofs_per_s": batch * 2 / el, "prove_only_proofs_per_s": batch * 2 / w.prove_s, "signers": min(batch, args.ring_size),
+                            "parity_ok": bool(ok_d and ok_p), "parity_proofs": 2}
+                parity_ok = parity_ok and distinct["parity_ok"]
+                others = {}
+                for rs in (256, 3000):
+                    leg = ring_size_leg(d, rs, batch, 3, 2)
+                    others[str(rs)] = leg
+                    parity_ok = parity_ok and leg["parity_ok"]
         line = {
             "metric": "ringvrf_proofs_per_sec",
             "value": value,
@@ -367,17 +531,20 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": f"RingVRF[Bandersnatch] prove_batch + batch_verify, ring_size {args.ring_size} (domain {n_dom}), "
                                    f"{batch} proofs per GPU per step, ZK rows random, ring/SRS/prover tables HBM-resident"
-                                   + (", known-tau SRS of 12289 points" if big else ""),
+                                   + (", known-tau SRS of 12289 points" if w.big else ""),
                        "ring_size": args.ring_size, "domain_size": n_dom, "batch_per_gpu": batch,
                        "sharding": "proofs sharded per rank, no collective" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_g1_accumulate", "avg_kernel_ms": avg_acc_s * 1e3,
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "k_g1_accumulate", "avg_kernel_ms": avg_acc_s * 1e3,
                          "launches_per_step": acc_launches / max(1, args.steps), "algorithmic_bytes_per_launch": alg_bytes_launch,
-                         # the kernel is integer-VALU bound, so the informative ceiling is the VALU issue rate: mixed
-                         # additions/s against 1024 SIMDs x 2.4 GHz / 4 cycles x 64 lanes / ~6800 instructions per
-                         # XYZZ mixed addition (10 Montgomery products of 649 instructions + ~310 add/sub/select)
+                         "timers": "HIP events per launch, in a second pass of the same K steps (the timed region runs without them); "
+                                   f"that pass took {elapsed_prof / args.steps * 1e3:.2f} ms per step",
+                         # the kernel is integer-VALU bound, so the informative ceiling is the VALU issue rate: mixed additions/s
+                         # against 1024 SIMDs x 2.4 GHz / 4.2 cycles x 64 lanes / MADD_INSTRUCTIONS (a derived ceiling: the issue
+                         # cost per instruction is measured, profiles/r02_ubench_valu.txt, the instruction count is the generated code's)
                          "valu": {"achieved_gadd_s": dense_adds / (acc_ms / 1e3) / 1e9 if acc_ms else None, "peak_gadd_s": VALU_PEAK_GADD_S,
                                   "frac": dense_adds / (acc_ms / 1e3) / 1e9 / VALU_PEAK_GADD_S if acc_ms else None,
+                                  "instructions_per_addition": MADD_INSTRUCTIONS,
                                   "note": "dense bucket additions only (7N pairs x windows per proof); by-parts and verify-side additions not counted"},
                          # per-proof unique traffic (11N scalars + 14 NTT passes' data + 784 B out), 3.17 KB per
                          # domain point = 6.5 MB per proof at N = 2048, over the whole job
@@ -389,18 +556,22 @@ def main() -> int:
             "prove_only_proofs_per_s": batch * args.steps / prove_s if prove_s else None,
             "verify_only_proofs_per_s": batch * args.steps / verify_s if verify_s else None,
             "gpu_kernel_ms_per_step": {k: round(v, 3) for k, v in kernel_ms.items() if v > 0.0005},
+            "bsn_scalar_mul": bsn,
             "g1_msm": g1,
-            "ring_root_s": ring_root_s,
+            "g1_msm_sharded": sharded,
+            "other_ring_sizes": others,
+            "distinct_signers": distinct,
+            "ring_root_s": w.ring_root_s,
             "setup_s": setup_s,
         }
         print(json.dumps(line))
         if not parity_ok:
             print("bench.py: PARITY FAILURE — GPU result differs from the oracle", file=sys.stderr)
-            return 1
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    return 0
+            rc = 1
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+    return rc
 
 
 if __name__ == "__main__":

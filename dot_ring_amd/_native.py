@@ -113,6 +113,16 @@ _PROTOTYPES.update({
                                        POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint32),
                                        c_char_p, c_size_t, c_char_p, c_char_p, c_char_p]),
 })
+_PROTOTYPES.update({
+    "dr_comm_unique_id": (c_int, [c_char_p]),
+    "dr_comm_create": (c_int, [c_void_p, c_char_p, c_int, c_int, POINTER(c_void_p)]),
+    "dr_comm_destroy": (None, [c_void_p]),
+    "dr_comm_rank": (c_int, [c_void_p]),
+    "dr_comm_world": (c_int, [c_void_p]),
+    "dr_comm_all_gather": (c_int, [c_void_p, c_char_p, c_size_t, c_char_p]),
+    "dr_g1_msm_sharded_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, POINTER(c_int)]),
+})
+COMM_ID_BYTES = 128
 RINGVRF_AUX_BYTES = 960
 PEDERSEN_AUX_BYTES = 288
 EXPORTED_SYMBOLS = tuple(_PROTOTYPES)

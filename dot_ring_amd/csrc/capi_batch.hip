@@ -1,0 +1,748 @@
+// libdotring_hip.so — C ABI, part 4 of 5: native batch orchestration.  Pedersen / IETF / Ring-VRF prove_batch and
+// batch_verify run the whole protocol in the library: GPU phases through the entry points of the other parts, the hashing
+// between them on worker threads (hosthash.hpp, hostproto.hpp).
+#include "capi_internal.hpp"
+
+using namespace dri;
+
+// The whole batch in one call: Pedersen VRF part (pedersen/vrf.py:86-126) then the ring proof
+// (proof_builder.py:38-315) — GPU phases through the entry points above, the hashing between them on worker threads.
+// Pedersen VRF prover for a batch (pedersen/vrf.py:86-126): head() = hash-to-curve, outputs, transcripts and blinding
+// factors (what the ring proof needs); tail() = blinded keys, nonces, R / O_k, challenge, responses and the 192 encoded
+// bytes.  The two halves may run on different contexts (streams) of the same GPU.
+struct PedersenBatch {
+    const drh::VrfSuite& su;
+    size_t B;
+    std::vector<uint8_t> us, xs, inputs, outs, blind, gb_pts, sc, ybar, ks, kbs, pts3, sc3, third;
+    std::vector<drh::Bytes> tr;
+    PedersenBatch(const drh::VrfSuite& s, size_t b) : su(s), B(b) {}
+
+    int head(dr_ctx* ctx, const uint8_t* alphas, const uint64_t* alpha_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts,
+             const uint64_t* salt_off, const uint8_t* secret_scalars, PhaseTrace& tr_) {
+        const drh::Mod256& mn = su.cv->n;
+        // 1. secrets mod n
+        xs.resize(B * 32);
+        for (size_t i = 0; i < B; i++) {
+            uint64_t x[4];
+            mn.reduce_bytes(secret_scalars + 32 * i, 32, false, x);
+            drh::store_le32(x, xs.data() + 32 * i);
+        }
+        // 2. I_i = encode_to_curve(salt || alpha), O_i = x_i * I_i
+        inputs.resize(B * 64); outs.resize(B * 64);
+        TRY(encode_and_mul(ctx, su, B, alphas, alpha_off, salts, salt_off, xs.data(), inputs.data(), outs.data()));
+        tr_.mark("encode+x*I");
+        // 3. transcripts, blinding factors
+        tr.assign(B, drh::Bytes());
+        blind.resize(B * 32); gb_pts.resize(B * 128); sc.resize(B * 64);
+        std::vector<int> bad(B, 0);
+        drh::parallel_for(B, [&](size_t i) {
+            drh::Bytes& t = tr[i];
+            t = su.suite_id;
+            drh::put8(t, 0x02);                                    // PEDERSEN_VRF
+            drh::put_le64(t, 1);                                   // one (input, output) pair
+            uint8_t enc[32];
+            drh::enc_te_point(inputs.data() + 64 * i, enc); drh::put(t, enc, 32);
+            drh::enc_te_point(outs.data() + 64 * i, enc); drh::put(t, enc, 32);
+            size_t adl = ad_off[i + 1] - ad_off[i];
+            drh::put_le64(t, adl);
+            drh::put(t, ads + ad_off[i], adl);
+            drh::Bytes tb = t;
+            drh::put8(tb, 0x12);                                   // PEDERSEN_BLINDING
+            uint64_t x[4], b[4];
+            drh::load_le32(xs.data() + 32 * i, x);
+            if (!drh::vrf_nonce(su, tb, x, b)) bad[i] = 1;
+            drh::store_le32(b, blind.data() + 32 * i);
+            std::memcpy(gb_pts.data() + 128 * i, su.generator, 64);
+            std::memcpy(gb_pts.data() + 128 * i + 64, su.blinding_base, 64);
+            std::memcpy(sc.data() + 64 * i, xs.data() + 32 * i, 32);
+            std::memcpy(sc.data() + 64 * i + 32, blind.data() + 32 * i, 32);
+        });
+        for (size_t i = 0; i < B; i++) if (bad[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
+        tr_.mark("blinding");
+        return DR_OK;
+    }
+
+    // out_proofs: 192 bytes per proof at `stride`; out_aux (nullable): O, Y_bar, R, O_k affine (4*64) + blinding (32) at aux_stride
+    int tail(dr_ctx* actx, uint8_t* out_proofs, size_t stride, uint8_t* out_aux, size_t aux_stride) {
+        const drh::Mod256& mn = su.cv->n;
+        const int cv = su.cv->id;
+        ybar.resize(B * 64); ks.resize(B * 32); kbs.resize(B * 32); pts3.resize(2 * B * 128); sc3.resize(2 * B * 64); third.resize(2 * B * 64);
+        // 4. blinded public keys  Y_bar_i = x_i*G + b_i*B
+        TRY(te_msm_groups(actx, cv, gb_pts.data(), sc.data(), B, 2, ybar.data()));
+        // 5. nonces
+        std::vector<int> bad2(B, 0);
+        drh::parallel_for(B, [&](size_t i) {
+            uint8_t enc[32];
+            drh::enc_te_point(ybar.data() + 64 * i, enc);
+            drh::put(tr[i], enc, 32);
+            uint64_t x[4], b[4], k[4], kb[4];
+            drh::load_le32(xs.data() + 32 * i, x);
+            drh::load_le32(blind.data() + 32 * i, b);
+            if (!drh::vrf_nonce(su, tr[i], x, k) || !drh::vrf_nonce(su, tr[i], b, kb)) bad2[i] = 1;
+            drh::store_le32(k, ks.data() + 32 * i);
+            drh::store_le32(kb, kbs.data() + 32 * i);
+            // group i: k*G + kb*B ; group B+i: k*I + 0*I
+            std::memcpy(pts3.data() + 128 * i, su.generator, 64);
+            std::memcpy(pts3.data() + 128 * i + 64, su.blinding_base, 64);
+            std::memcpy(sc3.data() + 64 * i, ks.data() + 32 * i, 32);
+            std::memcpy(sc3.data() + 64 * i + 32, kbs.data() + 32 * i, 32);
+            std::memcpy(pts3.data() + 128 * (B + i), inputs.data() + 64 * i, 64);
+            std::memcpy(pts3.data() + 128 * (B + i) + 64, inputs.data() + 64 * i, 64);
+            std::memcpy(sc3.data() + 64 * (B + i), ks.data() + 32 * i, 32);
+            std::memset(sc3.data() + 64 * (B + i) + 32, 0, 32);
+        });
+        for (size_t i = 0; i < B; i++) if (bad2[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
+        TRY(te_msm_groups(actx, cv, pts3.data(), sc3.data(), 2 * B, 2, third.data()));
+        // 6. challenge, responses, the 192 encoded bytes
+        drh::parallel_for(B, [&](size_t i) {
+            uint8_t* out = out_proofs + stride * i;
+            drh::enc_te_point(outs.data() + 64 * i, out);
+            drh::enc_te_point(ybar.data() + 64 * i, out + 32);
+            drh::enc_te_point(third.data() + 64 * i, out + 64);
+            drh::enc_te_point(third.data() + 64 * (B + i), out + 96);
+            uint64_t c[4], x[4], b[4], k[4], kb[4], s[4], sb[4];
+            drh::vrf_challenge(su, tr[i], out + 64, 2, c);
+            drh::load_le32(xs.data() + 32 * i, x);
+            drh::load_le32(blind.data() + 32 * i, b);
+            drh::load_le32(ks.data() + 32 * i, k);
+            drh::load_le32(kbs.data() + 32 * i, kb);
+            mn.mul(c, x, s);  mn.add(s, k, s);
+            mn.mul(c, b, sb); mn.add(sb, kb, sb);
+            drh::store_le32(s, out + 128);
+            drh::store_le32(sb, out + 160);
+            if (out_aux) {
+                uint8_t* a = out_aux + aux_stride * i;
+                std::memcpy(a, outs.data() + 64 * i, 64);
+                std::memcpy(a + 64, ybar.data() + 64 * i, 64);
+                std::memcpy(a + 128, third.data() + 64 * i, 64);
+                std::memcpy(a + 192, third.data() + 64 * (B + i), 64);
+                std::memcpy(a + 256, blind.data() + 32 * i, 32);
+            }
+        });
+        return DR_OK;
+    }
+};
+
+int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_t batch, const uint8_t* alphas, const uint64_t* alpha_off,
+                                    const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
+                                    const uint8_t* secret_scalars, const uint32_t* producer_index, const uint8_t* fs_prefix, size_t fs_prefix_len,
+                                    const uint8_t* zk_random48, uint8_t* out_proofs, uint8_t* out_aux) {
+    if (!p || !alpha_off || !ad_off || !secret_scalars || !producer_index || !fs_prefix || !out_proofs) return fail(DR_ERR_INVALID, "null argument");
+    if (batch == 0) return DR_OK;
+    if (batch > 4096) return fail(DR_ERR_INVALID, "batch must be at most 4096 per call");
+    drh::VrfSuite su;
+    TRY(load_suite(suite, su));
+    if (su.cv->id != ring_prover_curve(p)) return fail(DR_ERR_INVALID, "VRF suite and ring prover are on different curves");
+    for (size_t i = 0; i < batch; i++)
+        if (alpha_off[i + 1] < alpha_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
+            return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
+    dr_ctx* ctx = ring_prover_ctx(p);
+    const size_t B = batch;
+    PhaseTrace tr_("prove_batch");
+
+    PedersenBatch ped(su, B);
+    TRY(ped.head(ctx, alphas, alpha_off, ads, ad_off, salts, salt_off, secret_scalars, tr_));
+    std::vector<uint8_t>& blind = ped.blind;
+    // 4.-6. the rest of the Pedersen part needs nothing from the ring proof and the ring proof needs only the blinding
+    // factors: it runs on a second stream (own context: scratch + stream) from a helper thread while this thread drives
+    // the ring phases.  Its kernels are latency-bound (16..64 waves) and hide under the chip-filling MSMs.
+    dr_ctx* actx = nullptr;
+    TRY(ring_prover_aux_ctx(p, &actx));
+    actx->prof = ctx->prof;
+    int ped_rc = DR_OK;
+    std::string ped_err;
+    const bool overlap = std::getenv("DOTRING_PROVE_OVERLAP") == nullptr || std::atoi(std::getenv("DOTRING_PROVE_OVERLAP")) != 0;
+    std::thread ped_thread;
+    if (overlap) {
+        ped_thread = std::thread([&] {
+            ped_rc = ped.tail(actx, out_proofs, 784, out_aux, DR_RINGVRF_AUX_BYTES);
+            if (ped_rc != DR_OK) ped_err = dr_last_error();
+        });
+    } else {
+        TRY(ped.tail(ctx, out_proofs, 784, out_aux, DR_RINGVRF_AUX_BYTES));
+    }
+    struct Joiner {          // every exit path below must wait for the helper before the buffers it uses go away
+        std::thread& t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{ped_thread};
+
+    // 7. ring proof: witness columns
+    std::vector<uint8_t> zk;
+    if (zk_random48) {
+        zk.resize(B * 12 * 32);
+        drh::parallel_for(B * 12, [&](size_t j) {
+            uint64_t v[4];
+            drh::mod_p().reduce_bytes(zk_random48 + 48 * j, 48, false, v);
+            drh::store_le32(v, zk.data() + 32 * j);
+        });
+    }
+    std::vector<uint8_t> relation(B * 64), wit(B * 4 * 96), cq(B * 96), evals(B * 256), opens(B * 192);
+    std::vector<int> wit_inf(B * 4), cq_inf(B), open_inf(B * 2);
+    tr_.mark("spawn+zk");
+    TRY(dr_ring_prove_witness(p, B, producer_index, blind.data(), zk_random48 ? zk.data() : nullptr, relation.data(), wit.data(), wit_inf.data()));
+    tr_.mark("witness");
+    drh::FsTranscript base;
+    base.sh.update(fs_prefix, fs_prefix_len);
+    std::vector<drh::FsTranscript> fs(B, base);
+    std::vector<uint8_t> alphas7(B * 7 * 32), zetas(B * 32), nus(B * 8 * 32);
+    drh::parallel_for(B, [&](size_t i) {
+        fs[i].absorb_labeled("instance", relation.data() + 64 * i, 64);
+        uint8_t ser[4 * 96];
+        for (int c = 0; c < 4; c++) drh::g1_serialized(wit.data() + 96 * (4 * i + c), wit_inf[4 * i + c], ser + 96 * c);
+        fs[i].absorb_labeled("committed_cols", ser, sizeof ser);
+        fs[i].challenges("constraints_aggregation", 7, alphas7.data() + 224 * i);
+    });
+    tr_.mark("fs1");
+    TRY(dr_ring_prove_quotient(p, B, alphas7.data(), cq.data(), cq_inf.data()));
+    tr_.mark("quotient");
+    drh::parallel_for(B, [&](size_t i) {
+        uint8_t ser[96];
+        drh::g1_serialized(cq.data() + 96 * i, cq_inf[i], ser);
+        fs[i].absorb_labeled("quotient", ser, 96);
+        fs[i].challenges("evaluation_point", 1, zetas.data() + 32 * i);
+    });
+    tr_.mark("fs2");
+    TRY(dr_ring_prove_evals(p, B, zetas.data(), evals.data()));
+    tr_.mark("evals");
+    drh::parallel_for(B, [&](size_t i) {
+        fs[i].absorb_labeled("register_evaluations", evals.data() + 256 * i, 224);
+        fs[i].absorb_labeled("shifted_linearization_evaluation", evals.data() + 256 * i + 224, 32);
+        fs[i].challenges("kzg_aggregation", 8, nus.data() + 256 * i);
+    });
+    tr_.mark("fs3");
+    TRY(dr_ring_prove_openings(p, B, nus.data(), opens.data(), open_inf.data()));
+    tr_.mark("openings");
+    // 8. payload: 4 compressed commitments, 7 evaluations, C_q, l(zeta*omega), 2 opening proofs  (proof_payload.py:68-117)
+    std::vector<int> rc(B, DR_OK);
+    drh::parallel_for(B, [&](size_t i) {
+        uint8_t* out = out_proofs + 784 * i + 192;
+        int r = DR_OK;
+        for (int c = 0; c < 4 && r == DR_OK; c++) r = dr_g1_compress(wit.data() + 96 * (4 * i + c), wit_inf[4 * i + c], out + 48 * c);
+        std::memcpy(out + 192, evals.data() + 256 * i, 224);
+        if (r == DR_OK) r = dr_g1_compress(cq.data() + 96 * i, cq_inf[i], out + 416);
+        std::memcpy(out + 464, evals.data() + 256 * i + 224, 32);
+        if (r == DR_OK) r = dr_g1_compress(opens.data() + 192 * i, open_inf[2 * i], out + 496);
+        if (r == DR_OK) r = dr_g1_compress(opens.data() + 192 * i + 96, open_inf[2 * i + 1], out + 544);
+        rc[i] = r;
+        if (out_aux) {
+            uint8_t* a = out_aux + DR_RINGVRF_AUX_BYTES * i + 288;
+            for (int c = 0; c < 4; c++) drh::g1_serialized(wit.data() + 96 * (4 * i + c), wit_inf[4 * i + c], a + 96 * c);
+            drh::g1_serialized(cq.data() + 96 * i, cq_inf[i], a + 384);
+            drh::g1_serialized(opens.data() + 192 * i, open_inf[2 * i], a + 480);
+            drh::g1_serialized(opens.data() + 192 * i + 96, open_inf[2 * i + 1], a + 576);
+        }
+    });
+    for (size_t i = 0; i < B; i++) if (rc[i] != DR_OK) return rc[i];
+    tr_.mark("payload");
+    if (ped_thread.joinable()) ped_thread.join();
+    tr_.mark("join");
+    if (ped_rc != DR_OK) return fail(ped_rc, ped_err.empty() ? "Pedersen part failed" : ped_err);
+    return DR_OK;
+}
+
+// RingVRF.batch_verify over encoded proofs (vrf/ring/vrf.py:239-283, pedersen/vrf.py:171-242, ring_proof/verify.py:51-324,
+// pcs/kzg.py:304-338): decode + validate every point on the GPU, replay the transcripts on worker threads, fold all
+// claims into one Bandersnatch MSM (5B+2 points, must be the identity) and two G1 MSMs + one pairing equation.
+// C++ exceptions (allocation failures of the host-side staging vectors, thread creation) must not cross the C ABI
+int dr_ringvrf_prove_batch(dr_ring_prover* p, const dr_vrf_suite* suite, size_t batch, const uint8_t* alphas, const uint64_t* alpha_off,
+                           const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
+                           const uint8_t* secret_scalars, const uint32_t* producer_index, const uint8_t* fs_prefix, size_t fs_prefix_len,
+                           const uint8_t* zk_random48, uint8_t* out_proofs, uint8_t* out_aux) {
+    try {
+        return ringvrf_prove_batch_impl(p, suite, batch, alphas, alpha_off, ads, ad_off, salts, salt_off, secret_scalars, producer_index, fs_prefix,
+                                        fs_prefix_len, zk_random48, out_proofs, out_aux);
+    } catch (const std::bad_alloc&) {
+        return fail(DR_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_DEVICE, std::string("native prover: ") + e.what());
+    }
+}
+
+// Pedersen VRF batch verification core (pedersen/vrf.py:171-242) on decoded points: challenges, weights from one
+// transcript over all (c, s, s_b), then ONE (5B+2)-point MSM that must be the identity.  proofs: 192 bytes per proof at
+// `stride`; te_xy: the four decoded points of each proof (O, Y_bar, R, O_k affine); in_pts: encode_to_curve of the inputs.
+int pedersen_verify_core(dr_ctx* actx, const drh::VrfSuite& su, size_t B, const uint8_t* proofs, size_t stride,
+                                const std::vector<uint8_t>& te_xy, const std::vector<uint8_t>& in_pts, const uint8_t* ads,
+                                const uint64_t* ad_off, int& ped_ok) {
+    const drh::Mod256& mn = su.cv->n;
+    std::vector<uint8_t> cs(B * 32);
+    drh::parallel_for(B, [&](size_t i) {
+        const uint8_t* pr = proofs + stride * i;
+        drh::Bytes t = su.suite_id;
+        drh::put8(t, 0x02);
+        drh::put_le64(t, 1);
+        uint8_t enc[32];
+        drh::enc_te_point(in_pts.data() + 64 * i, enc);
+        drh::put(t, enc, 32);
+        drh::put(t, pr, 32);                                   // output point, as encoded in the proof
+        size_t adl = ad_off[i + 1] - ad_off[i];
+        drh::put_le64(t, adl);
+        drh::put(t, ads + ad_off[i], adl);
+        drh::put(t, pr + 32, 32);                              // blinded public key
+        uint64_t c[4];
+        drh::vrf_challenge(su, t, pr + 64, 2, c);              // R, O_k
+        drh::store_le32(c, cs.data() + 32 * i);
+    });
+    {
+        drh::Bytes absorbed = su.suite_id;
+        drh::put8(absorbed, 0x50);                             // BATCH_VERIFY
+        for (size_t i = 0; i < B; i++) {
+            drh::put(absorbed, cs.data() + 32 * i, 32);
+            drh::put(absorbed, proofs + stride * i + 128, 64);    // s, s_b
+        }
+        std::vector<uint8_t> weights(32 * B);
+        drh::vrf_squeeze(su.xof, absorbed.data(), absorbed.size(), weights.data(), weights.size());
+        std::vector<uint8_t> pts((5 * B + 2) * 64), sc((5 * B + 2) * 32);
+        std::vector<uint64_t> gen_part(B * 4), blind_part(B * 4);
+        drh::parallel_for(B, [&](size_t i) {
+            const uint8_t* pr = proofs + stride * i;
+            uint64_t w_io[4], w_cm[4], c[4], s[4], sb[4], t[4];
+            mn.reduce_bytes(weights.data() + 32 * i, 16, false, w_io);
+            mn.reduce_bytes(weights.data() + 32 * i + 16, 16, false, w_cm);
+            drh::load_le32(cs.data() + 32 * i, c);
+            drh::load_le32(pr + 128, s);
+            drh::load_le32(pr + 160, sb);
+            uint8_t* p = pts.data() + 320 * i;
+            uint8_t* k = sc.data() + 160 * i;
+            std::memcpy(p, te_xy.data() + 64 * (4 * i + 3), 64);       drh::store_le32(w_io, k);                       // O_k
+            std::memcpy(p + 64, te_xy.data() + 64 * (4 * i), 64);      mn.mul(w_io, c, t); drh::store_le32(t, k + 32);  // output
+            std::memcpy(p + 128, in_pts.data() + 64 * i, 64);          mn.mul(w_io, s, t); mn.neg(t, t); drh::store_le32(t, k + 64);   // input
+            std::memcpy(p + 192, te_xy.data() + 64 * (4 * i + 2), 64); drh::store_le32(w_cm, k + 96);                  // R
+            std::memcpy(p + 256, te_xy.data() + 64 * (4 * i + 1), 64); mn.mul(w_cm, c, t); drh::store_le32(t, k + 128); // Y_bar
+            mn.mul(w_cm, s, &gen_part[4 * i]);
+            mn.mul(w_cm, sb, &blind_part[4 * i]);
+        });
+        uint64_t gs[4] = {0, 0, 0, 0}, bs[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < B; i++) { mn.sub(gs, &gen_part[4 * i], gs); mn.sub(bs, &blind_part[4 * i], bs); }
+        std::memcpy(pts.data() + 320 * B, su.generator, 64);           drh::store_le32(gs, sc.data() + 160 * B);
+        std::memcpy(pts.data() + 320 * B + 64, su.blinding_base, 64);  drh::store_le32(bs, sc.data() + 160 * B + 32);
+        uint8_t sum[64];
+        TRY(te_msm(actx, su.cv->id, pts.data(), sc.data(), 5 * B + 2, sum));
+        uint8_t ident[64] = {0};
+        ident[32] = 1;
+        ped_ok = std::memcmp(sum, ident, 64) == 0 ? 1 : 0;
+    }
+    return DR_OK;
+}
+
+int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_ring_verifier_key* vk, size_t batch, const uint8_t* proofs,
+                                     const uint8_t* inputs, const uint64_t* in_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts,
+                                     const uint64_t* salt_off, const uint8_t seed32[32], int* ok) {
+    TRY(use_ctx(ctx));
+    if (!vk || !proofs || !in_off || !ad_off || !seed32 || !ok || !vk->fs_prefix) return fail(DR_ERR_INVALID, "null argument");
+    *ok = 0;
+    if (batch == 0) { *ok = 1; return DR_OK; }
+    if (batch > 4096) return fail(DR_ERR_INVALID, "batch must be at most 4096 per call");
+    if (vk->log2n < 9 || vk->log2n > 16) return fail(DR_ERR_INVALID, "bad domain size");
+    drh::VrfSuite su;
+    TRY(load_suite(suite, su));
+    for (size_t i = 0; i < batch; i++)
+        if (in_off[i + 1] < in_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
+            return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
+    const size_t B = batch;
+    const drh::Mod256& mn = su.cv->n;
+    const drh::Mod256& mp = drh::mod_p();
+    hipStream_t st = ctx->stream;
+
+    PhaseTrace tr_("verify_batch");
+    // ---- 1. canonical scalars; gather encoded points
+    std::vector<uint8_t> te_enc(B * 4 * 32), g1_enc(B * 7 * 48);
+    bool canonical = true;
+    for (size_t i = 0; i < B; i++) {
+        const uint8_t* pr = proofs + 784 * i;
+        std::memcpy(te_enc.data() + 128 * i, pr, 128);
+        uint64_t v[4];
+        for (int k = 0; k < 2; k++) { drh::load_le32(pr + 128 + 32 * k, v); if (drh::Mod256::geq(v, mn.m)) canonical = false; }      // dec_scalar
+        const uint8_t* pl = pr + 192;
+        for (int k = 0; k < 7; k++) { drh::load_le32(pl + 192 + 32 * k, v); if (drh::Mod256::geq(v, mp.m)) canonical = false; }
+        drh::load_le32(pl + 464, v); if (drh::Mod256::geq(v, mp.m)) canonical = false;
+        uint8_t* g = g1_enc.data() + 336 * i;
+        std::memcpy(g, pl, 192);                   // C_b, C_accip, C_accx, C_accy
+        std::memcpy(g + 192, pl + 416, 48);        // C_q
+        std::memcpy(g + 240, pl + 496, 96);        // Phi_zeta, Phi_zeta_omega
+    }
+    if (!canonical) return DR_OK;
+
+    // ---- 2. GPU: decode + validate the 4B Bandersnatch points, decompress the 7B G1 points; meanwhile a helper thread
+    // hashes the inputs to the curve on a second stream (all three kernels are latency-bound: a few dozen waves)
+    if (!ctx->aux) TRY(dr_ctx_create(ctx->device, &ctx->aux));
+    dr_ctx* actx = ctx->aux;
+    actx->prof = ctx->prof;
+    // One helper thread for the whole Pedersen side (second stream): hash the inputs to the curve right away, then wait at a
+    // gate until this thread has decoded and validated the proof points, then the challenges and the (5B+2)-point MSM.  The main
+    // thread never waits for the Elligator kernels (they took the decode phase from 2.2 to 3.1 ms when it joined them there).
+    const size_t n_te = 4 * B, n_g1 = 7 * B + 4;
+    std::vector<uint8_t> in_pts(B * 64), te_xy(n_te * 64);
+    int side_rc = DR_OK, ped_ok = 0;
+    std::string side_err;
+    std::mutex gate_m;
+    std::condition_variable gate_cv;
+    int gate = -1;                                   // -1 closed, 0 give up, 1 go on
+    auto open_gate = [&](int v) {
+        { std::lock_guard<std::mutex> lk(gate_m); if (gate < 0) gate = v; }
+        gate_cv.notify_all();
+    };
+    std::thread side([&] {
+        side_rc = encode_to_curve_msgs(actx, su, B, inputs, in_off, salts, salt_off, in_pts.data());
+        if (side_rc != DR_OK) { side_err = dr_last_error(); return; }
+        {
+            std::unique_lock<std::mutex> lk(gate_m);
+            gate_cv.wait(lk, [&] { return gate >= 0; });
+            if (gate == 0) return;
+        }
+        side_rc = pedersen_verify_core(actx, su, B, proofs, 784, te_xy, in_pts, ads, ad_off, ped_ok);
+        if (side_rc != DR_OK) side_err = dr_last_error();
+    });
+    struct Joiner {
+        std::thread& t;
+        std::function<void()> give_up;
+        ~Joiner() { give_up(); if (t.joinable()) t.join(); }
+    } joiner{side, [&] { open_gate(0); }};
+    TRY(ctx->io_a.reserve(n_te * 32));
+    TRY(ctx->io_b.reserve(n_te * 64));
+    TRY(ctx->io_c.reserve(n_te * 4 + n_g1 * 4));
+    HIP_TRY(hipMemcpyAsync(ctx->io_a.p, te_enc.data(), n_te * 32, hipMemcpyHostToDevice, st));
+    uint32_t* d_ok = ctx->io_c.as<uint32_t>();
+    TRY(launch(ctx, "k_bsn_decode_points", [&] {
+        launch_decode_points(ctx, st, su.cv->id, false, ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), d_ok, n_te);
+    }));
+    std::vector<uint32_t> flags(n_te + n_g1);
+    HIP_TRY(hipMemcpyAsync(te_xy.data(), ctx->io_b.p, n_te * 64, hipMemcpyDeviceToHost, st));
+    // G1: bases buffer = 7B decompressed points followed by C_px, C_py, C_s and G1[0]
+    Scratch &g1_bases = ctx->vfy_bases, &g1_in = ctx->vfy_in, &g1_std = ctx->vfy_std;
+    TRY(g1_bases.reserve(n_g1 * 96));
+    TRY(g1_in.reserve(7 * B * 48));
+    TRY(g1_std.reserve(n_g1 * 96));
+    HIP_TRY(hipMemcpyAsync(g1_in.p, g1_enc.data(), 7 * B * 48, hipMemcpyHostToDevice, st));
+    TRY(launch(ctx, "k_g1_decompress", [&] {
+        g1_launch_decompress(st, g1_in.as<uint8_t>(), g1_bases.as<uint32_t>(), d_ok + n_te, 7 * B);
+    }));
+    {
+        uint8_t tail_be[4 * 96];
+        std::memcpy(tail_be, vk->fixed_commitments, 3 * 96);
+        std::memcpy(tail_be + 288, vk->g1_generator, 96);
+        for (int k = 0; k < 3; k++) if (tail_be[96 * k] & 0x40) std::memset(tail_be + 96 * k, 0, 96);       // serialised infinity
+        std::vector<uint8_t> le;
+        TRY(g1_be_to_le_limbs(tail_be, 4, le, true));
+        HIP_TRY(hipMemcpyAsync(g1_bases.as<uint32_t>() + 7 * B * 24, le.data(), 4 * 96, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));          // `le` is a stack-lifetime staging buffer
+        g1_launch_bases_to_mont(st, g1_bases.as<uint32_t>() + 7 * B * 24, 4);
+    }
+    g1_launch_bases_from_mont(st, g1_bases.as<uint32_t>(), g1_std.as<uint32_t>(), 7 * B);
+    std::vector<uint8_t> g1_le(7 * B * 96);
+    HIP_TRY(hipMemcpyAsync(g1_le.data(), g1_std.p, 7 * B * 96, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(flags.data(), d_ok, (n_te + 7 * B) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t i = 0; i < n_te + 7 * B; i++) if (!flags[i]) return DR_OK;                  // malformed / invalid point: ok = 0
+    tr_.mark("decode");
+
+    // ---- 3. Pedersen part: the helper thread may go on (te_xy is complete)
+    open_gate(1);
+
+    // ---- 4. ring proofs: transcript replay + verifier scalar pass per proof, random linear combination of all claims
+    drh::RingVerifierDomain dm;
+    dm.init(vk->log2n, vk->omega_n, vk->seed_xy);
+    drh::FsTranscript base;
+    base.sh.update(vk->fs_prefix, vk->fs_prefix_len);
+    std::vector<uint8_t> lhs_sc(n_g1 * 32), rhs_sc(2 * B * 32);
+    std::vector<uint64_t> fixed_part(B * 16);           // per proof: r1*nu0, r1*nu1, r1*nu2, r1*agg + r2*l_zw
+    std::vector<int> bad(B, 0);
+    auto be_rec = [&](size_t idx, uint8_t out[96]) {     // device LE limbs -> serialize() form
+        const uint8_t* s = g1_le.data() + 96 * idx;
+        bool inf = true;
+        for (int j = 0; j < 96; j++) if (s[j]) { inf = false; break; }
+        if (inf) { std::memset(out, 0, 96); out[0] = 0x40; return; }
+        for (int j = 0; j < 48; j++) { out[j] = s[47 - j]; out[48 + j] = s[95 - j]; }
+    };
+    drh::parallel_for(B, [&](size_t i) {
+        const uint8_t* pr = proofs + 784 * i;
+        const uint8_t* pl = pr + 192;
+        drh::FsTranscript t = base;
+        uint8_t result_seed[64], ser[4 * 96], al[7 * 32], zeta[32], nus[8 * 32];
+        const uint8_t* relation = te_xy.data() + 64 * (4 * i + 1);            // blinded public key
+        t.absorb_labeled("instance", relation, 64);
+        for (int k = 0; k < 4; k++) be_rec(7 * i + k, ser + 96 * k);
+        t.absorb_labeled("committed_cols", ser, sizeof ser);
+        t.challenges("constraints_aggregation", 7, al);
+        be_rec(7 * i + 4, ser);
+        t.absorb_labeled("quotient", ser, 96);
+        t.challenges("evaluation_point", 1, zeta);
+        t.absorb_labeled("register_evaluations", pl + 192, 224);
+        t.absorb_labeled("shifted_linearization_evaluation", pl + 464, 32);
+        t.challenges("kzg_aggregation", 8, nus);
+        drh::te_add_affine(*su.cv, vk->seed_xy, relation, result_seed);
+        drh::RingClaimScalars cl;
+        if (!drh::ring_verifier_terms(*su.cv, dm, al, nus, zeta, pl + 192, pl + 464, result_seed, cl)) { bad[i] = 1; return; }
+        // verifier randomness: two non-zero coefficients per proof
+        uint64_t r[2][4];
+        for (int k = 0; k < 2; k++) {
+            drh::Shake256 sh;
+            sh.update(seed32, 32);
+            uint8_t ctr[9] = {0};
+            for (int j = 0; j < 8; j++) ctr[j] = (uint8_t)((uint64_t)(2 * i + k) >> (8 * j));
+            sh.update(ctr, 8);
+            uint8_t raw[48];
+            sh.digest(raw, 48);
+            mp.reduce_bytes(raw, 48, true, r[k]);
+            if (mp.is_zero(r[k])) mp.set_u64(1, r[k]);
+        }
+        uint64_t v[4], w[4];
+        uint8_t* L = lhs_sc.data() + 224 * i;
+        mp.mul(r[0], cl.nus[3], v); drh::store_le32(v, L);                                                      // C_b
+        mp.mul(r[0], cl.nus[4], v); mp.mul(r[1], cl.k_ip, w); mp.add(v, w, v); drh::store_le32(v, L + 32);       // C_accip
+        mp.mul(r[0], cl.nus[5], v); mp.mul(r[1], cl.k_x, w); mp.add(v, w, v); drh::store_le32(v, L + 64);        // C_accx
+        mp.mul(r[0], cl.nus[6], v); mp.mul(r[1], cl.k_y, w); mp.add(v, w, v); drh::store_le32(v, L + 96);        // C_accy
+        mp.mul(r[0], cl.nus[7], v); drh::store_le32(v, L + 128);                                                 // C_q
+        mp.mul(r[0], cl.zeta, v); drh::store_le32(v, L + 160);                                                   // Phi_zeta
+        mp.mul(r[1], cl.zeta_omega, v); drh::store_le32(v, L + 192);                                             // Phi_zeta_omega
+        drh::store_le32(r[0], rhs_sc.data() + 64 * i);
+        drh::store_le32(r[1], rhs_sc.data() + 64 * i + 32);
+        uint64_t* fp = &fixed_part[16 * i];
+        for (int k = 0; k < 3; k++) mp.mul(r[0], cl.nus[k], fp + 4 * k);
+        mp.mul(r[0], cl.agg_zeta, v); mp.mul(r[1], cl.l_zw, w); mp.add(v, w, fp + 12);
+    });
+    for (size_t i = 0; i < B; i++) if (bad[i]) return DR_OK;
+    tr_.mark("transcripts");
+    {
+        uint64_t acc[4][4] = {{0}};
+        for (size_t i = 0; i < B; i++)
+            for (int k = 0; k < 4; k++) mp.add(acc[k], &fixed_part[16 * i + 4 * k], acc[k]);
+        mp.neg(acc[3], acc[3]);                                                   // - sum_v on G1[0]
+        for (int k = 0; k < 4; k++) drh::store_le32(acc[k], lhs_sc.data() + 224 * B + 32 * k);
+    }
+    // two MSMs over the decompressed bases (already resident): lhs over all 7B+4 points, rhs with zero scalars on
+    // everything but the 2B opening proofs (zero digits cost nothing).  Two single MSMs rather than a batch of two:
+    // the final 255-doubling window combination of a single MSM runs on the host (0.2 ms), a batch leaves it to one
+    // GPU lane per MSM (4 ms).
+    std::vector<uint8_t> rhs_full(n_g1 * 32, 0);
+    for (size_t i = 0; i < B; i++) std::memcpy(rhs_full.data() + 224 * i + 160, rhs_sc.data() + 64 * i, 64);
+    TRY(ctx->scalars.reserve(n_g1 * 32));
+    uint8_t pair_g1[2 * 96];
+    int pair_inf[2] = {0, 0};
+    // the two MSMs are independent and each is a short latency chain (sort, accumulate, reduce, fold): the rhs runs on
+    // a third stream from a helper thread while this thread does the lhs
+    if (!ctx->aux2) TRY(dr_ctx_create(ctx->device, &ctx->aux2));
+    dr_ctx* bctx = ctx->aux2;
+    bctx->prof = ctx->prof;
+    int rhs_rc = DR_OK;
+    std::string rhs_err;
+    std::thread rhs_thread([&] {
+        rhs_rc = [&]() -> int {
+            TRY(use_ctx(bctx));
+            TRY(bctx->scalars.reserve(n_g1 * 32));
+            HIP_TRY(hipMemcpyAsync(bctx->scalars.p, rhs_full.data(), n_g1 * 32, hipMemcpyHostToDevice, bctx->stream));
+            return msm_to_bytes(bctx, g1_bases.as<uint32_t>(), bctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1 + 96, pair_inf + 1);
+        }();
+        if (rhs_rc != DR_OK) rhs_err = dr_last_error();
+    });
+    struct RhsJoiner {
+        std::thread& t;
+        ~RhsJoiner() { if (t.joinable()) t.join(); }
+    } rhs_joiner{rhs_thread};
+    HIP_TRY(hipMemcpyAsync(ctx->scalars.p, lhs_sc.data(), n_g1 * 32, hipMemcpyHostToDevice, st));
+    TRY(msm_to_bytes(ctx, g1_bases.as<uint32_t>(), ctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1, pair_inf));
+    rhs_thread.join();
+    tr_.mark("g1 msms");
+    if (rhs_rc != DR_OK) return fail(rhs_rc, rhs_err.empty() ? "rhs MSM failed" : rhs_err);
+    const int inf_r = pair_inf[1];
+    // (a vanishing rhs can only come from r1 = r2 = 0 or infinity openings: the pairing equation then demands lhs = O)
+    if (!inf_r) {                                                                 // e(lhs, G2[0]) * e(-rhs, G2[1]) == 1
+        drh::Fq y;
+        if (!drh::Fq::load_be(y, pair_g1 + 144)) return fail(DR_ERR_DEVICE, "MSM result out of range");
+        y.neg().store_be(pair_g1 + 144);
+    }
+    int pok = 0;
+    TRY(dr_pairing_check(pair_g1, vk->g2, 2, &pok));
+    tr_.mark("pairing");
+    side.join();
+    tr_.mark("pedersen join");
+    if (side_rc != DR_OK) return fail(side_rc, side_err.empty() ? "Pedersen part failed" : side_err);
+    *ok = pok && ped_ok;
+    return DR_OK;
+}
+
+int dr_ringvrf_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_ring_verifier_key* vk, size_t batch, const uint8_t* proofs,
+                            const uint8_t* inputs, const uint64_t* in_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts,
+                            const uint64_t* salt_off, const uint8_t seed32[32], int* ok) {
+    try {
+        return ringvrf_verify_batch_impl(ctx, suite, vk, batch, proofs, inputs, in_off, ads, ad_off, salts, salt_off, seed32, ok);
+    } catch (const std::bad_alloc&) {
+        return fail(DR_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_DEVICE, std::string("native verifier: ") + e.what());
+    }
+}
+
+// PedersenVRF.prove for a batch (pedersen/vrf.py:86-126): 192 bytes per proof; same code as the Pedersen part of
+// dr_ringvrf_prove_batch.  out_aux (nullable): per proof O, Y_bar, R, O_k affine (4*64) and the blinding factor (32).
+int dr_pedersen_prove_batch(dr_ctx* ctx, const dr_vrf_suite* suite, size_t batch, const uint8_t* alphas, const uint64_t* alpha_off,
+                            const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
+                            const uint8_t* secret_scalars, uint8_t* out_proofs, uint8_t* out_aux) {
+    try {
+        TRY(use_ctx(ctx));
+        if (!alpha_off || !ad_off || !secret_scalars || !out_proofs) return fail(DR_ERR_INVALID, "null argument");
+        if (batch == 0) return DR_OK;
+        if (batch > 65536) return fail(DR_ERR_INVALID, "batch must be at most 65536 per call");
+        drh::VrfSuite su;
+        TRY(load_suite(suite, su));
+        for (size_t i = 0; i < batch; i++)
+            if (alpha_off[i + 1] < alpha_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
+                return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
+        PhaseTrace tr_("pedersen_prove_batch");
+        PedersenBatch ped(su, batch);
+        TRY(ped.head(ctx, alphas, alpha_off, ads, ad_off, salts, salt_off, secret_scalars, tr_));
+        TRY(ped.tail(ctx, out_proofs, 192, out_aux, DR_PEDERSEN_AUX_BYTES));
+        tr_.mark("tail");
+        return DR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(DR_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_DEVICE, std::string("native prover: ") + e.what());
+    }
+}
+
+// PedersenVRF.batch_verify (pedersen/vrf.py:171-242) over ENCODED proofs (192 bytes each): point decoding + subgroup
+// checks and hash-to-curve on the GPU, challenges on worker threads, one (5B+2)-point MSM.  *ok = 1 iff all verify.
+int dr_pedersen_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, size_t batch, const uint8_t* proofs, const uint8_t* inputs,
+                             const uint64_t* in_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
+                             int* ok) {
+    try {
+        TRY(use_ctx(ctx));
+        if (!proofs || !in_off || !ad_off || !ok) return fail(DR_ERR_INVALID, "null argument");
+        *ok = 0;
+        if (batch == 0) { *ok = 1; return DR_OK; }
+        if (batch > 65536) return fail(DR_ERR_INVALID, "batch must be at most 65536 per call");
+        drh::VrfSuite su;
+        TRY(load_suite(suite, su));
+        const size_t B = batch;
+        const drh::Mod256& mn = su.cv->n;
+        for (size_t i = 0; i < B; i++)
+            if (in_off[i + 1] < in_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
+                return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
+        std::vector<uint8_t> te_enc(B * 128), te_xy(B * 256), flags(B * 4), in_pts(B * 64);
+        for (size_t i = 0; i < B; i++) {
+            std::memcpy(te_enc.data() + 128 * i, proofs + 192 * i, 128);
+            uint64_t v[4];
+            for (int k = 0; k < 2; k++) { drh::load_le32(proofs + 192 * i + 128 + 32 * k, v); if (drh::Mod256::geq(v, mn.m)) return DR_OK; }   // dec_scalar
+        }
+        TRY(te_decode_points(ctx, su.cv->id, false, te_enc.data(), 4 * B, te_xy.data(), flags.data()));
+        for (size_t i = 0; i < 4 * B; i++) if (!flags[i]) return DR_OK;
+        TRY(encode_to_curve_msgs(ctx, su, B, inputs, in_off, salts, salt_off, in_pts.data()));
+        int ped_ok = 0;
+        TRY(pedersen_verify_core(ctx, su, B, proofs, 192, te_xy, in_pts, ads, ad_off, ped_ok));
+        *ok = ped_ok;
+        return DR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(DR_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_DEVICE, std::string("native verifier: ") + e.what());
+    }
+}
+
+// TinyVRF.prove / ThinVRF.prove for a batch (vrf/ietf/tiny.py:53-70, thin.py): I = encode_to_curve, pk = x G, O = x I;
+// transcript over the two (input, output) pairs (G, pk), (I, O); delinearised input M = G + z I; k = nonce; R = k M;
+// c = challenge(R); s = k + c x.  Tiny proof = O || c (16) || s (80 bytes), Thin proof = O || R || s (96 bytes).
+int dr_ietf_prove_batch(dr_ctx* ctx, const dr_vrf_suite* suite, int thin, size_t batch, const uint8_t* alphas, const uint64_t* alpha_off,
+                        const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
+                        const uint8_t* secret_scalars, uint8_t* out_proofs, uint8_t* out_aux) {
+    try {
+        TRY(use_ctx(ctx));
+        if (!alpha_off || !ad_off || !secret_scalars || !out_proofs) return fail(DR_ERR_INVALID, "null argument");
+        if (batch == 0) return DR_OK;
+        if (batch > 65536) return fail(DR_ERR_INVALID, "batch must be at most 65536 per call");
+        drh::VrfSuite su;
+        TRY(load_suite(suite, su));
+        const size_t B = batch, plen = thin ? 96 : 80;
+        const drh::Mod256& mn = su.cv->n;
+        const int cv = su.cv->id;
+        for (size_t i = 0; i < B; i++)
+            if (alpha_off[i + 1] < alpha_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
+                return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
+        std::vector<uint8_t> xs(B * 32), inputs(B * 64);
+        for (size_t i = 0; i < B; i++) {
+            uint64_t x[4];
+            mn.reduce_bytes(secret_scalars + 32 * i, 32, false, x);
+            drh::store_le32(x, xs.data() + 32 * i);
+        }
+        TRY(encode_to_curve_msgs(ctx, su, B, alphas, alpha_off, salts, salt_off, inputs.data()));
+        // pk_i = x_i G and O_i = x_i I_i in one launch
+        std::vector<uint8_t> pts(2 * B * 64), sc(2 * B * 32), firsts(2 * B * 64);
+        for (size_t i = 0; i < B; i++) {
+            std::memcpy(pts.data() + 64 * i, su.generator, 64);
+            std::memcpy(pts.data() + 64 * (B + i), inputs.data() + 64 * i, 64);
+            std::memcpy(sc.data() + 32 * i, xs.data() + 32 * i, 32);
+            std::memcpy(sc.data() + 32 * (B + i), xs.data() + 32 * i, 32);
+        }
+        TRY(te_scalar_mul_batch(ctx, cv, pts.data(), sc.data(), 2 * B, firsts.data()));
+        const uint8_t* pks = firsts.data();
+        const uint8_t* outs = firsts.data() + 64 * B;
+        // transcripts, delinearisation scalar z, nonces
+        std::vector<drh::Bytes> tr(B);
+        std::vector<uint8_t> gpts(B * 128), gsc(B * 64), ks(B * 32);
+        std::vector<int> bad(B, 0);
+        uint8_t enc_g[32];
+        drh::enc_te_point(su.generator, enc_g);
+        drh::parallel_for(B, [&](size_t i) {
+            drh::Bytes& t = tr[i];
+            t = su.suite_id;
+            drh::put8(t, thin ? 0x01 : 0x00);                      // THIN_VRF / TINY_VRF
+            drh::put_le64(t, 2);
+            uint8_t enc[32];
+            drh::put(t, enc_g, 32);
+            drh::enc_te_point(pks + 64 * i, enc); drh::put(t, enc, 32);
+            drh::enc_te_point(inputs.data() + 64 * i, enc); drh::put(t, enc, 32);
+            drh::enc_te_point(outs + 64 * i, enc); drh::put(t, enc, 32);
+            size_t adl = ad_off[i + 1] - ad_off[i];
+            drh::put_le64(t, adl);
+            drh::put(t, ads + ad_off[i], adl);
+            drh::Bytes d = t;
+            drh::put8(d, 0x30);                                    // DELINEARIZE
+            uint8_t raw[16];
+            drh::vrf_squeeze(su.xof, d.data(), d.size(), raw, 16);
+            uint64_t z[4], x[4], k[4], one[4] = {1, 0, 0, 0};
+            mn.reduce_bytes(raw, 16, false, z);
+            std::memcpy(gpts.data() + 128 * i, su.generator, 64);
+            std::memcpy(gpts.data() + 128 * i + 64, inputs.data() + 64 * i, 64);
+            drh::store_le32(one, gsc.data() + 64 * i);
+            drh::store_le32(z, gsc.data() + 64 * i + 32);
+            drh::load_le32(xs.data() + 32 * i, x);
+            if (!drh::vrf_nonce(su, t, x, k)) bad[i] = 1;
+            drh::store_le32(k, ks.data() + 32 * i);
+        });
+        for (size_t i = 0; i < B; i++) if (bad[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
+        std::vector<uint8_t> merged(B * 64), rs(B * 64);
+        TRY(te_msm_groups(ctx, cv, gpts.data(), gsc.data(), B, 2, merged.data()));
+        TRY(te_scalar_mul_batch(ctx, cv, merged.data(), ks.data(), B, rs.data()));
+        drh::parallel_for(B, [&](size_t i) {
+            uint8_t* out = out_proofs + plen * i;
+            uint8_t enc_r[32];
+            drh::enc_te_point(outs + 64 * i, out);
+            drh::enc_te_point(rs.data() + 64 * i, enc_r);
+            uint64_t c[4], x[4], k[4], s[4];
+            drh::vrf_challenge(su, tr[i], enc_r, 1, c);
+            drh::load_le32(xs.data() + 32 * i, x);
+            drh::load_le32(ks.data() + 32 * i, k);
+            mn.mul(c, x, s);
+            mn.add(s, k, s);
+            if (out_aux) {
+                std::memcpy(out_aux + 128 * i, outs + 64 * i, 64);
+                std::memcpy(out_aux + 128 * i + 64, rs.data() + 64 * i, 64);
+            }
+            if (thin) {
+                std::memcpy(out + 32, enc_r, 32);
+                drh::store_le32(s, out + 64);
+            } else {
+                uint8_t cb[32];
+                drh::store_le32(c, cb);
+                std::memcpy(out + 32, cb, 16);
+                drh::store_le32(s, out + 48);
+            }
+        });
+        return DR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(DR_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_DEVICE, std::string("native prover: ") + e.what());
+    }
+}
+

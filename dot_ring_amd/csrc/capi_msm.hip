@@ -1,0 +1,833 @@
+// libdotring_hip.so — C ABI, part 2 of 5: the G1 Pippenger pipeline over kernels_g1.hip.h, seam B (SRS handles, MSM entry
+// points, G1 codecs) and the pairing entry points.
+#include "capi_internal.hpp"
+#include "kernels_g1.hip.h"
+
+using namespace dri;
+
+namespace {
+// ---- window plan for the GPU Pippenger.  Scalars are reduced mod r (< 2^255) on the device and the 256 bits
+// are tiled by W = ceil(256/c) windows of width cmax or cmax-1 (see WindowTable).  Work ~ W*n mixed adds +
+// W*2^(c-1)*(2 full adds) + per-chunk scalar multiplications; a full add costs ~1.4 mixed adds; pick the c
+// minimising that, within [7,16] (W <= 37 fits the table).
+bool table_window_ok(int c) { return c >= 7 && c <= 22; }     // one bucket set per MSM: wider windows stay cheap
+int pick_window(size_t n) {
+    int best = 7;
+    double best_cost = 1e300;
+    for (int c = 7; c <= 16; c++) {
+        int W = (256 + c - 1) / c;
+        double cost = (double)W * ((double)n + 2.8 * (double)(1u << (c - 1)) + 40.0 * (double)((1u << (c - 1)) / 16 + 1));
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+
+struct MsmPlan {
+    dr::WindowTable wt;
+    int W;
+    uint32_t H, L, T;
+};
+dr::WindowTable make_window_table(int c) {
+    dr::WindowTable wt;
+    wt.W = (256 + c - 1) / c;
+    int base = 256 / wt.W, rem = 256 % wt.W;
+    wt.cmax = base + (rem ? 1 : 0);
+    int bit = 0;
+    for (int w = 0; w < wt.W; w++) {
+        int width = base + (w >= wt.W - rem ? 1 : 0);
+        wt.start[w] = (uint8_t)bit;
+        wt.width[w] = (uint8_t)width;
+        bit += width;
+    }
+    return wt;
+}
+
+MsmPlan make_plan(size_t n, int force_c) {
+    MsmPlan p;
+    int c = window_ok(force_c) ? force_c : pick_window(n);
+    p.W = (256 + c - 1) / c;
+    int base = 256 / p.W, rem = 256 % p.W;       // `rem` windows of width base+1 (placed on top), the rest base
+    p.wt.W = p.W;
+    p.wt.cmax = base + (rem ? 1 : 0);
+    int bit = 0;
+    for (int w = 0; w < p.W; w++) {
+        int width = base + (w >= p.W - rem ? 1 : 0);
+        p.wt.start[w] = (uint8_t)bit;
+        p.wt.width[w] = (uint8_t)width;
+        bit += width;
+    }
+    p.H = 1u << (p.wt.cmax - 1);
+    p.L = std::min<uint32_t>(p.H, g_chunk_len);
+    p.T = p.H / p.L;
+    return p;
+}
+}  // namespace
+
+int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch,
+               std::vector<drh::G1>& results, const MsmTable* tbl) {
+    results.assign(batch, drh::G1::inf());
+    if (n == 0 || batch == 0) return DR_OK;
+    if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "MSM size must be below 2^31");
+    const bool single = tbl != nullptr && tbl->table != nullptr;
+    // comb table + many MSMs: a plain sum of looked-up points per MSM, nothing to sort or reduce
+    if (single && tbl->comb && batch >= 32 && g_use_comb) {
+        TRY(ctx->result.reserve(batch * 192));
+        // threads per MSM: enough waves to fill 1024 SIMDs x 3 resident waves, at most 4 waves (one block)
+        unsigned waves = (unsigned)std::max<size_t>(1, std::min<size_t>(4, (3072 + batch / 2) / batch));
+        while (waves > 1 && (size_t)waves * 64 > n) waves--;
+        const unsigned threads = waves * 64;
+        const size_t lds = (size_t)tbl->wt.W * threads * 2;
+        TRY(ctx->partial.reserve(batch * threads * 192));
+        TRY(launch(ctx, "k_g1_comb_msm", [&] {
+            hipLaunchKernelGGL(dr::k_g1_comb_msm, dim3((unsigned)batch), dim3(threads), lds, ctx->stream, d_scalars, (uint32_t)n, tbl->wt, tbl->comb,
+                               tbl->comb_h, tbl->offset, ctx->partial.as<uint32_t>());
+        }));
+        TRY(launch(ctx, "k_g1_reduce_windows", [&] {
+            hipLaunchKernelGGL(dr::k_g1_reduce_windows, dim3((unsigned)batch), dim3(dr::RW_BLOCK), 0, ctx->stream, ctx->partial.as<uint32_t>(), threads,
+                               ctx->result.as<uint32_t>());
+        }));
+        return DR_OK;
+    }
+    MsmPlan pl = make_plan(n, g_force_c);
+    if (single) {
+        pl.wt = tbl->wt;
+        pl.W = tbl->wt.W;
+        pl.H = 1u << (tbl->wt.cmax - 1);
+        pl.L = std::min<uint32_t>(pl.H, g_chunk_len);
+        pl.T = pl.H / pl.L;
+        d_bases = tbl->table;
+        if ((uint64_t)pl.W * tbl->stride >= (1ull << 31)) return fail(DR_ERR_INVALID, "window table too large");
+    }
+    // table mode: split the points of each MSM into index groups when one bucket set per MSM would leave lanes idle
+    uint32_t groups = 1;
+    if (single) {
+        const size_t target_lanes = 524288;       // 8 waves per SIMD: finer slices balance better than 4 (2^20 bases: accumulate 3.98 -> 3.6 ms)
+        while (groups < 64 && batch * groups * (size_t)pl.H < target_lanes && (size_t)n / (groups * 2) >= 64) groups *= 2;
+        static const int force_groups = std::getenv("DOTRING_MSM_GROUPS") ? std::atoi(std::getenv("DOTRING_MSM_GROUPS")) : 0;
+        if (force_groups > 0 && batch == 1 && (size_t)n / (size_t)force_groups >= 64) groups = (uint32_t)force_groups;
+    }
+    const size_t windows = batch * (size_t)pl.W;                   // digit rows
+    const size_t bsets = single ? batch * groups : windows;        // bucket sets
+    // few bucket sets of moderate size (a single MSM over a window table): the reduction is a latency chain of
+    // 2L additions + a log2(H)-bit double-and-add + the fold of H/L partial sums; L = 4 makes it ~40 % shorter
+    if (single && pl.L == 16 && pl.H >= 256 && pl.H <= 4096 && bsets * (size_t)(pl.H / 16) < ((size_t)1 << 17)) {
+        pl.L = 4;
+        pl.T = pl.H / 4;
+    }
+    // the same for a small MSM over plain bases (the verifier's 2- and 11-point folds): 41 -> 16 dependent additions
+    if (!single && pl.L == 16 && pl.H >= 16 && bsets * (size_t)(pl.H / 16) < ((size_t)1 << 12)) {
+        pl.L = 4;
+        pl.T = pl.H / 4;
+    }
+    const size_t nbuckets = bsets * pl.H;
+    const size_t ndigits = windows * n;
+    if (nbuckets >= (1ull << 32) || ndigits >= (1ull << 32))
+        return fail(DR_ERR_INVALID, "MSM batch too large for one launch (split the batch)");
+    TRY(ctx->counts.reserve(nbuckets * 4));
+    TRY(ctx->offsets.reserve((nbuckets + 1) * 4));
+    const unsigned szblocks = div_up(nbuckets, dr::SZ_TILE);
+    const size_t ncells = (size_t)dr::SZ_CLASSES * szblocks;
+    TRY(ctx->tiles.reserve((size_t)(div_up(std::max(ncells, nbuckets), dr::SCAN_TILE) + 1) * 4));
+    TRY(ctx->perm.reserve(nbuckets * 4));
+    TRY(ctx->cells.reserve(ncells * 4));
+    TRY(ctx->cell_off.reserve(ncells * 4));
+    TRY(ctx->buckets.reserve(nbuckets * 192));
+    TRY(ctx->partial.reserve(bsets * pl.T * 192));
+    TRY(ctx->winsum.reserve(bsets * 192));
+    hipStream_t st = ctx->stream;
+    auto exclusive_scan = [&](const uint32_t* in, uint32_t* out, size_t count) {
+        const unsigned nt = div_up(count, dr::SCAN_TILE);
+        hipLaunchKernelGGL(dr::k_scan_tiles, dim3(nt), dim3(dr::SCAN_BLOCK), 0, st, in, out, ctx->tiles.as<uint32_t>(), count);
+        hipLaunchKernelGGL(dr::k_scan_tile_sums, dim3(1), dim3(dr::SCAN_BLOCK), 0, st, ctx->tiles.as<uint32_t>(), nt, ctx->tiles.as<uint32_t>() + nt);
+        hipLaunchKernelGGL(dr::k_scan_add, dim3(div_up(count, 256)), dim3(256), 0, st, out, ctx->tiles.as<uint32_t>(), count);
+    };
+    // Sorting the digits by bucket.  Small bucket sets fed by a bounded number of digits (the batched prover) are
+    // sorted by one workgroup each, entirely in LDS; a few huge sets (one 2^20-point MSM) use global atomics.
+    const size_t per_set_scalars = single ? (n + groups - 1) / groups : n;
+    const size_t per_set_digits = single ? per_set_scalars * (size_t)pl.W : n;
+    const bool lds_sort = pl.H <= dr::SORT_MAX_H && bsets >= 64 && per_set_digits <= (1u << 20) && bsets * per_set_digits < (1ull << 32);
+    if (lds_sort) {
+        dr::SortSetParams sp;
+        sp.n = (uint32_t)n; sp.batch = (uint32_t)batch; sp.H = pl.H; sp.groups = groups; sp.single = single ? 1 : 0;
+        sp.tbl_stride = single ? tbl->stride : 0; sp.tbl_offset = single ? tbl->offset : 0;
+        sp.capacity = (uint32_t)per_set_digits;
+        sp.short_from = single ? tbl->short_from : 0xffffffffu;
+        sp.n_short = single ? std::min<uint32_t>(tbl->n_short, (uint32_t)n) : 0;
+        TRY(ctx->sorted.reserve(bsets * per_set_digits * 4));
+        TRY(launch(ctx, "k_g1_sort_sets", [&] {
+            hipLaunchKernelGGL(dr::k_g1_sort_sets, dim3((unsigned)bsets), dim3(dr::SORT_BLOCK), 0, st, d_scalars, pl.wt, sp,
+                               ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
+        }));
+    } else {
+        TRY(ctx->digits.reserve(ndigits * 4));
+        TRY(ctx->cursor.reserve(nbuckets * 4));
+        TRY(ctx->sorted.reserve(ndigits * 4));
+        HIP_TRY(hipMemsetAsync(ctx->counts.p, 0, nbuckets * 4, st));
+        HIP_TRY(hipMemsetAsync(ctx->cursor.p, 0, nbuckets * 4, st));
+        TRY(launch(ctx, "k_g1_digits", [&] {
+            hipLaunchKernelGGL(dr::k_g1_digits, dim3(div_up(n * batch, 256)), dim3(256), 0, st, d_scalars, (uint32_t)n,
+                               (uint32_t)batch, pl.wt, single ? 1 : 0, groups, ctx->digits.as<int32_t>(), ctx->counts.as<uint32_t>());
+        }));
+        TRY(launch(ctx, "k_scan", [&] { exclusive_scan(ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), nbuckets); }));
+        TRY(launch(ctx, "k_g1_scatter", [&] {
+            hipLaunchKernelGGL(dr::k_g1_scatter, dim3(div_up(ndigits, 256)), dim3(256), 0, st, ctx->digits.as<int32_t>(),
+                               (uint32_t)n, windows, pl.H, single ? pl.W : 0, single ? tbl->stride : 0u, single ? tbl->offset : 0u, groups,
+                               ctx->offsets.as<uint32_t>(), ctx->cursor.as<uint32_t>(),
+                               ctx->sorted.as<uint32_t>());
+        }));
+    }
+    // size-ordered bucket permutation for the accumulate kernel
+    TRY(launch(ctx, "k_size_sort", [&] {
+        hipLaunchKernelGGL(dr::k_size_hist, dim3(szblocks), dim3(dr::SZ_BLOCK), 0, st, ctx->counts.as<uint32_t>(), nbuckets, szblocks,
+                           ctx->cells.as<uint32_t>());
+        exclusive_scan(ctx->cells.as<uint32_t>(), ctx->cell_off.as<uint32_t>(), ncells);
+        hipLaunchKernelGGL(dr::k_size_place, dim3(szblocks), dim3(dr::SZ_BLOCK), 0, st, ctx->counts.as<uint32_t>(), nbuckets, szblocks,
+                           ctx->cell_off.as<uint32_t>(), ctx->perm.as<uint32_t>());
+    }));
+    TRY(launch(ctx, "k_g1_accumulate", [&] {
+        hipLaunchKernelGGL(dr::k_g1_accumulate, dim3(div_up(nbuckets, 256)), dim3(256), 0, st, d_bases,
+                           ctx->sorted.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(),
+                           ctx->buckets.as<uint32_t>(), nbuckets);
+    }));
+    // many bucket sets (batched prover): level-wise reduction, 2 additions per entry and no scalar multiplications;
+    // few sets (single MSMs): chunk sums + double-and-add, whose latency is one short chain
+    const bool leveled = g_reduce_levels && pl.L == 16 && pl.H >= 256 && bsets * (size_t)(pl.H / 16) >= g_level_threshold;
+    if (leveled) {
+        // level outputs live in ctx->partial: [S | C] per level, sizes sets * H/16, sets * H/256, ...
+        size_t total = 0;
+        for (uint32_t n = pl.H; n > 16; n /= 16) total += 2 * bsets * (n / 16);
+        TRY(ctx->partial.reserve(total * 192));
+        uint32_t* base = ctx->partial.as<uint32_t>();
+        const uint32_t* in_s = ctx->buckets.as<uint32_t>();
+        const uint32_t* in_c = nullptr;
+        uint32_t n = pl.H;
+        int level = 0;
+        size_t off = 0;
+        while (n > 16) {
+            level++;
+            const size_t cnt = bsets * (n / 16);
+            uint32_t* out_s = base + off * 48;
+            uint32_t* out_c = base + (off + cnt) * 48;
+            TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
+                if (in_c)
+                    hipLaunchKernelGGL(dr::k_g1_reduce_level<true>, dim3(div_up(cnt, 128)), dim3(128), 0, st, in_s, in_c, bsets, n, 16u, level, out_s, out_c);
+                else
+                    hipLaunchKernelGGL(dr::k_g1_reduce_level<false>, dim3(div_up(cnt, 128)), dim3(128), 0, st, in_s, in_c, bsets, n, 16u, level, out_s, out_c);
+            }));
+            in_s = out_s; in_c = out_c;
+            off += 2 * cnt;
+            n /= 16;
+        }
+        TRY(launch(ctx, "k_g1_reduce_windows", [&] {
+            hipLaunchKernelGGL(dr::k_g1_reduce_final, dim3(div_up(bsets, 64)), dim3(64), 0, st, in_s, in_c, bsets, n, level, ctx->winsum.as<uint32_t>());
+        }));
+    } else {
+        TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
+            hipLaunchKernelGGL(dr::k_g1_reduce_chunks, dim3(div_up(bsets * pl.T, 128)), dim3(128), 0, st,
+                               ctx->buckets.as<uint32_t>(), bsets, pl.H, pl.L, ctx->partial.as<uint32_t>());
+        }));
+        TRY(launch(ctx, "k_g1_reduce_windows", [&] {
+            hipLaunchKernelGGL(dr::k_g1_reduce_windows, dim3((unsigned)bsets), dim3(dr::RW_BLOCK), 0, st,
+                               ctx->partial.as<uint32_t>(), pl.T, ctx->winsum.as<uint32_t>());
+        }));
+    }
+
+    static_assert(sizeof(drh::G1) == 192, "XYZZ layout");
+    if (single) {
+        // the bucket-set sum IS the MSM value: no window combination
+        if (groups > 1 || batch == 1) {
+            // few MSMs: fetch the per-group sums and add them on the host (<= 64 additions per MSM)
+            std::vector<drh::G1> parts(bsets);
+            HIP_TRY(hipMemcpyAsync(parts.data(), ctx->winsum.p, bsets * 192, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            g1_dev_to_host(parts.data(), parts.size());
+            for (size_t b = 0; b < batch; b++) {
+                drh::G1 acc = drh::G1::inf();
+                for (uint32_t g = 0; g < groups; g++) acc = drh::g1_add(acc, parts[b * groups + g]);
+                results[b] = acc;
+            }
+            if (batch > 1) {      // keep the batched contract: results in ctx->result for the device-side affine pass
+                TRY(ctx->result.reserve(batch * 192));
+                std::vector<drh::G1> up(results);
+                g1_host_to_dev(up.data(), up.size());
+                HIP_TRY(hipMemcpyAsync(ctx->result.p, up.data(), batch * 192, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipStreamSynchronize(st));
+            }
+        } else {
+            TRY(ctx->result.reserve(batch * 192));
+            HIP_TRY(hipMemcpyAsync(ctx->result.p, ctx->winsum.p, batch * 192, hipMemcpyDeviceToDevice, st));
+        }
+    } else if (batch == 1) {
+        // window combination on the host: a 255-doubling serial chain is ~50x faster on one CPU core
+        std::vector<drh::G1> ws(pl.W);
+        HIP_TRY(hipMemcpyAsync(ws.data(), ctx->winsum.p, (size_t)pl.W * 192, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        g1_dev_to_host(ws.data(), ws.size());
+        drh::G1 acc = ws[pl.W - 1];
+        for (int w = pl.W - 2; w >= 0; w--) {
+            for (int j = 0; j < pl.wt.width[w]; j++) acc = drh::g1_dbl(acc);
+            acc = drh::g1_add(acc, ws[w]);
+        }
+        results[0] = acc;
+    } else {
+        TRY(ctx->result.reserve(batch * 192));
+        TRY(launch(ctx, "k_g1_horner", [&] {
+            hipLaunchKernelGGL(dr::k_g1_horner, dim3(div_up(batch, 64)), dim3(64), 0, st, ctx->winsum.as<uint32_t>(),
+                               (uint32_t)batch, pl.wt, ctx->result.as<uint32_t>());
+        }));
+        // results stay in ctx->result; msm_batch_results_to_bytes() finishes them on the device
+    }
+    if (ctx->prof) TRY(prof_collect(ctx));
+    return DR_OK;
+}
+
+MsmTable srs_table(const dr_srs* srs, size_t offset) {
+    MsmTable t;
+    if (srs->d_table) {
+        t.table = srs->d_table;
+        t.wt = srs->table_wt;
+        t.stride = (uint32_t)srs->count;
+        t.offset = (uint32_t)offset;
+        t.comb = srs->d_comb;
+        t.comb_h = srs->comb_h;
+    }
+    return t;
+}
+
+// MSM(s) with results written as BE affine records
+int msm_to_bytes(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch, uint8_t* out_be_xy, int* is_inf,
+                 const MsmTable* tbl) {
+    std::vector<drh::G1> res;
+    TRY(msm_device(ctx, d_bases, d_scalars, n, batch, res, tbl));
+    if (batch == 1 || n == 0) {
+        for (size_t b = 0; b < batch; b++) g1_result_to_bytes(res[b], out_be_xy + 96 * b, is_inf ? is_inf + b : nullptr);
+        return DR_OK;
+    }
+    return msm_batch_results_to_bytes(ctx, batch, out_be_xy, is_inf);
+}
+
+// batch > 1: results were left in ctx->result (XYZZ).  The affine conversion is one 381-bit field inversion per
+// result: on the GPU a branch-free binary-Euclid chain (≈ 0.5 ms of pure latency per call, whatever the batch; 0.85 ms with
+// the Fermat power it replaced).  Measured alternative for whole batches (DOTRING_AFFINE_ON_HOST=1): download XYZZ and invert
+// on the worker threads — less GPU time but more wall time per 1024 proofs, so the kernel stays the default there.
+int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, int* is_inf) {
+    static const bool on_host = std::getenv("DOTRING_AFFINE_ON_HOST") && std::atoi(std::getenv("DOTRING_AFFINE_ON_HOST")) != 0;
+    // a handful of results (a single proof's 4 witness commitments, 2 openings): the kernel's one inversion chain is 0.6 ms of
+    // latency whatever the count, the host inverts in ~15 us each
+    if (on_host || batch <= 16) {
+        static_assert(sizeof(drh::G1) == 192, "XYZZ layout");
+        std::vector<drh::G1> res(batch);
+        HIP_TRY(hipMemcpyAsync(res.data(), ctx->result.p, batch * 192, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->prof) TRY(prof_collect(ctx));
+        g1_dev_to_host(res.data(), res.size());
+        drh::parallel_for(batch, [&](size_t b) { g1_result_to_bytes(res[b], out_be_xy + 96 * b, is_inf ? is_inf + b : nullptr); });
+        return DR_OK;
+    }
+    TRY(ctx->io_c.reserve(batch * 96));
+    TRY(launch(ctx, "k_g1_results_affine", [&] {
+        hipLaunchKernelGGL(dr::k_g1_results_affine, dim3(div_up(batch, 64)), dim3(64), 0, ctx->stream, ctx->result.as<uint32_t>(),
+                           (uint32_t)batch, ctx->io_c.as<uint32_t>());
+    }));
+    std::vector<uint8_t> le(batch * 96);
+    HIP_TRY(hipMemcpyAsync(le.data(), ctx->io_c.p, batch * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) TRY(prof_collect(ctx));
+    for (size_t b = 0; b < batch; b++) {
+        bool allz = true;
+        for (int j = 0; j < 96; j++) if (le[96 * b + j]) { allz = false; break; }
+        if (is_inf) is_inf[b] = allz ? 1 : 0;
+        for (int j = 0; j < 48; j++) {
+            out_be_xy[96 * b + j] = le[96 * b + 47 - j];
+            out_be_xy[96 * b + 48 + j] = le[96 * b + 95 - j];
+        }
+    }
+    return DR_OK;
+}
+
+void g1_result_to_bytes(const drh::G1& r, uint8_t* out96, int* is_inf) {
+    drh::Fq ax, ay;
+    if (!drh::g1_to_affine(r, ax, ay)) {
+        std::memset(out96, 0, 96);
+        if (is_inf) *is_inf = 1;
+        return;
+    }
+    ax.store_be(out96);
+    ay.store_be(out96 + 48);
+    if (is_inf) *is_inf = 0;
+}
+
+// BE x||y records -> LE standard-form limbs (device converts to Montgomery). Validates range; infinity -> zeros.
+int g1_be_to_le_limbs(const uint8_t* be, size_t m, std::vector<uint8_t>& le, bool check_curve) {
+    le.resize(m * 96);
+    for (size_t i = 0; i < m; i++) {
+        const uint8_t* rec = be + 96 * i;
+        uint8_t* dst = le.data() + 96 * i;
+        bool inf = (rec[0] & 0x40) != 0;
+        if (!inf) {
+            bool allz = true;
+            for (int j = 0; j < 96; j++) if (rec[j]) { allz = false; break; }
+            inf = allz;
+        }
+        if (inf) { std::memset(dst, 0, 96); continue; }
+        if (rec[0] & 0xe0) return fail(DR_ERR_INVALID, "invalid BLS12-381 G1 encoding");
+        for (int j = 0; j < 48; j++) { dst[j] = rec[47 - j]; dst[48 + j] = rec[95 - j]; }
+        drh::Fq x, y;
+        if (!drh::Fq::load_le(x, dst) || !drh::Fq::load_le(y, dst + 48))
+            return fail(DR_ERR_INVALID, "invalid BLS12-381 G1 encoding");
+        if (check_curve && !drh::g1_on_curve(x, y)) return fail(DR_ERR_INVALID, "invalid BLS12-381 G1 encoding");
+    }
+    return DR_OK;
+}
+
+
+void g1_launch_decompress(hipStream_t st, const uint8_t* d_enc, uint32_t* d_bases, uint32_t* d_ok, size_t n) {
+    hipLaunchKernelGGL(dr::k_g1_decompress, dim3(div_up(n, 64)), dim3(64), 0, st, d_enc, d_bases, d_ok, (uint32_t)n);
+}
+void g1_launch_bases_to_mont(hipStream_t st, uint32_t* d_bases, size_t n) {
+    hipLaunchKernelGGL(dr::k_g1_bases_to_mont, dim3(div_up(n, 256)), dim3(256), 0, st, d_bases, (uint32_t)n);
+}
+void g1_launch_bases_from_mont(hipStream_t st, const uint32_t* d_bases, uint32_t* d_out, size_t n) {
+    hipLaunchKernelGGL(dr::k_g1_bases_from_mont, dim3(div_up(n, 256)), dim3(256), 0, st, d_bases, d_out, (uint32_t)n);
+}
+
+// ------------------------------------------------------------------------------- seam B
+int dr_srs_load(dr_ctx* ctx, const uint8_t* g1_be_xy, size_t m, dr_srs** out) {
+    TRY(use_ctx(ctx));
+    if (!out) return fail(DR_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    if (!g1_be_xy || m == 0) return fail(DR_ERR_INVALID, "empty SRS");
+    if (m >= (1ull << 31)) return fail(DR_ERR_INVALID, "SRS too large");
+    std::vector<uint8_t> le;
+    TRY(g1_be_to_le_limbs(g1_be_xy, m, le, /*check_curve=*/m <= 65536));
+    dr_srs* s = new (std::nothrow) dr_srs();
+    if (!s) return fail(DR_ERR_NOMEM, "out of host memory");
+    s->device = ctx->device;
+    s->count = m;
+    hipError_t e = hipMalloc((void**)&s->d_bases, m * 96);
+    if (e != hipSuccess) {
+        delete s;
+        return fail(DR_ERR_NOMEM, "hipMalloc for the SRS failed");
+    }
+    e = hipMemcpyAsync(s->d_bases, le.data(), m * 96, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dr::k_g1_bases_to_mont, dim3(div_up(m, 256)), dim3(256), 0, ctx->stream, s->d_bases, (uint32_t)m);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e != hipSuccess) {
+        (void)hipFree(s->d_bases);
+        delete s;
+        return fail(DR_ERR_DEVICE, std::string("SRS upload: ") + hipGetErrorString(e));
+    }
+    *out = s;
+    return DR_OK;
+}
+
+int dr_srs_synthetic(dr_ctx* ctx, const uint8_t seed_be_xy[96], uint32_t first, size_t count, dr_srs** out) {
+    TRY(use_ctx(ctx));
+    if (!out || !seed_be_xy) return fail(DR_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (count == 0 || count >= (1ull << 31) || (uint64_t)first + count >= (1ull << 32) || first == 0)
+        return fail(DR_ERR_INVALID, "bad synthetic SRS range");
+    std::vector<uint8_t> le;
+    TRY(g1_be_to_le_limbs(seed_be_xy, 1, le, true));
+    dr_srs* s = new (std::nothrow) dr_srs();
+    if (!s) return fail(DR_ERR_NOMEM, "out of host memory");
+    s->device = ctx->device;
+    s->count = count;
+    uint32_t* d_seed = nullptr;
+    hipError_t e = hipMalloc((void**)&s->d_bases, count * 96);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_seed, 96);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_seed, le.data(), 96, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dr::k_g1_bases_to_mont, dim3(1), dim3(64), 0, ctx->stream, d_seed, 1u);
+        hipLaunchKernelGGL(dr::k_g1_synth_bases, dim3(div_up(count, 128)), dim3(128), 0, ctx->stream, s->d_bases, (uint32_t)count, first, d_seed);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (d_seed) (void)hipFree(d_seed);
+    if (e != hipSuccess) {
+        if (s->d_bases) (void)hipFree(s->d_bases);
+        delete s;
+        return fail(e == hipErrorOutOfMemory ? DR_ERR_NOMEM : DR_ERR_DEVICE, std::string("synthetic SRS: ") + hipGetErrorString(e));
+    }
+    *out = s;
+    return DR_OK;
+}
+
+int dr_srs_powers(dr_ctx* ctx, const uint8_t base_be_xy[96], const uint8_t tau_le[32], size_t count, dr_srs** out) {
+    TRY(use_ctx(ctx));
+    if (!out || !base_be_xy || !tau_le) return fail(DR_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (count == 0 || count >= (1ull << 28)) return fail(DR_ERR_INVALID, "bad SRS size");
+    drh::Fr tau;
+    if (!drh::Fr::load_le(tau, tau_le)) return fail(DR_ERR_INVALID, "tau is not a canonical scalar");
+    std::vector<uint8_t> le;
+    TRY(g1_be_to_le_limbs(base_be_xy, 1, le, true));
+    std::vector<uint8_t> pw(count * 32);
+    drh::Fr t = drh::Fr::one();
+    for (size_t i = 0; i < count; i++) {
+        t.store_le(pw.data() + 32 * i);
+        t = t * tau;
+    }
+    dr_srs* s = new (std::nothrow) dr_srs();
+    if (!s) return fail(DR_ERR_NOMEM, "out of host memory");
+    s->device = ctx->device;
+    s->count = count;
+    uint32_t *d_seed = nullptr, *d_pw = nullptr;
+    hipError_t e = hipMalloc((void**)&s->d_bases, count * 96);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_seed, 96);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_pw, count * 32);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_seed, le.data(), 96, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pw, pw.data(), count * 32, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dr::k_g1_bases_to_mont, dim3(1), dim3(64), 0, ctx->stream, d_seed, 1u);
+        hipLaunchKernelGGL(dr::k_g1_scalar_bases, dim3(div_up(count, 64)), dim3(64), 0, ctx->stream, s->d_bases, (uint32_t)count, d_pw, d_seed);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (d_seed) (void)hipFree(d_seed);
+    if (d_pw) (void)hipFree(d_pw);
+    if (e != hipSuccess) {
+        if (s->d_bases) (void)hipFree(s->d_bases);
+        delete s;
+        return fail(e == hipErrorOutOfMemory ? DR_ERR_NOMEM : DR_ERR_DEVICE, std::string("SRS powers: ") + hipGetErrorString(e));
+    }
+    *out = s;
+    return DR_OK;
+}
+
+int dr_g2_mul(const uint8_t g2_be[192], const uint8_t scalar_le[32], uint8_t out_be[192]) {
+    if (!g2_be || !scalar_le || !out_be) return fail(DR_ERR_INVALID, "null buffer");
+    drh::G2Affine Q;
+    Q.inf = false;
+    if (!drh::Fq::load_be(Q.x.c1, g2_be) || !drh::Fq::load_be(Q.x.c0, g2_be + 48) || !drh::Fq::load_be(Q.y.c1, g2_be + 96) ||
+        !drh::Fq::load_be(Q.y.c0, g2_be + 144) || !drh::g2_on_curve(Q))
+        return fail(DR_ERR_INVALID, "invalid BLS12-381 G2 encoding");
+    drh::G2Affine R = drh::g2_mul(Q, scalar_le);
+    std::memset(out_be, 0, 192);
+    if (R.inf) { out_be[0] = 0x40; return DR_OK; }
+    R.x.c1.store_be(out_be);
+    R.x.c0.store_be(out_be + 48);
+    R.y.c1.store_be(out_be + 96);
+    R.y.c0.store_be(out_be + 144);
+    return DR_OK;
+}
+
+int dr_srs_download(dr_ctx* ctx, const dr_srs* srs, size_t offset, size_t count, uint8_t* out_be_xy) {
+    TRY(use_ctx(ctx));
+    if (!srs || !out_be_xy) return fail(DR_ERR_INVALID, "null argument");
+    if (offset > srs->count || count > srs->count - offset) return fail(DR_ERR_INVALID, "range exceeds SRS size");
+    if (count == 0) return DR_OK;
+    TRY(ctx->io_a.reserve(count * 96));
+    hipLaunchKernelGGL(dr::k_g1_bases_from_mont, dim3(div_up(count, 256)), dim3(256), 0, ctx->stream,
+                       srs->d_bases + offset * 24, ctx->io_a.as<uint32_t>(), (uint32_t)count);
+    std::vector<uint8_t> le(count * 96);
+    HIP_TRY(hipMemcpyAsync(le.data(), ctx->io_a.p, count * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < count; i++)
+        for (int j = 0; j < 48; j++) {
+            out_be_xy[96 * i + j] = le[96 * i + 47 - j];
+            out_be_xy[96 * i + 48 + j] = le[96 * i + 95 - j];
+        }
+    return DR_OK;
+}
+
+int dr_srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits) {
+    TRY(use_ctx(ctx));
+    if (!srs) return fail(DR_ERR_INVALID, "null argument");
+    if (srs->device != ctx->device) return fail(DR_ERR_INVALID, "SRS lives on another device");
+    if (srs->d_comb) { (void)hipFree(srs->d_comb); srs->d_comb = nullptr; srs->comb_h = 0; }     // derived from the window table
+    if (window_bits == 0) {
+        if (srs->d_table) (void)hipFree(srs->d_table);
+        srs->d_table = nullptr;
+        return DR_OK;
+    }
+    if (!table_window_ok(window_bits)) return fail(DR_ERR_INVALID, "window_bits must be in 7..22 (0 drops the table)");
+    dr::WindowTable wt = make_window_table(window_bits);
+    if ((uint64_t)wt.W * srs->count >= (1ull << 31)) return fail(DR_ERR_INVALID, "window table too large");
+    if (srs->d_table) (void)hipFree(srs->d_table);
+    srs->d_table = nullptr;
+    HIP_TRY(hipMalloc((void**)&srs->d_table, (size_t)wt.W * srs->count * 96));
+    hipLaunchKernelGGL(dr::k_g1_window_table, dim3(div_up(srs->count, 128)), dim3(128), 0, ctx->stream, srs->d_bases, (uint32_t)srs->count, wt,
+                       srs->d_table);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(srs->d_table);
+        srs->d_table = nullptr;
+        return fail(DR_ERR_DEVICE, std::string("window table: ") + hipGetErrorString(e));
+    }
+    srs->table_wt = wt;
+    return DR_OK;
+}
+
+int dr_srs_precompute_comb(dr_ctx* ctx, dr_srs* srs) {
+    TRY(use_ctx(ctx));
+    if (!srs) return fail(DR_ERR_INVALID, "null argument");
+    if (srs->device != ctx->device) return fail(DR_ERR_INVALID, "SRS lives on another device");
+    if (!srs->d_table) return fail(DR_ERR_INVALID, "dr_srs_precompute must come first");
+    if (srs->d_comb) return DR_OK;
+    const dr::WindowTable& wt = srs->table_wt;
+    if (wt.cmax > 14) return fail(DR_ERR_INVALID, "comb tables need window_bits <= 14");
+    const uint32_t Hc = 1u << (wt.cmax - 1);
+    const size_t rows = (size_t)srs->count * wt.W;
+    const size_t bytes = rows * Hc * (size_t)dr::COMB_STRIDE * 4;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (bytes + ((size_t)8 << 30) > free_b) return fail(DR_ERR_NOMEM, "comb table of " + std::to_string(bytes >> 20) + " MiB does not fit");
+    uint32_t* comb = nullptr;
+    if (hipMalloc((void**)&comb, bytes) != hipSuccess) return fail(DR_ERR_NOMEM, "comb table allocation failed");
+    // rows per launch bounded by 4 GiB of staging (XYZZ + prefix product per entry)
+    const size_t per_row = (size_t)Hc * (192 + 48);
+    const size_t chunk = std::max<size_t>(128, std::min<size_t>(rows, ((size_t)4 << 30) / per_row) / 128 * 128);
+    uint32_t *tx = nullptr, *tp = nullptr;
+    hipError_t e = hipMalloc((void**)&tx, chunk * Hc * 192);
+    if (e == hipSuccess) e = hipMalloc((void**)&tp, chunk * Hc * 48);
+    for (size_t lo = 0; e == hipSuccess && lo < rows; lo += chunk) {
+        const uint32_t cnt = (uint32_t)std::min(chunk, rows - lo);
+        hipLaunchKernelGGL(dr::k_g1_comb_build, dim3(div_up(cnt, 128)), dim3(128), 0, ctx->stream, srs->d_table, (uint32_t)srs->count, wt, Hc, lo, cnt,
+                           comb, tx, tp);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (tx) (void)hipFree(tx);
+    if (tp) (void)hipFree(tp);
+    if (e != hipSuccess) {
+        (void)hipFree(comb);
+        return fail(e == hipErrorOutOfMemory ? DR_ERR_NOMEM : DR_ERR_DEVICE, std::string("comb table: ") + hipGetErrorString(e));
+    }
+    srs->d_comb = comb;
+    srs->comb_h = Hc;
+    return DR_OK;
+}
+
+void dr_srs_destroy(dr_srs* srs) {
+    if (!srs) return;
+    (void)hipSetDevice(srs->device);
+    if (srs->d_comb) (void)hipFree(srs->d_comb);
+    for (auto& it : srs->lagrange_prefix) dr_srs_destroy(it.second);
+    srs->lagrange_prefix.clear();
+    if (srs->d_table) (void)hipFree(srs->d_table);
+    if (srs->d_bases) (void)hipFree(srs->d_bases);
+    delete srs;
+}
+
+size_t dr_srs_size(const dr_srs* srs) { return srs ? srs->count : 0; }
+
+int dr_g1_msm_batch_dev(dr_ctx* ctx, const dr_srs* srs, const void* d_scalars, size_t n, size_t batch, uint8_t* out_be_xy, int* is_inf) {
+    TRY(use_ctx(ctx));
+    if (!srs || !out_be_xy) return fail(DR_ERR_INVALID, "null argument");
+    if (srs->device != ctx->device) return fail(DR_ERR_INVALID, "SRS lives on another device");
+    if (n > srs->count) return fail(DR_ERR_INVALID, "polynomial degree exceeds SRS size");
+    MsmTable t = srs_table(srs, 0);
+    return msm_to_bytes(ctx, srs->d_bases, (const uint32_t*)d_scalars, n, batch, out_be_xy, is_inf, &t);
+}
+
+int dr_g1_msm_batch(dr_ctx* ctx, const dr_srs* srs, const uint8_t* scalars, size_t n, size_t batch, uint8_t* out_be_xy, int* is_inf) {
+    TRY(use_ctx(ctx));
+    if (n && batch && !scalars) return fail(DR_ERR_INVALID, "null buffer");
+    TRY(ctx->scalars.reserve(n * batch * 32));
+    if (n && batch) HIP_TRY(hipMemcpyAsync(ctx->scalars.p, scalars, n * batch * 32, hipMemcpyHostToDevice, ctx->stream));
+    return dr_g1_msm_batch_dev(ctx, srs, ctx->scalars.p, n, batch, out_be_xy, is_inf);
+}
+
+int dr_g1_msm_dev(dr_ctx* ctx, const dr_srs* srs, size_t offset, const void* d_scalars, size_t n, uint8_t out_be_xy[96], int* is_inf) {
+    TRY(use_ctx(ctx));
+    if (!srs || !out_be_xy) return fail(DR_ERR_INVALID, "null argument");
+    if (srs->device != ctx->device) return fail(DR_ERR_INVALID, "SRS lives on another device");
+    if (offset > srs->count || n > srs->count - offset) return fail(DR_ERR_INVALID, "polynomial degree exceeds SRS size");
+    std::vector<drh::G1> res;
+    MsmTable t = srs_table(srs, offset);
+    TRY(msm_device(ctx, srs->d_bases + offset * 24, (const uint32_t*)d_scalars, n, 1, res, &t));
+    g1_result_to_bytes(res[0], out_be_xy, is_inf);
+    return DR_OK;
+}
+
+int dr_g1_msm(dr_ctx* ctx, const dr_srs* srs, size_t offset, const uint8_t* scalars, size_t n, uint8_t out_be_xy[96], int* is_inf) {
+    TRY(use_ctx(ctx));
+    if (n && !scalars) return fail(DR_ERR_INVALID, "null buffer");
+    TRY(ctx->scalars.reserve(n * 32));
+    if (n) HIP_TRY(hipMemcpyAsync(ctx->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    return dr_g1_msm_dev(ctx, srs, offset, ctx->scalars.p, n, out_be_xy, is_inf);
+}
+
+int dr_g1_msm_points(dr_ctx* ctx, const uint8_t* pts_be_xy, const uint8_t* scalars, size_t n, uint8_t out_be_xy[96], int* is_inf) {
+    TRY(use_ctx(ctx));
+    if (!out_be_xy) return fail(DR_ERR_INVALID, "null argument");
+    if (n == 0) {
+        std::memset(out_be_xy, 0, 96);
+        if (is_inf) *is_inf = 1;
+        return DR_OK;
+    }
+    if (!pts_be_xy || !scalars) return fail(DR_ERR_INVALID, "null buffer");
+    std::vector<uint8_t> le;
+    TRY(g1_be_to_le_limbs(pts_be_xy, n, le, true));
+    TRY(ctx->io_a.reserve(n * 96));
+    TRY(ctx->scalars.reserve(n * 32));
+    HIP_TRY(hipMemcpyAsync(ctx->io_a.p, le.data(), n * 96, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->scalars.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(dr::k_g1_bases_to_mont, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, ctx->io_a.as<uint32_t>(), (uint32_t)n);
+    std::vector<drh::G1> res;
+    TRY(msm_device(ctx, ctx->io_a.as<uint32_t>(), ctx->scalars.as<uint32_t>(), n, 1, res));
+    g1_result_to_bytes(res[0], out_be_xy, is_inf);
+    return DR_OK;
+}
+
+int dr_g1_sum(const uint8_t* pts_be_xy, size_t n, uint8_t out_be_xy[96], int* is_inf) {
+    if (!out_be_xy || (n && !pts_be_xy)) return fail(DR_ERR_INVALID, "null buffer");
+    std::vector<uint8_t> le;
+    TRY(g1_be_to_le_limbs(pts_be_xy, n, le, true));
+    drh::G1 acc = drh::G1::inf();
+    for (size_t i = 0; i < n; i++) {
+        drh::G1 p;
+        bool allz = true;
+        for (int j = 0; j < 96; j++) if (le[96 * i + j]) { allz = false; break; }
+        if (allz) continue;
+        drh::Fq::load_le(p.x, le.data() + 96 * i);
+        drh::Fq::load_le(p.y, le.data() + 96 * i + 48);
+        p.zz = drh::Fq::one();
+        p.zzz = drh::Fq::one();
+        acc = drh::g1_add(acc, p);
+    }
+    g1_result_to_bytes(acc, out_be_xy, is_inf);
+    return DR_OK;
+}
+
+namespace {
+int miller_product(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, drh::Fq12& f) {
+    std::vector<uint8_t> le;
+    TRY(g1_be_to_le_limbs(g1_be_xy, n, le, true));
+    std::vector<drh::Fq> px, py;
+    std::vector<drh::G2Affine> qs;
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t* q = g2_be + 192 * i;
+        drh::G2Affine Q;
+        bool allz = true;
+        for (int j = 0; j < 192; j++) if (q[j]) { allz = false; break; }
+        Q.inf = allz || (q[0] & 0x40);
+        bool p_inf = true;
+        for (int j = 0; j < 96; j++) if (le[96 * i + j]) { p_inf = false; break; }
+        if (Q.inf || p_inf) continue;                       // e(O, Q) = e(P, O) = 1
+        // zcash layout: x.c1 || x.c0 || y.c1 || y.c0, 48-byte big-endian each (pcs/srs.py:78-88)
+        if (!drh::Fq::load_be(Q.x.c1, q) || !drh::Fq::load_be(Q.x.c0, q + 48) || !drh::Fq::load_be(Q.y.c1, q + 96) ||
+            !drh::Fq::load_be(Q.y.c0, q + 144) || !drh::g2_on_curve(Q))
+            return fail(DR_ERR_INVALID, "invalid BLS12-381 G2 encoding");
+        drh::Fq x, y;
+        drh::Fq::load_le(x, le.data() + 96 * i);
+        drh::Fq::load_le(y, le.data() + 96 * i + 48);
+        px.push_back(x); py.push_back(y); qs.push_back(Q);
+    }
+    f = drh::multi_miller_loop(px.data(), py.data(), qs.data(), qs.size());
+    return DR_OK;
+}
+}  // namespace
+
+int dr_pairing_check(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, int* ok) {
+    if (!ok || (n && (!g1_be_xy || !g2_be))) return fail(DR_ERR_INVALID, "null buffer");
+    drh::Fq12 f;
+    TRY(miller_product(g1_be_xy, g2_be, n, f));
+    *ok = drh::final_exponentiation_check(f) == drh::Fq12::one() ? 1 : 0;
+    return DR_OK;
+}
+
+// diagnostic: the fast final exponentiation (Frobenius maps + x-chain, exponent 3(p^12-1)/r) against the plain
+// square-and-multiply one; *consistent = 1 iff fast == reference^3 for this Miller-loop product
+int dr_pairing_selfcheck(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, int* consistent) {
+    if (!consistent || (n && (!g1_be_xy || !g2_be))) return fail(DR_ERR_INVALID, "null buffer");
+    drh::Fq12 f;
+    TRY(miller_product(g1_be_xy, g2_be, n, f));
+    drh::Fq12 ref = drh::final_exponentiation(f);
+    *consistent = drh::final_exponentiation_check(f) == ref * ref * ref ? 1 : 0;
+    return DR_OK;
+}
+
+int dr_g1_compress(const uint8_t xy[96], int is_inf, uint8_t out[48]) {
+    if (!xy || !out) return fail(DR_ERR_INVALID, "null buffer");
+    bool inf = is_inf != 0 || (xy[0] & 0x40);
+    if (!inf) {
+        bool allz = true;
+        for (int j = 0; j < 96; j++) if (xy[j]) { allz = false; break; }
+        inf = allz;
+    }
+    if (inf) {
+        std::memset(out, 0, 48);
+        out[0] = 0xc0;
+        return DR_OK;
+    }
+    drh::Fq x, y;
+    if (!drh::Fq::load_be(x, xy) || !drh::Fq::load_be(y, xy + 48)) return fail(DR_ERR_INVALID, "invalid BLS12-381 G1 encoding");
+    std::memcpy(out, xy, 48);
+    out[0] |= 0x80;
+    drh::Fq ys = y.from_mont(), nys = y.neg().from_mont();
+    if (drh::Fq::gt_std(ys, nys)) out[0] |= 0x20;
+    return DR_OK;
+}
+
+int dr_g1_decompress(const uint8_t in[48], uint8_t out_xy[96], int* is_inf) {
+    if (!in || !out_xy) return fail(DR_ERR_INVALID, "null buffer");
+    uint8_t flags = in[0] >> 5;
+    if (!(flags & 4)) return fail(DR_ERR_INVALID, "invalid BLS12-381 G1 encoding");
+    uint8_t xb[48];
+    std::memcpy(xb, in, 48);
+    xb[0] &= 0x1f;
+    if (flags & 2) {
+        bool allz = true;
+        for (int j = 0; j < 48; j++) if (xb[j]) { allz = false; break; }
+        if (!allz || (flags & 1)) return fail(DR_ERR_INVALID, "invalid BLS12-381 G1 encoding");
+        std::memset(out_xy, 0, 96);
+        if (is_inf) *is_inf = 1;
+        return DR_OK;
+    }
+    drh::Fq x;
+    if (!drh::Fq::load_be(x, xb)) return fail(DR_ERR_INVALID, "invalid BLS12-381 G1 encoding");
+    drh::Fq rhs = x.sqr() * x + drh::Fq::from_u64(4);
+    // p = 3 mod 4: y = rhs^((p+1)/4)
+    static const uint64_t E[6] = {0xee7fbfffffffeaabULL, 0x07aaffffac54ffffULL, 0xd9cc34a83dac3d89ULL,
+                                  0xd91dd2e13ce144afULL, 0x92c6e9ed90d2eb35ULL, 0x0680447a8e5ff9a6ULL};
+    drh::Fq y = rhs.pow(E, 6);
+    if (y.sqr() != rhs) return fail(DR_ERR_INVALID, "invalid BLS12-381 G1 encoding");
+    drh::Fq ny = y.neg();
+    bool y_larger = drh::Fq::gt_std(y.from_mont(), ny.from_mont());
+    if (y_larger != ((flags & 1) != 0)) y = ny;
+    std::memcpy(out_xy, xb, 48);
+    y.store_be(out_xy + 48);
+    if (is_inf) *is_inf = 0;
+    return DR_OK;
+}
+
+// KZG.decompress_g1 for n points in one launch (zcash 48-byte encodings -> BE x||y records; ok[i] = 0 for malformed
+// encodings, infinity decodes to an all-zero record with ok = 1)
+int dr_g1_decompress_batch(dr_ctx* ctx, const uint8_t* enc, size_t n, uint8_t* out_be_xy, uint8_t* ok) {
+    TRY(use_ctx(ctx));
+    if (n == 0) return DR_OK;
+    if (!enc || !out_be_xy || !ok) return fail(DR_ERR_INVALID, "null buffer");
+    if (n >= (1ull << 28)) return fail(DR_ERR_INVALID, "batch too large");
+    TRY(ctx->vfy_in.reserve(n * 48));
+    TRY(ctx->vfy_bases.reserve(n * 96));
+    TRY(ctx->vfy_std.reserve(n * 96));
+    TRY(ctx->io_c.reserve(n * 4));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemcpyAsync(ctx->vfy_in.p, enc, n * 48, hipMemcpyHostToDevice, st));
+    TRY(launch(ctx, "k_g1_decompress", [&] {
+        hipLaunchKernelGGL(dr::k_g1_decompress, dim3(div_up(n, 64)), dim3(64), 0, st, ctx->vfy_in.as<uint8_t>(), ctx->vfy_bases.as<uint32_t>(),
+                           ctx->io_c.as<uint32_t>(), (uint32_t)n);
+        hipLaunchKernelGGL(dr::k_g1_bases_from_mont, dim3(div_up(n, 256)), dim3(256), 0, st, ctx->vfy_bases.as<uint32_t>(), ctx->vfy_std.as<uint32_t>(),
+                           (uint32_t)n);
+    }));
+    std::vector<uint8_t> le(n * 96);
+    std::vector<uint32_t> flags(n);
+    HIP_TRY(hipMemcpyAsync(le.data(), ctx->vfy_std.p, n * 96, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(flags.data(), ctx->io_c.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ctx->prof) TRY(prof_collect(ctx));
+    for (size_t i = 0; i < n; i++) {
+        ok[i] = flags[i] ? 1 : 0;
+        for (int j = 0; j < 48; j++) {
+            out_be_xy[96 * i + j] = le[96 * i + 47 - j];
+            out_be_xy[96 * i + 48 + j] = le[96 * i + 95 - j];
+        }
+    }
+    return DR_OK;
+}
+
+int dr_g1_serialize_check(const uint8_t xy[96]) {
+    std::vector<uint8_t> le;
+    return g1_be_to_le_limbs(xy, 1, le, true);
+}

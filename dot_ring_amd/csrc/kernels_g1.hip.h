@@ -17,6 +17,7 @@
 // Pipeline: k_g1_digits -> scan (3 small kernels) -> k_g1_scatter -> k_g1_accumulate (dominant)
 //           -> k_g1_reduce_chunks -> k_g1_reduce_windows -> [host or k_g1_horner] combine windows.
 #pragma once
+#include "dev_types.hpp"
 #include "g1.hip.h"
 
 namespace dr {
@@ -145,15 +146,7 @@ __global__ __launch_bounds__(256) void k_g1_bases_from_mont(const uint32_t* base
     store_words12(q + 12, w);
 }
 
-// Window table: the 256 scalar bits are tiled by W windows of width cmax or cmax-1 (wider ones on top), so every
-// window has about the same number of live buckets.  A narrow top window would otherwise hold only a few bits
-// and funnel n/2^t points into each of its few buckets — one lane then walks a chain thousands of points long.
-struct WindowTable {
-    int W, cmax;
-    uint8_t start[40];   // first bit of window w   (W <= 40: widths >= 7 ... see make_plan)
-    uint8_t width[40];
-};
-constexpr int MAX_WINDOWS = 40;
+// (WindowTable — how the 256 scalar bits are tiled by windows — lives in dev_types.hpp: the host plans it.)
 
 // ---- 1. signed window digits + bucket histogram.  One lane per scalar.
 // `single` = the bases are a fixed-base window table (k_g1_window_table): all windows of an MSM share ONE bucket set.

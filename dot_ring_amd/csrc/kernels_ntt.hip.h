@@ -10,6 +10,7 @@
 // HBM (Montgomery form), cached in the context.  Elements are converted to Montgomery form on the first load
 // and back (fused with the optional scale) on the last store, so a transform moves 2 x 32 B per element per pass.
 #pragma once
+#include "dev_types.hpp"
 #include "curve.hip.h"
 #include "hostmath.hpp"
 
@@ -159,14 +160,6 @@ __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_strided(uint32_t* __restrict_
 }
 
 // ---- host driver ---------------------------------------------------------------------------------------------
-struct TwiddleCache {
-    struct Entry {
-        unsigned log2n;
-        drh::Fr omega;
-        uint32_t* d_tw;
-    };
-    std::vector<Entry> entries;
-};
 inline FrArg to_arg(const drh::Fr& v) {   // raw limbs (whatever form v is in)
     FrArg a;
     for (int i = 0; i < 4; i++) {

@@ -10,7 +10,7 @@
 // elements — what the NTT and MSM kernels consume); per-ring tables (fixed columns on the 4N domain, Lagrange
 // rows, x - w^(N-4), ring points) are kept in MONTGOMERY form.  Batch-major layouts: [proof][column][index].
 #pragma once
-#include "kernels_bsn.hip.h"
+#include "kernels_te.hip.h"
 #include "kernels_ntt.hip.h"
 
 namespace dr {

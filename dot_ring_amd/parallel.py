@@ -1,12 +1,28 @@
-"""Multi-GPU sharding helpers (one process per GPU, torch.distributed: RCCL on GPUs, gloo in CPU tests).
+"""Multi-GPU sharding of the Ring-VRF hot path: one process per GPU, RCCL over xGMI, no PyTorch.
 
-The Ring-VRF hot path shards two ways: across independent proofs (no collective at all) and across
-the bases of one large MSM.  Only the second needs an exchange: each rank reduces its shard of (base, scalar)
-pairs to ONE G1 point, the points are all-gathered (96 bytes per rank — latency-bound on xGMI, nowhere near the
-per-link bandwidth) and every rank adds them up.  Point addition is not an RCCL reduction op, so this is an
-all-gather followed by a local group-law fold, not an all-reduce.
+The path shards two ways.  Across independent proofs there is no collective at all: rank g proves and verifies
+its own slice.  Across the bases of ONE large MSM (the reference's KZG.commit, dot_ring/ring_proof/pcs/kzg.py:152-175)
+each rank reduces its shard of (base, scalar) pairs to one G1 point, the points are all-gathered (97 bytes per rank —
+latency-bound on xGMI, nowhere near the per-link bandwidth) and every rank folds them with the group law.  Point addition
+is not an RCCL reduction op, so this is an all-gather followed by a local fold, not an all-reduce.
+
+Communicators (same small interface: rank, world, all_gather(bytes) -> list[bytes], barrier(), close()):
+
+* `RcclComm`   — the product path: ncclAllGather through the C ABI (`dr_comm_*`, dot_ring_amd/csrc/capi_comm.hip).  The
+                 ncclUniqueId travels from rank 0 to the others over a TCP socket on MASTER_ADDR (the launcher —
+                 `python -m torch.distributed.run` or anything else that sets RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT —
+                 is only a process starter; torch is never imported).
+* `SocketComm` — the same exchange over plain TCP through rank 0: CPU tests, and rehearsals of N ranks on a box with fewer
+                 GPUs (RCCL refuses two ranks on one device).
+* `TorchComm`  — an existing torch.distributed group (gloo in the CPU tests).
 """
 from __future__ import annotations
+
+import ctypes
+import os
+import socket
+import struct
+import time
 
 from . import _native
 
@@ -20,27 +36,223 @@ def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def all_gather_points(point: bytes | None, group=None) -> list:
+# ------------------------------------------------------------------------------------------------ rendezvous
+def env_rank_world() -> tuple[int, int, int]:
+    """(rank, local_rank, world) as the launcher exported them (defaults: a single process)."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def _comm_endpoint() -> tuple[str, int]:
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("DOTRING_COMM_PORT", "0")) or int(os.environ.get("MASTER_PORT", "29500")) + 1
+    return addr, port
+
+
+def _recv_exact(conn: socket.socket, n: int) -> bytes:
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = conn.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the rendezvous socket")
+        buf += chunk
+    return bytes(buf)
+
+
+class SocketComm:
+    """All-gather through rank 0 over TCP (star).  Rank 0 listens on (addr, port); every other rank keeps one connection."""
+
+    def __init__(self, rank: int, world: int, addr: str | None = None, port: int | None = None, timeout: float = 120.0):
+        if world < 1 or not 0 <= rank < world:
+            raise ValueError("bad rank / world size")
+        d_addr, d_port = _comm_endpoint()
+        self.rank, self.world = rank, world
+        self._addr, self._port = addr or d_addr, port or d_port
+        self._peers: list[socket.socket | None] = []
+        self._up: socket.socket | None = None
+        self._srv: socket.socket | None = None
+        if world == 1:
+            return
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((self._addr, self._port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            self._srv = srv
+            peers: list[socket.socket | None] = [None] * world
+            for _ in range(world - 1):
+                conn, _ = srv.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.settimeout(timeout)
+                (r,) = struct.unpack("<I", _recv_exact(conn, 4))
+                if not 0 < r < world or peers[r] is not None:
+                    raise ConnectionError(f"unexpected rank {r} at the rendezvous")
+                peers[r] = conn
+            self._peers = peers
+        else:
+            deadline = time.monotonic() + timeout
+            while True:
+                try:
+                    up = socket.create_connection((self._addr, self._port), timeout=timeout)
+                    break
+                except OSError:
+                    if time.monotonic() > deadline:
+                        raise
+                    time.sleep(0.05)
+            up.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            up.sendall(struct.pack("<I", rank))
+            self._up = up
+
+    def all_gather(self, mine: bytes) -> list[bytes]:
+        if self.world == 1:
+            return [bytes(mine)]
+        n = len(mine)
+        if self.rank == 0:
+            parts = [bytes(mine)] + [_recv_exact(self._peers[r], n) for r in range(1, self.world)]
+            blob = b"".join(parts)
+            for r in range(1, self.world):
+                self._peers[r].sendall(blob)
+            return parts
+        self._up.sendall(mine)
+        blob = _recv_exact(self._up, n * self.world)
+        return [blob[i * n : (i + 1) * n] for i in range(self.world)]
+
+    def broadcast(self, data: bytes | None, nbytes: int) -> bytes:
+        """`data` of rank 0 to everyone (all ranks pass the length)."""
+        return self.all_gather(data if self.rank == 0 else bytes(nbytes))[0]
+
+    def barrier(self) -> None:
+        self.all_gather(b"\0")
+
+    def close(self) -> None:
+        for s in [self._up, self._srv] + [p for p in self._peers if p is not None]:
+            if s is not None:
+                try:
+                    s.close()
+                except OSError:
+                    pass
+        self._up = self._srv = None
+        self._peers = []
+
+
+class RcclComm:
+    """ncclAllGather over the ranks of a job, one rank = one GPU context (`dr_comm_*`).  Creation is a collective."""
+
+    def __init__(self, ctx: "_native.Context", rank: int, world: int, bootstrap: SocketComm | None = None):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        own_boot = bootstrap is None
+        boot = bootstrap or SocketComm(rank, world)
+        try:
+            uid = ctypes.create_string_buffer(_native.COMM_ID_BYTES)
+            if rank == 0:
+                _native._check(_native.lib().dr_comm_unique_id(uid))
+            uid_bytes = boot.broadcast(uid.raw if rank == 0 else None, _native.COMM_ID_BYTES)
+        finally:
+            if own_boot:
+                boot.close()
+        handle = ctypes.c_void_p()
+        _native._check(_native.lib().dr_comm_create(ctx.handle, uid_bytes, rank, world, ctypes.byref(handle)))
+        self.handle = handle
+
+    def all_gather(self, mine: bytes) -> list[bytes]:
+        n = len(mine)
+        out = ctypes.create_string_buffer(max(1, n * self.world))
+        _native._check(_native.lib().dr_comm_all_gather(self.handle, bytes(mine), n, out))
+        return [out.raw[i * n : (i + 1) * n] for i in range(self.world)]
+
+    def barrier(self) -> None:
+        self.ctx.sync()
+        self.all_gather(b"\0")
+
+    def g1_msm_sharded_dev(self, srs, d_scalars, n_local: int, offset: int = 0) -> bytes | None:
+        """The native fused path: local MSM -> ncclAllGather -> fold, one call (`dr_g1_msm_sharded_dev`)."""
+        out, inf = ctypes.create_string_buffer(96), ctypes.c_int(0)
+        _native._check(_native.lib().dr_g1_msm_sharded_dev(self.ctx.handle, self.handle, srs.handle, offset, d_scalars.ptr, n_local, out,
+                                                           ctypes.byref(inf)))
+        return None if inf.value else out.raw
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            _native.lib().dr_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TorchComm:
+    """An initialised torch.distributed process group (gloo on CPU, nccl = RCCL on GPUs) behind the same interface."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self._dist, self._group = dist, group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def all_gather(self, mine: bytes) -> list[bytes]:
+        import torch
+
+        if self.world == 1:
+            return [bytes(mine)]
+        on_gpu = self._dist.get_backend(self._group) == "nccl"
+        t = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+        if on_gpu:
+            t = t.cuda()
+        gathered = [torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(gathered, t, group=self._group)
+        return [bytes(g.cpu().numpy().tobytes()) for g in gathered]
+
+    def barrier(self) -> None:
+        if self.world > 1:
+            self._dist.barrier(group=self._group)
+
+    def close(self) -> None:
+        pass
+
+
+def make_comm(ctx=None, backend: str | None = None):
+    """The communicator of this process as the launcher's environment describes it.  backend: "rccl" (default with a GPU
+    context), "socket" (DOTRING_COMM=socket: ranks may share a GPU; also the CPU tests)."""
+    rank, _, world = env_rank_world()
+    backend = backend or os.environ.get("DOTRING_COMM", "rccl" if ctx is not None else "socket")
+    if backend == "socket":
+        return SocketComm(rank, world)
+    if backend == "rccl":
+        if ctx is None:
+            raise ValueError("the RCCL communicator needs a GPU context")
+        return RcclComm(ctx, rank, world)
+    raise ValueError(f"unknown communicator backend {backend!r}")
+
+
+# ------------------------------------------------------------------------------------------------ base-sharded MSM
+def _pack_point(point: bytes | None) -> bytes:
+    return (bytes(96) + b"\x01") if point is None else (bytes(point) + b"\x00")
+
+
+def all_gather_points(point: bytes | None, comm=None) -> list:
     """All-gather one affine G1 point (96-byte BE record, None = infinity) from every rank."""
-    import torch
-    import torch.distributed as dist
-
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return [point]
-    world = dist.get_world_size(group)
-    on_gpu = dist.get_backend(group) == "nccl"
-    mine = torch.frombuffer(bytearray(point if point is not None else bytes(96)), dtype=torch.uint8)
-    if on_gpu:
-        mine = mine.cuda()
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
-    out = []
-    for g in gathered:
-        raw = bytes(g.cpu().numpy().tobytes())
-        out.append(None if raw == bytes(96) else raw)
-    return out
+    if comm is None:
+        comm = TorchComm()
+    return [None if rec[96] else rec[:96] for rec in comm.all_gather(_pack_point(point))]
 
 
-def combine_partials(point: bytes | None, group=None) -> bytes | None:
-    """Sum of every rank's partial MSM result; identical on all ranks."""
-    return _native.g1_sum(all_gather_points(point, group))
+def combine_partials(point: bytes | None, comm=None) -> bytes | None:
+    """Sum of every rank's partial MSM result; identical on all ranks.  `comm`: any communicator above (a
+    torch.distributed group object is accepted for backward compatibility)."""
+    if comm is not None and not hasattr(comm, "all_gather"):
+        comm = TorchComm(comm)
+    return _native.g1_sum(all_gather_points(point, comm))
+
+
+def g1_msm_sharded(ctx, comm, srs_shard, d_scalars, n_local: int, offset: int = 0) -> bytes | None:
+    """One MSM whose (base, scalar) pairs are sharded over the ranks of `comm`: `srs_shard` / `d_scalars` hold this rank's
+    n_local pairs in HBM.  Runs the local MSM on the GPU, exchanges one point per rank, folds; the same 96 bytes (or None
+    for infinity) on every rank.  With an RcclComm the whole thing is one native call."""
+    if isinstance(comm, RcclComm):
+        return comm.g1_msm_sharded_dev(srs_shard, d_scalars, n_local, offset)
+    part = ctx.g1_msm_dev(srs_shard, d_scalars, n_local, offset) if n_local else None
+    return combine_partials(part, comm)

@@ -159,6 +159,26 @@ DR_API int dr_g1_msm_points(dr_ctx *ctx, const uint8_t *pts_be_xy /* n*96 */, co
 /* host-side sum of a few affine points (combining per-GPU partial MSM results after an all-gather) */
 DR_API int dr_g1_sum(const uint8_t *pts_be_xy /* n*96 */, size_t n, uint8_t out_be_xy[96], int *is_inf);
 
+/* ---- multi-GPU: the base-sharded MSM (second mode; the shape of the one MSM to shard is the reference's
+ * KZG.commit, dot_ring/ring_proof/pcs/kzg.py:152-175; its process-sharded bench is tests/benchmark/bench_ring_proof.py:168-182).
+ * One process per GPU.  Rank g reduces its shard of (base, scalar) pairs to one point; the points are exchanged with RCCL
+ * ncclAllGather over xGMI (97 bytes per rank) and every rank folds them with the group law.  librccl is dlopen'ed on first
+ * use; no PyTorch anywhere.  dr_comm_unique_id runs on ONE rank, its 128 bytes reach the others through the launcher's
+ * channel (dot_ring_amd/parallel.py: a TCP socket on MASTER_ADDR), then every rank calls dr_comm_create (a collective). */
+#define DR_COMM_ID_BYTES 128
+typedef struct dr_comm dr_comm;
+DR_API int dr_comm_unique_id(uint8_t out_id[DR_COMM_ID_BYTES]);
+DR_API int dr_comm_create(dr_ctx *ctx, const uint8_t id[DR_COMM_ID_BYTES], int rank, int world, dr_comm **out);
+DR_API void dr_comm_destroy(dr_comm *comm);
+DR_API int dr_comm_rank(const dr_comm *comm);
+DR_API int dr_comm_world(const dr_comm *comm);
+/* host-to-host all-gather of `bytes` bytes per rank (staged through HBM, ncclAllGather on the context's stream) */
+DR_API int dr_comm_all_gather(dr_comm *comm, const void *send, size_t bytes, void *recv /* world*bytes */);
+/* this rank's n_local pairs (srs[offset..], device-resident scalars) of one MSM sharded over the communicator;
+ * the result is the whole MSM, identical on every rank */
+DR_API int dr_g1_msm_sharded_dev(dr_ctx *ctx, dr_comm *comm, const dr_srs *srs, size_t offset, const void *d_scalars, size_t n_local,
+                                 uint8_t out_be_xy[96], int *is_inf);
+
 /* Host-side pairing product check: *ok = 1 iff prod_i e(P_i, Q_i) == 1.  G2 points are 192-byte records in the SRS
  * file layout x.c1 || x.c0 || y.c1 || y.c0 (big-endian, dot_ring/ring_proof/pcs/srs.py:78-88).  Replaces
  * blst.PT + PT.finalverify (dot_ring/ring_proof/pcs/pairing.py:24-31); stays on the CPU (2 Miller loops per batch). */

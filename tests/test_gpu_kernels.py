@@ -36,6 +36,32 @@ def test_bsn_scalar_mul_batch_matches_oracle(ctx):
     assert got == want
 
 
+def config2_inputs(n=4096):
+    """BASELINE configs[1] / SURVEY 8(d) config 2: P_i = public key of secret_from_seed(sha256("bsn-pt" || LE64(i))) — valid
+    prime-order points — and k_i = sha256("bsn-k" || LE64(i)) as a little-endian integer mod n."""
+    from oracle.pyref import vrf as ovrf
+
+    pks = [ovrf.secret_from_seed(bsn.SHA512, hashlib.sha256(b"bsn-pt" + i.to_bytes(8, "little")).digest())[0] for i in range(n)]
+    return [bsn.dec_point(pk) for pk in pks], _seeded_scalars(n)
+
+
+def test_bsn_scalar_mul_config2_4096(ctx):
+    """BASELINE configs[1] at its stated size: 4096 variable-base scalar multiplications, bit-exact against the oracle's
+    restatement of the reference kernel (curve/specs/bandersnatch.py:177-191 -> glv.py:191 -> bandersnatch_te.pyx:480)."""
+    n = 4096
+    pts, ks = config2_inputs(n)
+    raw_p, raw_k = coracle.te_pack(pts), coracle.scalars_pack(ks)
+    got = ctx.bsn_scalar_mul_batch(raw_p, raw_k)
+    assert got == coracle.te_mul_batch_raw(raw_p, raw_k, n, glv=True)
+    assert got == coracle.te_mul_batch_raw(raw_p, raw_k, n, glv=False)
+    # device-resident variant (the one bench.py times) gives the same bytes
+    d_p, d_k, d_o = ctx.alloc(64 * n).upload(raw_p), ctx.alloc(32 * n).upload(raw_k), ctx.alloc(64 * n)
+    ctx.bsn_scalar_mul_batch_dev(d_p, d_k, n, d_o)
+    assert d_o.download() == got
+    for b in (d_p, d_k, d_o):
+        b.free()
+
+
 def test_bsn_scalar_mul_identity_and_kat(ctx):
     # identity input, and the reference KAT pk = sk*G (tests/golden/ark-vrf/bandersnatch_sha-512_ell2_tiny.json #1)
     sk = int.from_bytes(bytes.fromhex("c9922b7a9849b9928e15c655dd2f22ceef737cc355024f43d4b04bf4398c270d"), "little")
@@ -143,9 +169,9 @@ def test_g1_msm_batch_matches_singles(ctx, srs_bytes, window):
     srs.close()
 
 
-@pytest.mark.parametrize("log2n,table", [(16, 0), (16, 12), (18, 16)])
+@pytest.mark.parametrize("log2n,table", [(16, 0), (16, 12), (18, 16), (20, 16)])
 def test_g1_msm_synthetic_bases_closed_form(ctx, log2n, table):
-    """BASELINE configs[2] sizes (2^16; 2^20 runs in bench.py): no SRS of that size exists, so bases are (1+i)*G
+    """BASELINE configs[2] sizes (2^16 and 2^20): no SRS of that size exists, so bases are (1+i)*G
     generated on the GPU and the MSM must equal [sum k_i (1+i)]*G — one oracle scalar multiplication; the first 4096
     pairs are also checked against the oracle's Pippenger."""
     import bench

@@ -2,7 +2,7 @@
 // G1 points when every lane shares one inversion over its own K pairs (Montgomery's trick), next to the XYZZ mixed-addition
 // chain k_g1_accumulate runs today?  Same memory behaviour as the real thing would have: operands are gathered by index from
 // a 13 MB table of affine points (the size of the prover's window table), prefix products and results stream through HBM.
-//   build: hipcc --offload-arch=gfx950 -O3 -I dot_ring_amd/csrc tools/ubench_affine.hip -o tools/ubench_affine
+//   build: hipcc --offload-arch=gfx950 -O3 -I dot_ring_amd/csrc -I tools tools/ubench_affine.hip -o tools/ubench_affine
 //   run:   tools/ubench_affine [K ...]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -11,9 +11,9 @@
 
 #include <vector>
 
-#include "kernels_g1.hip.h"
+#include "legacy_g1_fq32.hip.h"   // round-1 arithmetic (12 x 32-bit limbs): this experiment was run on it
 
-using namespace dr;
+using namespace legacy;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 // baseline: one lane = one chain of K mixed additions over gathered table points (what k_g1_accumulate does per bucket)

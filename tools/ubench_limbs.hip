@@ -2,7 +2,7 @@
 // over points gathered from a 13 MB table — the prover's window table) with the Fq product as it is today
 // (12 x 32-bit limbs: v_mad_u64_u32 + v_addc_co_u32 per partial product, field.hip.h) against 14 x 28-bit signed limbs
 // (one v_mad_i64_i32 per partial product, lazy reduction, fq28.hip.h).  Results of the two chains are compared word for word.
-//   build: hipcc --offload-arch=gfx950 -O3 -I dot_ring_amd/csrc tools/ubench_limbs.hip -o tools/ubench_limbs
+//   build: hipcc --offload-arch=gfx950 -O3 -I dot_ring_amd/csrc -I tools tools/ubench_limbs.hip -o tools/ubench_limbs
 //   run:   tools/ubench_limbs [K ...]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -11,8 +11,8 @@
 
 #include <vector>
 
-#include "kernels_g1.hip.h"
-#include "curve28.hip.h"
+#include "legacy_g1_fq32.hip.h"   // the 12 x 32-bit arithmetic of round 1, namespace legacy
+#include "g1.hip.h"               // the 14 x 28-bit arithmetic the library uses
 
 using namespace dr;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
@@ -21,13 +21,13 @@ __global__ __launch_bounds__(256) void k_chain32(const uint32_t* __restrict__ ta
                                                  uint32_t* __restrict__ out) {
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= lanes) return;
-    G1Xyzz acc = g1_inf();
+    legacy::G1Xyzz acc = legacy::g1_inf();
 #pragma unroll 1
     for (uint32_t j = 0; j < K; j++) {
         const uint32_t e = idx[(size_t)j * lanes + lane];
-        acc = g1_madd(acc, g1_neg_affine(load_affine(table, e & 0x7fffffffu), (e >> 31) != 0));
+        acc = legacy::g1_madd(acc, legacy::g1_neg_affine(legacy::load_affine(table, e & 0x7fffffffu), (e >> 31) != 0));
     }
-    store_xyzz(out, lane, acc);
+    legacy::store_xyzz(out, lane, acc);
 }
 
 // table of 32-bit-limb Montgomery values (x 2^384) -> 28-bit-limb Montgomery values (x 2^392), canonical words
@@ -42,17 +42,15 @@ __global__ __launch_bounds__(256) ATTR void NAME(const uint32_t* __restrict__ ta
                                                  uint32_t* __restrict__ out) { \
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x; \
     if (lane >= lanes) return; \
-    G1Xyzz28 acc = g1_inf28(); \
+    G1Xyzz acc = g1_inf(); \
 _Pragma("unroll 1") \
     for (uint32_t j = 0; j < K; j++) { \
         const uint32_t e = idx[(size_t)j * lanes + lane]; \
-        G1Affine28 q = load_affine28(table28, e & 0x7fffffffu); \
-        q.y = cneg(q.y, (e >> 31) != 0); \
-        g1_madd28(acc, q); \
+        acc = g1_madd(acc, g1_neg_affine(load_affine(table28, e & 0x7fffffffu), (e >> 31) != 0)); \
     } \
     const Fq28 k384 = Fq28::constant<Fq28Params::K384>(); \
     uint32_t* o = out + (size_t)lane * 48; \
-    if (acc.inf) acc = g1_inf28(); \
+    if (acc.inf) acc = g1_inf(); \
     store_fq28(o, mul(acc.x, k384)); \
     store_fq28(o + 12, mul(carry(acc.y), k384)); \
     store_fq28(o + 24, mul(acc.zz, k384)); \
@@ -70,10 +68,10 @@ int main(int argc, char** argv) {
     uint32_t *d_seed, *d_table, *d_table28, *d_idx, *d_o32, *d_o28;
     CK(hipMalloc(&d_seed, sizeof GEN));
     CK(hipMemcpy(d_seed, GEN, sizeof GEN, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_g1_bases_to_mont, dim3(1), dim3(64), 0, 0, d_seed, 1u);
+    hipLaunchKernelGGL(legacy::k_g1_bases_to_mont, dim3(1), dim3(64), 0, 0, d_seed, 1u);
     CK(hipMalloc(&d_table, (size_t)T * 96));
     CK(hipMalloc(&d_table28, (size_t)T * 96));
-    hipLaunchKernelGGL(k_g1_synth_bases, dim3((T + 255) / 256), dim3(256), 0, 0, d_table, T, 1u, d_seed);
+    hipLaunchKernelGGL(legacy::k_g1_synth_bases, dim3((T + 255) / 256), dim3(256), 0, 0, d_table, T, 1u, d_seed);
     hipLaunchKernelGGL(k_table_to28, dim3((2 * T + 255) / 256), dim3(256), 0, 0, d_table, d_table28, 2 * T);
     CK(hipDeviceSynchronize());
     std::vector<uint32_t> ks;
