@@ -16,6 +16,10 @@ struct PedersenBatch {
     std::vector<uint8_t> us, xs, inputs, outs, blind, gb_pts, sc, ybar, ks, kbs, pts3, sc3, third;
     std::vector<drh::Bytes> tr;
     PedersenBatch(const drh::VrfSuite& s, size_t b) : su(s), B(b) {}
+    ~PedersenBatch() {          // secret scalars, blinding factors and nonces (and the scalar vectors built from them) do not outlive the call
+        for (std::vector<uint8_t>* v : {&xs, &blind, &ks, &kbs, &sc, &sc3})
+            if (!v->empty()) explicit_bzero(v->data(), v->size());
+    }
 
     int head(dr_ctx* ctx, const uint8_t* alphas, const uint64_t* alpha_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts,
              const uint64_t* salt_off, const uint8_t* secret_scalars, PhaseTrace& tr_) {
@@ -154,10 +158,7 @@ int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_
     const bool overlap = std::getenv("DOTRING_PROVE_OVERLAP") == nullptr || std::atoi(std::getenv("DOTRING_PROVE_OVERLAP")) != 0;
     std::thread ped_thread;
     if (overlap) {
-        ped_thread = std::thread([&] {
-            ped_rc = ped.tail(actx, out_proofs, 784, out_aux, DR_RINGVRF_AUX_BYTES);
-            if (ped_rc != DR_OK) ped_err = dr_last_error();
-        });
+        ped_thread = std::thread([&] { run_guarded(ped_rc, ped_err, [&] { return ped.tail(actx, out_proofs, 784, out_aux, DR_RINGVRF_AUX_BYTES); }); });
     } else {
         TRY(ped.tail(ctx, out_proofs, 784, out_aux, DR_RINGVRF_AUX_BYTES));
     }
@@ -383,15 +384,15 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         gate_cv.notify_all();
     };
     std::thread side([&] {
-        side_rc = encode_to_curve_msgs(actx, su, B, inputs, in_off, salts, salt_off, in_pts.data());
-        if (side_rc != DR_OK) { side_err = dr_last_error(); return; }
-        {
-            std::unique_lock<std::mutex> lk(gate_m);
-            gate_cv.wait(lk, [&] { return gate >= 0; });
-            if (gate == 0) return;
-        }
-        side_rc = pedersen_verify_core(actx, su, B, proofs, 784, te_xy, in_pts, ads, ad_off, ped_ok);
-        if (side_rc != DR_OK) side_err = dr_last_error();
+        run_guarded(side_rc, side_err, [&]() -> int {
+            TRY(encode_to_curve_msgs(actx, su, B, inputs, in_off, salts, salt_off, in_pts.data()));
+            {
+                std::unique_lock<std::mutex> lk(gate_m);
+                gate_cv.wait(lk, [&] { return gate >= 0; });
+                if (gate == 0) return DR_OK;
+            }
+            return pedersen_verify_core(actx, su, B, proofs, 784, te_xy, in_pts, ads, ad_off, ped_ok);
+        });
     });
     struct Joiner {
         std::thread& t;
@@ -527,13 +528,12 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
     int rhs_rc = DR_OK;
     std::string rhs_err;
     std::thread rhs_thread([&] {
-        rhs_rc = [&]() -> int {
+        run_guarded(rhs_rc, rhs_err, [&]() -> int {
             TRY(use_ctx(bctx));
             TRY(bctx->scalars.reserve(n_g1 * 32));
             HIP_TRY(hipMemcpyAsync(bctx->scalars.p, rhs_full.data(), n_g1 * 32, hipMemcpyHostToDevice, bctx->stream));
             return msm_to_bytes(bctx, g1_bases.as<uint32_t>(), bctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1 + 96, pair_inf + 1);
-        }();
-        if (rhs_rc != DR_OK) rhs_err = dr_last_error();
+        });
     });
     struct RhsJoiner {
         std::thread& t;

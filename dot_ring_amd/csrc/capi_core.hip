@@ -378,8 +378,16 @@ int te_msm(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_t* scalars, s
         out_xy[32] = 1;
         return DR_OK;
     }
-    // fold 64 terms at a time on the device (one launch); the n/64 partial sums are then added on the host in extended
-    // coordinates — a second device pass would pay a full scalar-multiplication latency for scalars that are all 1
+    // from a few hundred terms: the bucket method (K4, capi_msm.hip) — ~W additions per term instead of a full scalar
+    // multiplication (~250 doublings + 64 additions) per term
+    static const size_t pip_from = std::getenv("DOTRING_BSN_PIPPENGER_FROM") ? (size_t)std::atol(std::getenv("DOTRING_BSN_PIPPENGER_FROM")) : 256;
+    if (pip_from > 0 && n >= pip_from) {
+        if (!pts_xy || !scalars) return fail(DR_ERR_INVALID, "null buffer");
+        TRY(check_fr_elems(pts_xy, 2 * n, "point"));
+        return te_msm_pippenger(ctx, cv, pts_xy, scalars, n, out_xy);
+    }
+    // below that: fold 64 terms at a time on the device (one launch); the n/64 partial sums are then added on the host in
+    // extended coordinates — a second device pass would pay a full scalar-multiplication latency for scalars that are all 1
     if (n <= 64) return te_msm_groups(ctx, cv, pts_xy, scalars, 1, n, out_xy);
     const size_t parts = (n + 63) / 64;
     std::vector<uint8_t> part(parts * 64);

@@ -123,12 +123,19 @@ int prof_collect(dr_ctx* ctx);
 template <class F>
 int launch(dr_ctx* ctx, const char* name, F&& f) {
     if (ctx->prof) {
-        hipEvent_t a, b;
-        HIP_TRY(hipEventCreate(&a));
-        HIP_TRY(hipEventCreate(&b));
-        HIP_TRY(hipEventRecord(a, ctx->stream));
-        f();
-        HIP_TRY(hipEventRecord(b, ctx->stream));
+        hipEvent_t a = nullptr, b = nullptr;
+        hipError_t e = hipEventCreate(&a);
+        if (e == hipSuccess) e = hipEventCreate(&b);
+        if (e == hipSuccess) e = hipEventRecord(a, ctx->stream);
+        if (e == hipSuccess) {
+            f();
+            e = hipEventRecord(b, ctx->stream);
+        }
+        if (e != hipSuccess) {            // no event may outlive a failed launch
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+            return fail(e == hipErrorOutOfMemory ? DR_ERR_NOMEM : DR_ERR_DEVICE, std::string("kernel timer: ") + hipGetErrorString(e));
+        }
         ctx->prof_pending.push_back({name, {a, b}});
     } else {
         f();
@@ -193,6 +200,21 @@ bool window_ok(int c);
 
 }  // namespace dri
 
+// body of a helper std::thread: status and message go to the joining thread; no exception may escape (std::terminate)
+template <class F>
+void run_guarded(int& rc, std::string& err, F&& f) {
+    try {
+        rc = f();
+        if (rc != DR_OK) err = dr_last_error();
+    } catch (const std::bad_alloc&) {
+        rc = DR_ERR_NOMEM;
+        err = "out of host memory";
+    } catch (const std::exception& e) {
+        rc = DR_ERR_DEVICE;
+        err = e.what();
+    }
+}
+
 // ---- helpers shared between translation units (global scope, hidden visibility)
 bool ctx_alive(dr_ctx* c);
 
@@ -251,6 +273,8 @@ int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, in
 int msm_to_bytes(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch, uint8_t* out_be_xy, int* is_inf,
                  const MsmTable* tbl = nullptr);
 int g1_be_to_le_limbs(const uint8_t* be, size_t m, std::vector<uint8_t>& le, bool check_curve);
+// K4: one twisted Edwards MSM by the bucket method (n from a few hundred terms)
+int te_msm_pippenger(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_t* scalars, size_t n, uint8_t out_xy[64]);
 // launch wrappers around kernels_g1.hip.h for the batch verifier
 void g1_launch_decompress(hipStream_t st, const uint8_t* d_enc, uint32_t* d_bases, uint32_t* d_ok, size_t n);
 void g1_launch_bases_to_mont(hipStream_t st, uint32_t* d_bases, size_t n);

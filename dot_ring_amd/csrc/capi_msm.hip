@@ -2,6 +2,7 @@
 // points, G1 codecs) and the pairing entry points.
 #include "capi_internal.hpp"
 #include "kernels_g1.hip.h"
+#include "kernels_te_msm.hip.h"
 
 using namespace dri;
 
@@ -27,10 +28,10 @@ struct MsmPlan {
     int W;
     uint32_t H, L, T;
 };
-dr::WindowTable make_window_table(int c) {
+dr::WindowTable make_window_table(int c, int bits = 256) {      // `bits` scalar bits tiled by ceil(bits / c) windows of near-equal width
     dr::WindowTable wt;
-    wt.W = (256 + c - 1) / c;
-    int base = 256 / wt.W, rem = 256 % wt.W;
+    wt.W = (bits + c - 1) / c;
+    int base = bits / wt.W, rem = bits % wt.W;
     wt.cmax = base + (rem ? 1 : 0);
     int bit = 0;
     for (int w = 0; w < wt.W; w++) {
@@ -380,6 +381,118 @@ int g1_be_to_le_limbs(const uint8_t* be, size_t m, std::vector<uint8_t>& le, boo
     return DR_OK;
 }
 
+
+// ------------------------------------------------------------------------------- K4: twisted Edwards Pippenger
+// One variable-base MSM on Bandersnatch / JubJub by the bucket method (kernels_te_msm.hip.h).  Bucket sets are
+// (window, index group) pairs so that a few thousand terms still make tens of thousands of bucket lanes; digits, counting
+// sort and size ordering are the G1 pipeline's kernels.  The W x G set sums come back to the host for the final combination.
+namespace {
+struct TeHost {                 // extended coordinates over the host field (same Montgomery form as the device's Fr)
+    drh::Fr x, y, z, t;
+};
+TeHost te_host_identity() { return {drh::Fr::zero(), drh::Fr::one(), drh::Fr::one(), drh::Fr::zero()}; }
+TeHost te_host_add(const TeHost& p, const TeHost& q, const drh::Fr& d, const drh::Fr& neg_a) {      // add-2008-hwcd, unified
+    drh::Fr A = p.x * q.x, B = p.y * q.y, C = p.t * d * q.t, D = p.z * q.z;
+    drh::Fr E = (p.x + p.y) * (q.x + q.y) - A - B, F = D - C, G = D + C, H = B + A * neg_a;
+    return {E * F, G * H, F * G, E * H};
+}
+}  // namespace
+
+int te_msm_pippenger(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_t* scalars, size_t n, uint8_t out_xy[64]) {
+    TRY(use_ctx(ctx));
+    const drh::TeCurveHost* cu = drh::te_curve(cv);
+    if (!cu) return fail(DR_ERR_INVALID, "unknown curve id");
+    if (n == 0 || n >= (1ull << 26)) return fail(DR_ERR_INVALID, "bad MSM size");
+    // scalars mod n (253 / 252 bits: the signed recoding over 256-bit windows never carries out of the top)
+    std::vector<uint8_t> ks(n * 32);
+    auto red = [&](size_t i) {
+        uint64_t k[4];
+        cu->n.reduce_bytes(scalars + 32 * i, 32, false, k);
+        drh::store_le32(k, ks.data() + 32 * i);
+    };
+    if (n >= 4096) drh::parallel_for(n, red);
+    else for (size_t i = 0; i < n; i++) red(i);
+    // window width by size (the reference's rule grows the same way, bandersnatch.py:23-36); index groups until a bucket
+    // holds ~8 points or 64 groups
+    const int c = n < 4096 ? 7 : n < 16384 ? 8 : n < 65536 ? 9 : 10;
+    // tile scalar_bits + 1 bits, not 256: a top window holding one or two live bits would put half of all points into one bucket
+    const dr::WindowTable wt = make_window_table(c, (int)cu->scalar_bits + 1);
+    const uint32_t H = 1u << (wt.cmax - 1), L = 8, T = H / L;
+    uint32_t groups = 1;
+    while (groups < 64 && n / ((size_t)groups * 2 * H) >= 8) groups *= 2;
+    const size_t sets = (size_t)wt.W * groups, nbuckets = sets * H;
+    const size_t per_set = (n + groups - 1) / groups;
+    hipStream_t st = ctx->stream;
+    TRY(ctx->io_a.reserve(n * 64));
+    TRY(ctx->io_b.reserve(n * 96));
+    TRY(ctx->scalars.reserve(n * 32));
+    TRY(ctx->counts.reserve(nbuckets * 4));
+    TRY(ctx->offsets.reserve((nbuckets + 1) * 4));
+    TRY(ctx->sorted.reserve(sets * per_set * 4));
+    const unsigned szblocks = div_up(nbuckets, dr::SZ_TILE);
+    const size_t ncells = (size_t)dr::SZ_CLASSES * szblocks;
+    TRY(ctx->tiles.reserve((size_t)(div_up(ncells, dr::SCAN_TILE) + 1) * 4));
+    TRY(ctx->perm.reserve(nbuckets * 4));
+    TRY(ctx->cells.reserve(ncells * 4));
+    TRY(ctx->cell_off.reserve(ncells * 4));
+    TRY(ctx->buckets.reserve(nbuckets * 128));
+    TRY(ctx->partial.reserve(sets * T * 128));
+    TRY(ctx->winsum.reserve(sets * 128));
+    HIP_TRY(hipMemcpyAsync(ctx->io_a.p, pts_xy, n * 64, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->scalars.p, ks.data(), n * 32, hipMemcpyHostToDevice, st));
+    dr::SortSetParams sp{};
+    sp.n = (uint32_t)n; sp.batch = 1; sp.H = H; sp.groups = groups; sp.single = 0;
+    sp.capacity = (uint32_t)per_set; sp.short_from = 0xffffffffu; sp.n_short = 0;
+    TRY(launch(ctx, "k_te_msm_prepare", [&] {
+        LAUNCH_CV(cv, dr::k_te_msm_prepare, dim3(div_up(n, 256)), dim3(256), 0, st, ctx->io_a.as<uint32_t>(), (uint32_t)n, ctx->io_b.as<uint32_t>());
+    }));
+    TRY(launch(ctx, "k_g1_sort_sets", [&] {
+        hipLaunchKernelGGL(dr::k_g1_sort_sets, dim3((unsigned)sets), dim3(dr::SORT_BLOCK), 0, st, ctx->scalars.as<uint32_t>(), wt, sp,
+                           ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
+    }));
+    TRY(launch(ctx, "k_size_sort", [&] {
+        hipLaunchKernelGGL(dr::k_size_hist, dim3(szblocks), dim3(dr::SZ_BLOCK), 0, st, ctx->counts.as<uint32_t>(), nbuckets, szblocks,
+                           ctx->cells.as<uint32_t>());
+        const unsigned nt = div_up(ncells, dr::SCAN_TILE);
+        hipLaunchKernelGGL(dr::k_scan_tiles, dim3(nt), dim3(dr::SCAN_BLOCK), 0, st, ctx->cells.as<uint32_t>(), ctx->cell_off.as<uint32_t>(),
+                           ctx->tiles.as<uint32_t>(), ncells);
+        hipLaunchKernelGGL(dr::k_scan_tile_sums, dim3(1), dim3(dr::SCAN_BLOCK), 0, st, ctx->tiles.as<uint32_t>(), nt, ctx->tiles.as<uint32_t>() + nt);
+        hipLaunchKernelGGL(dr::k_scan_add, dim3(div_up(ncells, 256)), dim3(256), 0, st, ctx->cell_off.as<uint32_t>(), ctx->tiles.as<uint32_t>(), ncells);
+        hipLaunchKernelGGL(dr::k_size_place, dim3(szblocks), dim3(dr::SZ_BLOCK), 0, st, ctx->counts.as<uint32_t>(), nbuckets, szblocks,
+                           ctx->cell_off.as<uint32_t>(), ctx->perm.as<uint32_t>());
+    }));
+    TRY(launch(ctx, "k_te_msm_accumulate", [&] {
+        LAUNCH_CV(cv, dr::k_te_msm_accumulate, dim3(div_up(nbuckets, 256)), dim3(256), 0, st, ctx->io_b.as<uint32_t>(), ctx->sorted.as<uint32_t>(),
+                  ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(), ctx->buckets.as<uint32_t>(), nbuckets);
+        LAUNCH_CV(cv, dr::k_te_msm_accumulate_heavy, dim3((unsigned)nbuckets), dim3(64), 0, st, ctx->io_b.as<uint32_t>(), ctx->sorted.as<uint32_t>(),
+                  ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->buckets.as<uint32_t>(), nbuckets);
+    }));
+    TRY(launch(ctx, "k_te_msm_reduce", [&] {
+        LAUNCH_CV(cv, dr::k_te_msm_reduce, dim3(div_up(sets * T, 128)), dim3(128), 0, st, ctx->buckets.as<uint32_t>(), sets, H, L,
+                  ctx->partial.as<uint32_t>());
+        LAUNCH_CV(cv, dr::k_te_msm_fold, dim3(div_up(sets, 64)), dim3(64), 0, st, ctx->partial.as<uint32_t>(), sets, T, ctx->winsum.as<uint32_t>());
+    }));
+    static_assert(sizeof(TeHost) == 128, "extended point layout");
+    std::vector<TeHost> sums(sets);
+    HIP_TRY(hipMemcpyAsync(sums.data(), ctx->winsum.p, sets * 128, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ctx->prof) TRY(prof_collect(ctx));
+    // device layout is X, Y, Z, T; TeHost is x, y, z, t in that order
+    uint8_t D_LE[32];
+    drh::store_le32(cu->d, D_LE);
+    drh::Fr d, neg_a = drh::Fr::from_u64(cu->neg_a[0]);
+    if (!drh::Fr::load_le(d, D_LE)) return fail(DR_ERR_DEVICE, "bad curve constant");
+    TeHost acc = te_host_identity();
+    for (int w = wt.W - 1; w >= 0; w--) {
+        if (w != wt.W - 1)
+            for (int j = 0; j < wt.width[w]; j++) acc = te_host_add(acc, acc, d, neg_a);
+        for (uint32_t g = 0; g < groups; g++) acc = te_host_add(acc, sums[(size_t)w * groups + g], d, neg_a);
+    }
+    drh::Fr zi = acc.z.inv();
+    (acc.x * zi).store_le(out_xy);
+    (acc.y * zi).store_le(out_xy + 32);
+    return DR_OK;
+}
 
 void g1_launch_decompress(hipStream_t st, const uint8_t* d_enc, uint32_t* d_bases, uint32_t* d_ok, size_t n) {
     hipLaunchKernelGGL(dr::k_g1_decompress, dim3(div_up(n, 64)), dim3(64), 0, st, d_enc, d_bases, d_ok, (uint32_t)n);

@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -51,6 +52,7 @@ class WorkerPool {
         std::atomic<size_t> next{0}, done{0};
         std::mutex m;
         std::condition_variable cv;
+        std::exception_ptr error;          // first exception thrown by f on any thread; rethrown by run() on the caller
     };
     std::mutex m_;
     std::condition_variable cv_;
@@ -63,7 +65,12 @@ class WorkerPool {
             size_t c = j.next.fetch_add(1, std::memory_order_relaxed);
             if (c >= j.chunks) return;
             size_t lo = c * j.chunk, hi = std::min(j.n, lo + j.chunk);
-            for (size_t i = lo; i < hi; i++) (*j.f)(i);
+            try {
+                for (size_t i = lo; i < hi; i++) (*j.f)(i);
+            } catch (...) {                 // an exception escaping a worker thread would terminate the host process
+                std::lock_guard<std::mutex> lk(j.m);
+                if (!j.error) j.error = std::current_exception();
+            }
             if (j.done.fetch_add(1, std::memory_order_acq_rel) + 1 == j.chunks) {
                 std::lock_guard<std::mutex> lk(j.m);
                 j.cv.notify_all();
@@ -116,6 +123,7 @@ public:
         }
         std::unique_lock<std::mutex> lk(j->m);
         j->cv.wait(lk, [&] { return j->done.load(std::memory_order_acquire) == j->chunks; });
+        if (j->error) std::rethrow_exception(j->error);
     }
 };
 inline WorkerPool* worker_pool() {
@@ -124,7 +132,9 @@ inline WorkerPool* worker_pool() {
     static WorkerPool pool(host_threads() - 1);
     return &pool;
 }
-// f(i) for i in [0, n); f must not throw.  Short loops stay on the calling thread.
+// f(i) for i in [0, n).  Short loops stay on the calling thread.  An exception thrown by f on a worker (std::bad_alloc from a
+// staging buffer) is carried to the calling thread and rethrown there, where the C entry points' try / catch turn it into a
+// status code.
 template <class F>
 void parallel_for(size_t n, F f) {
     unsigned t = host_threads();
@@ -140,12 +150,20 @@ void parallel_for(size_t n, F f) {
     }
     std::vector<std::thread> pool;
     pool.reserve(t);
+    std::mutex em;
+    std::exception_ptr error;
     for (unsigned k = 0; k < t; k++)
-        pool.emplace_back([=] {
+        pool.emplace_back([=, &em, &error] {
             size_t lo = n * k / t, hi = n * (k + 1) / t;
-            for (size_t i = lo; i < hi; i++) f(i);
+            try {
+                for (size_t i = lo; i < hi; i++) f(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(em);
+                if (!error) error = std::current_exception();
+            }
         });
     for (auto& th : pool) th.join();
+    if (error) std::rethrow_exception(error);
 }
 
 // ---------------------------------------------------------------- arithmetic modulo a runtime odd 256-bit modulus

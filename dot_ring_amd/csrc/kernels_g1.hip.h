@@ -379,9 +379,13 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
         i_hi = (uint32_t)(((uint64_t)(g + 1) * n_eff + sp.groups - 1) / sp.groups);
         w_lo = 0; w_hi = wt.W;
     } else {
-        b = set / wt.W;
-        w_lo = (int)(set % wt.W); w_hi = w_lo + 1;
-        i_lo = 0; i_hi = sp.n;
+        // set = ((b * W) + w) * groups + g: window w of scalar vector b, index group g (groups > 1: the variable-base
+        // Bandersnatch Pippenger, where one bucket set per window would leave the chip empty)
+        const uint32_t sw = set / sp.groups, g = set % sp.groups;
+        b = sw / wt.W;
+        w_lo = (int)(sw % wt.W); w_hi = w_lo + 1;
+        i_lo = (uint32_t)(((uint64_t)g * sp.n + sp.groups - 1) / sp.groups);
+        i_hi = (uint32_t)(((uint64_t)(g + 1) * sp.n + sp.groups - 1) / sp.groups);
     }
     for (uint32_t j = threadIdx.x; j < H; j += SORT_BLOCK) bins[j] = 0;
     __syncthreads();

@@ -104,5 +104,7 @@ class IetfVRF(VRF):
     @classmethod
     def proof_to_hash(cls, gamma, mul_cofactor: bool = False) -> bytes:
         if mul_cofactor:
-            gamma = gamma.double().double()
+            # gamma * cofactor (tiny.py:88, pedersen/vrf.py:167): 4 = two doublings on Bandersnatch, 8 = three on JubJub
+            for _ in range(cls.cv.curve.params.cofactor.bit_length() - 1):
+                gamma = gamma.double()
         return point_to_hash(cls.cv, gamma)

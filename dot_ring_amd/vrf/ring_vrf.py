@@ -1,6 +1,7 @@
 """Ring, RingRoot and RingVRF (dot_ring/vrf/ring/{members,root,vrf}.py, ring_proof/proof_payload.py)."""
 from __future__ import annotations
 
+import hashlib
 import os
 import secrets
 import threading
@@ -264,7 +265,26 @@ class RingVRF(VRF):
         d["c_q"] = Column("C_q", [], _commitment=g1(4), _has_commitment=True)
         d["l_zeta_omega"] = le(656)
         d["open_agg_zeta"], d["open_l_zeta_omega"] = g1(5), g1(6)
+        d["_snapshot"] = self._field_state()
         return d[name]
+
+    def __setattr__(self, name, value):
+        d = self.__dict__
+        if name in RingVRF._FIELDS and "_aux" in d:
+            self.__getattr__(name)          # fill every field from the auxiliary record first: the lazy fill must not undo this write
+        object.__setattr__(self, name, value)
+
+    def _field_state(self):
+        """What the encoded bytes depend on, as plain values: a natively produced proof keeps its 784 bytes only while this
+        still equals the state captured when the fields were materialised (the reference's tests mutate proofs in place,
+        tests/test_ark_vrf.py:146, and every later encode() / verify must see the mutation)."""
+        d = self.__dict__
+        ped = d.get("pedersen_proof")
+        pts = tuple((q.x, q.y) for q in (ped.output_point, ped.blinded_pk, ped.result_point, ped.ok)) if ped is not None else None
+        cm = lambda c: getattr(c, "_commitment", c)
+        return (pts, None if ped is None else (ped.s, ped.sb), tuple(cm(d.get(nm)) for nm in ("c_b", "c_accip", "c_accx", "c_accy", "c_q")),
+                tuple(d.get(nm) for nm in ("px_zeta", "py_zeta", "s_zeta", "b_zeta", "accip_zeta", "accx_zeta", "accy_zeta", "l_zeta_omega")),
+                d.get("open_agg_zeta"), d.get("open_l_zeta_omega"))
 
     @classmethod
     def _payload_len(cls, params) -> int:
@@ -275,9 +295,12 @@ class RingVRF(VRF):
         return PedersenVRF[cls.cv].proof_len() + cls._payload_len(RingProofParams(cv=cls.cv))
 
     def encode(self) -> bytes:
-        raw = self.__dict__.get("_raw")
+        d = self.__dict__
+        raw = d.get("_raw")
         if raw is not None:
-            return raw
+            if "_aux" in d or d.get("_snapshot") == self._field_state():       # fields never read, or read and unchanged
+                return raw
+            d.pop("_raw", None)                                                # mutated in place: the stored bytes are stale
         pcs = RingProofParams(cv=self.cv).pcs
         le = lambda v: int(v).to_bytes(RING_SCALAR_LEN, "little")
         return (self.pedersen_proof.encode()
@@ -401,14 +424,17 @@ class RingVRF(VRF):
         if memo is None:
             memo = {}
             cls._pk_memo = memo
-        distinct = [sk for sk in dict.fromkeys(bytes(sk) for sk in secret_keys) if sk not in memo]
+        # the memo is keyed by a hash of the secret key: the process keeps no copy of secret material beyond the call
+        tag = lambda sk: hashlib.blake2b(bytes(sk), digest_size=16, person=b"dotring-pk-memo").digest()
+        tags = [tag(sk) for sk in secret_keys]
+        distinct = {t: sk for t, sk in zip(tags, secret_keys) if t not in memo}
         if distinct:
-            derived = scalar_mul_batch([gen] * len(distinct), [int.from_bytes(sk, "little") for sk in distinct])
+            derived = scalar_mul_batch([gen] * len(distinct), [int.from_bytes(sk, "little") for sk in distinct.values()])
             if len(memo) + len(distinct) > 4096:
                 memo.clear()
-            memo.update((sk, pt.point_to_string()) for sk, pt in zip(distinct, derived))
-        for sk, pk in zip(secret_keys, producer_keys):
-            if pk != memo[bytes(sk)]:
+            memo.update((t, pt.point_to_string()) for t, pt in zip(distinct, derived))
+        for t, pk in zip(tags, producer_keys):
+            if pk != memo[t]:
                 raise ValueError("producer_key does not match secret_key")
         root = ring_root
         if root is None or root.px.coeffs is None or root.py.coeffs is None or root.s.coeffs is None or len(root.s.evals) < ring.params.domain_size:

@@ -470,3 +470,72 @@ def test_prove_batch_in_two_concurrent_halves_gives_the_same_proofs(ctx, monkeyp
     assert one == two
     assert len(runtime.contexts()) >= max(2, before)
     assert d.RingVRF[cv].batch_verify(d.RingVRF[cv].decode_batch(two), al, al, ring, root)
+
+
+def test_natively_produced_proof_sees_in_place_mutation(ctx, golden_dir):
+    """The reference's tests mutate proof objects and expect verification to notice (tests/test_ark_vrf.py:146).  Proofs
+    from prove_batch keep their 784 encoded bytes: a mutation — of a scalar field, of a nested Pedersen field, or written
+    before any field was ever read — must change encode() and make verify AND batch_verify fail."""
+    import dot_ring_amd as d
+
+    cv = d.Bandersnatch
+    vrf = d.RingVRF[cv]
+    v = _load(golden_dir, "ark-vrf/bandersnatch_sha-512_ell2_ring.json")[0]
+    keys = vrf.parse_keys(bytes.fromhex(v["ring_pks"]))
+    params = d.RingProofParams(test_vectors=True, cv=cv)
+    ring = d.Ring(keys, params)
+    root = d.RingRoot.from_ring(ring, params)
+    sk = bytes.fromhex(v["sk"])
+    pk = cv.public_key_from_secret(sk)
+    al, ad = bytes.fromhex(v["alpha"]), bytes.fromhex(v["ad"])
+
+    def fresh():
+        return vrf.prove_batch([al], [ad], [sk], [pk], ring, root)[0]
+
+    good = fresh()
+    want = good.encode()
+    assert vrf.batch_verify([good], [al], [ad], ring, root)
+    # reading fields does not invalidate anything
+    _ = good.pedersen_proof.s, good.b_zeta
+    assert good.encode() == want and vrf.batch_verify([good], [al], [ad], ring, root)
+
+    p = fresh()
+    p.b_zeta = (p.b_zeta + 1) % d.KZG.scalar_modulus        # written after a read
+    assert p.encode() != want
+    assert not p.verify(al, ad, ring, root) and not vrf.batch_verify([p], [al], [ad], ring, root)
+
+    p = fresh()
+    p.l_zeta_omega = 5                                               # written before any field was read
+    assert p.l_zeta_omega == 5 and p.encode() != want and p.encode()[:192] == want[:192]
+    assert not vrf.batch_verify([p], [al], [ad], ring, root)
+
+    import dataclasses
+
+    p = fresh()
+    ped = p.pedersen_proof                                           # (the mirror's Pedersen proof objects are frozen: replace, not assign)
+    p.pedersen_proof = dataclasses.replace(ped, s=(ped.s + 1) % cv.curve.params.subgroup_order)      # responses off by one
+    assert p.encode() != want
+    assert not p.verify(al, ad, ring, root) and not vrf.batch_verify([p], [al], [ad], ring, root)
+    assert vrf.batch_verify([fresh()], [al], [ad], ring, root)
+
+
+def test_proof_to_hash_multiplies_by_the_curve_cofactor(ctx):
+    """proof_to_hash(gamma, mul_cofactor=True) hashes gamma * cofactor (tiny.py:88, pedersen/vrf.py:167): 4 on Bandersnatch,
+    8 on JubJub — checked against the oracle's affine arithmetic for Tiny, Pedersen and Ring."""
+    import dot_ring_amd as d
+    from oracle.pyref import bandersnatch as obsn
+    from oracle.pyref import vrf as ovrf
+
+    for cv, suite, h in ((d.Bandersnatch, obsn.SHA512, 4), (d.JubJub, obsn.JUBJUB, 8)):
+        sk = (77).to_bytes(32, "little")
+        gamma = d.TinyVRF[cv].prove(b"cofactor", sk, b"ad").output_point
+        with obsn.using(suite):
+            assert obsn.COFACTOR == h == cv.curve.params.cofactor
+            g = (gamma.x, gamma.y)
+            hg = obsn.mul_py(g, h)
+            want_plain = ovrf.point_to_hash(suite, g)
+            want_cof = ovrf.point_to_hash(suite, hg)
+        assert want_plain != want_cof
+        for scheme in (d.TinyVRF[cv], d.PedersenVRF[cv], d.RingVRF[cv]):
+            assert scheme.proof_to_hash(gamma) == want_plain
+            assert scheme.proof_to_hash(gamma, mul_cofactor=True) == want_cof

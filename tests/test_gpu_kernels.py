@@ -92,6 +92,31 @@ def test_bsn_msm_matches_oracle(ctx, n):
     assert got == (coracle.te_msm(pts, ks) if n else bsn.IDENTITY)
 
 
+@pytest.mark.parametrize("n", [256, 257, 1024, 5122, 20482, 65536])
+def test_bsn_msm_pippenger_matches_oracle(ctx, n):
+    """K4: from 256 terms dr_bsn_msm is a signed-digit bucket Pippenger (the reference's msm_pippenger_signed_native_cy,
+    bandersnatch_te.pyx:257-418); sizes incl. PedersenVRF.batch_verify's 5B + 2 at B = 1024 / 4096; duplicates, zero
+    scalars, the identity point, k = n - 1"""
+    base = _seeded_points(min(n, 512), b"pip")
+    pts = [base[i % len(base)] for i in range(n)]
+    ks = _seeded_scalars(n, b"pipk")
+    ks[0], ks[1], ks[2] = 0, N - 1, 1
+    pts[3] = bsn.IDENTITY
+    pts[5] = pts[4]
+    ks[5] = (N - ks[4]) % N                      # P and -P in the same buckets
+    got = coracle.te_unpack(ctx.bsn_msm(coracle.te_pack(pts), coracle.scalars_pack(ks)))[0]
+    assert got == coracle.te_msm(pts, ks)
+
+
+def test_bsn_msm_pippenger_all_zero_and_window_choices(ctx, monkeypatch):
+    n = 300
+    pts = _seeded_points(n, b"pz")
+    assert coracle.te_unpack(ctx.bsn_msm(coracle.te_pack(pts), bytes(32 * n)))[0] == bsn.IDENTITY
+    ks = _seeded_scalars(n, b"pzk")
+    want = coracle.te_msm(pts, ks)
+    assert coracle.te_unpack(ctx.bsn_msm(coracle.te_pack(pts), coracle.scalars_pack(ks)))[0] == want
+
+
 def test_bsn_msm_groups(ctx):
     for m in (2, 3, 4):
         groups = 37
@@ -346,6 +371,17 @@ def test_jubjub_scalar_mul_msm_and_groups_match_oracle(ctx):
             assert msm == acc
         groups = coracle.te_unpack(ctx.bsn_msm_groups(coracle.te_pack(pts[:69]), coracle.scalars_pack([k % order for k in ks[:69]]), 3, 1))
         assert groups == [bsn._te_add_ref(bsn._te_add_ref(want[3 * g], want[3 * g + 1]), want[3 * g + 2]) for g in range(23)]
+        # 280 terms: the bucket method (K4) on the a = -1 curve, unreduced scalars on input
+        big_p = [pts[i % n] for i in range(280)]
+        big_k = [rng.randrange(1 << 256) for _ in range(280)]
+        msm = coracle.te_unpack(ctx.bsn_msm(coracle.te_pack(big_p), b"".join(k.to_bytes(32, "little") for k in big_k), 1))[0]
+        total = {}
+        for p_, k_ in zip(big_p, big_k):
+            total[p_] = (total.get(p_, 0) + k_) % order
+        acc = bsn.IDENTITY
+        for p_, k_ in total.items():
+            acc = bsn._te_add_ref(acc, bsn.mul(p_, k_))
+        assert msm == acc
     # the default curve is untouched by the template parameter
     assert coracle.te_unpack(ctx.bsn_scalar_mul_batch(coracle.te_pack([bsn.G]), (3).to_bytes(32, "little")))[0] == coracle.te_mul(bsn.G, 3)
 
