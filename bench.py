@@ -19,6 +19,7 @@ Secondary measurements in the same JSON line (rank 0, one GPU):
   g1_msm             BASELINE configs[2]: one G1 Pippenger MSM over 2^20 (and 2^16) synthetic bases
   other_ring_sizes   the metric's other ring sizes: 256 (N = 1024) and 3000 (N = 4096, known-tau SRS: BASELINE configs[4]'s shape)
   distinct_signers   the headline workload with 1024 different signing keys instead of one
+  single_call_ms     latency of one RingVRF.prove / one RingVRF.verify (the reference's own benchmark shape, docs/BENCHMARK.md:63-73)
 With N ranks (one per GPU) every rank proves and verifies its own 1024 proofs — independent units, no collective — and the
 base-sharded MSM leg (`g1_msm_sharded`) runs one MSM over bases sharded across the ranks with an RCCL all-gather of the partial
 points (dot_ring_amd/parallel.py, dr_comm_*).  No PyTorch anywhere: the launcher only has to export RANK / LOCAL_RANK /
@@ -316,6 +317,31 @@ class RingWorkload:
         return ok, cpu_proofs, cpu_s
 
 
+def single_call_leg(w: "RingWorkload", reps: int = 10):
+    """Latency of ONE RingVRF.prove and ONE RingVRF.verify on the headline ring (the reference publishes 534.57 ms / 3.99 ms for
+    them, docs/BENCHMARK.md:72-73); fresh inputs per call so nothing is memoised, minimum and median over `reps`."""
+    vrf, ring, root = w.vrf, w.ring, w.root
+    proofs = []
+    t_prove, t_verify = [], []
+    for i in range(reps + 1):
+        al, ad = b"single-call-input" + i.to_bytes(4, "little"), b"single-call-ad"
+        t = time.perf_counter()
+        pr = vrf.prove(al, ad, w.signer_sk, w.signer_pk, ring, root)
+        t_prove.append(time.perf_counter() - t)
+        proofs.append((al, ad, vrf.decode(pr.encode())))
+    ok = True
+    for al, ad, pr in proofs:
+        t = time.perf_counter()
+        ok = pr.verify(al, ad, ring, root) and ok
+        t_verify.append(time.perf_counter() - t)
+    bad = proofs[0][2].verify(proofs[1][0], proofs[0][1], ring, root)               # wrong input must fail
+    t_prove, t_verify = sorted(t_prove[1:]), sorted(t_verify[1:])
+    return {"prove_ms_min": t_prove[0] * 1e3, "prove_ms_median": t_prove[len(t_prove) // 2] * 1e3,
+            "verify_ms_min": t_verify[0] * 1e3, "verify_ms_median": t_verify[len(t_verify) // 2] * 1e3,
+            "reference_ms": {"prove": 534.57, "verify": 3.99, "source": "docs/BENCHMARK.md:72-73 (M1 Max, one core)"},
+            "verified": bool(ok and not bad), "reps": reps}
+
+
 def ring_size_leg(d, ring_size: int, batch: int, steps: int, parity_proofs: int):
     w = RingWorkload(d, ring_size, batch)
     elapsed, all_ok = w.run(steps, 1)
@@ -492,7 +518,7 @@ def main() -> int:
                                                     "NOT measured in this run)") if traffic else None
             except Exception:
                 traffic = None
-        g1 = bsn = others = distinct = None
+        g1 = bsn = others = distinct = single = None
         if world == 1 and args.msm_log2n > 0:
             g1 = g1_msm_measurement(ctx, args.msm_log2n, 10, 17, True)
             parity_ok = parity_ok and g1.get("parity_closed_form", True) and g1.get("parity_sample", True)
@@ -503,6 +529,8 @@ def main() -> int:
         if world == 1 and args.extras:
             bsn = bsn_scalar_mul_measurement(ctx, d.Bandersnatch, 4096, 20)
             parity_ok = parity_ok and bsn["parity_ok"]
+            single = single_call_leg(w)
+            parity_ok = parity_ok and single["verified"]
             if args.ring_size == 1024 and batch >= 2:
                 # 1024 different signing keys (the reference bench — and the headline — sign every proof with one key)
                 w.distinct_signers()
@@ -561,6 +589,7 @@ def main() -> int:
             "g1_msm_sharded": sharded,
             "other_ring_sizes": others,
             "distinct_signers": distinct,
+            "single_call_ms": single,
             "ring_root_s": w.ring_root_s,
             "setup_s": setup_s,
         }

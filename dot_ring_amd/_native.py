@@ -114,6 +114,7 @@ _PROTOTYPES.update({
                                        c_char_p, c_size_t, c_char_p, c_char_p, c_char_p]),
 })
 _PROTOTYPES.update({
+    "dr_te_fixed_base_msm_groups": (c_int, [c_void_p, c_int, c_char_p, c_size_t, c_char_p, c_size_t, c_void_p]),
     "dr_comm_unique_id": (c_int, [c_char_p]),
     "dr_comm_create": (c_int, [c_void_p, c_char_p, c_int, c_int, POINTER(c_void_p)]),
     "dr_comm_destroy": (None, [c_void_p]),
@@ -434,6 +435,16 @@ class Context:
             _check(lib().dr_bsn_msm_groups(self.handle, pts_xy, scalars, groups, m, out))
         else:
             _check(lib().dr_te_msm_groups(self.handle, curve, pts_xy, scalars, groups, m, out))
+        return out.raw[: 64 * groups]
+
+    def te_fixed_base_msm_groups(self, bases_xy: bytes, scalars: bytes, curve: int = CURVE_BANDERSNATCH) -> bytes:
+        """out[g] = sum_j scalars[g*m+j] * bases[j] over m = len(bases_xy) / 64 constant bases (fixed-base window tables)."""
+        m = len(bases_xy) // 64
+        if m == 0 or len(bases_xy) != 64 * m or len(scalars) % (32 * m):
+            raise ValueError("Points and scalars must have same length (a multiple of the number of bases)")
+        groups = len(scalars) // (32 * m)
+        out = ctypes.create_string_buffer(max(64 * groups, 1))
+        _check(lib().dr_te_fixed_base_msm_groups(self.handle, curve, bases_xy, m, scalars, groups, out))
         return out.raw[: 64 * groups]
 
     def encode_to_curve_batch(self, suite: "VrfSuiteStruct", msgs, salts=None) -> bytes:

@@ -2,6 +2,7 @@
 // batch_verify run the whole protocol in the library: GPU phases through the entry points of the other parts, the hashing
 // between them on worker threads (hosthash.hpp, hostproto.hpp).
 #include "capi_internal.hpp"
+#include "hostsmall.hpp"
 
 using namespace dri;
 
@@ -71,8 +72,13 @@ struct PedersenBatch {
         const drh::Mod256& mn = su.cv->n;
         const int cv = su.cv->id;
         ybar.resize(B * 64); ks.resize(B * 32); kbs.resize(B * 32); pts3.resize(2 * B * 128); sc3.resize(2 * B * 64); third.resize(2 * B * 64);
-        // 4. blinded public keys  Y_bar_i = x_i*G + b_i*B
-        TRY(te_msm_groups(actx, cv, gb_pts.data(), sc.data(), B, 2, ybar.data()));
+        // 4. blinded public keys  Y_bar_i = x_i*G + b_i*B: both bases are constants of the suite -> fixed-base window tables
+        static const bool fixed = std::getenv("DOTRING_BSN_FIXED_BASE") == nullptr || std::atoi(std::getenv("DOTRING_BSN_FIXED_BASE")) != 0;
+        uint8_t gb[128];
+        std::memcpy(gb, su.generator, 64);
+        std::memcpy(gb + 64, su.blinding_base, 64);
+        if (fixed) TRY(te_fixed_base_groups(actx, cv, gb, sc.data(), B, 2, ybar.data()));
+        else TRY(te_msm_groups(actx, cv, gb_pts.data(), sc.data(), B, 2, ybar.data()));
         // 5. nonces
         std::vector<int> bad2(B, 0);
         drh::parallel_for(B, [&](size_t i) {
@@ -96,7 +102,13 @@ struct PedersenBatch {
             std::memset(sc3.data() + 64 * (B + i) + 32, 0, 32);
         });
         for (size_t i = 0; i < B; i++) if (bad2[i]) return fail(DR_ERR_INVALID, "nonce scalar is zero");
-        TRY(te_msm_groups(actx, cv, pts3.data(), sc3.data(), 2 * B, 2, third.data()));
+        if (fixed) {
+            // R_i = k_i*G + kb_i*B from the tables; O_k,i = k_i * I_i is the one variable-base multiplication left
+            TRY(te_fixed_base_groups(actx, cv, gb, sc3.data(), B, 2, third.data()));
+            TRY(te_scalar_mul_batch(actx, cv, inputs.data(), ks.data(), B, third.data() + 64 * B));
+        } else {
+            TRY(te_msm_groups(actx, cv, pts3.data(), sc3.data(), 2 * B, 2, third.data()));
+        }
         // 6. challenge, responses, the 192 encoded bytes
         drh::parallel_for(B, [&](size_t i) {
             uint8_t* out = out_proofs + stride * i;
@@ -399,42 +411,93 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         std::function<void()> give_up;
         ~Joiner() { give_up(); if (t.joinable()) t.join(); }
     } joiner{side, [&] { open_gate(0); }};
-    TRY(ctx->io_a.reserve(n_te * 32));
-    TRY(ctx->io_b.reserve(n_te * 64));
-    TRY(ctx->io_c.reserve(n_te * 4 + n_g1 * 4));
-    HIP_TRY(hipMemcpyAsync(ctx->io_a.p, te_enc.data(), n_te * 32, hipMemcpyHostToDevice, st));
-    uint32_t* d_ok = ctx->io_c.as<uint32_t>();
-    TRY(launch(ctx, "k_bsn_decode_points", [&] {
-        launch_decode_points(ctx, st, su.cv->id, false, ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), d_ok, n_te);
-    }));
-    std::vector<uint32_t> flags(n_te + n_g1);
-    HIP_TRY(hipMemcpyAsync(te_xy.data(), ctx->io_b.p, n_te * 64, hipMemcpyDeviceToHost, st));
-    // G1: bases buffer = 7B decompressed points followed by C_px, C_py, C_s and G1[0]
+    // One or two proofs: every launch chain below would be pure latency (0.7 - 2 ms each), so the points are decoded and the two
+    // G1 folds done on the host (hostsmall.hpp: ~80 us per point, ~0.4 ms per fold); the Pedersen side keeps its stream.
+    static const size_t host_max = std::getenv("DOTRING_VERIFY_HOST_MAX") ? (size_t)std::atol(std::getenv("DOTRING_VERIFY_HOST_MAX")) : 2;
+    const bool small = B <= host_max;
     Scratch &g1_bases = ctx->vfy_bases, &g1_in = ctx->vfy_in, &g1_std = ctx->vfy_std;
-    TRY(g1_bases.reserve(n_g1 * 96));
-    TRY(g1_in.reserve(7 * B * 48));
-    TRY(g1_std.reserve(n_g1 * 96));
-    HIP_TRY(hipMemcpyAsync(g1_in.p, g1_enc.data(), 7 * B * 48, hipMemcpyHostToDevice, st));
-    TRY(launch(ctx, "k_g1_decompress", [&] {
-        g1_launch_decompress(st, g1_in.as<uint8_t>(), g1_bases.as<uint32_t>(), d_ok + n_te, 7 * B);
-    }));
-    {
-        uint8_t tail_be[4 * 96];
-        std::memcpy(tail_be, vk->fixed_commitments, 3 * 96);
-        std::memcpy(tail_be + 288, vk->g1_generator, 96);
-        for (int k = 0; k < 3; k++) if (tail_be[96 * k] & 0x40) std::memset(tail_be + 96 * k, 0, 96);       // serialised infinity
-        std::vector<uint8_t> le;
-        TRY(g1_be_to_le_limbs(tail_be, 4, le, true));
-        HIP_TRY(hipMemcpyAsync(g1_bases.as<uint32_t>() + 7 * B * 24, le.data(), 4 * 96, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));          // `le` is a stack-lifetime staging buffer
-        g1_launch_bases_to_mont(st, g1_bases.as<uint32_t>() + 7 * B * 24, 4);
-    }
-    g1_launch_bases_from_mont(st, g1_bases.as<uint32_t>(), g1_std.as<uint32_t>(), 7 * B);
     std::vector<uint8_t> g1_le(7 * B * 96);
-    HIP_TRY(hipMemcpyAsync(g1_le.data(), g1_std.p, 7 * B * 96, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(flags.data(), d_ok, (n_te + 7 * B) * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (size_t i = 0; i < n_te + 7 * B; i++) if (!flags[i]) return DR_OK;                  // malformed / invalid point: ok = 0
+    std::vector<drh::G1AffineHost> host_bases;
+    if (small) {
+        std::vector<int> good(n_te + 7 * B, 0);
+        auto decode_one = [&](size_t j) {
+            if (j < n_te) {
+                good[j] = drh::te_decode_checked(*su.cv, te_enc.data() + 32 * j, te_xy.data() + 64 * j) ? 1 : 0;
+                return;
+            }
+            const size_t k = j - n_te;
+            uint8_t be[96];
+            int inf = 0;
+            if (dr_g1_decompress(g1_enc.data() + 48 * k, be, &inf) != DR_OK) return;
+            uint8_t* le = g1_le.data() + 96 * k;
+            if (inf) std::memset(le, 0, 96);
+            else for (int q = 0; q < 48; q++) { le[q] = be[47 - q]; le[48 + q] = be[95 - q]; }
+            good[j] = 1;
+        };
+        {   // a thread per few points: 4B + 7B decodings of 35 - 80 us each
+            const size_t total = n_te + 7 * B;
+            const unsigned nt = (unsigned)std::min<size_t>(std::min<size_t>(total, drh::host_threads()), 8);
+            std::vector<std::thread> pool;
+            for (unsigned k = 1; k < nt; k++)
+                pool.emplace_back([&, k] { for (size_t j = k; j < total; j += nt) decode_one(j); });
+            for (size_t j = 0; j < total; j += nt) decode_one(j);
+            for (auto& th : pool) th.join();
+        }
+        for (int g : good) if (!g) return DR_OK;                     // malformed / invalid point: ok = 0
+        host_bases.resize(n_g1);
+        for (size_t k = 0; k < 7 * B; k++) {
+            const uint8_t* le = g1_le.data() + 96 * k;
+            bool inf = true;
+            for (int q = 0; q < 96; q++) if (le[q]) { inf = false; break; }
+            host_bases[k].inf = inf;
+            if (!inf && (!drh::Fq::load_le(host_bases[k].x, le) || !drh::Fq::load_le(host_bases[k].y, le + 48))) return DR_OK;
+        }
+        for (int k = 0; k < 4; k++) {
+            const uint8_t* be = k < 3 ? vk->fixed_commitments + 96 * k : vk->g1_generator;
+            drh::G1AffineHost& hb = host_bases[7 * B + k];
+            hb.inf = (be[0] & 0x40) != 0;
+            if (!hb.inf) {
+                if (be[0] & 0xe0) return fail(DR_ERR_INVALID, "invalid BLS12-381 G1 encoding");
+                if (!drh::Fq::load_be(hb.x, be) || !drh::Fq::load_be(hb.y, be + 48) || !drh::g1_on_curve(hb.x, hb.y))
+                    return fail(DR_ERR_INVALID, "invalid BLS12-381 G1 encoding");
+            }
+        }
+    } else {
+        TRY(ctx->io_a.reserve(n_te * 32));
+        TRY(ctx->io_b.reserve(n_te * 64));
+        TRY(ctx->io_c.reserve(n_te * 4 + n_g1 * 4));
+        HIP_TRY(hipMemcpyAsync(ctx->io_a.p, te_enc.data(), n_te * 32, hipMemcpyHostToDevice, st));
+        uint32_t* d_ok = ctx->io_c.as<uint32_t>();
+        TRY(launch(ctx, "k_bsn_decode_points", [&] {
+            launch_decode_points(ctx, st, su.cv->id, false, ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), d_ok, n_te);
+        }));
+        std::vector<uint32_t> flags(n_te + n_g1);
+        HIP_TRY(hipMemcpyAsync(te_xy.data(), ctx->io_b.p, n_te * 64, hipMemcpyDeviceToHost, st));
+        // G1: bases buffer = 7B decompressed points followed by C_px, C_py, C_s and G1[0]
+        TRY(g1_bases.reserve(n_g1 * 96));
+        TRY(g1_in.reserve(7 * B * 48));
+        TRY(g1_std.reserve(n_g1 * 96));
+        HIP_TRY(hipMemcpyAsync(g1_in.p, g1_enc.data(), 7 * B * 48, hipMemcpyHostToDevice, st));
+        TRY(launch(ctx, "k_g1_decompress", [&] {
+            g1_launch_decompress(st, g1_in.as<uint8_t>(), g1_bases.as<uint32_t>(), d_ok + n_te, 7 * B);
+        }));
+        {
+            uint8_t tail_be[4 * 96];
+            std::memcpy(tail_be, vk->fixed_commitments, 3 * 96);
+            std::memcpy(tail_be + 288, vk->g1_generator, 96);
+            for (int k = 0; k < 3; k++) if (tail_be[96 * k] & 0x40) std::memset(tail_be + 96 * k, 0, 96);       // serialised infinity
+            std::vector<uint8_t> le;
+            TRY(g1_be_to_le_limbs(tail_be, 4, le, true));
+            HIP_TRY(hipMemcpyAsync(g1_bases.as<uint32_t>() + 7 * B * 24, le.data(), 4 * 96, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));          // `le` is a stack-lifetime staging buffer
+            g1_launch_bases_to_mont(st, g1_bases.as<uint32_t>() + 7 * B * 24, 4);
+        }
+        g1_launch_bases_from_mont(st, g1_bases.as<uint32_t>(), g1_std.as<uint32_t>(), 7 * B);
+        HIP_TRY(hipMemcpyAsync(g1_le.data(), g1_std.p, 7 * B * 96, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(flags.data(), d_ok, (n_te + 7 * B) * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t i = 0; i < n_te + 7 * B; i++) if (!flags[i]) return DR_OK;                  // malformed / invalid point: ok = 0
+    }
     tr_.mark("decode");
 
     // ---- 3. Pedersen part: the helper thread may go on (te_xy is complete)
@@ -517,33 +580,59 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
     // GPU lane per MSM (4 ms).
     std::vector<uint8_t> rhs_full(n_g1 * 32, 0);
     for (size_t i = 0; i < B; i++) std::memcpy(rhs_full.data() + 224 * i + 160, rhs_sc.data() + 64 * i, 64);
-    TRY(ctx->scalars.reserve(n_g1 * 32));
     uint8_t pair_g1[2 * 96];
     int pair_inf[2] = {0, 0};
-    // the two MSMs are independent and each is a short latency chain (sort, accumulate, reduce, fold): the rhs runs on
-    // a third stream from a helper thread while this thread does the lhs
-    if (!ctx->aux2) TRY(dr_ctx_create(ctx->device, &ctx->aux2));
-    dr_ctx* bctx = ctx->aux2;
-    bctx->prof = ctx->prof;
-    int rhs_rc = DR_OK;
-    std::string rhs_err;
-    std::thread rhs_thread([&] {
-        run_guarded(rhs_rc, rhs_err, [&]() -> int {
-            TRY(use_ctx(bctx));
-            TRY(bctx->scalars.reserve(n_g1 * 32));
-            HIP_TRY(hipMemcpyAsync(bctx->scalars.p, rhs_full.data(), n_g1 * 32, hipMemcpyHostToDevice, bctx->stream));
-            return msm_to_bytes(bctx, g1_bases.as<uint32_t>(), bctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1 + 96, pair_inf + 1);
+    if (small) {
+        // both folds on the host: the rhs (2B live terms) on a helper thread, the lhs split over two more
+        drh::G1 rhs_pt = drh::G1::inf();
+        int rhs_rc = DR_OK;
+        std::string rhs_err;
+        std::thread rhs_thread([&] {
+            run_guarded(rhs_rc, rhs_err, [&]() -> int { rhs_pt = drh::g1_msm_small(host_bases.data(), rhs_full.data(), n_g1, 1); return DR_OK; });
         });
-    });
-    struct RhsJoiner {
-        std::thread& t;
-        ~RhsJoiner() { if (t.joinable()) t.join(); }
-    } rhs_joiner{rhs_thread};
-    HIP_TRY(hipMemcpyAsync(ctx->scalars.p, lhs_sc.data(), n_g1 * 32, hipMemcpyHostToDevice, st));
-    TRY(msm_to_bytes(ctx, g1_bases.as<uint32_t>(), ctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1, pair_inf));
-    rhs_thread.join();
+        struct RhsJoiner {
+            std::thread& t;
+            ~RhsJoiner() { if (t.joinable()) t.join(); }
+        } rhs_joiner{rhs_thread};
+        drh::G1 lhs_pt = drh::g1_msm_small(host_bases.data(), lhs_sc.data(), n_g1, 2);
+        rhs_thread.join();
+        if (rhs_rc != DR_OK) return fail(rhs_rc, rhs_err);
+        auto put = [&](const drh::G1& pt, int slot) {
+            drh::Fq ax, ay;
+            if (!drh::g1_to_affine(pt, ax, ay)) { std::memset(pair_g1 + 96 * slot, 0, 96); pair_inf[slot] = 1; return; }
+            ax.store_be(pair_g1 + 96 * slot);
+            ay.store_be(pair_g1 + 96 * slot + 48);
+            pair_inf[slot] = 0;
+        };
+        put(lhs_pt, 0);
+        put(rhs_pt, 1);
+    } else {
+        TRY(ctx->scalars.reserve(n_g1 * 32));
+        // the two MSMs are independent and each is a short latency chain (sort, accumulate, reduce, fold): the rhs runs on
+        // a third stream from a helper thread while this thread does the lhs
+        if (!ctx->aux2) TRY(dr_ctx_create(ctx->device, &ctx->aux2));
+        dr_ctx* bctx = ctx->aux2;
+        bctx->prof = ctx->prof;
+        int rhs_rc = DR_OK;
+        std::string rhs_err;
+        std::thread rhs_thread([&] {
+            run_guarded(rhs_rc, rhs_err, [&]() -> int {
+                TRY(use_ctx(bctx));
+                TRY(bctx->scalars.reserve(n_g1 * 32));
+                HIP_TRY(hipMemcpyAsync(bctx->scalars.p, rhs_full.data(), n_g1 * 32, hipMemcpyHostToDevice, bctx->stream));
+                return msm_to_bytes(bctx, g1_bases.as<uint32_t>(), bctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1 + 96, pair_inf + 1);
+            });
+        });
+        struct RhsJoiner {
+            std::thread& t;
+            ~RhsJoiner() { if (t.joinable()) t.join(); }
+        } rhs_joiner{rhs_thread};
+        HIP_TRY(hipMemcpyAsync(ctx->scalars.p, lhs_sc.data(), n_g1 * 32, hipMemcpyHostToDevice, st));
+        TRY(msm_to_bytes(ctx, g1_bases.as<uint32_t>(), ctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1, pair_inf));
+        rhs_thread.join();
+        if (rhs_rc != DR_OK) return fail(rhs_rc, rhs_err.empty() ? "rhs MSM failed" : rhs_err);
+    }
     tr_.mark("g1 msms");
-    if (rhs_rc != DR_OK) return fail(rhs_rc, rhs_err.empty() ? "rhs MSM failed" : rhs_err);
     const int inf_r = pair_inf[1];
     // (a vanishing rhs can only come from r1 = r2 = 0 or infinity openings: the pairing equation then demands lhs = O)
     if (!inf_r) {                                                                 // e(lhs, G2[0]) * e(-rhs, G2[1]) == 1
@@ -673,7 +762,13 @@ int dr_ietf_prove_batch(dr_ctx* ctx, const dr_vrf_suite* suite, int thin, size_t
             std::memcpy(sc.data() + 32 * i, xs.data() + 32 * i, 32);
             std::memcpy(sc.data() + 32 * (B + i), xs.data() + 32 * i, 32);
         }
-        TRY(te_scalar_mul_batch(ctx, cv, pts.data(), sc.data(), 2 * B, firsts.data()));
+        static const bool fixed = std::getenv("DOTRING_BSN_FIXED_BASE") == nullptr || std::atoi(std::getenv("DOTRING_BSN_FIXED_BASE")) != 0;
+        if (fixed) {                    // pk = x G from the generator's window table; O = x I is variable-base
+            TRY(te_fixed_base_groups(ctx, cv, su.generator, xs.data(), B, 1, firsts.data()));
+            TRY(te_scalar_mul_batch(ctx, cv, inputs.data(), xs.data(), B, firsts.data() + 64 * B));
+        } else {
+            TRY(te_scalar_mul_batch(ctx, cv, pts.data(), sc.data(), 2 * B, firsts.data()));
+        }
         const uint8_t* pks = firsts.data();
         const uint8_t* outs = firsts.data() + 64 * B;
         // transcripts, delinearisation scalar z, nonces

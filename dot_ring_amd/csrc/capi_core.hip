@@ -152,6 +152,7 @@ void dr_ctx_destroy(dr_ctx* ctx) {
         (void)hipEventDestroy(it.second.second);
     }
     for (auto& e : ctx->twiddles.entries) (void)hipFree(e.d_tw);
+    for (auto& fb : ctx->fixed_bases) (void)hipFree(fb.d_table);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -362,6 +363,64 @@ int te_msm_groups(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_t* sca
     if (ctx->prof) TRY(prof_collect(ctx));
     return DR_OK;
 }
+// ---- fixed-base multiplication (kernels_te.hip.h: k_te_fixed_table / k_te_fixed_base_groups)
+static int te_fixed_table(dr_ctx* ctx, int cv, const uint8_t base_xy[64], const uint32_t** out) {
+    for (auto& fb : ctx->fixed_bases)
+        if (fb.cv == cv && std::memcmp(fb.base_xy, base_xy, 64) == 0) { *out = fb.d_table; return DR_OK; }
+    TRY(check_fr_elems(base_xy, 2, "base point"));
+    uint32_t *d_base = nullptr, *d_table = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_table, (size_t)dr::TE_FIXED_TABLE_WORDS * 4));
+    hipError_t e = hipMalloc((void**)&d_base, 64);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_base, base_xy, 64, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        LAUNCH_CV(cv, dr::k_te_fixed_table, dim3(1), dim3(64), 0, ctx->stream, d_base, d_table);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (d_base) (void)hipFree(d_base);
+    if (e != hipSuccess) {
+        (void)hipFree(d_table);
+        return fail(e == hipErrorOutOfMemory ? DR_ERR_NOMEM : DR_ERR_DEVICE, std::string("fixed-base table: ") + hipGetErrorString(e));
+    }
+    dr_ctx::FixedBase fb;
+    fb.cv = cv;
+    std::memcpy(fb.base_xy, base_xy, 64);
+    fb.d_table = d_table;
+    ctx->fixed_bases.push_back(fb);
+    *out = d_table;
+    return DR_OK;
+}
+
+int te_fixed_base_groups(dr_ctx* ctx, int cv, const uint8_t* bases_xy, const uint8_t* scalars, size_t groups, size_t m, uint8_t* out_xy, bool sync) {
+    TRY(use_ctx(ctx));
+    TRY(check_curve(cv));
+    if (groups == 0) return DR_OK;
+    if (m == 0 || m > 4) return fail(DR_ERR_INVALID, "1..4 fixed bases per group");
+    if (!bases_xy || !scalars || !out_xy) return fail(DR_ERR_INVALID, "null buffer");
+    if (groups * m >= (1ull << 31)) return fail(DR_ERR_INVALID, "batch too large");
+    dr::TeFixedTables tabs{};
+    for (size_t j = 0; j < m; j++) TRY(te_fixed_table(ctx, cv, bases_xy + 64 * j, &tabs.t[j]));
+    for (size_t j = m; j < 4; j++) tabs.t[j] = tabs.t[0];
+    uint32_t mpad = 1;
+    while (mpad < m) mpad <<= 1;
+    const uint32_t per_block = 64 / (mpad * dr::TE_FIXED_LANES);
+    TRY(ctx->io_b.reserve(groups * m * 32));
+    TRY(ctx->io_c.reserve(groups * 64));
+    HIP_TRY(hipMemcpyAsync(ctx->io_b.p, scalars, groups * m * 32, hipMemcpyHostToDevice, ctx->stream));
+    TRY(launch(ctx, "k_bsn_fixed_base", [&] {
+        LAUNCH_CV(cv, dr::k_te_fixed_base_groups, dim3(div_up(groups, per_block)), dim3(64), 0, ctx->stream, tabs, ctx->io_b.as<uint32_t>(),
+                  ctx->io_c.as<uint32_t>(), (uint32_t)groups, (uint32_t)m, mpad);
+    }));
+    HIP_TRY(hipMemcpyAsync(out_xy, ctx->io_c.p, groups * 64, hipMemcpyDeviceToHost, ctx->stream));
+    if (sync) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->prof) TRY(prof_collect(ctx));
+    }
+    return DR_OK;
+}
+int dr_te_fixed_base_msm_groups(dr_ctx* ctx, int curve, const uint8_t* bases_xy, size_t m, const uint8_t* scalars, size_t groups, uint8_t* out_xy) {
+    return te_fixed_base_groups(ctx, curve, bases_xy, scalars, groups, m, out_xy, true);
+}
+
 int dr_bsn_msm_groups(dr_ctx* ctx, const uint8_t* pts_xy, const uint8_t* scalars, size_t groups, size_t m, uint8_t* out_xy) {
     return te_msm_groups(ctx, dr::CV_BANDERSNATCH, pts_xy, scalars, groups, m, out_xy);
 }

@@ -97,6 +97,13 @@ struct dr_ctx {
     dr_ctx* aux2 = nullptr;                  // third stream: the verifier's two G1 MSMs run side by side
     std::vector<dr_ctx*> helpers;            // further streams working for this context (a prover's Pedersen stream): profiling only
     dr::TwiddleCache twiddles;
+    // fixed-base window tables of constant points (generator, blinding base): built on first use, 48 KB each
+    struct FixedBase {
+        int cv;
+        uint8_t base_xy[64];
+        uint32_t* d_table;
+    };
+    std::vector<FixedBase> fixed_bases;
 };
 
 struct dr_srs {
@@ -225,6 +232,9 @@ int glv_split_scalars(const uint8_t* scalars, size_t n, std::vector<uint32_t>& o
 int te_scalar_mul_batch(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_t* scalars, size_t n, uint8_t* out_xy);
 int te_msm(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_t* scalars, size_t n, uint8_t out_xy[64]);
 int te_msm_groups(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_t* scalars, size_t groups, size_t m, uint8_t* out_xy);
+// sum_j k[g*m+j] * Base_j for `groups` groups over m <= 4 CONSTANT bases (fixed-base window tables, cached per context)
+int te_fixed_base_groups(dr_ctx* ctx, int cv, const uint8_t* bases_xy /* m*64 */, const uint8_t* scalars /* groups*m*32 */, size_t groups,
+                         size_t m, uint8_t* out_xy /* groups*64 */, bool sync = true);
 int te_decode_points(dr_ctx* ctx, int cv, bool tai, const uint8_t* enc, size_t n, uint8_t* out_xy, uint8_t* ok);
 void launch_decode_points(dr_ctx* ctx, hipStream_t st, int cv, bool tai, const uint32_t* d_enc, uint32_t* d_xy, uint32_t* d_ok, size_t n);
 int load_suite(const dr_vrf_suite* s, drh::VrfSuite& out);

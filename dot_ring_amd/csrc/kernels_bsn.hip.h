@@ -175,17 +175,6 @@ DR_DEV TePoint bsn_window_core(uint32_t* tab, int lane, const TePoint& P, const 
     }
     return acc;
 }
-DR_DEV TePoint te_shfl_down(const TePoint& p, unsigned delta) {
-    TePoint o;
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        o.x.l[t] = __shfl_down(p.x.l[t], delta, 64);
-        o.y.l[t] = __shfl_down(p.y.l[t], delta, 64);
-        o.z.l[t] = __shfl_down(p.z.l[t], delta, 64);
-        o.t.l[t] = __shfl_down(p.t.l[t], delta, 64);
-    }
-    return o;
-}
 // one half of a GLV pair: the lane's base (P or psi(P), negated when its half-scalar is negative) times |k_half|
 // split: per term 12 words — |k1| (4), |k2| (4), neg1, neg2, 2 pad
 DR_DEV TePoint bsn_glv_half(uint32_t* tab, int lane, const uint32_t* __restrict__ pts, const uint32_t* __restrict__ split, size_t term, bool second) {

@@ -279,4 +279,122 @@ DR_DEV Fr fr_pow_limbs(const Fr& a, const uint32_t (&e)[8]) {
     return r;
 }
 
+
+DR_DEV TePoint te_shfl_down(const TePoint& p, unsigned delta) {
+    TePoint o;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        o.x.l[t] = __shfl_down(p.x.l[t], delta, 64);
+        o.y.l[t] = __shfl_down(p.y.l[t], delta, 64);
+        o.z.l[t] = __shfl_down(p.z.l[t], delta, 64);
+        o.t.l[t] = __shfl_down(p.t.l[t], delta, 64);
+    }
+    return o;
+}
+
+// acc + (x2, y2, d*t2) with Z2 = 1  (add-2008-hwcd: D = Z1, C = T1 * d t2)
+template <int CV>
+DR_DEV TePoint te_madd(const TePoint& p, const Fr& x2, const Fr& y2, const Fr& dt2) {
+    Fr A = mul(p.x, x2), B = mul(p.y, y2), C = mul(p.t, dt2);
+    Fr E = sub(sub(mul(add(p.x, p.y), add(x2, y2)), A), B);
+    Fr F = sub(p.z, C), G = add(p.z, C), H = sub(B, te_mul_a<CV>(A));
+    TePoint r;
+    r.x = mul(E, F);
+    r.y = mul(G, H);
+    r.t = mul(E, H);
+    r.z = mul(F, G);
+    return r;
+}
+
+
+// ---- fixed-base scalar multiplication -------------------------------------------------------------------------------
+// The sigma protocols multiply two CONSTANT points all the time — the generator G and the Pedersen blinding base B
+// (vrf/pedersen/vrf.py:94,104,111: x*G + b*B, k*G + k_b*B; pk = sk*G) — and their launches are latency chains, not
+// throughput: a variable-base multiplication is ~250 dependent doublings.  With a table of every window multiple,
+//     table[w][e] = (e + 1) * 16^w * P   (w < 64, e < 8; affine, as (x, y, d x y) in Montgomery form: 48 KB per base),
+// k*P is the sum of 64 signed table entries — no doublings — and the sum splits over 4 lanes of 16 windows each plus two
+// shuffle additions: a dependent chain of 18 additions instead of ~320 operations.
+constexpr int TE_FIXED_WINDOWS = 64, TE_FIXED_ENTRIES = 8, TE_FIXED_LANES = 4;
+constexpr int TE_FIXED_TABLE_WORDS = TE_FIXED_WINDOWS * TE_FIXED_ENTRIES * 24;
+
+// one block of 64 lanes: lane w derives 16^w * P by 4w doublings, then its 8 multiples, each normalised to affine
+template <int CV>
+__global__ __launch_bounds__(64) void k_te_fixed_table(const uint32_t* __restrict__ base_xy /* 16 words std */, uint32_t* __restrict__ table) {
+    const int w = threadIdx.x;
+    TePoint P;
+    P.x = to_mont(load_fr_std(base_xy)); P.y = to_mont(load_fr_std(base_xy + 8)); P.z = Fr::one(); P.t = mul(P.x, P.y);
+#pragma unroll 1
+    for (int i = 0; i < 4 * w; i++) P = te_dbl<true, CV>(P);
+    TePoint cur = P;
+#pragma unroll 1
+    for (int e = 0; e < TE_FIXED_ENTRIES; e++) {
+        if (e > 0) cur = te_add<CV>(cur, P);
+        const Fr zi = inv(cur.z);
+        const Fr x = mul(cur.x, zi), y = mul(cur.y, zi);
+        uint32_t* o = table + ((size_t)w * TE_FIXED_ENTRIES + e) * 24;
+        store_fr_std(o, x);
+        store_fr_std(o + 8, y);
+        store_fr_std(o + 16, mul(te_d_mont<CV>(), mul(x, y)));
+    }
+}
+
+struct TeFixedTables {              // up to 4 bases per group (kernel argument)
+    const uint32_t* t[4];
+};
+
+// out[g] = sum_{j<m} k[g*m + j] * Base_j for `groups` groups; term j of every group multiplies base j (m <= 4).
+// Lane layout inside a wave: group-major, then term, then the 4 window quarters; a group is mpad * 4 lanes (mpad = m
+// rounded up to a power of two), folded with shuffles.
+template <int CV>
+__global__ __launch_bounds__(64) void k_te_fixed_base_groups(TeFixedTables tabs, const uint32_t* __restrict__ ks, uint32_t* __restrict__ out,
+                                                             uint32_t groups, uint32_t m, uint32_t mpad) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t width = mpad * TE_FIXED_LANES;                    // lanes per group: 4, 8 or 16
+    const uint32_t per_block = 64 / width;
+    const uint32_t g = blockIdx.x * per_block + lane / width;
+    const uint32_t j = (lane % width) / TE_FIXED_LANES, q = lane % TE_FIXED_LANES;
+    const bool live = g < groups && j < m;
+    uint32_t k[8];
+    {
+        const Fr kk = load_fr_std(ks + (live ? (size_t)g * m + j : 0) * 8);
+#pragma unroll
+        for (int t = 0; t < 8; t++) k[t] = kk.l[t];
+    }
+    reduce_mod_order<CV>(k);
+    // signed 4-bit recoding of the whole scalar (the carry chain starts at the bottom), as in bsn_scalar_mul_core
+    uint32_t dig[8];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t v = ((k[w] >> (4 * i)) & 15u) + carry;
+            carry = v >= 8u ? 1u : 0u;
+            packed |= ((v + 8u) & 15u) << (4 * i);
+        }
+        dig[w] = packed;
+    }
+    const uint32_t* table = tabs.t[live ? j : 0];
+    TePoint acc = te_identity();
+    // this lane's 16 windows are the two digit words 2q, 2q + 1 (selected without indexing the register array)
+    const uint32_t d_lo = q == 0 ? dig[0] : q == 1 ? dig[2] : q == 2 ? dig[4] : dig[6];
+    const uint32_t d_hi = q == 0 ? dig[1] : q == 1 ? dig[3] : q == 2 ? dig[5] : dig[7];
+#pragma unroll 1
+    for (int i = 0; i < 16; i++) {
+        const uint32_t word = i < 8 ? d_lo : d_hi;
+        const int d = (int)((word >> (4 * (i & 7))) & 15u) - 8;
+        if (d == 0) continue;
+        const int mag = d < 0 ? -d : d;
+        const uint32_t* e = table + ((size_t)(16 * q + i) * TE_FIXED_ENTRIES + (mag - 1)) * 24;
+        Fr x = load_fr_std(e), y = load_fr_std(e + 8), dt = load_fr_std(e + 16);
+        if (d < 0) { x = neg(x); dt = neg(dt); }
+        acc = te_madd<CV>(acc, x, y, dt);
+    }
+    if (!live) acc = te_identity();
+#pragma unroll 1
+    for (uint32_t s = width >> 1; s > 0; s >>= 1) acc = te_add<CV>(acc, te_shfl_down(acc, s));
+    if (g < groups && (lane % width) == 0) te_store_affine(out + (size_t)g * 16, acc);
+}
+
 }  // namespace dr

@@ -40,20 +40,6 @@ __global__ void k_te_msm_prepare(const uint32_t* __restrict__ pts /* n*16 std */
     store_fr_std(o + 16, mul(te_d_mont<CV>(), mul(x, y)));
 }
 
-// acc + (x2, y2, d*t2) with Z2 = 1  (add-2008-hwcd: D = Z1, C = T1 * d t2)
-template <int CV>
-DR_DEV TePoint te_madd(const TePoint& p, const Fr& x2, const Fr& y2, const Fr& dt2) {
-    Fr A = mul(p.x, x2), B = mul(p.y, y2), C = mul(p.t, dt2);
-    Fr E = sub(sub(mul(add(p.x, p.y), add(x2, y2)), A), B);
-    Fr F = sub(p.z, C), G = add(p.z, C), H = sub(B, te_mul_a<CV>(A));
-    TePoint r;
-    r.x = mul(E, F);
-    r.y = mul(G, H);
-    r.t = mul(E, H);
-    r.z = mul(F, G);
-    return r;
-}
-
 // A bucket longer than this is not walked by one lane but by a whole wave (k_te_msm_accumulate_heavy): skewed scalars — many
 // equal ones, or values much shorter than the windows cover — put thousands of points into one bucket, and a single lane
 // adding them one after the other would be the whole kernel's run time.
@@ -86,17 +72,6 @@ __global__ __launch_bounds__(256) void k_te_msm_accumulate(const uint32_t* __res
     store_te_ext(buckets, b, te_msm_walk<CV>(table, sorted, offsets[b], len, 0, 1));
 }
 
-DR_DEV TePoint te_shfl_down(const TePoint& p, unsigned delta) {
-    TePoint o;
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        o.x.l[t] = __shfl_down(p.x.l[t], delta, 64);
-        o.y.l[t] = __shfl_down(p.y.l[t], delta, 64);
-        o.z.l[t] = __shfl_down(p.z.l[t], delta, 64);
-        o.t.l[t] = __shfl_down(p.t.l[t], delta, 64);
-    }
-    return o;
-}
 // one wave per bucket; returns at once unless the bucket is heavy: lanes stride over the list, a shuffle tree folds the 64 sums
 template <int CV>
 __global__ __launch_bounds__(64) void k_te_msm_accumulate_heavy(const uint32_t* __restrict__ table, const uint32_t* __restrict__ sorted,

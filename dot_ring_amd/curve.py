@@ -312,8 +312,21 @@ def scalar_mul_batch(points, scalars):
     if not points:
         return []
     cls = type(points[0])
+    first = points[0]
+    if all(p is first for p in points) and (first.x, first.y) in _fixed_bases(cls):
+        # k_i * G (key derivation, curve.py:384) or k_i * B: the constant's fixed-base window table — 64 table additions
+        # over four lanes instead of ~250 dependent doublings (dr_te_fixed_base_msm_groups)
+        raw = runtime.context().te_fixed_base_msm_groups(pack_points([first]), pack_scalars(scalars, cls._N), cls._CV)
+        return unpack_points(cls, raw)
     raw = runtime.context().bsn_scalar_mul_batch(pack_points(points), pack_scalars(scalars, cls._N), cls._CV)
     return unpack_points(cls, raw)
+
+
+def _fixed_bases(cls):
+    """the suite's constant points that get a fixed-base table: generator and Pedersen blinding base"""
+    params = cls.curve.params
+    bb = params.auxiliary_points.blinding_base
+    return (tuple(params.generator),) + ((tuple(bb),) if bb else ())
 
 
 def msm_groups(points, scalars, m: int):

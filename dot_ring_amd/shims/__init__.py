@@ -5,5 +5,5 @@
 * `ntt_plan.BlsScalarNTTPlan` — dot_ring/ring_proof/polynomial/ntt.pyx:29-163
 
 A maintainer of the reference switches three import lines; tests/test_gpu_shims.py calls every function
-with the reference's own argument shapes and compares with the oracle.
+with the reference's own argument shapes and compares with the CPU restatement of the reference (tests only).
 """

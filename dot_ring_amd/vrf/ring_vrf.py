@@ -532,9 +532,20 @@ class RingVRF(VRF):
         return bool(ring.params.pcs.batch_verify_linear_preconverted(list(self._linear_claims(message, ring, ring_root))))
 
     def verify(self, input: bytes, ad_data: bytes, ring: Ring, ring_root: RingRoot) -> bool:
+        cls = type(self)
+        if cls._native_verifier_serves(ring, ring_root):
+            # one proof through the native verifier (dr_ringvrf_verify_batch with B = 1): below DOTRING_VERIFY_HOST_MAX proofs it
+            # decodes the points and folds the two small G1 MSMs on host cores while the Pedersen checks run on the GPU — every
+            # kernel launch chain it would otherwise wait for is 0.7 - 2 ms of pure latency
+            return ring_root.matches_ring(ring) and cls._batch_verify_native([self], [input], [ad_data], ring, ring_root)
         p_ok = self.pedersen_proof.verify(input, ad_data)
         r_ok = self.verify_ring_proof(self.pedersen_proof.blinded_pk, ring, ring_root)
         return p_ok and r_ok
+
+    @classmethod
+    def _native_verifier_serves(cls, ring: Ring, ring_root: RingRoot) -> bool:
+        return (device_prover.supported(ring.params) and os.environ.get("DOTRING_NATIVE_HOST", "1") != "0"
+                and cls.proof_len() == 784 and ring_root.params is not None)
 
     @classmethod
     def proof_to_hash(cls, gamma, mul_cofactor: bool = False) -> bytes:
@@ -583,8 +594,7 @@ class RingVRF(VRF):
     def batch_verify(cls, proofs, inputs, additional_data, ring: Ring, ring_root: RingRoot) -> bool:
         if not ring_root.matches_ring(ring):
             return False
-        if (device_prover.supported(ring.params) and os.environ.get("DOTRING_NATIVE_HOST", "1") != "0"
-                and cls.proof_len() == 784 and ring_root.params is not None):
+        if cls._native_verifier_serves(ring, ring_root):
             return cls._batch_verify_native(proofs, inputs, additional_data, ring, ring_root)
         if not PedersenVRF[cls.cv].batch_verify([p.pedersen_proof for p in proofs], inputs, additional_data):
             return False

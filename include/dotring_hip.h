@@ -108,6 +108,14 @@ DR_API int dr_te_msm(dr_ctx *ctx, int curve, const uint8_t *pts_xy, const uint8_
 DR_API int dr_te_msm_groups(dr_ctx *ctx, int curve, const uint8_t *pts_xy, const uint8_t *scalars, size_t groups, size_t m, uint8_t *out_xy);
 DR_API int dr_te_decode_points(dr_ctx *ctx, int curve, const uint8_t *enc, size_t n, uint8_t *out_xy, uint8_t *ok);
 
+/* Fixed-base multiplication for CONSTANT points — the generator G and the Pedersen blinding base B of the sigma protocols
+ * (dot_ring/vrf/pedersen/vrf.py:94,104,111: x*G + b*B, k*G + k_b*B; curve.py:384 pk = sk*G):
+ * out[g] = sum_{j<m} scalars[g*m+j] * bases[j], m <= 4.  The first call with a base builds its window table in HBM
+ * (every multiple (e+1)*16^w*P, 48 KB, cached in the context); a multiplication is then 64 table additions and no doubling,
+ * spread over four lanes.  Results are the canonical affine points, as dr_bsn_msm_groups gives them. */
+DR_API int dr_te_fixed_base_msm_groups(dr_ctx *ctx, int curve, const uint8_t *bases_xy /* m*64 */, size_t m,
+                                       const uint8_t *scalars /* groups*m*32 */, size_t groups, uint8_t *out_xy /* groups*64 */);
+
 /* square root in the Bandersnatch base field; DR_ERR_NOTSQUARE if none exists. Host-side, no ctx. */
 DR_API int dr_fr_sqrt(const uint8_t in[32], uint8_t out[32]);
 

@@ -117,6 +117,29 @@ def test_bsn_msm_pippenger_all_zero_and_window_choices(ctx, monkeypatch):
     assert coracle.te_unpack(ctx.bsn_msm(coracle.te_pack(pts), coracle.scalars_pack(ks)))[0] == want
 
 
+def test_fixed_base_tables_match_oracle(ctx):
+    """dr_te_fixed_base_msm_groups: k*G, x*G + b*B (the Pedersen prover's constant bases, vrf/pedersen/vrf.py:94-111) from the
+    window tables against the oracle's variable-base arithmetic; edge scalars 0, 1, n-1, n, 2^256-1, every digit +-8"""
+    gen = bsn.G
+    bb = bsn.SHA512.blinding_base
+    ks = _seeded_scalars(150, b"fixed", mod=1 << 256)
+    ks[:8] = [0, 1, N - 1, N, (1 << 256) - 1, int("8" * 63, 16), int("7" * 63, 16), 2]
+    raw = b"".join(k.to_bytes(32, "little") for k in ks)
+    got = coracle.te_unpack(ctx.te_fixed_base_msm_groups(coracle.te_pack([gen]), raw))
+    assert got == [coracle.te_mul(gen, k % N) for k in ks]
+    got = coracle.te_unpack(ctx.te_fixed_base_msm_groups(coracle.te_pack([gen, bb]), raw))
+    assert got == [bsn.add(coracle.te_mul(gen, ks[2 * i] % N), coracle.te_mul(bb, ks[2 * i + 1] % N)) for i in range(75)]
+    got = coracle.te_unpack(ctx.te_fixed_base_msm_groups(coracle.te_pack([gen, bb, gen]), raw))      # 3 bases: groups padded to 4 terms
+    assert got == [bsn.add(bsn.add(coracle.te_mul(gen, ks[3 * i] % N), coracle.te_mul(bb, ks[3 * i + 1] % N)), coracle.te_mul(gen, ks[3 * i + 2] % N))
+                   for i in range(50)]
+    with bsn.using(bsn.JUBJUB):                                      # a = -1 curve, 252-bit order
+        jk = [k % (1 << 256) for k in ks[:40]]
+        got = coracle.te_unpack(ctx.te_fixed_base_msm_groups(coracle.te_pack([bsn.G]), b"".join(k.to_bytes(32, "little") for k in jk), 1))
+        assert got == [bsn.mul(bsn.G, k) for k in jk]
+    with pytest.raises(ValueError):
+        ctx.te_fixed_base_msm_groups(coracle.te_pack([gen] * 5), raw[: 32 * 5])
+
+
 def test_bsn_msm_groups(ctx):
     for m in (2, 3, 4):
         groups = 37
