@@ -55,7 +55,8 @@ ALG_BYTES_PER_PAIR = 128       # 96 B affine base + 32 B scalar per (base, scala
 ALG_BYTES_PER_SCALAR_MUL = 160  # 64 B point + 32 B scalar + 64 B result
 MSM_KERNELS = ("k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_sort_sets", "k_size_sort", "k_g1_accumulate", "k_g1_reduce_chunks",
                "k_g1_reduce_windows", "k_g1_horner", "k_g1_results_affine")
-RING_KERNELS = ("k_bsn_scalar_mul", "k_bsn_encode_to_curve", "k_bsn_msm_groups", "k_bsn_pippenger", "k_ring_chain", "k_ring_columns", "k_ntt_local",
+RING_KERNELS = ("k_bsn_scalar_mul", "k_bsn_encode_to_curve", "k_bsn_msm_groups", "k_bsn_fixed_base", "k_te_msm_prepare", "k_te_msm_accumulate",
+                "k_te_msm_reduce", "k_ring_chain", "k_ring_columns", "k_ntt_local",
                 "k_ntt_strided", "k_ring_pad", "k_ring_constraints", "k_ring_quotient", "k_ring_eval", "k_ring_linpoly",
                 "k_ring_aggpoly", "k_syndiv", "k_ring_diff", "k_bsn_decode_points", "k_g1_decompress")
 

@@ -118,6 +118,13 @@ DR_DEV Fq28 sqr(const Fq28& a) {
     montsqr14x28_asm<Fq28Params>(r.l, a.l);
     return r;
 }
+// a b + c d with one Montgomery reduction (montmul2_14x28_asm): 657 instructions against 2 x 461.  Operand bounds: the column
+// sums hold 14 (|a_i b_j| + |c_i d_j| + m p) — one operand may carry limbs up to 2^29, the others stay below 2^28.
+DR_DEV Fq28 mul2(const Fq28& a, const Fq28& b, const Fq28& c, const Fq28& d) {
+    Fq28 r;
+    montmul2_14x28_asm<Fq28Params>(r.l, a.l, b.l, c.l, d.l);
+    return r;
+}
 DR_DEV Fq28 mul_cxx(const Fq28& a, const Fq28& b) {
     using FP = Fq28Params;
     Fq28 r;

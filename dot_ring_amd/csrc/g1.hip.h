@@ -183,7 +183,7 @@ DR_DEV G1Xyzz g1_madd(const G1Xyzz& acc, const G1Affine& q) {
     Fq28 Q = mul(acc.x, PP);
     G1Xyzz r;
     r.x = carry(sub(sub(sub(sqr(R), PPP), Q), Q));       // (-3 * 2^28, 2^28) -> N
-    r.y = sub(mul(R, sub(Q, r.x)), mul(acc.y, PPP));     // d
+    r.y = mul2(R, sub(Q, r.x), neg(acc.y), PPP);         // R (Q - X3) - Y1 PPP with one reduction: N (so also d)
     r.zz = mul(acc.zz, PP);
     r.zzz = mul(acc.zzz, PPP);
     r.inf = 0;
@@ -209,8 +209,8 @@ DR_DEV G1Xyzz g1_add(const G1Xyzz& p, const G1Xyzz& q) {
     Fq28 Q = mul(U1, PP);
     G1Xyzz r;
     r.x = carry(sub(sub(sub(sqr(R), PPP), Q), Q));
-    r.y = sub(mul(R, sub(Q, r.x)), mul(S1, PPP));
-    r.zz = mul(mul(p.zz, q.zz), PP);
+    r.y = sub(mul(R, sub(Q, r.x)), mul(S1, PPP));       // (two products here: the fused form needs 70 operand registers at once and
+    r.zz = mul(mul(p.zz, q.zz), PP);                     //  pushes the reduction kernels past 256 VGPRs = one resident wave)
     r.zzz = mul(mul(p.zzz, q.zzz), PPP);
     r.inf = 0;
     return r;

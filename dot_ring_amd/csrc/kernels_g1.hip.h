@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void k_g1_accumulate(const uint32_t* __restric
 constexpr int RC_BLOCK = 128;
 DR_DEV void park_put(uint32_t* park, const G1Xyzz& v) { put_raw(park + threadIdx.x, RC_BLOCK, v); }
 DR_DEV G1Xyzz park_get(const uint32_t* park) { return get_raw(park + threadIdx.x, RC_BLOCK); }
-__global__ __launch_bounds__(RC_BLOCK) void k_g1_reduce_chunks(const uint32_t* __restrict__ buckets, size_t windows,
+__global__ __launch_bounds__(RC_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_reduce_chunks(const uint32_t* __restrict__ buckets, size_t windows,
                                                                uint32_t H, uint32_t L, uint32_t* __restrict__ partial) {
     __shared__ uint32_t park[XYZZ_RAW_WORDS * RC_BLOCK];         // 28.5 KB: one parked XYZZ value per lane, raw limbs (private slots: no barriers)
     const uint32_t T = H / L;
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(RC_BLOCK) void k_g1_reduce_chunks(const uint32_t* _
 
 // one workgroup per window: lanes stride over the T chunk results, then an LDS tree folds the workgroup.
 constexpr int RW_BLOCK = 128;
-__global__ __launch_bounds__(RW_BLOCK) void k_g1_reduce_windows(const uint32_t* __restrict__ partial, uint32_t T,
+__global__ __launch_bounds__(RW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_reduce_windows(const uint32_t* __restrict__ partial, uint32_t T,
                                                                 uint32_t* __restrict__ winsum) {
     // scratch-free like the other reduction kernels: ONE inlined addition serves the strided pass over the T chunk results and
     // the log2(RW_BLOCK) tree levels (operand picked per step; an infinite operand leaves acc as it is)

@@ -174,6 +174,28 @@ def test_generated_montgomery_sequences(header, mul_name, sqr_name, n, bits, p):
         av = sum(x << (bits * i) for i, x in enumerate(a))
         got = sum(res[f"r[{i}]"] << (bits * i) for i in range(n))
         assert (got * R - av * av) % p == 0
+    # fused a b + c d (one reduction): a with limbs up to 2^29, the others below 2^28, both signs
+    mul2 = _parse(header, "montmul2_14x28_asm")
+    assert sum(1 for l in mul2[0] if l.startswith("v_mad")) == 3 * n * n
+    for trial in range(24):
+        a, av = _lazy(rng, n, bits, 1 << 29, p, 8)
+        b, bv = _lazy(rng, n, bits, 1 << bits, p, 8)
+        c, cv_ = _lazy(rng, n, bits, 1 << bits, p, 4)
+        d_, dv = _lazy(rng, n, bits, 1 << bits, p, 2)
+        if trial == 0:
+            a = [(1 << 29) - 1] * (n - 1) + [3]; av = sum(x << (bits * i) for i, x in enumerate(a))
+            b = [(1 << bits) - 1] * (n - 1) + [3]; bv = sum(x << (bits * i) for i, x in enumerate(b))
+            c = [-((1 << bits) - 1)] * (n - 1) + [-3]; cv_ = sum(x << (bits * i) for i, x in enumerate(c))
+            d_ = [-((1 << bits) - 1)] * (n - 1) + [-3]; dv = sum(x << (bits * i) for i, x in enumerate(d_))
+        vals = dict(consts)
+        for nm, arr in (("a", a), ("b", b), ("c", c), ("d", d_)):
+            vals.update({f"{nm}[{i}]": arr[i] for i in range(n)})
+        res = _run(*mul2, vals)
+        limbs = [res[f"r[{i}]"] for i in range(n)]
+        assert all(0 <= x < (1 << bits) for x in limbs[:-1])
+        got = sum(x << (bits * i) for i, x in enumerate(limbs))
+        assert (got * R - (av * bv + cv_ * dv)) % p == 0
+        assert -p // 2 < got < p + p // 2
     # zero, one, p - 1 in canonical limbs
     for av in (0, 1, p - 1, R % p):
         for bv in (0, 1, p - 1):
