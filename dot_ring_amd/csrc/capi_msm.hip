@@ -189,6 +189,10 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         hipLaunchKernelGGL(dr::k_g1_accumulate, dim3(div_up(nbuckets, 256)), dim3(256), 0, st, d_bases,
                            ctx->sorted.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(),
                            ctx->buckets.as<uint32_t>(), nbuckets);
+        // buckets of >= 255 entries (skewed scalars only): a wave each; returns at once when there are none
+        hipLaunchKernelGGL(dr::k_g1_accumulate_heavy, dim3(2048), dim3(64), 0, st, d_bases, ctx->sorted.as<uint32_t>(),
+                           ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(), ctx->cell_off.as<uint32_t>(),
+                           szblocks, ctx->buckets.as<uint32_t>());
     }));
     // many bucket sets (batched prover): level-wise reduction, 2 additions per entry and no scalar multiplications;
     // few sets (single MSMs): chunk sums + double-and-add, whose latency is one short chain

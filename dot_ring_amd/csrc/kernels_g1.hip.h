@@ -463,6 +463,25 @@ __global__ __launch_bounds__(SZ_BLOCK) void k_size_place(const uint32_t* __restr
 // ---- 4. bucket accumulation: one lane per bucket walks its segment with mixed additions.  DOMINANT KERNEL.
 // Algorithmic traffic: 96 B base + 32 B scalar per (base,scalar) pair; the gather of bases is the
 // only large stream, the segment lists are 4 B per entry.
+// A bucket of the largest size class (>= 255 entries; the size ordering puts those first in `perm`) is left to
+// k_g1_accumulate_heavy, where a whole wave walks it: skewed scalars — a 0/1 column, many equal values — put thousands of
+// points into one bucket, and one lane adding them one after the other would be the kernel's whole run time (6145 equal
+// scalars: 28 ms in one lane, 0.5 ms in a wave).  The prover's dense MSMs (~66 points per bucket, Poisson) never get there.
+constexpr uint32_t G1_HEAVY_BUCKET = 255;
+
+DR_DEV G1Xyzz g1_walk(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, uint32_t beg, uint32_t len, uint32_t first,
+                      uint32_t stride) {
+    G1Xyzz acc = g1_inf();
+#pragma unroll 1
+    for (uint32_t p = first; p < len; p += stride) {
+        uint32_t e = sorted[beg + p];
+        G1Affine q = load_affine(bases, e & 0x7fffffffu);
+        q = g1_neg_affine(q, (e >> 31) != 0);
+        acc = g1_madd(acc, q);
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void k_g1_accumulate(const uint32_t* __restrict__ bases,
                                                        const uint32_t* __restrict__ sorted,
                                                        const uint32_t* __restrict__ offsets,
@@ -472,16 +491,40 @@ __global__ __launch_bounds__(256) void k_g1_accumulate(const uint32_t* __restric
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nbuckets) return;
     const size_t b = perm[t];
-    uint32_t beg = offsets[b], len = counts[b];
-    G1Xyzz acc = g1_inf();
-#pragma unroll 1
-    for (uint32_t p = 0; p < len; p++) {
-        uint32_t e = sorted[beg + p];
-        G1Affine q = load_affine(bases, e & 0x7fffffffu);
-        q = g1_neg_affine(q, (e >> 31) != 0);
-        acc = g1_madd(acc, q);
+    const uint32_t len = counts[b];
+    if (len >= G1_HEAVY_BUCKET) return;
+    store_xyzz(buckets, b, g1_walk(bases, sorted, offsets[b], len, 0, 1));
+}
+
+DR_DEV G1Xyzz xyzz_shfl_down(const G1Xyzz& p, unsigned delta) {
+    G1Xyzz o;
+#pragma unroll
+    for (int t = 0; t < L28; t++) {
+        o.x.l[t] = __shfl_down(p.x.l[t], delta, 64);
+        o.y.l[t] = __shfl_down(p.y.l[t], delta, 64);
+        o.zz.l[t] = __shfl_down(p.zz.l[t], delta, 64);
+        o.zzz.l[t] = __shfl_down(p.zzz.l[t], delta, 64);
     }
-    store_xyzz(buckets, b, acc);
+    o.inf = __shfl_down(p.inf, delta, 64);
+    return o;
+}
+// one wave per heavy bucket (perm[0 .. n_heavy), n_heavy = the exclusive scan's offset of size class 1): the lanes stride over
+// the list, a shuffle tree folds their 64 partial sums.  Grid-stride, so a fixed small grid serves any number of heavy buckets.
+__global__ __launch_bounds__(64) void k_g1_accumulate_heavy(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                            const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_offsets,
+                                                            uint32_t nblocks, uint32_t* __restrict__ buckets) {
+    const uint32_t n_heavy = cell_offsets[nblocks];                 // cells are [class][block]: class 1 starts where class 0 ends
+#pragma unroll 1
+    for (uint32_t t = blockIdx.x; t < n_heavy; t += gridDim.x) {
+        const size_t b = perm[t];
+        const uint32_t len = counts[b];
+        if (len < G1_HEAVY_BUCKET) continue;
+        G1Xyzz acc = g1_walk(bases, sorted, offsets[b], len, threadIdx.x, 64);
+#pragma unroll 1
+        for (unsigned d = 32; d >= 1; d >>= 1) acc = g1_add(acc, xyzz_shfl_down(acc, d));
+        if (threadIdx.x == 0) store_xyzz(buckets, b, acc);
+    }
 }
 
 // ---- 5. bucket reduction.  Window value = sum_j (j+1) * B_j.  Chunk [s, s+L): running sums give

@@ -217,6 +217,37 @@ def test_g1_msm_batch_matches_singles(ctx, srs_bytes, window):
     srs.close()
 
 
+@pytest.mark.parametrize("table", [0, 12])
+def test_g1_msm_skewed_scalars_take_the_heavy_bucket_kernel(ctx, srs_bytes, table):
+    """every scalar equal / a 0-1 column / r - 1 everywhere: thousands of points in ONE bucket per window — walked by a whole
+    wave (k_g1_accumulate_heavy) instead of one lane; results against the oracle, alone and inside a batch"""
+    import time
+
+    n = 6145
+    srs = ctx.srs_load(srs_bytes[: 96 * n])
+    if table:
+        srs.precompute(table)
+    rng = random.Random(255)
+    cols = {
+        "ones": [1] * n,
+        "same": [0x123456789ABCDEF0123456789ABCDEF] * n,
+        "bits": [rng.randrange(2) for _ in range(n)],
+        "minus one": [coracle.FR_P - 1] * n,
+        "three values": [rng.choice([5, 1 << 200, coracle.FR_P - 7]) for _ in range(n)],
+    }
+    for name, col in cols.items():
+        raw = b"".join(k.to_bytes(32, "little") for k in col)
+        t0 = time.perf_counter()
+        got = ctx.g1_msm(srs, raw)
+        assert time.perf_counter() - t0 < 0.5, name          # one lane per bucket took 28 ms and more here; the wave kernel < 2 ms
+        assert got == _oracle_msm_be(srs_bytes, raw, n), name
+    batch = b"".join(b"".join(k.to_bytes(32, "little") for k in col) for col in cols.values())
+    got = ctx.g1_msm_batch(srs, batch, n)
+    for g, col in zip(got, cols.values()):
+        assert g == _oracle_msm_be(srs_bytes, b"".join(k.to_bytes(32, "little") for k in col), n)
+    srs.close()
+
+
 @pytest.mark.parametrize("log2n,table", [(16, 0), (16, 12), (18, 16), (20, 16)])
 def test_g1_msm_synthetic_bases_closed_form(ctx, log2n, table):
     """BASELINE configs[2] sizes (2^16 and 2^20): no SRS of that size exists, so bases are (1+i)*G

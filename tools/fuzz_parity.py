@@ -136,5 +136,36 @@ for table in (0, 9, 12, 14):
     srs.close()
 report("g1 msm shapes", total, wrong, t0)
 
+# 7. Bandersnatch bucket Pippenger (K4, from 256 terms): random sizes, uniform / short / repeated scalars (heavy buckets)
+t0 = time.perf_counter()
+wrong = total = 0
+base = [coracle.te_mul(bsn.G, rng.randrange(1, bsn.N)) for _ in range(300)]
+for _ in range(max(2, int(4 * scale))):
+    n = rng.choice([256, 257, 1000, 4095, 4096, 5122, 16383, 20482])
+    kind = rng.choice(["uniform", "short", "repeated", "sparse"])
+    pts = [base[rng.randrange(300)] for _ in range(n)]
+    if kind == "uniform":
+        ks = [rng.randrange(bsn.N) for _ in range(n)]
+    elif kind == "short":
+        ks = [rng.randrange(1 << rng.choice([1, 9, 64, 128, 129])) for _ in range(n)]
+    elif kind == "repeated":
+        vals = [rng.randrange(bsn.N) for _ in range(3)]
+        ks = [rng.choice(vals) for _ in range(n)]
+    else:
+        ks = [rng.randrange(bsn.N) if rng.random() < 0.05 else 0 for _ in range(n)]
+    got = coracle.te_unpack(ctx.bsn_msm(coracle.te_pack(pts), coracle.scalars_pack(ks)))[0]
+    wrong += got != coracle.te_msm(pts, ks)
+    total += 1
+report("bsn pippenger shapes", total, wrong, t0)
+
+# 8. fixed-base tables (generator, blinding base): full-width scalars
+t0 = time.perf_counter()
+n = int(2000 * scale)
+ks = [rng.randrange(1 << 256) for _ in range(2 * n)]
+raw = b"".join(k.to_bytes(32, "little") for k in ks)
+got = coracle.te_unpack(ctx.te_fixed_base_msm_groups(coracle.te_pack([bsn.G, bsn.SHA512.blinding_base]), raw))
+want = [bsn.add(coracle.te_mul(bsn.G, ks[2 * i] % bsn.N), coracle.te_mul(bsn.SHA512.blinding_base, ks[2 * i + 1] % bsn.N)) for i in range(n)]
+report("fixed-base x*G + b*B", n, sum(g != w for g, w in zip(got, want)), t0)
+
 print("FUZZ", "FAILED" if bad else "OK")
 sys.exit(1 if bad else 0)
