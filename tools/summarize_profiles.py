@@ -4,7 +4,7 @@ HBM bytes follow the gfx950 rule of /opt/skills/guides/MI355X_MICROARCH.md: (2*F
 usage: python tools/summarize_profiles.py r01 [workload-name]"""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 workload = sys.argv[2] if len(sys.argv) > 2 else "ringvrf_ring1024_batch1024"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
@@ -23,11 +23,11 @@ def short(name):
 
 
 # the --stats summary averages every launch of the process, set-up included (one 60 ms launch builds the by-parts
-# bases); the bench line's figure is the timed region only.  From the kernel trace: the last steps * 6 accumulate launches
-# (profile_round.sh profiles 2 timed steps; launches per step from the bench line).
+# bases); the bench line's figure comes from its second pass (the same K steps with the per-kernel timers on).  From the
+# kernel trace: the last 2 * per_step accumulate launches = that pass of the profiled run (profile_round.sh uses --steps 2).
 trace = glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True)
 if trace:
-    rows = [r for r in csv.DictReader(open(trace[0])) if "k_g1_accumulate" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(trace[0])) if r["Kernel_Name"].split("(")[0].endswith("k_g1_accumulate")]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     per_step = int(round(json.loads(line)["roofline"].get("launches_per_step", 6)))
     timed = rows[-2 * per_step:]
@@ -57,6 +57,8 @@ if acc and "FETCH_SIZE" in acc and "WRITE_SIZE" in acc:
     traffic = {
         "_note": "HBM bytes per k_g1_accumulate launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
                  "(2*FETCH_SIZE + WRITE_SIZE)*1024 per the gfx950 correction; average over the launches of one bench step",
+        "_source": f"profiles/hbm_traffic.json: rocprofv3 --pmc passes of tools/profile_round.sh {tag} (a separate run of the same workload, "
+                   "NOT measured inside bench.py)",
         workload: {
             "k_g1_accumulate_bytes_per_launch": (2 * acc["FETCH_SIZE"] + acc["WRITE_SIZE"]) * 1024,
             "FETCH_SIZE_KB": acc["FETCH_SIZE"],
