@@ -115,6 +115,7 @@ _PROTOTYPES.update({
 })
 _PROTOTYPES.update({
     "dr_te_fixed_base_msm_groups": (c_int, [c_void_p, c_int, c_char_p, c_size_t, c_char_p, c_size_t, c_void_p]),
+    "dr_host_random_expand": (c_int, [c_char_p, c_void_p, c_size_t]),
     "dr_comm_unique_id": (c_int, [c_char_p]),
     "dr_comm_create": (c_int, [c_void_p, c_char_p, c_int, c_int, POINTER(c_void_p)]),
     "dr_comm_destroy": (None, [c_void_p]),
@@ -170,6 +171,16 @@ def host_hash(kind: int, data: bytes, out_len: int) -> bytes:
     out = ctypes.create_string_buffer(out_len)
     _check(lib().dr_host_hash(kind, data, len(data), out, out_len))
     return out.raw
+
+
+def random_expand(seed32: bytes, nbytes: int) -> bytes:
+    """nbytes of SHAKE256(seed || LE64(block)) output in 576-byte blocks, hashed on the library's worker threads: turns one
+    32-byte secret seed from the OS into the hidden rows of a whole batch of ring proofs."""
+    if len(seed32) != 32:
+        raise ValueError("seed must be 32 bytes")
+    out = ctypes.create_string_buffer(max(1, nbytes))
+    _check(lib().dr_host_random_expand(seed32, out, nbytes))
+    return out.raw[:nbytes]
 
 
 def hash_to_field_batch(suite: VrfSuiteStruct, msgs) -> bytes:

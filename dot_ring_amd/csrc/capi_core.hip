@@ -570,6 +570,25 @@ int dr_host_hash(int kind, const uint8_t* data, size_t len, uint8_t* out, size_t
     return fail(DR_ERR_INVALID, "unknown hash kind");
 }
 
+int dr_host_random_expand(const uint8_t seed[32], uint8_t* out, size_t len) {
+    if (!seed || (len && !out)) return fail(DR_ERR_INVALID, "null buffer");
+    try {
+        const size_t block = 576, blocks = (len + block - 1) / block;
+        drh::parallel_for(blocks, [&](size_t j) {
+            drh::Shake256 sh;
+            sh.update(seed, 32);
+            uint8_t ctr[8];
+            for (int i = 0; i < 8; i++) ctr[i] = (uint8_t)((uint64_t)j >> (8 * i));
+            sh.update(ctr, 8);
+            const size_t lo = j * block, n = std::min(block, len - lo);
+            sh.digest(out + lo, n);
+        });
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_NOMEM, std::string("random expand: ") + e.what());
+    }
+    return DR_OK;
+}
+
 int load_suite(const dr_vrf_suite* s, drh::VrfSuite& out) {
     if (!s || !s->suite_id || s->suite_id_len == 0 || s->suite_id_len > 200) return fail(DR_ERR_INVALID, "bad VRF suite");
     out.suite_id.assign(s->suite_id, s->suite_id + s->suite_id_len);

@@ -99,6 +99,9 @@ struct Sha512 {
 };
 
 // ---------------------------------------------------------------- Keccak-f[1600] sponge (SHAKE128: rate 168, SHAKE256: rate 136)
+// Fully unrolled rounds on 25 local lanes (theta, rho + pi, chi, iota fused; rotation counts and lane moves are compile-time):
+// the transcript replay of a batch verifier is ~20 permutations per proof, i.e. this function is most of its host time.
+inline uint64_t keccak_rol(uint64_t v, int n) { return (v << n) | (v >> (64 - n)); }
 inline void keccak_f1600(uint64_t st[25]) {
     static const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
                                     0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
@@ -106,29 +109,36 @@ inline void keccak_f1600(uint64_t st[25]) {
                                     0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
                                     0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
                                     0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-    static const int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
-    static const int PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    uint64_t a00 = st[0], a01 = st[1], a02 = st[2], a03 = st[3], a04 = st[4], a05 = st[5], a06 = st[6], a07 = st[7], a08 = st[8], a09 = st[9],
+             a10 = st[10], a11 = st[11], a12 = st[12], a13 = st[13], a14 = st[14], a15 = st[15], a16 = st[16], a17 = st[17], a18 = st[18],
+             a19 = st[19], a20 = st[20], a21 = st[21], a22 = st[22], a23 = st[23], a24 = st[24];
     for (int round = 0; round < 24; round++) {
-        uint64_t bc[5];
-        for (int i = 0; i < 5; i++) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
-        for (int i = 0; i < 5; i++) {
-            uint64_t t = bc[(i + 4) % 5] ^ ((bc[(i + 1) % 5] << 1) | (bc[(i + 1) % 5] >> 63));
-            for (int j = 0; j < 25; j += 5) st[j + i] ^= t;
-        }
-        uint64_t t = st[1];
-        for (int i = 0; i < 24; i++) {
-            int j = PIL[i];
-            uint64_t keep = st[j];
-            st[j] = (t << ROT[i]) | (t >> (64 - ROT[i]));
-            t = keep;
-        }
-        for (int j = 0; j < 25; j += 5) {
-            uint64_t r[5];
-            for (int i = 0; i < 5; i++) r[i] = st[j + i];
-            for (int i = 0; i < 5; i++) st[j + i] = r[i] ^ (~r[(i + 1) % 5] & r[(i + 2) % 5]);
-        }
-        st[0] ^= RC[round];
+        // theta
+        const uint64_t c0 = a00 ^ a05 ^ a10 ^ a15 ^ a20, c1 = a01 ^ a06 ^ a11 ^ a16 ^ a21, c2 = a02 ^ a07 ^ a12 ^ a17 ^ a22,
+                       c3 = a03 ^ a08 ^ a13 ^ a18 ^ a23, c4 = a04 ^ a09 ^ a14 ^ a19 ^ a24;
+        const uint64_t d0 = c4 ^ keccak_rol(c1, 1), d1 = c0 ^ keccak_rol(c2, 1), d2 = c1 ^ keccak_rol(c3, 1), d3 = c2 ^ keccak_rol(c4, 1),
+                       d4 = c3 ^ keccak_rol(c0, 1);
+        // rho + pi: b[y][2x+3y] = rol(a[x][y] ^ d[x], r[x][y])   (lane index = x + 5y)
+        const uint64_t b00 = a00 ^ d0;
+        const uint64_t b10 = keccak_rol(a01 ^ d1, 1), b20 = keccak_rol(a02 ^ d2, 62), b05 = keccak_rol(a03 ^ d3, 28), b15 = keccak_rol(a04 ^ d4, 27);
+        const uint64_t b16 = keccak_rol(a05 ^ d0, 36), b01 = keccak_rol(a06 ^ d1, 44), b11 = keccak_rol(a07 ^ d2, 6), b21 = keccak_rol(a08 ^ d3, 55),
+                       b06 = keccak_rol(a09 ^ d4, 20);
+        const uint64_t b07 = keccak_rol(a10 ^ d0, 3), b17 = keccak_rol(a11 ^ d1, 10), b02 = keccak_rol(a12 ^ d2, 43), b12 = keccak_rol(a13 ^ d3, 25),
+                       b22 = keccak_rol(a14 ^ d4, 39);
+        const uint64_t b23 = keccak_rol(a15 ^ d0, 41), b08 = keccak_rol(a16 ^ d1, 45), b18 = keccak_rol(a17 ^ d2, 15), b03 = keccak_rol(a18 ^ d3, 21),
+                       b13 = keccak_rol(a19 ^ d4, 8);
+        const uint64_t b14 = keccak_rol(a20 ^ d0, 18), b24 = keccak_rol(a21 ^ d1, 2), b09 = keccak_rol(a22 ^ d2, 61), b19 = keccak_rol(a23 ^ d3, 56),
+                       b04 = keccak_rol(a24 ^ d4, 14);
+        // chi + iota
+        a00 = b00 ^ (~b01 & b02) ^ RC[round]; a01 = b01 ^ (~b02 & b03); a02 = b02 ^ (~b03 & b04); a03 = b03 ^ (~b04 & b00); a04 = b04 ^ (~b00 & b01);
+        a05 = b05 ^ (~b06 & b07); a06 = b06 ^ (~b07 & b08); a07 = b07 ^ (~b08 & b09); a08 = b08 ^ (~b09 & b05); a09 = b09 ^ (~b05 & b06);
+        a10 = b10 ^ (~b11 & b12); a11 = b11 ^ (~b12 & b13); a12 = b12 ^ (~b13 & b14); a13 = b13 ^ (~b14 & b10); a14 = b14 ^ (~b10 & b11);
+        a15 = b15 ^ (~b16 & b17); a16 = b16 ^ (~b17 & b18); a17 = b17 ^ (~b18 & b19); a18 = b18 ^ (~b19 & b15); a19 = b19 ^ (~b15 & b16);
+        a20 = b20 ^ (~b21 & b22); a21 = b21 ^ (~b22 & b23); a22 = b22 ^ (~b23 & b24); a23 = b23 ^ (~b24 & b20); a24 = b24 ^ (~b20 & b21);
     }
+    st[0] = a00; st[1] = a01; st[2] = a02; st[3] = a03; st[4] = a04; st[5] = a05; st[6] = a06; st[7] = a07; st[8] = a08; st[9] = a09;
+    st[10] = a10; st[11] = a11; st[12] = a12; st[13] = a13; st[14] = a14; st[15] = a15; st[16] = a16; st[17] = a17; st[18] = a18; st[19] = a19;
+    st[20] = a20; st[21] = a21; st[22] = a22; st[23] = a23; st[24] = a24;
 }
 
 template <int RATE>
@@ -141,7 +151,14 @@ struct Shake {
         const uint8_t* p = (const uint8_t*)data;
         while (len) {
             size_t take = RATE - pos < len ? RATE - pos : len;
-            for (size_t i = 0; i < take; i++) st[(pos + i) >> 3] ^= (uint64_t)p[i] << (8 * ((pos + i) & 7));
+            size_t i = 0;
+            for (; i < take && ((pos + i) & 7); i++) st[(pos + i) >> 3] ^= (uint64_t)p[i] << (8 * ((pos + i) & 7));
+            for (; i + 8 <= take; i += 8) {          // whole lanes (x86-64: little-endian, as Keccak's byte order)
+                uint64_t w;
+                std::memcpy(&w, p + i, 8);
+                st[(pos + i) >> 3] ^= w;
+            }
+            for (; i < take; i++) st[(pos + i) >> 3] ^= (uint64_t)p[i] << (8 * ((pos + i) & 7));
             pos += take; p += take; len -= take;
             if (pos == RATE) { keccak_f1600(st); pos = 0; }
         }
@@ -157,7 +174,7 @@ struct Shake {
         size_t off = 0;
         while (n) {
             size_t take = RATE - off < n ? RATE - off : n;
-            for (size_t i = 0; i < take; i++) out[i] = (uint8_t)(s[(off + i) >> 3] >> (8 * ((off + i) & 7)));
+            std::memcpy(out, reinterpret_cast<const uint8_t*>(s) + off, take);      // little-endian lanes
             out += take; n -= take; off += take;
             if (off == RATE && n) { keccak_f1600(s); off = 0; }
         }

@@ -425,9 +425,11 @@ class RingVRF(VRF):
             memo = {}
             cls._pk_memo = memo
         # the memo is keyed by a hash of the secret key: the process keeps no copy of secret material beyond the call
-        tag = lambda sk: hashlib.blake2b(bytes(sk), digest_size=16, person=b"dotring-pk-memo").digest()
-        tags = [tag(sk) for sk in secret_keys]
-        distinct = {t: sk for t, sk in zip(tags, secret_keys) if t not in memo}
+        tag = lambda sk: hashlib.blake2b(sk, digest_size=16, person=b"dotring-pk-memo").digest()
+        sk_bytes = [bytes(sk) for sk in secret_keys]
+        tag_of = {sk: tag(sk) for sk in dict.fromkeys(sk_bytes)}     # one hash per distinct key of THIS call (a local, not kept)
+        tags = [tag_of[sk] for sk in sk_bytes]
+        distinct = {t: sk for sk, t in tag_of.items() if t not in memo}
         if distinct:
             derived = scalar_mul_batch([gen] * len(distinct), [int.from_bytes(sk, "little") for sk in distinct.values()])
             if len(memo) + len(distinct) > 4096:
@@ -472,7 +474,9 @@ class RingVRF(VRF):
         def prove_span(lo: int, hi: int) -> list:
             # runs on the calling thread or on a helper thread: runtime.context() / get_device_prover give each thread its own
             # stream, scratch and per-ring prover state
-            zk = None if ring.params.test_vectors else secrets.token_bytes(48 * 12 * (hi - lo))
+            # hidden rows: 12 x 48 random bytes per proof, expanded from a fresh 32-byte OS seed by the library's worker threads
+            # (SHAKE256 in counter mode; os.urandom alone took 1.5 ms per 1024 proofs on the calling thread)
+            zk = None if ring.params.test_vectors else _native.random_expand(secrets.token_bytes(32), 48 * 12 * (hi - lo))
             raw, aux = device_prover.get_device_prover(ring, 0).ringvrf_prove_batch(
                 suite, alphas[lo:hi], additional_data[lo:hi], salts[lo:hi] if salts else None,
                 b"".join(bytes(sk) if len(sk) == 32 else le(int.from_bytes(sk, "little") % sp.subgroup_order) for sk in secret_keys[lo:hi]),

@@ -257,6 +257,10 @@ DR_API int dr_ring_prove_openings(dr_ring_prover *p, size_t batch, const uint8_t
  */
 enum { DR_HASH_SHA512 = 0, DR_HASH_SHAKE128 = 1, DR_HASH_SHAKE256 = 2 };
 DR_API int dr_host_hash(int kind, const uint8_t *data, size_t len, uint8_t *out, size_t out_len);
+/* out = SHAKE256(seed || LE64(0))[0..576) || SHAKE256(seed || LE64(1))[0..576) || ... (len bytes), hashed on the worker threads.
+ * dr_ringvrf_prove_batch's zk_random48 for a batch (12 x 48 bytes per proof: the hidden rows of columns/columns.py:139-146, drawn
+ * with `secrets` in the reference) comes from one 32-byte OS seed this way. */
+DR_API int dr_host_random_expand(const uint8_t seed[32], uint8_t *out, size_t len);
 
 typedef struct dr_vrf_suite {
     const uint8_t *suite_id;        /* e.g. "Bandersnatch-SHA512-ELL2-v1" (bandersnatch.py:74-87) */
