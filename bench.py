@@ -51,6 +51,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 # x 2.4 GHz at ~4.2 cycles per instruction (profiles/r02_ubench_valu.txt: v_mad_i64_i32 4.2-4.4, VOP2 2.6)
 MADD_INSTRUCTIONS = 8 * 461 + 2 * 383 + 330
 VALU_PEAK_GADD_S = 1024 * 2.4e9 / 4.2 * 64 / MADD_INSTRUCTIONS / 1e9
+# the same bucket walk in isolation (tools/ubench_limbs.hip: 2048 chained additions per lane over the prover's 13 MB table,
+# profiles/r02_ubench_limbs_fused.txt): an empirical ceiling for the kernel's inner loop on this chip
+MEASURED_CHAIN_GADD_S = 7.56
 ALG_BYTES_PER_PAIR = 128       # 96 B affine base + 32 B scalar per (base, scalar) pair
 ALG_BYTES_PER_SCALAR_MUL = 160  # 64 B point + 32 B scalar + 64 B result
 MSM_KERNELS = ("k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_sort_sets", "k_size_sort", "k_g1_accumulate", "k_g1_reduce_chunks",
@@ -574,6 +577,8 @@ def main() -> int:
                          "valu": {"achieved_gadd_s": dense_adds / (acc_ms / 1e3) / 1e9 if acc_ms else None, "peak_gadd_s": VALU_PEAK_GADD_S,
                                   "frac": dense_adds / (acc_ms / 1e3) / 1e9 / VALU_PEAK_GADD_S if acc_ms else None,
                                   "instructions_per_addition": MADD_INSTRUCTIONS,
+                                  "isolated_chain_gadd_s": MEASURED_CHAIN_GADD_S,
+                                  "frac_of_isolated_chain": dense_adds / (acc_ms / 1e3) / 1e9 / MEASURED_CHAIN_GADD_S if acc_ms else None,
                                   "note": "dense bucket additions only (7N pairs x windows per proof); by-parts and verify-side additions not counted"},
                          # per-proof unique traffic (11N scalars + 14 NTT passes' data + 784 B out), 3.17 KB per
                          # domain point = 6.5 MB per proof at N = 2048, over the whole job
