@@ -6,7 +6,7 @@
 namespace dr {
 
 // Constants of the Elligator map and of Tonelli-Shanks, in Montgomery form, computed once per context on the host
-// (capi.hip: bsn_consts_init) instead of by every lane: the Montgomery-model coefficients derived from a = -5 and d
+// (capi_core.hip: bsn_consts_init) instead of by every lane: the Montgomery-model coefficients derived from a = -5 and d
 // (A_M = 2(a+d)/(a-d), B_M = 4/(a-d)) and c_pow[j] = (5^Q)^(2^j), 5 the non-residue, p - 1 = Q * 2^32.
 struct BsnConsts {
     uint32_t mont_b[8], a_over_b[8], inv_b2[8];
