@@ -197,7 +197,25 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     // many bucket sets (batched prover): level-wise reduction, 2 additions per entry and no scalar multiplications;
     // few sets (single MSMs): chunk sums + double-and-add, whose latency is one short chain
     const bool leveled = g_reduce_levels && pl.L == 16 && pl.H >= 256 && bsets * (size_t)(pl.H / 16) >= g_level_threshold;
-    if (leveled) {
+    // many sets of <= 2048 buckets (every batched MSM of the prover): first level with 2 additions per bucket, then one workgroup
+    // per set scans and folds its <= 128 chunk results (DOTRING_MSM_SETSCAN=0: the chunk + double-and-add kernels below)
+    static const bool setscan_on = std::getenv("DOTRING_MSM_SETSCAN") == nullptr || std::atoi(std::getenv("DOTRING_MSM_SETSCAN")) != 0;
+    const bool setscan = setscan_on && pl.L == 16 && pl.T >= 8 && pl.T <= 256 && bsets >= 256;
+    if (setscan) {
+        const size_t cnt = bsets * pl.T;
+        TRY(ctx->partial.reserve(2 * cnt * 192));
+        uint32_t* out_s = ctx->partial.as<uint32_t>();
+        uint32_t* out_c = out_s + cnt * 48;
+        TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
+            hipLaunchKernelGGL(dr::k_g1_reduce_level1, dim3(div_up(cnt, 128)), dim3(128), 0, st, ctx->buckets.as<uint32_t>(), bsets, pl.H, 16u,
+                               out_s, out_c);
+        }));
+        TRY(launch(ctx, "k_g1_reduce_windows", [&] {
+            const uint32_t per_block = dr::RS_BLOCK / (pl.T / dr::RS_GROUP);
+            hipLaunchKernelGGL(dr::k_g1_reduce_set_scan, dim3(div_up(bsets, per_block)), dim3(dr::RS_BLOCK), 0, st, out_s, out_c, bsets, pl.T,
+                               ctx->winsum.as<uint32_t>());
+        }));
+    } else if (leveled) {
         // level outputs live in ctx->partial: [S | C] per level, sizes sets * H/16, sets * H/256, ...
         size_t total = 0;
         for (uint32_t n = pl.H; n > 16; n /= 16) total += 2 * bsets * (n / 16);
@@ -215,9 +233,9 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
             uint32_t* out_c = base + (off + cnt) * 48;
             TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
                 if (in_c)
-                    hipLaunchKernelGGL(dr::k_g1_reduce_level<true>, dim3(div_up(cnt, 128)), dim3(128), 0, st, in_s, in_c, bsets, n, 16u, level, out_s, out_c);
+                    hipLaunchKernelGGL(dr::k_g1_reduce_level, dim3(div_up(cnt, 128)), dim3(128), 0, st, in_s, in_c, bsets, n, 16u, level, out_s, out_c);
                 else
-                    hipLaunchKernelGGL(dr::k_g1_reduce_level<false>, dim3(div_up(cnt, 128)), dim3(128), 0, st, in_s, in_c, bsets, n, 16u, level, out_s, out_c);
+                    hipLaunchKernelGGL(dr::k_g1_reduce_level1, dim3(div_up(cnt, 128)), dim3(128), 0, st, in_s, bsets, n, 16u, out_s, out_c);
             }));
             in_s = out_s; in_c = out_c;
             off += 2 * cnt;

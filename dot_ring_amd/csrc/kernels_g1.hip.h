@@ -611,8 +611,31 @@ __global__ __launch_bounds__(RW_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
 // last <= 16 entries.  Latency is a few serial levels: only worth it when the first level alone fills the chip.
 // Both kernels are scratch-free: ONE inlined addition per loop (operands muxed), the scaling doublings in a second
 // loop with one inlined doubling.
-template <bool HAS_C>
-__global__ __launch_bounds__(128) void k_g1_reduce_level(const uint32_t* __restrict__ in_s, const uint32_t* __restrict__ in_c /* unused at level 1 */,
+// level 1 (94 % of the work): two accumulators only — q += run; run += B_i; q waits in LDS (see k_g1_reduce_chunks)
+__global__ __launch_bounds__(RC_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_reduce_level1(const uint32_t* __restrict__ in_s, size_t sets,
+                                                                                                        uint32_t n_in, uint32_t L,
+                                                                                                        uint32_t* __restrict__ out_s,
+                                                                                                        uint32_t* __restrict__ out_c) {
+    __shared__ uint32_t park[XYZZ_RAW_WORDS * RC_BLOCK];
+    const uint32_t T = n_in / L;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= sets * T) return;
+    size_t set = gid / T;
+    uint32_t s = (uint32_t)(gid % T) * L;
+    G1Xyzz run = g1_inf();
+    park_put(park, run);
+#pragma unroll 1
+    for (uint32_t step = 0; step < 2 * L; step++) {
+        const bool first = (step & 1) == 0;
+        G1Xyzz b = first ? park_get(park) : load_xyzz(in_s, set * n_in + s + (step >> 1));
+        G1Xyzz r = g1_add(run, b);
+        if (first) park_put(park, r); else run = r;
+    }
+    store_xyzz(out_s, gid, run);
+    store_xyzz(out_c, gid, park_get(park));
+}
+// levels >= 2 (only when a set has more than 2048 buckets and there are many sets): entries S_i with corrections C_i
+__global__ __launch_bounds__(128) void k_g1_reduce_level(const uint32_t* __restrict__ in_s, const uint32_t* __restrict__ in_c,
                                                          size_t sets, uint32_t n_in, uint32_t L, int level,
                                                          uint32_t* __restrict__ out_s, uint32_t* __restrict__ out_c) {
     const uint32_t T = n_in / L;
@@ -620,45 +643,93 @@ __global__ __launch_bounds__(128) void k_g1_reduce_level(const uint32_t* __restr
     if (gid >= sets * T) return;
     size_t set = gid / T;
     uint32_t s = (uint32_t)(gid % T) * L;
-    if constexpr (!HAS_C) {
-        // level 1 (94 % of the work): two accumulators only — q += run; run += B_i; q waits in LDS (see k_g1_reduce_chunks)
-        __shared__ uint32_t park[XYZZ_RAW_WORDS * RC_BLOCK];
-        G1Xyzz run = g1_inf();
-        park_put(park, run);
+    G1Xyzz run = g1_inf(), q = g1_inf(), c = g1_inf();
+    // per entry: q += run; run += S_i; c += C_i; after the loop one more step: c += L^(level-1) q
+    const uint32_t steps = L * 3;
 #pragma unroll 1
-        for (uint32_t step = 0; step < 2 * L; step++) {
-            const bool first = (step & 1) == 0;
-            G1Xyzz b = first ? park_get(park) : load_xyzz(in_s, set * n_in + s + (step >> 1));
-            G1Xyzz r = g1_add(run, b);
-            if (first) park_put(park, r); else run = r;
+    for (uint32_t step = 0; step <= steps; step++) {
+        if (step == steps) {
+#pragma unroll 1
+            for (int k = 0; k < 4 * (level - 1); k++) q = g1_dbl(q);
         }
-        store_xyzz(out_s, gid, run);
-        store_xyzz(out_c, gid, park_get(park));
-        return;
-    } else {
-        G1Xyzz run = g1_inf(), q = g1_inf(), c = g1_inf();
-        // per entry: q += run; run += S_i; c += C_i; after the loop one more step: c += L^(level-1) q
-        const uint32_t steps = L * 3;
-#pragma unroll 1
-        for (uint32_t step = 0; step <= steps; step++) {
-            if (step == steps) {
-#pragma unroll 1
-                for (int k = 0; k < 4 * (level - 1); k++) q = g1_dbl(q);
-            }
-            const uint32_t i = step / 3, ph = step == steps ? 3u : step % 3;
-            const size_t idx = set * n_in + s + (i < L ? i : 0);
-            G1Xyzz a, b;
-            if (ph == 0) { a = q; b = run; }
-            else if (ph == 1) { a = run; b = load_xyzz(in_s, idx); }
-            else if (ph == 2) { a = c; b = load_xyzz(in_c, idx); }
-            else { a = c; b = q; }
-            G1Xyzz r = g1_add(a, b);
-            if (ph == 0) q = r; else if (ph == 1) run = r; else c = r;
-        }
-        store_xyzz(out_s, gid, run);
-        store_xyzz(out_c, gid, c);
+        const uint32_t i = step / 3, ph = step == steps ? 3u : step % 3;
+        const size_t idx = set * n_in + s + (i < L ? i : 0);
+        G1Xyzz a, b;
+        if (ph == 0) { a = q; b = run; }
+        else if (ph == 1) { a = run; b = load_xyzz(in_s, idx); }
+        else if (ph == 2) { a = c; b = load_xyzz(in_c, idx); }
+        else { a = c; b = q; }
+        G1Xyzz r = g1_add(a, b);
+        if (ph == 0) q = r; else if (ph == 1) run = r; else c = r;
     }
+    store_xyzz(out_s, gid, run);
+    store_xyzz(out_c, gid, c);
 }
+// ---- 5c. a few lanes per bucket set finish the first level (the batched prover's MSMs: thousands of sets of T = H/16 <= 128
+// first-level chunks).  With S_t the chunk sums and Q_t the chunk corrections of k_g1_reduce_level1,
+//     value = 16 * sum_t (t+1) S_t - sum_t Q_t.
+// Lane l of a set takes 4 consecutive chunks: a running sum gives R_l = sum S_t and w_l = sum (t - 4l + 1) S_t over its block, so
+//     sum_t (t+1) S_t = sum_l w_l + 4 sum_l l R_l,    sum_l l R_l = sum_{k >= 1} X_k,   X_k = sum_{l >= k} R_l:
+// a suffix scan of the R_l over the set's T/4 lanes (log2 steps), Y_l = 16 (w_l + 4 X_l [l >= 1]) - sum Q_t per lane, then a tree
+// sum of the Y_l.  Per set: T/4 lanes x (8 + 2 log2(T/4) + 11) operations — 930 for T = 128, against the 128 x 17 of the
+// chunk kernel's double-and-add tail plus the fold, and 2 additions per bucket at the first level instead of 3.
+// Sets are packed into 64-lane workgroups; one inlined addition and one inlined doubling, operands muxed per step.
+constexpr int RS_BLOCK = 64, RS_GROUP = 4;
+// (no occupancy cap: three live accumulators need ~390 registers, and with T/4 lanes per set the launch is at most one wave
+// per SIMD anyway)
+__global__ __launch_bounds__(RS_BLOCK) void k_g1_reduce_set_scan(const uint32_t* __restrict__ in_s, const uint32_t* __restrict__ in_c, size_t sets,
+                                                                 uint32_t T /* power of two, 8 .. 256 */, uint32_t* __restrict__ winsum) {
+    __shared__ uint32_t sm[RS_BLOCK * XYZZ_RAW_WORDS];
+    const uint32_t LS = T / RS_GROUP;                       // lanes per set (a power of two <= 64)
+    const uint32_t per_block = RS_BLOCK / LS;
+    const uint32_t l = threadIdx.x % LS;
+    const size_t set = (size_t)blockIdx.x * per_block + threadIdx.x / LS;
+    const bool live = set < sets;
+    const size_t c0 = (live ? set : 0) * T + (size_t)l * RS_GROUP;      // first chunk of this lane
+    int lg = 0;
+    while ((1u << lg) < LS) lg++;
+    // steps: 0..7 local running sums (run += S_t; w += run, t descending), then lg scan steps on R, one combine step
+    // (v = 4 X [l >= 1] + w), one scaling step (v = 16 v), 4 correction steps (v -= Q_t), lg tree steps
+    G1Xyzz run = g1_inf(), w = g1_inf(), v = g1_inf();
+    const int n_local = 2 * RS_GROUP, s_scan = n_local, s_comb = s_scan + lg, s_corr = s_comb + 1, s_tree = s_corr + RS_GROUP, s_end = s_tree + lg;
+#pragma unroll 1
+    for (int step = 0; step < s_end; step++) {
+        G1Xyzz a, b = g1_inf();
+        int dst;                                            // 0: run, 1: w, 2: v
+        if (step < n_local) {
+            if ((step & 1) == 0) { a = run; if (live) b = load_xyzz(in_s, c0 + (RS_GROUP - 1 - (step >> 1))); dst = 0; }
+            else { a = w; b = run; dst = 1; }
+        } else if (step < s_comb) {                         // suffix scan of the block sums: run_l += run_{l + 2^k}
+            const uint32_t dist = 1u << (step - s_scan);
+            put_raw(sm + threadIdx.x, RS_BLOCK, run);
+            __syncthreads();
+            if (l + dist < LS) b = get_raw(sm + threadIdx.x + dist, RS_BLOCK);
+            __syncthreads();
+            a = run; dst = 0;
+        } else if (step == s_comb) {                        // v = 4 X_l (lanes >= 1) + w_l, then x 16
+            if (l >= 1) { v = g1_dbl(run); v = g1_dbl(v); }
+            a = v; b = w; dst = 2;
+        } else if (step < s_tree) {                         // corrections; the x 16 comes first
+            if (step == s_corr) {
+#pragma unroll 1
+                for (int k = 0; k < 4; k++) v = g1_dbl(v);
+            }
+            if (live) { b = load_xyzz(in_c, c0 + (step - s_corr)); b.y = neg(b.y); }
+            a = v; dst = 2;
+        } else {                                            // tree over the set's lanes
+            const uint32_t dist = LS >> (step - s_tree + 1);
+            put_raw(sm + threadIdx.x, RS_BLOCK, v);
+            __syncthreads();
+            if (l < dist) b = get_raw(sm + threadIdx.x + dist, RS_BLOCK);
+            __syncthreads();
+            a = v; dst = 2;
+        }
+        const G1Xyzz r = g1_add(a, b);
+        if (dst == 0) run = r; else if (dst == 1) w = r; else v = r;
+    }
+    if (live && l == 0) store_xyzz(winsum, set, v);
+}
+
 // one lane per set: direct running sum over the last n <= 16 entries, then value = L^levels * W - sum C
 __global__ __launch_bounds__(64) void k_g1_reduce_final(const uint32_t* __restrict__ in_s, const uint32_t* __restrict__ in_c, size_t sets, uint32_t n, int levels,
                                   uint32_t* __restrict__ winsum) {

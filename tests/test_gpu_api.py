@@ -327,7 +327,7 @@ def test_tuning_knobs_do_not_change_the_bytes(ctx):
         {"DOTRING_SRS_WINDOW": "0", "DOTRING_NATIVE_HOST": "0", "DOTRING_PROVE_PIPELINE": "2"},
         {"DOTRING_SRS_COMB": "1", "DOTRING_SRS_WINDOW": "9", "DOTRING_PS_COMB": "1", "DOTRING_PS_WINDOW": "8"},
         {"DOTRING_BSN_GLV": "0", "DOTRING_MSM_LEVEL_LANES": "1", "DOTRING_HOST_POOL": "0", "DOTRING_MSM_GROUPS": "3"},
-        {"DOTRING_BSN_FIXED_BASE": "0", "DOTRING_BSN_PIPPENGER_FROM": "0"},
+        {"DOTRING_BSN_FIXED_BASE": "0", "DOTRING_BSN_PIPPENGER_FROM": "0", "DOTRING_MSM_SETSCAN": "0", "DOTRING_VERIFY_HOST_MAX": "0"},
     ]
     digests = []
     for extra in variants:
