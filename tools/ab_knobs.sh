@@ -1,9 +1,11 @@
-for cfg in "X=1" "DOTRING_MSM_LEVEL_LANES=65536" "DOTRING_MSM_LEVEL_LANES=1000000000" "DOTRING_MSM_CHUNK=8" "DOTRING_SRS_WINDOW=13" "DOTRING_SRS_WINDOW=11" "DOTRING_PROVE_PARTS=2"; do
-  env $cfg python bench.py --extras 0 --msm-log2n 0 --cpu-proofs 0 --steps 4 > gpurun_out/ab.json 2> gpurun_out/ab.err
+#!/bin/bash
+# A/B of environment knobs inside ONE GPU-box call: bash tools/ab_knobs.sh "X=1" "DOTRING_PROVE_PARTS=2" ...
+for cfg in "$@"; do
+  env $cfg python bench.py --extras 0 --msm-log2n 0 --cpu-proofs 2 --cpu-workers 0 --steps 4 > gpurun_out/ab.json 2> gpurun_out/ab.err
   python - "$cfg" <<PY
 import json,sys
 l=json.loads(open("gpurun_out/ab.json").read().strip().splitlines()[-1])
 k=l["gpu_kernel_ms_per_step"]
-print(sys.argv[1], "value=%.0f prove_only=%.0f" % (l["value"], l["prove_only_proofs_per_s"]), {n:k.get(n) for n in ("k_g1_accumulate","k_g1_reduce_chunks","k_g1_reduce_windows","k_g1_sort_sets")})
+print(sys.argv[1], "value=%.0f prove_only=%.0f verify_only=%.0f parity=%s" % (l["value"], l["prove_only_proofs_per_s"], l["verify_only_proofs_per_s"], l["parity_ok"]), {n:k.get(n) for n in ("k_g1_accumulate","k_g1_reduce_chunks","k_g1_reduce_windows","k_g1_sort_sets")})
 PY
 done
