@@ -207,8 +207,9 @@ __global__ void k_g1_digits(const uint32_t* __restrict__ scalars, uint32_t n, ui
 // ---- 2. exclusive scan of the histogram (three passes; the array is at most a few million entries)
 constexpr int SCAN_BLOCK = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 
+template <int BLOCK = SCAN_BLOCK>
 DR_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t* smem, uint32_t& total) {
-    // wave scan with shuffles, then scan of the 4 wave totals through LDS
+    // wave scan with shuffles, then scan of the BLOCK / 64 wave totals through LDS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t x = v;
 #pragma unroll
@@ -219,7 +220,7 @@ DR_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t* smem, uint32_t& total
     if (lane == 63) smem[wave] = x;
     __syncthreads();
     uint32_t base = 0, tot = 0;
-    for (int w = 0; w < SCAN_BLOCK / 64; w++) {
+    for (int w = 0; w < BLOCK / 64; w++) {
         uint32_t t = smem[w];
         if (w < wave) base += t;
         tot += t;
@@ -321,6 +322,7 @@ struct SortSetParams {
     uint32_t tbl_stride, tbl_offset;
     uint32_t capacity;                  // entries reserved per set in `sorted`
     uint32_t short_from, n_short;       // scalar vectors b >= short_from are zero beyond n_short entries: not even read
+    uint32_t n_pad, digits_per_set;     // staged variant: row length (a multiple of 8) and u16 digits reserved per set
 };
 
 DR_DEV void load_scalar_mod_r(const uint32_t* __restrict__ scalars, size_t idx, uint32_t (&k)[9]) {
@@ -342,7 +344,7 @@ DR_DEV void load_scalar_mod_r(const uint32_t* __restrict__ scalars, size_t idx, 
 // visit the signed digits of scalar k: f(window, digit) for windows [w_lo, w_hi) (the carry chain always starts at 0).
 // The scalar words are indexed only by the unrolled outer loop: a run-time index (k[start >> 5]) would put the array in
 // scratch memory and cost one memory round trip per digit (measured: 5.4 -> 1.x ms for the prover's sort kernel).
-template <class F>
+template <bool WITH_ZEROS = false, class F>
 DR_DEV void for_each_digit(const uint32_t (&k)[9], const WindowTable& wt, int w_lo, int w_hi, F&& f) {
     uint32_t carry = 0;
     int w = 0;
@@ -356,7 +358,7 @@ DR_DEV void for_each_digit(const uint32_t (&k)[9], const WindowTable& wt, int w_
             int32_t d;
             if (raw > half) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
             else { d = (int32_t)raw; carry = 0; }
-            if (w >= w_lo && d != 0) f(w, d);
+            if (w >= w_lo && (WITH_ZEROS || d != 0)) f(w, d);
             w++;
         }
     }
@@ -423,6 +425,127 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
             uint32_t entry = sp.single ? (uint32_t)w * sp.tbl_stride + sp.tbl_offset + i : i;
             sorted[base + pos] = entry | (d < 0 ? 0x80000000u : 0u);
         });
+    }
+}
+
+// ---- 3a'. the same sort with COALESCED stores (round 2).  The kernel above writes every (index, sign) entry as a scattered
+// 4-byte store into its set's 0.5 MB segment: 139 M stores per dense prover launch, 32-byte sectors, 3 of the kernel's 5 ms.
+// Here the sorted segment is assembled in LDS, one chunk of ~26 k entries at a time, and copied out in whole lines:
+//   pass 1   histogram in LDS as before, and every digit is written once as a u16 (sign << 15 | magnitude), row-major by
+//            window so that lanes write consecutive addresses (2 bytes per entry instead of recomputing the digits later);
+//   scan     bucket offsets; bucket ranges [jb_k, jb_k+1) whose segments start inside chunk k (positions [k C, (k+1) C));
+//   pass 2.k re-read the u16 digits (16-byte loads, L2 / Infinity-Cache hits), take the entries whose bucket lies in chunk k,
+//            place them in the LDS stage at (position - k C), copy the stage out.  A bucket that runs past the stage (skewed
+//            scalars) stores its overflow directly.
+// One workgroup of 1024 lanes per set (144 KB of LDS: one workgroup per CU, four waves per SIMD).
+constexpr int SORT2_BLOCK = 1024;
+constexpr uint32_t SORT2_CAP = 28672, SORT2_CHUNK = 26624, SORT2_MAX_CHUNKS = 64;
+
+__global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint32_t* __restrict__ scalars, WindowTable wt, SortSetParams sp,
+                                                                    uint16_t* __restrict__ digits16, uint32_t* __restrict__ counts,
+                                                                    uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t bins[SORT_MAX_H];
+    __shared__ uint32_t stage[SORT2_CAP];
+    __shared__ uint32_t cs[SORT2_MAX_CHUNKS + 1], jb[SORT2_MAX_CHUNKS + 1];
+    __shared__ uint32_t smem[SORT2_BLOCK / 64];
+    const uint32_t H = sp.H, set = blockIdx.x, tid = threadIdx.x;
+    uint32_t b, i_lo, i_hi;
+    int w_lo, w_hi;
+    if (sp.single) {
+        b = set / sp.groups;
+        uint32_t g = set % sp.groups;
+        const uint32_t n_eff = b >= sp.short_from ? sp.n_short : sp.n;
+        i_lo = (uint32_t)(((uint64_t)g * n_eff + sp.groups - 1) / sp.groups);
+        i_hi = (uint32_t)(((uint64_t)(g + 1) * n_eff + sp.groups - 1) / sp.groups);
+        w_lo = 0; w_hi = wt.W;
+    } else {
+        const uint32_t sw = set / sp.groups, g = set % sp.groups;
+        b = sw / wt.W;
+        w_lo = (int)(sw % wt.W); w_hi = w_lo + 1;
+        i_lo = (uint32_t)(((uint64_t)g * sp.n + sp.groups - 1) / sp.groups);
+        i_hi = (uint32_t)(((uint64_t)(g + 1) * sp.n + sp.groups - 1) / sp.groups);
+    }
+    const uint32_t n_set = i_hi - i_lo, n_pad = (n_set + 7u) & ~7u, rows = (uint32_t)(w_hi - w_lo);
+    uint16_t* dg = digits16 + (size_t)set * sp.digits_per_set;
+    for (uint32_t j = tid; j < H; j += SORT2_BLOCK) bins[j] = 0;
+    for (uint32_t k = tid; k <= SORT2_MAX_CHUNKS; k += SORT2_BLOCK) { cs[k] = 0xffffffffu; jb[k] = H; }
+    __syncthreads();
+    // pass 1: histogram + the digits as u16 rows [window][scalar], zero-padded to n_pad
+    for (uint32_t ii = tid; ii < n_pad; ii += SORT2_BLOCK) {
+        if (ii < n_set) {
+            uint32_t k[9];
+            load_scalar_mod_r(scalars, (size_t)b * sp.n + i_lo + ii, k);
+            for_each_digit<true>(k, wt, w_lo, w_hi, [&](int w, int32_t d) {
+                const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+                dg[(size_t)(w - w_lo) * n_pad + ii] = (uint16_t)(mag | (d < 0 ? 0x8000u : 0u));
+                if (d != 0) atomicAdd(&bins[mag - 1], 1u);
+            });
+        } else {
+            for (uint32_t r = 0; r < rows; r++) dg[(size_t)r * n_pad + ii] = 0;
+        }
+    }
+    __syncthreads();
+    // counts out; exclusive scan of the bins; bucket range and first position of every chunk
+    const uint32_t per = (H + SORT2_BLOCK - 1) / SORT2_BLOCK, lo = tid * per < H ? tid * per : H, hi = lo + per < H ? lo + per : H;
+    uint32_t local = 0;
+    for (uint32_t j = lo; j < hi; j++) {
+        uint32_t c = bins[j];
+        counts[(size_t)set * H + j] = c;
+        local += c;
+    }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan<SORT2_BLOCK>(local, smem, total);
+    const uint32_t base = set * sp.capacity;
+    const uint32_t K = (total + SORT2_CHUNK - 1) / SORT2_CHUNK;            // <= SORT2_MAX_CHUNKS (host: capacity / SORT2_CHUNK)
+    for (uint32_t j = lo; j < hi; j++) {
+        uint32_t c = bins[j];
+        bins[j] = run;                                  // becomes the placement cursor
+        offsets[(size_t)set * H + j] = base + run;
+        const uint32_t k = run / SORT2_CHUNK;           // chunk in which this bucket's segment starts (k <= K; k == K only for
+        atomicMin(&jb[k], j);                           //  empty buckets at the very end)
+        atomicMin(&cs[k], run);
+        run += c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // chunks in which no bucket starts (a bucket longer than a chunk) inherit the next chunk's bounds
+        cs[K] = total; jb[K] = H;
+        for (int k = (int)K - 1; k >= 0; k--) {
+            if (cs[k] == 0xffffffffu) cs[k] = cs[k + 1];
+            if (jb[k] > jb[k + 1]) jb[k] = jb[k + 1];
+        }
+    }
+    __syncthreads();
+    // pass 2: chunk by chunk
+    const uint32_t tbl = sp.single ? sp.tbl_offset : 0u;
+    for (uint32_t k = 0; k < K; k++) {
+        const uint32_t j_lo = jb[k], j_hi = jb[k + 1], p_lo = cs[k], p_hi = cs[k + 1], c0 = k * SORT2_CHUNK;
+        if (j_lo < j_hi) {
+            for (uint32_t r = 0; r < rows; r++) {
+                const uint4* row = reinterpret_cast<const uint4*>(dg + (size_t)r * n_pad);
+                const uint32_t row_entry = (sp.single ? (uint32_t)(w_lo + (int)r) * sp.tbl_stride : 0u) + tbl + i_lo;
+                for (uint32_t v = tid; v < n_pad / 8; v += SORT2_BLOCK) {
+                    const uint4 q = row[v];
+                    const uint32_t words[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        const uint32_t dd = (words[t >> 1] >> (16 * (t & 1))) & 0xffffu;
+                        const uint32_t j = (dd & 0x7fffu) - 1u;              // dd == 0 -> 0xffffffff: outside every range
+                        if (j >= j_lo && j < j_hi) {
+                            const uint32_t pos = atomicAdd(&bins[j], 1u);
+                            const uint32_t entry = (row_entry + v * 8 + (uint32_t)t) | ((dd & 0x8000u) << 16);
+                            const uint32_t rel = pos - c0;
+                            if (rel < SORT2_CAP) stage[rel] = entry;
+                            else sorted[base + pos] = entry;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t r_lo = p_lo - c0, r_hi = (p_hi - c0) < SORT2_CAP ? (p_hi - c0) : SORT2_CAP;
+        for (uint32_t rel = r_lo + tid; rel < r_hi; rel += SORT2_BLOCK) sorted[base + c0 + rel] = stage[rel];
+        __syncthreads();
     }
 }
 
