@@ -158,17 +158,23 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         // sets of more than a few thousand entries: the sorted segment is assembled in LDS and written in whole lines
         // (k_g1_sort_sets_staged; DOTRING_MSM_SORT_STAGED=0: scattered 4-byte stores as in round 1)
         static const bool staged_on = std::getenv("DOTRING_MSM_SORT_STAGED") == nullptr || std::atoi(std::getenv("DOTRING_MSM_SORT_STAGED")) != 0;
-        const bool staged = staged_on && per_set_digits >= 4096 && per_set_digits / dr::SORT2_CHUNK + 1 <= dr::SORT2_MAX_CHUNKS;
+        const bool small_h = pl.H <= dr::SORT2_SMALL_H;
+        const uint32_t stage_chunk = (small_h ? dr::SORT2_CAP_SMALL_H : dr::SORT2_CAP_LARGE_H) - dr::SORT2_SLACK;
+        const bool staged = staged_on && per_set_digits >= 4096 && per_set_digits / stage_chunk + 1 <= dr::SORT2_MAX_CHUNKS;
         if (staged) {
             sp.n_pad = (uint32_t)((per_set_scalars + 7) & ~(size_t)7);
             sp.digits_per_set = sp.n_pad * (uint32_t)(single ? pl.W : 1);
             TRY(ctx->digits.reserve(bsets * (size_t)sp.digits_per_set * 2));
         }
         TRY(launch(ctx, "k_g1_sort_sets", [&] {
-            if (staged)
-                hipLaunchKernelGGL(dr::k_g1_sort_sets_staged, dim3((unsigned)bsets), dim3(dr::SORT2_BLOCK), 0, st, d_scalars, pl.wt, sp,
-                                   ctx->digits.as<uint16_t>(), ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(),
-                                   ctx->sorted.as<uint32_t>());
+            if (staged && small_h)
+                hipLaunchKernelGGL((dr::k_g1_sort_sets_staged<dr::SORT2_SMALL_H, dr::SORT2_CAP_SMALL_H>), dim3((unsigned)bsets), dim3(dr::SORT2_BLOCK),
+                                   0, st, d_scalars, pl.wt, sp, ctx->digits.as<uint16_t>(), ctx->counts.as<uint32_t>(),
+                                   ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
+            else if (staged)
+                hipLaunchKernelGGL((dr::k_g1_sort_sets_staged<dr::SORT_MAX_H, dr::SORT2_CAP_LARGE_H>), dim3((unsigned)bsets), dim3(dr::SORT2_BLOCK),
+                                   0, st, d_scalars, pl.wt, sp, ctx->digits.as<uint16_t>(), ctx->counts.as<uint32_t>(),
+                                   ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
             else
                 hipLaunchKernelGGL(dr::k_g1_sort_sets, dim3((unsigned)bsets), dim3(dr::SORT_BLOCK), 0, st, d_scalars, pl.wt, sp,
                                    ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());

@@ -438,13 +438,18 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
 //            place them in the LDS stage at (position - k C), copy the stage out.  A bucket that runs past the stage (skewed
 //            scalars) stores its overflow directly.
 // One workgroup of 1024 lanes per set (144 KB of LDS: one workgroup per CU, four waves per SIMD).
+// Two instances: up to 2048 buckets per set (the prover's 12-bit SRS windows: 8 KB of bins, 36864 staged entries — four
+// chunks for a dense 135 k-entry set) and up to 8192 (32 KB of bins, 28672 staged entries).
 constexpr int SORT2_BLOCK = 1024;
-constexpr uint32_t SORT2_CAP = 28672, SORT2_CHUNK = 26624, SORT2_MAX_CHUNKS = 64;
+constexpr uint32_t SORT2_SLACK = 2048, SORT2_MAX_CHUNKS = 64;
+constexpr uint32_t SORT2_CAP_SMALL_H = 36864, SORT2_CAP_LARGE_H = 28672, SORT2_SMALL_H = 2048;
 
+template <uint32_t MAX_H, uint32_t SORT2_CAP>
 __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint32_t* __restrict__ scalars, WindowTable wt, SortSetParams sp,
                                                                     uint16_t* __restrict__ digits16, uint32_t* __restrict__ counts,
                                                                     uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
-    __shared__ uint32_t bins[SORT_MAX_H];
+    constexpr uint32_t SORT2_CHUNK = SORT2_CAP - SORT2_SLACK;
+    __shared__ uint32_t bins[MAX_H];
     __shared__ uint32_t stage[SORT2_CAP];
     __shared__ uint32_t cs[SORT2_MAX_CHUNKS + 1], jb[SORT2_MAX_CHUNKS + 1];
     __shared__ uint32_t smem[SORT2_BLOCK / 64];
@@ -521,11 +526,15 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
     for (uint32_t k = 0; k < K; k++) {
         const uint32_t j_lo = jb[k], j_hi = jb[k + 1], p_lo = cs[k], p_hi = cs[k + 1], c0 = k * SORT2_CHUNK;
         if (j_lo < j_hi) {
-            for (uint32_t r = 0; r < rows; r++) {
-                const uint4* row = reinterpret_cast<const uint4*>(dg + (size_t)r * n_pad);
+            // the rows x (n_pad / 8) sixteen-byte vectors of the set as one index space (no idle lanes at row ends)
+            const uint32_t nv = n_pad / 8, nvec = rows * nv;
+            const uint4* vecs = reinterpret_cast<const uint4*>(dg);
+            uint32_t r = 0, v = tid;
+            for (uint32_t idx = tid; idx < nvec; idx += SORT2_BLOCK, v += SORT2_BLOCK) {
+                while (v >= nv) { v -= nv; r++; }
                 const uint32_t row_entry = (sp.single ? (uint32_t)(w_lo + (int)r) * sp.tbl_stride : 0u) + tbl + i_lo;
-                for (uint32_t v = tid; v < n_pad / 8; v += SORT2_BLOCK) {
-                    const uint4 q = row[v];
+                {
+                    const uint4 q = vecs[idx];
                     const uint32_t words[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                     for (int t = 0; t < 8; t++) {
