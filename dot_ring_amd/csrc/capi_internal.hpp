@@ -16,6 +16,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <array>
 #include <memory>
 #include <mutex>
 #include <set>

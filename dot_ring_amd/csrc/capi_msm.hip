@@ -846,11 +846,24 @@ int dr_g1_sum(const uint8_t* pts_be_xy, size_t n, uint8_t out_be_xy[96], int* is
 }
 
 namespace {
-int miller_product(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, drh::Fq12& f) {
+// prepared G2 points by their 192-byte encoding (a verifier key has two; a handful of SRS files per process)
+const drh::G2Prepared* g2_prepared_cached(const uint8_t enc[192], const drh::G2Affine& q) {
+    static std::mutex m;
+    static std::vector<std::pair<std::array<uint8_t, 192>, std::unique_ptr<drh::G2Prepared>>> cache;
+    std::array<uint8_t, 192> key;
+    std::memcpy(key.data(), enc, 192);
+    std::lock_guard<std::mutex> lock(m);
+    for (auto& e : cache) if (e.first == key) return e.second.get();
+    if (cache.size() >= 16) cache.erase(cache.begin());
+    cache.emplace_back(key, std::make_unique<drh::G2Prepared>(drh::g2_prepare(q)));
+    return cache.back().second.get();
+}
+int miller_product(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, drh::Fq12& f, bool prepared = true) {
     std::vector<uint8_t> le;
     TRY(g1_be_to_le_limbs(g1_be_xy, n, le, true));
     std::vector<drh::Fq> px, py;
     std::vector<drh::G2Affine> qs;
+    std::vector<const drh::G2Prepared*> preps;
     for (size_t i = 0; i < n; i++) {
         const uint8_t* q = g2_be + 192 * i;
         drh::G2Affine Q;
@@ -868,8 +881,10 @@ int miller_product(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, drh:
         drh::Fq::load_le(x, le.data() + 96 * i);
         drh::Fq::load_le(y, le.data() + 96 * i + 48);
         px.push_back(x); py.push_back(y); qs.push_back(Q);
+        if (prepared) preps.push_back(g2_prepared_cached(q, Q));
     }
-    f = drh::multi_miller_loop(px.data(), py.data(), qs.data(), qs.size());
+    f = prepared ? drh::multi_miller_loop_prepared(px.data(), py.data(), preps.data(), preps.size())
+                 : drh::multi_miller_loop(px.data(), py.data(), qs.data(), qs.size());
     return DR_OK;
 }
 }  // namespace
@@ -882,14 +897,16 @@ int dr_pairing_check(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, in
     return DR_OK;
 }
 
-// diagnostic: the fast final exponentiation (Frobenius maps + x-chain, exponent 3(p^12-1)/r) against the plain
-// square-and-multiply one; *consistent = 1 iff fast == reference^3 for this Miller-loop product
+// diagnostic: the check's Miller loop (prepared G2 points, sparse line products) against the plain affine one, and its
+// final exponentiation (Frobenius maps + x-chain with cyclotomic squarings, exponent 3(p^12-1)/r) against the plain
+// square-and-multiply one; *consistent = 1 iff the loops agree and fast == reference^3 for this product
 int dr_pairing_selfcheck(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, int* consistent) {
     if (!consistent || (n && (!g1_be_xy || !g2_be))) return fail(DR_ERR_INVALID, "null buffer");
-    drh::Fq12 f;
+    drh::Fq12 f, f_plain;
     TRY(miller_product(g1_be_xy, g2_be, n, f));
-    drh::Fq12 ref = drh::final_exponentiation(f);
-    *consistent = drh::final_exponentiation_check(f) == ref * ref * ref ? 1 : 0;
+    TRY(miller_product(g1_be_xy, g2_be, n, f_plain, false));            // affine Miller loop, slopes computed on the fly
+    drh::Fq12 ref = drh::final_exponentiation(f_plain);
+    *consistent = (f == f_plain && drh::final_exponentiation_check(f) == ref * ref * ref) ? 1 : 0;
     return DR_OK;
 }
 
