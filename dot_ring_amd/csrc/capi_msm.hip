@@ -147,6 +147,18 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     const size_t per_set_scalars = single ? (n + groups - 1) / groups : n;
     const size_t per_set_digits = single ? per_set_scalars * (size_t)pl.W : n;
     const bool lds_sort = pl.H <= dr::SORT_MAX_H && bsets >= 64 && per_set_digits <= (1u << 20) && bsets * per_set_digits < (1ull << 32);
+    // a few huge sets over a window table (one 2^20-point MSM): two-pass partition sort (k_g1_part_scatter / k_g1_part_sort;
+    // DOTRING_MSM_PART_SORT=0: digits -> global histogram -> scan -> global scatter)
+    static const bool part_on = std::getenv("DOTRING_MSM_PART_SORT") == nullptr || std::atoi(std::getenv("DOTRING_MSM_PART_SORT")) != 0;
+    uint32_t part_p = 1, part_shift = 0;
+    {
+        const size_t chunk = dr::PART_STAGE - dr::PART_SLACK;
+        while (part_p < dr::PART_MAX_P && (pl.H / part_p > dr::PART_MAX_HP || per_set_digits / part_p > chunk - chunk / 16)) part_p *= 2;
+        while ((pl.H >> part_shift) > part_p) part_shift++;
+    }
+    const bool part_sort = part_on && !lds_sort && single && batch == 1 && pl.W <= 32 && per_set_scalars <= 65536 && pl.H >= part_p &&
+                           pl.H / part_p <= dr::PART_MAX_HP && per_set_digits / part_p <= 48 * (size_t)(dr::PART_STAGE - dr::PART_SLACK) &&
+                           bsets * per_set_digits < (1ull << 32) && per_set_digits >= 65536;
     if (lds_sort) {
         dr::SortSetParams sp;
         sp.n = (uint32_t)n; sp.batch = (uint32_t)batch; sp.H = pl.H; sp.groups = groups; sp.single = single ? 1 : 0;
@@ -178,6 +190,25 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
             else
                 hipLaunchKernelGGL(dr::k_g1_sort_sets, dim3((unsigned)bsets), dim3(dr::SORT_BLOCK), 0, st, d_scalars, pl.wt, sp,
                                    ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
+        }));
+    } else if (part_sort) {
+        dr::PartParams pp{};
+        pp.n = (uint32_t)n; pp.H = pl.H; pp.groups = groups; pp.P = part_p; pp.pshift = part_shift;
+        pp.tile = std::min<uint32_t>(2048, dr::PART_TILE_ENTRIES / (uint32_t)pl.W);
+        pp.tiles_per_set = (uint32_t)((per_set_scalars + pp.tile - 1) / pp.tile);
+        pp.cap_part = (uint32_t)per_set_digits; pp.capacity = (uint32_t)per_set_digits;
+        pp.tbl_stride = tbl->stride; pp.tbl_offset = tbl->offset;
+        TRY(ctx->digits.reserve(bsets * (size_t)part_p * per_set_digits * 4));
+        TRY(ctx->cursor.reserve(bsets * (size_t)part_p * 4));
+        TRY(ctx->sorted.reserve(bsets * per_set_digits * 4));
+        HIP_TRY(hipMemsetAsync(ctx->cursor.p, 0, bsets * (size_t)part_p * 4, st));
+        TRY(launch(ctx, "k_g1_part_scatter", [&] {
+            hipLaunchKernelGGL(dr::k_g1_part_scatter, dim3((unsigned)(bsets * pp.tiles_per_set)), dim3(dr::PART_BLOCK), 0, st, d_scalars, pl.wt, pp,
+                               ctx->cursor.as<uint32_t>(), ctx->digits.as<uint32_t>());
+        }));
+        TRY(launch(ctx, "k_g1_part_sort", [&] {
+            hipLaunchKernelGGL(dr::k_g1_part_sort, dim3((unsigned)(bsets * part_p)), dim3(dr::PART_BLOCK), 0, st, ctx->digits.as<uint32_t>(),
+                               ctx->cursor.as<uint32_t>(), pp, ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
         }));
     } else {
         TRY(ctx->digits.reserve(ndigits * 4));

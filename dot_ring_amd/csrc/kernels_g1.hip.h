@@ -558,6 +558,174 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
     }
 }
 
+// ---- 3a''. two-pass sort for a FEW HUGE bucket sets (one 2^20-point MSM over a window table: 16 index groups x 32768
+// buckets, a million entries per set — too many for one workgroup's LDS, and the digits -> global-atomic histogram -> scan ->
+// global-atomic scatter chain above costs 1.5 ms of the 5.3 ms MSM).
+//   pass A (k_g1_part_scatter): a workgroup takes a tile of scalars of one set (2048 at 16 windows), computes their digits and splits the
+//     entries by the top bits of the bucket index into P partitions: per-wave counters in LDS, the tile's entries grouped by
+//     partition in an LDS stage, ONE global atomic per (tile, partition) to reserve room in that partition's stream, then the
+//     stage is copied out in runs of ~1000 entries.  A stream entry packs sign | bucket-in-partition (10 bits) | window (5) |
+//     scalar index within the set (16).
+//   pass B (k_g1_part_sort): one workgroup per (set, partition) sorts its ~32 k entries by bucket entirely in LDS (histogram,
+//     scan, placement into a stage, coalesced copy-out — k_g1_sort_sets_staged's second half on a stream instead of digit
+//     rows), and writes counts / offsets / sorted in the layout the accumulate kernel reads.
+// Every partition stream has room for ALL entries of its set, so no scalar distribution can overflow one.
+constexpr int PART_BLOCK = 1024;
+constexpr uint32_t PART_TILE_ENTRIES = 32768, PART_MAX_P = 32, PART_MAX_HP = 1024, PART_STAGE = 36864, PART_SLACK = 2048;
+
+struct PartParams {
+    uint32_t n, H, groups, tiles_per_set, P, pshift;      // pshift = log2(H / P): bucket >> pshift = partition
+    uint32_t tile;                                        // scalars per pass-A workgroup: tile * W <= PART_TILE_ENTRIES
+    uint32_t cap_part;                                    // entries reserved per partition stream
+    uint32_t capacity;                                    // entries reserved per set in `sorted`
+    uint32_t tbl_stride, tbl_offset;
+};
+
+DR_DEV void part_set_range(const PartParams& pp, uint32_t set, uint32_t& b, uint32_t& i_lo, uint32_t& i_hi) {
+    b = set / pp.groups;
+    const uint32_t g = set % pp.groups;
+    i_lo = (uint32_t)(((uint64_t)g * pp.n + pp.groups - 1) / pp.groups);
+    i_hi = (uint32_t)(((uint64_t)(g + 1) * pp.n + pp.groups - 1) / pp.groups);
+}
+
+__global__ __launch_bounds__(PART_BLOCK) void k_g1_part_scatter(const uint32_t* __restrict__ scalars, WindowTable wt, PartParams pp,
+                                                                uint32_t* __restrict__ part_fill, uint32_t* __restrict__ streams) {
+    constexpr int WAVES = PART_BLOCK / 64;
+    __shared__ uint32_t stage[PART_TILE_ENTRIES];
+    __shared__ uint32_t cnt[WAVES][PART_MAX_P];                   // per-wave counts, then per-wave cursors into the stage
+    __shared__ uint32_t pbase[PART_MAX_P + 1], gbase[PART_MAX_P];
+    const uint32_t set = blockIdx.x / pp.tiles_per_set, tile = blockIdx.x % pp.tiles_per_set, tid = threadIdx.x, wave = tid >> 6;
+    uint32_t b, i_lo, i_hi;
+    part_set_range(pp, set, b, i_lo, i_hi);
+    const uint32_t t_lo = i_lo + tile * pp.tile < i_hi ? i_lo + tile * pp.tile : i_hi, t_hi = t_lo + pp.tile < i_hi ? t_lo + pp.tile : i_hi;
+    for (uint32_t k = tid; k < WAVES * PART_MAX_P; k += PART_BLOCK) (&cnt[0][0])[k] = 0;
+    __syncthreads();
+    const uint32_t lowmask = (1u << pp.pshift) - 1u;
+    // count per (wave, partition)
+    for (uint32_t i = t_lo + tid; i < t_hi; i += PART_BLOCK) {
+        uint32_t k[9];
+        load_scalar_mod_r(scalars, (size_t)b * pp.n + i, k);
+        for_each_digit(k, wt, 0, wt.W, [&](int, int32_t d) {
+            const uint32_t j = (uint32_t)(d < 0 ? -d : d) - 1u;
+            atomicAdd(&cnt[wave][j >> pp.pshift], 1u);
+        });
+    }
+    __syncthreads();
+    // stage layout: partition-major, wave-minor; cnt becomes the cursor of each (wave, partition) run
+    if (tid < 64) {
+        uint32_t total = 0;
+        if (tid < pp.P) for (int w = 0; w < WAVES; w++) total += cnt[w][tid];
+        uint32_t x = total;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            uint32_t y = __shfl_up(x, s, 64);
+            if ((int)tid >= s) x += y;
+        }
+        if (tid < pp.P) {
+            uint32_t run = x - total;
+            pbase[tid] = run;
+            gbase[tid] = total ? atomicAdd(&part_fill[(size_t)set * pp.P + tid], total) : 0u;
+            for (int w = 0; w < WAVES; w++) { uint32_t c = cnt[w][tid]; cnt[w][tid] = run; run += c; }
+        }
+        if (tid == pp.P - 1) pbase[pp.P] = x;
+    }
+    __syncthreads();
+    for (uint32_t i = t_lo + tid; i < t_hi; i += PART_BLOCK) {
+        uint32_t k[9];
+        load_scalar_mod_r(scalars, (size_t)b * pp.n + i, k);
+        const uint32_t local = i - i_lo;
+        for_each_digit(k, wt, 0, wt.W, [&](int w, int32_t d) {
+            const uint32_t j = (uint32_t)(d < 0 ? -d : d) - 1u;
+            const uint32_t pos = atomicAdd(&cnt[wave][j >> pp.pshift], 1u);
+            stage[pos] = (d < 0 ? 0x80000000u : 0u) | ((j & lowmask) << 21) | ((uint32_t)w << 16) | local;
+        });
+    }
+    __syncthreads();
+    // copy out: entry idx of the stage belongs to the partition whose [pbase[p], pbase[p+1]) holds it
+    const uint32_t total = pbase[pp.P];
+    for (uint32_t idx = tid; idx < total; idx += PART_BLOCK) {
+        uint32_t lo = 0, hi = pp.P;                                 // largest p with pbase[p] <= idx
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pbase[mid] <= idx) lo = mid; else hi = mid; }
+        streams[((size_t)set * pp.P + lo) * pp.cap_part + gbase[lo] + (idx - pbase[lo])] = stage[idx];
+    }
+}
+
+__global__ __launch_bounds__(PART_BLOCK) void k_g1_part_sort(const uint32_t* __restrict__ streams, const uint32_t* __restrict__ part_fill,
+                                                             PartParams pp, uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                                             uint32_t* __restrict__ sorted) {
+    constexpr uint32_t CHUNK = PART_STAGE - PART_SLACK, MAX_CHUNKS = 64;
+    __shared__ uint32_t bins[PART_MAX_HP];
+    __shared__ uint32_t stage[PART_STAGE];
+    __shared__ uint32_t cs[MAX_CHUNKS + 1], jb[MAX_CHUNKS + 1];
+    __shared__ uint32_t smem[PART_BLOCK / 64];
+    __shared__ uint32_t part_base_s;
+    const uint32_t blk = blockIdx.x, set = blk / pp.P, part = blk % pp.P, tid = threadIdx.x, HP = 1u << pp.pshift;
+    uint32_t b, i_lo, i_hi;
+    part_set_range(pp, set, b, i_lo, i_hi);
+    const uint32_t n_ent = part_fill[blk];
+    const uint32_t* src = streams + (size_t)blk * pp.cap_part;
+    for (uint32_t j = tid; j < HP; j += PART_BLOCK) bins[j] = 0;
+    for (uint32_t k = tid; k <= MAX_CHUNKS; k += PART_BLOCK) { cs[k] = 0xffffffffu; jb[k] = HP; }
+    if (tid == 0) {
+        uint32_t pb = 0;
+        for (uint32_t q = 0; q < part; q++) pb += part_fill[(size_t)set * pp.P + q];
+        part_base_s = pb;
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < n_ent; idx += PART_BLOCK) atomicAdd(&bins[(src[idx] >> 21) & 0x3ffu], 1u);
+    __syncthreads();
+    const uint32_t per = (HP + PART_BLOCK - 1) / PART_BLOCK, lo = tid * per < HP ? tid * per : HP, hi = lo + per < HP ? lo + per : HP;
+    uint32_t local = 0;
+    const size_t bucket0 = (size_t)set * pp.H + (size_t)part * HP;
+    for (uint32_t j = lo; j < hi; j++) {
+        const uint32_t c = bins[j];
+        counts[bucket0 + j] = c;
+        local += c;
+    }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan<PART_BLOCK>(local, smem, total);
+    const uint32_t base = set * pp.capacity + part_base_s;
+    const uint32_t K = (total + CHUNK - 1) / CHUNK;                 // 1 for evenly spread scalars; <= MAX_CHUNKS (host)
+    for (uint32_t j = lo; j < hi; j++) {
+        const uint32_t c = bins[j];
+        bins[j] = run;
+        offsets[bucket0 + j] = base + run;
+        const uint32_t k = run / CHUNK;
+        atomicMin(&jb[k], j);
+        atomicMin(&cs[k], run);
+        run += c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        cs[K] = total; jb[K] = HP;
+        for (int k = (int)K - 1; k >= 0; k--) {
+            if (cs[k] == 0xffffffffu) cs[k] = cs[k + 1];
+            if (jb[k] > jb[k + 1]) jb[k] = jb[k + 1];
+        }
+    }
+    __syncthreads();
+    const uint32_t entry0 = pp.tbl_offset + i_lo;
+    for (uint32_t k = 0; k < K; k++) {
+        const uint32_t j_lo = jb[k], j_hi = jb[k + 1], p_lo = cs[k], p_hi = cs[k + 1], c0 = k * CHUNK;
+        if (j_lo < j_hi) {
+            for (uint32_t idx = tid; idx < n_ent; idx += PART_BLOCK) {
+                const uint32_t e = src[idx], j = (e >> 21) & 0x3ffu;
+                if (j >= j_lo && j < j_hi) {
+                    const uint32_t pos = atomicAdd(&bins[j], 1u);
+                    const uint32_t entry = (((e >> 16) & 31u) * pp.tbl_stride + entry0 + (e & 0xffffu)) | (e & 0x80000000u);
+                    const uint32_t rel = pos - c0;
+                    if (rel < PART_STAGE) stage[rel] = entry;
+                    else sorted[base + pos] = entry;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t r_lo = p_lo - c0, r_hi = (p_hi - c0) < PART_STAGE ? (p_hi - c0) : PART_STAGE;
+        for (uint32_t rel = r_lo + tid; rel < r_hi; rel += PART_BLOCK) sorted[base + c0 + rel] = stage[rel];
+        __syncthreads();
+    }
+}
+
 // ---- 3b. order buckets by size (descending) so that the 64 lanes of a wave walk chains of nearly equal length.
 // A wave otherwise waits for its longest bucket: with ~20 points per bucket (Poisson) a third of the lane-cycles idle.
 // Counting sort over 256 size classes (sizes >= 255 share the first class): per-workgroup histograms in LDS, a scan

@@ -271,6 +271,34 @@ def test_g1_msm_synthetic_bases_closed_form(ctx, log2n, table):
     srs.close()
 
 
+def test_g1_msm_partition_sort_skewed_and_ragged(ctx):
+    """the two-pass partition sort of one huge table MSM (k_g1_part_scatter / k_g1_part_sort) away from uniformly random
+    scalars: a ragged size (index groups of unequal length, a last tile of a few scalars), every scalar equal (one bucket per
+    window gets everything: a partition of many stage chunks, entries past the LDS stage), a 0/1 column, three distinct values,
+    zero scalars mixed in — closed form [sum k_i (1 + i)] G each time"""
+    import bench
+
+    n = (1 << 18) + 37
+    srs = ctx.srs_synthetic(bench.G1_BE, n, first=1)
+    srs.precompute(16)
+    rng = random.Random(4242)
+    vals, _ = bench.seeded_scalars(n, b"part")
+    cols = {
+        "random": vals,
+        "same": [0x1234567 << 180 | 0xABCDEF] * n,
+        "bits": [rng.randrange(2) for _ in range(n)],
+        "three values, zeros": [rng.choice([0, 5, 1 << 200, coracle.FR_P - 7]) for _ in range(n)],
+        "minus one": [coracle.FR_P - 1] * n,
+    }
+    for name, col in cols.items():
+        raw = b"".join(k.to_bytes(32, "little") for k in col)
+        got = ctx.g1_msm(srs, raw)
+        expect = sum(k * (1 + i) for i, k in enumerate(col)) % coracle.FR_P
+        want = coracle.g1_msm_raw(bench.be_to_le_points(bench.G1_BE), expect.to_bytes(32, "little"), 1)
+        assert got == bytes(want)[:48][::-1] + bytes(want)[48:][::-1], name
+    srs.close()
+
+
 @pytest.mark.parametrize("bits,batch", [(12, 2100), (9, 16500)])
 def test_g1_msm_many_bucket_sets_level_reduction(ctx, srs_bytes, bits, batch):
     """Thousands of small MSMs over a window table take the level-wise bucket reduction (k_g1_reduce_level/_final:

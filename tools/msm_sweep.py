@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from dot_ring_amd import _native
 
-KERNELS = ("k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_sort_sets", "k_size_sort", "k_g1_accumulate", "k_g1_reduce_chunks", "k_g1_reduce_windows", "k_g1_horner", "k_g1_results_affine")
+KERNELS = ("k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_part_scatter", "k_g1_part_sort", "k_g1_sort_sets", "k_size_sort", "k_g1_accumulate", "k_g1_reduce_chunks", "k_g1_reduce_windows", "k_g1_horner", "k_g1_results_affine")
 
 def run(log2n, window=0, reps=2, table=0):
     if window:
