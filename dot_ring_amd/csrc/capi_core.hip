@@ -73,7 +73,10 @@ int bsn_consts_init(hipStream_t st) {
     Fr aob = mont_a * mont_b.inv(), inv_b2 = mont_b.sqr().inv();
     static const uint64_t Q[4] = {0xfffe5bfeffffffffULL, 0x09a1d80553bda402ULL, 0x299d7d483339d808ULL, 0x0000000073eda753ULL};   // (p-1) / 2^32
     dr::BsnConsts h;
-    auto put = [](uint32_t (&w)[8], const Fr& v) { std::memcpy(w, v.l, 32); };     // Montgomery limbs, same R on host and device
+    // the device's twisted Edwards kernels keep Fr in Montgomery form with R = 2^261 (fr29.hip.h), the host with R = 2^256:
+    // (32 v) in the host's form has the words of v in the device's
+    const Fr thirty_two = Fr::from_u64(32);
+    auto put = [&](uint32_t (&w)[8], const Fr& v) { const Fr t = v * thirty_two; std::memcpy(w, t.l, 32); };
     put(h.mont_b, mont_b); put(h.a_over_b, aob); put(h.inv_b2, inv_b2);
     static const uint8_t GLV_B_LE[32] = {0xb4, 0x10, 0x25, 0x17, 0x4d, 0x01, 0x0f, 0xee, 0xd6, 0xf4, 0x9a, 0x0d, 0x77, 0x12, 0xa7, 0x2e,
                                          0x88, 0x1a, 0x51, 0x63, 0x3a, 0x0d, 0xf0, 0x61, 0xa5, 0x26, 0x84, 0x82, 0x8b, 0xf2, 0xc9, 0x52};

@@ -1,5 +1,6 @@
 // Modular inversion by Bernstein-Yang division steps ("Fast constant-time gcd computation and modular inversion", 2019) on
-// 14 signed limbs of 28 bits — the radix fq28.hip.h computes in, so no repacking on the way in or out.
+// signed unsaturated limbs — 14 x 28 bits for Fq (fq28.hip.h), 9 x 29 bits for Fr (fr29.hip.h): the radix the fields compute
+// in, so no repacking on the way in or out.  The text below speaks of the Fq instance.
 //
 //   divstep(delta, f, g) = (1 - delta, g, (g - f) / 2)          if delta > 0 and g odd
 //                          (1 + delta, f, (g + (g mod 2) f) / 2) otherwise                          (f odd throughout)
@@ -27,32 +28,32 @@
 
 namespace dr {
 
-constexpr int DIVSTEP_BATCH = 28;
-constexpr int DIVSTEP_MAX_BATCHES = 40;         // 1120 >= 1101 steps
-
-// P: the modulus as 14 limbs of 28 bits (odd, < 2^381 so that 21 p fits the signed top limb); n0 = -p^-1 mod 2^28.
-// x: limbs 0..12 in [0, 2^28), 0 <= value < p.  out: x^-1 mod p up to sign and size — a signed value with |out| < 21 p and
-// out * x = 1 (mod p) (0 for x = 0), limbs 0..12 in (-2^28, 2^28): a lazy operand for the Montgomery product that follows.
-// Returns the number of batches taken (tests).
-DR_DIVSTEP_FN int inv_divsteps28(const uint32_t (&P)[14], uint32_t n0, const int32_t (&x)[14], int32_t (&out)[14]) {
-    constexpr int64_t M = 0x0fffffff;
-    int32_t f[14], g[14], d[14], e[14];
+// N limbs of BITS bits; P: the modulus (odd; 21 p — or MAX_BATCHES / 2 + 1 times p — must fit the signed top limb);
+// n0 = -p^-1 mod 2^BITS; MAX_BATCHES * BITS >= floor((49 bitlen(p) + 57) / 17).
+// x: limbs 0..N-2 in [0, 2^BITS), 0 <= value < p.  out: x^-1 mod p up to size — a signed value with |out| < (MAX_BATCHES / 2 + 1) p
+// and out * x = 1 (mod p) (0 for x = 0), limbs 0..N-2 in (-2^BITS, 2^BITS): a lazy operand for the Montgomery product that
+// follows.  Returns the number of batches taken (tests).
+template <int N, int BITS, int MAX_BATCHES>
+DR_DIVSTEP_FN int inv_divsteps(const uint32_t (&P)[N], uint32_t n0, const int32_t (&x)[N], int32_t (&out)[N]) {
+    constexpr int64_t M = ((int64_t)1 << BITS) - 1;
+    constexpr int32_t HALF = (int32_t)1 << (BITS - 1);
+    int32_t f[N], g[N], d[N], e[N];
 #pragma unroll
-    for (int i = 0; i < 14; i++) { f[i] = (int32_t)P[i]; g[i] = x[i]; d[i] = 0; e[i] = 0; }
+    for (int i = 0; i < N; i++) { f[i] = (int32_t)P[i]; g[i] = x[i]; d[i] = 0; e[i] = 0; }
     e[0] = 1;
     int32_t delta = 1;
     int batches = 0;
 #pragma unroll 1
-    for (; batches < DIVSTEP_MAX_BATCHES; batches++) {
+    for (; batches < MAX_BATCHES; batches++) {
         int32_t any = 0;
 #pragma unroll
-        for (int i = 0; i < 14; i++) any |= g[i];
+        for (int i = 0; i < N; i++) any |= g[i];
         if (any == 0) break;
-        // ---- 28 steps on the low words
-        uint32_t f0 = (uint32_t)f[0] | ((uint32_t)f[1] << 28), g0 = (uint32_t)g[0] | ((uint32_t)g[1] << 28);
+        // ---- BITS steps on the low words
+        uint32_t f0 = (uint32_t)f[0] | ((uint32_t)f[1] << BITS), g0 = (uint32_t)g[0] | ((uint32_t)g[1] << BITS);
         int32_t u = 1, v = 0, q = 0, r = 1;
 #pragma unroll 4
-        for (int i = 0; i < DIVSTEP_BATCH; i++) {
+        for (int i = 0; i < BITS; i++) {
             const bool swap = delta > 0 && (g0 & 1u);
             const uint32_t f1 = swap ? g0 : f0, g1 = swap ? 0u - f0 : g0;
             const int32_t u1 = swap ? q : u, v1 = swap ? r : v, q1 = swap ? -u : q, r1 = swap ? -v : r;
@@ -66,53 +67,59 @@ DR_DIVSTEP_FN int inv_divsteps28(const uint32_t (&P)[14], uint32_t n0, const int
             v = v1 << 1;
             delta++;
         }
-        // ---- (f, g) <- t (f, g) / 2^28 (exact)
+        // ---- (f, g) <- t (f, g) / 2^BITS (exact)
         {
             int64_t cf = (int64_t)u * f[0] + (int64_t)v * g[0];
             int64_t cg = (int64_t)q * f[0] + (int64_t)r * g[0];
-            cf >>= 28;
-            cg >>= 28;
+            cf >>= BITS;
+            cg >>= BITS;
 #pragma unroll
-            for (int i = 1; i < 14; i++) {
+            for (int i = 1; i < N; i++) {
                 cf += (int64_t)u * f[i] + (int64_t)v * g[i];
                 cg += (int64_t)q * f[i] + (int64_t)r * g[i];
                 f[i - 1] = (int32_t)(cf & M);
                 g[i - 1] = (int32_t)(cg & M);
-                cf >>= 28;
-                cg >>= 28;
+                cf >>= BITS;
+                cg >>= BITS;
             }
-            f[13] = (int32_t)cf;
-            g[13] = (int32_t)cg;
+            f[N - 1] = (int32_t)cf;
+            g[N - 1] = (int32_t)cg;
         }
-        // ---- (d, e) <- t (d, e) / 2^28 mod p
+        // ---- (d, e) <- t (d, e) / 2^BITS mod p
         {
             int64_t cd = (int64_t)u * d[0] + (int64_t)v * e[0];
             int64_t ce = (int64_t)q * d[0] + (int64_t)r * e[0];
             int32_t md = (int32_t)(((uint32_t)cd * n0) & (uint32_t)M), me = (int32_t)(((uint32_t)ce * n0) & (uint32_t)M);
-            md = (md ^ 0x8000000) - 0x8000000;                          // centred: [-2^27, 2^27)
-            me = (me ^ 0x8000000) - 0x8000000;
+            md = (md ^ HALF) - HALF;                                    // centred: [-2^(BITS-1), 2^(BITS-1))
+            me = (me ^ HALF) - HALF;
             cd += (int64_t)md * (int32_t)P[0];
             ce += (int64_t)me * (int32_t)P[0];
-            cd >>= 28;
-            ce >>= 28;
+            cd >>= BITS;
+            ce >>= BITS;
 #pragma unroll
-            for (int i = 1; i < 14; i++) {
+            for (int i = 1; i < N; i++) {
                 cd += (int64_t)u * d[i] + (int64_t)v * e[i] + (int64_t)md * (int32_t)P[i];
                 ce += (int64_t)q * d[i] + (int64_t)r * e[i] + (int64_t)me * (int32_t)P[i];
                 d[i - 1] = (int32_t)(cd & M);
                 e[i - 1] = (int32_t)(ce & M);
-                cd >>= 28;
-                ce >>= 28;
+                cd >>= BITS;
+                ce >>= BITS;
             }
-            d[13] = (int32_t)cd;
-            e[13] = (int32_t)ce;
+            d[N - 1] = (int32_t)cd;
+            e[N - 1] = (int32_t)ce;
         }
     }
     // g = 0, f = +-1 (x != 0): x^-1 = f d.  f = -1 shows in the signed top limb.
-    const bool negate = f[13] < 0;
+    const bool negate = f[N - 1] < 0;
 #pragma unroll
-    for (int i = 0; i < 14; i++) out[i] = negate ? -d[i] : d[i];
+    for (int i = 0; i < N; i++) out[i] = negate ? -d[i] : d[i];
     return batches;
+}
+
+// Fq: 14 x 28 bits, 40 batches cover the 1101 steps of a 381-bit modulus
+constexpr int DIVSTEP_MAX_BATCHES = 40;
+DR_DIVSTEP_FN int inv_divsteps28(const uint32_t (&P)[14], uint32_t n0, const int32_t (&x)[14], int32_t (&out)[14]) {
+    return inv_divsteps<14, 28, DIVSTEP_MAX_BATCHES>(P, n0, x, out);
 }
 
 }  // namespace dr

@@ -21,7 +21,7 @@ ACC = "v[2:3]"
 ACC_LO = "v2"
 
 
-def gen(name: str, n: int, bits: int, square: bool) -> str:
+def gen(name: str, n: int, bits: int, square: bool, neg_n0: bool = False) -> str:
     mask = (1 << bits) - 1
     # operands: outputs r[0..n-1] (double as m), [a2[0..n-1] when squaring]; inputs a[], b[] (mul only), p[] (sgpr), n0 (sgpr)
     R = lambda i: f"%{i}"
@@ -64,7 +64,10 @@ def gen(name: str, n: int, bits: int, square: bool) -> str:
                 continue
             mac(M(i), P(k - i))
         if k < n:
-            lines.append(f"v_mul_lo_u32 {M(k)}, {ACC_LO}, {N0}")
+            if neg_n0:                  # n0 = -1 mod 2^B (p = 1 mod 2^B): m_k = -acc mod 2^B, a subtraction instead of a product
+                lines.append(f"v_sub_u32 {M(k)}, 0, {ACC_LO}")
+            else:
+                lines.append(f"v_mul_lo_u32 {M(k)}, {ACC_LO}, {N0}")
             lines.append(f"v_and_b32 {M(k)}, {hex(mask)}, {M(k)}")
             mac(M(k), P(0))
         else:
@@ -96,9 +99,10 @@ DR_DEV void {name}({args}) {{
 '''
 
 
-def gen2(name: str, n: int, bits: int) -> str:
+def gen2(name: str, n: int, bits: int, neg_n0: bool = False) -> str:
     """(a b + c d + m p) / R with ONE reduction: the two products share every column sum (3 n^2 multiply-adds instead of 4 n^2).
-    Column bound for 14 x 28: 14 (|a_i b_j| + |c_i d_j| + m p) < 2^63 needs e.g. |a_i| < 2^29, the other limbs below 2^28."""
+    Column bound for 14 x 28: 14 (|a_i b_j| + |c_i d_j| + m p) < 2^63 needs e.g. |a_i| < 2^29, the other limbs below 2^28;
+    for 9 x 29: 9 (2 * 2^58 + 2^58) = 2^62.75 — all four operands with limbs below 2^29."""
     mask = (1 << bits) - 1
     R = lambda i: f"%{i}"
     A = lambda i: f"%{n + i}"
@@ -127,7 +131,10 @@ def gen2(name: str, n: int, bits: int) -> str:
                 continue
             mac(M(i), P(k - i))
         if k < n:
-            lines.append(f"v_mul_lo_u32 {M(k)}, {ACC_LO}, {N0}")
+            if neg_n0:                  # n0 = -1 mod 2^B (p = 1 mod 2^B): m_k = -acc mod 2^B, a subtraction instead of a product
+                lines.append(f"v_sub_u32 {M(k)}, 0, {ACC_LO}")
+            else:
+                lines.append(f"v_mul_lo_u32 {M(k)}, {ACC_LO}, {N0}")
             lines.append(f"v_and_b32 {M(k)}, {hex(mask)}, {M(k)}")
             mac(M(k), P(0))
         else:
@@ -156,6 +163,9 @@ def main(path):
     out.append(gen("montmul14x28_asm", 14, 28, False))
     out.append(gen("montsqr14x28_asm", 14, 28, True))
     out.append(gen2("montmul2_14x28_asm", 14, 28))
+    out.append(gen("montmul9x29_asm", 9, 29, False, neg_n0=True))          # Fr: p = 1 mod 2^32
+    out.append(gen("montsqr9x29_asm", 9, 29, True, neg_n0=True))
+    out.append(gen2("montmul2_9x29_asm", 9, 29, neg_n0=True))
     with open(path, "w") as f:
         f.write("".join(out))
 

@@ -5,7 +5,7 @@
 
 namespace dr {
 
-// Constants of the Elligator map and of Tonelli-Shanks, in Montgomery form, computed once per context on the host
+// Constants of the Elligator map and of Tonelli-Shanks, in Montgomery form (2^261: the host multiplies its 2^256 form by 32), computed once per context on the host
 // (capi_core.hip: bsn_consts_init) instead of by every lane: the Montgomery-model coefficients derived from a = -5 and d
 // (A_M = 2(a+d)/(a-d), B_M = 4/(a-d)) and c_pow[j] = (5^Q)^(2^j), 5 the non-residue, p - 1 = Q * 2^32.
 struct BsnConsts {
@@ -14,37 +14,32 @@ struct BsnConsts {
     uint32_t glv_b[8], glv_c[8];         // endomorphism coefficients (bandersnatch.py:58-67), Montgomery form
 };
 __device__ BsnConsts g_bsn_consts;
-DR_DEV Fr bsn_const(const uint32_t (&w)[8]) {
-    Fr r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = w[i];
-    return r;
-}
+DR_DEV Fs bsn_const(const uint32_t (&w)[8]) { return unpack29(w); }
 
 // Tonelli-Shanks (the reference's sqrt_mod_bls_scalar_cy, bandersnatch_te.pyx:421-477) with the squareness test folded
 // in: with w = x^((Q-1)/2), R = w x and t = R w = x^Q; x is a square iff t^(2^31) = 1, which the first pass of the
 // order search finds out anyway — no separate Legendre exponentiation.  Returns false for non-residues.
-DR_DEV bool fr_sqrt(const Fr& x, Fr& root) {
+DR_DEV bool fr_sqrt(const Fs& x, Fs& root) {
     root = x;
-    if (x.is_zero()) return true;
+    if (is_zero(x)) return true;
     constexpr uint32_t QM1H[8] = {0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u, 0u};   // (Q-1)/2
     uint32_t e[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) e[i] = QM1H[i];
-    Fr w = fr_pow_limbs(x, e);
-    Fr R = mul(w, x);
-    Fr t = mul(R, w);
-    const Fr one = Fr::one();
+    Fs w = fr_pow_limbs(x, e);
+    Fs R = mul(w, x);
+    Fs t = mul(R, w);
+    const Fs one = Fs::one();
     int M = 32, j = 0;             // current c = c_pow[j], of order 2^M
 #pragma unroll 1
     for (int guard = 0; guard < 34; guard++) {
-        if (t == one) break;
+        if (equal(t, one)) break;
         int i = 1;
-        Fr tmp = sqr(t);
+        Fs tmp = sqr(t);
 #pragma unroll 1
-        while (!(tmp == one) && i < M) { tmp = sqr(tmp); i++; }
+        while (!equal(tmp, one) && i < M) { tmp = sqr(tmp); i++; }
         if (i == M) return false;                      // order of t is 2^M: not a square
-        Fr b = bsn_const(g_bsn_consts.c_pow[j + M - i - 1]);
+        const Fs b = bsn_const(g_bsn_consts.c_pow[j + M - i - 1]);
         j += M - i;
         M = i;
         t = mul(t, bsn_const(g_bsn_consts.c_pow[j]));  // c <- b^2
@@ -56,35 +51,36 @@ DR_DEV bool fr_sqrt(const Fr& x, Fr& root) {
 
 // Elligator 2 onto the Montgomery model up to the point (s, t) = (x B_M, y B_M); the inversion 1/(1 + Z u^2) is
 // supplied by the caller so that the two maps of one input share ONE inversion (Montgomery's trick).
-struct EllHalf { Fr tv1, den; };
-DR_DEV EllHalf ell2_prepare(const Fr& u) {
-    Fr five = Fr::zero(); five.l[0] = 5; five = to_mont(five);
+struct EllHalf { Fs tv1, den; };
+DR_DEV EllHalf ell2_prepare(const Fs& u) {
+    Fr five_std = Fr::zero(); five_std.l[0] = 5;
+    const Fs five = fs_from_std(five_std);
     EllHalf h;
     h.tv1 = mul(five, sqr(u));                         // Z = 5
-    if (add(h.tv1, Fr::one()).is_zero()) h.tv1 = Fr::zero();
-    h.den = add(h.tv1, Fr::one());
+    if (is_zero(add(h.tv1, Fs::one()))) h.tv1 = Fs::zero();
+    h.den = carry(add(h.tv1, Fs::one()));              // carried: it meets the partner's denominator in a product
     return h;
 }
 // second half: the birational map to the twisted Edwards model, inversion-free (extended coordinates)
-DR_DEV TePoint ell2_finish(const EllHalf& h, const Fr& inv_den) {
-    const Fr aob = bsn_const(g_bsn_consts.a_over_b), inv_b2 = bsn_const(g_bsn_consts.inv_b2), mont_b = bsn_const(g_bsn_consts.mont_b);
-    Fr x1 = neg(mul(aob, inv_den));
-    Fr gx1 = mul(add(mul(add(x1, aob), x1), inv_b2), x1);
-    Fr y;
+DR_DEV TePoint ell2_finish(const EllHalf& h, const Fs& inv_den) {
+    const Fs aob = bsn_const(g_bsn_consts.a_over_b), inv_b2 = bsn_const(g_bsn_consts.inv_b2), mont_b = bsn_const(g_bsn_consts.mont_b);
+    Fs x1 = neg(mul(aob, inv_den));
+    Fs gx1 = mul(add(mul(add(x1, aob), x1), inv_b2), x1);
+    Fs y;
     bool e2 = fr_sqrt(gx1, y);
-    Fr x = x1;
+    Fs x = x1;
     if (!e2) {
         x = sub(neg(x1), aob);
         (void)fr_sqrt(mul(h.tv1, gx1), y);             // Z u^2 g(x1) is a square when g(x1) is not
     }
-    bool odd = (from_mont(y).l[0] & 1u) != 0;
+    bool odd = (fs_to_std(y).l[0] & 1u) != 0;
     if (e2 != odd) y = neg(y);                          // e2 XOR e3 -> negate
-    Fr s = mul(x, mont_b), t = mul(y, mont_b);
+    Fs s = mul(x, mont_b), t = mul(y, mont_b);
     // (s,t) -> (v,w) = (s/t, (s-1)/(s+1)); with Z = (s+1) t:  X = s (s+1), Y = (s-1) t; exceptional case -> (0,1)
-    Fr sp1 = add(s, Fr::one());
-    Fr Z = mul(sp1, t);
-    if (Z.is_zero()) return te_identity();
-    Fr X = mul(s, sp1), Y = mul(sub(s, Fr::one()), t);
+    Fs sp1 = add(s, Fs::one());
+    Fs Z = mul(sp1, t);
+    if (is_zero(Z)) return te_identity();
+    Fs X = mul(s, sp1), Y = mul(sub(s, Fs::one()), t);
     TePoint r;
     r.x = mul(X, Z); r.y = mul(Y, Z); r.z = sqr(Z); r.t = mul(X, Y);
     return r;
@@ -99,15 +95,15 @@ __global__ __launch_bounds__(64) void k_bsn_encode_to_curve(const uint32_t* __re
     const uint32_t half = gid & 1u;
     const bool live = i < n;
     if (!live) i = n - 1;                                  // keep the pair (and the shuffles) converged
-    EllHalf h = ell2_prepare(to_mont(load_fr_std(us + (size_t)i * 16 + 8 * half)));
-    Fr other;
+    EllHalf h = ell2_prepare(fs_from_std(load_fr_std(us + (size_t)i * 16 + 8 * half)));
+    Fs other;
 #pragma unroll
-    for (int t = 0; t < 8; t++) other.l[t] = __shfl_xor(h.den.l[t], 1, 64);
-    Fr both = inv(mul(h.den, other));                      // den = 1 + Z u^2 is never zero (tv1 = -1 was mapped to 0)
+    for (int t = 0; t < L29; t++) other.l[t] = __shfl_xor(h.den.l[t], 1, 64);
+    Fs both = inv(mul(h.den, other));                      // den = 1 + Z u^2 is never zero (tv1 = -1 was mapped to 0)
     TePoint q = ell2_finish(h, mul(both, other));
     TePoint p;
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
+    for (int t = 0; t < L29; t++) {
         p.x.l[t] = __shfl_xor(q.x.l[t], 1, 64);
         p.y.l[t] = __shfl_xor(q.y.l[t], 1, 64);
         p.z.l[t] = __shfl_xor(q.z.l[t], 1, 64);
@@ -125,12 +121,12 @@ __global__ __launch_bounds__(64) void k_bsn_encode_to_curve(const uint32_t* __re
 // same signed 4-bit window core over 33 windows instead of 64, and one shuffle adds them up: the dependent chain — which
 // is what a launch of a few thousand scalar multiplications costs — is half as long, the total work unchanged.
 // psi(x, y) = (f h : g x y : h x y), f = c (1 - y^2), g = b (y^2 + b), h = y^2 - b, returned in extended coordinates.
-DR_DEV TePoint bsn_endomorphism(const Fr& x, const Fr& y) {
-    const Fr b = bsn_const(g_bsn_consts.glv_b), c = bsn_const(g_bsn_consts.glv_c);
-    Fr y2 = sqr(y), xy = mul(x, y);
-    Fr f = mul(c, sub(Fr::one(), y2)), g = mul(b, add(y2, b)), h = sub(y2, b);
-    Fr X = mul(f, h), Y = mul(g, xy), Z = mul(h, xy);
-    if (Z.is_zero()) return te_identity();            // x y = 0: the identity (or 2-/4-torsion, never a subgroup point)
+DR_DEV TePoint bsn_endomorphism(const Fs& x, const Fs& y) {
+    const Fs b = bsn_const(g_bsn_consts.glv_b), c = bsn_const(g_bsn_consts.glv_c);
+    Fs y2 = sqr(y), xy = mul(x, y);
+    Fs f = mul(c, sub(Fs::one(), y2)), g = mul(b, add(y2, b)), h = sub(y2, b);
+    Fs X = mul(f, h), Y = mul(g, xy), Z = mul(h, xy);
+    if (is_zero(Z)) return te_identity();            // x y = 0: the identity (or 2-/4-torsion, never a subgroup point)
     TePoint r;
     r.x = mul(X, Z); r.y = mul(Y, Z); r.z = sqr(Z); r.t = mul(X, Y);
     return r;
@@ -178,11 +174,11 @@ DR_DEV TePoint bsn_window_core(uint32_t* tab, int lane, const TePoint& P, const 
 // one half of a GLV pair: the lane's base (P or psi(P), negated when its half-scalar is negative) times |k_half|
 // split: per term 12 words — |k1| (4), |k2| (4), neg1, neg2, 2 pad
 DR_DEV TePoint bsn_glv_half(uint32_t* tab, int lane, const uint32_t* __restrict__ pts, const uint32_t* __restrict__ split, size_t term, bool second) {
-    Fr px = to_mont(load_fr_std(pts + term * 16));
-    Fr py = to_mont(load_fr_std(pts + term * 16 + 8));
+    Fs px = fs_from_std(load_fr_std(pts + term * 16));
+    Fs py = fs_from_std(load_fr_std(pts + term * 16 + 8));
     TePoint base;
     if (second) base = bsn_endomorphism(px, py);
-    else { base.x = px; base.y = py; base.z = Fr::one(); base.t = mul(px, py); }
+    else { base.x = px; base.y = py; base.z = Fs::one(); base.t = mul(px, py); }
     const uint32_t* s = split + term * 12;
     base = te_cneg(base, s[8 + (second ? 1 : 0)] != 0);
     uint32_t k[5];
@@ -249,16 +245,16 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_decode_points(const uint32_t*
         valid = borrow != 0;
     }
     if (!valid) ys = Fr::zero();
-    const Fr one = Fr::one();
-    Fr y = to_mont(ys);
-    Fr y2 = sqr(y);
-    Fr den = sub(te_mul_a(one), mul(te_d_mont(), y2));
-    if (den.is_zero()) { valid = false; den = one; }
-    Fr x2 = mul(sub(one, y2), inv(den));
-    Fr x;
+    const Fs one = Fs::one();
+    Fs y = fs_from_std(ys);
+    Fs y2 = sqr(y);
+    Fs den = sub(te_mul_a(one), mul(te_d_mont(), y2));
+    if (is_zero(den)) { valid = false; den = one; }
+    Fs x2 = mul(sub(one, y2), inv(den));
+    Fs x;
     if (!fr_sqrt(x2, x)) { valid = false; x = one; }
     {
-        Fr xs = from_mont(x), nxs = from_mont(neg(x));
+        Fr xs = fs_to_std(x), nxs = fs_to_std(neg(x));
         bool x_larger = false;
 #pragma unroll
         for (int j = 7; j >= 0; j--) {
@@ -269,9 +265,9 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_decode_points(const uint32_t*
     TePoint P;
     P.x = x; P.y = y; P.z = one; P.t = mul(x, y);
     TePoint Q = te_dbl<false>(te_dbl<false>(P));
-    if (Q.x.is_zero()) { valid = false; Q = P; }    // 4P = O (x = 0 also covers the order-2 point (0,-1), which 4 kills anyway)
-    Fr zi = inv(Q.z.is_zero() ? one : Q.z);
-    Fr qx = mul(Q.x, zi), qy = mul(Q.y, zi);
+    if (is_zero(Q.x)) { valid = false; Q = P; }    // 4P = O (x = 0 also covers the order-2 point (0,-1), which 4 kills anyway)
+    Fs zi = inv(is_zero(Q.z) ? one : Q.z);
+    Fs qx = mul(Q.x, zi), qy = mul(Q.y, zi);
     // [4^-1 mod n] Q by GLV on the lane pair (Q = 4P lies in the prime-order subgroup, where psi acts as lambda):
     // 4^-1 = k1 + k2 lambda with k1 > 0 > k2, both below 2^127
     TePoint base;
@@ -286,10 +282,10 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_decode_points(const uint32_t*
     kh[4] = 0;
     TePoint R = bsn_window_core<33>(tab, lane, base, kh);
     R = te_add(R, te_shfl_down(R, 1));
-    if (!(R.x == mul(x, R.z)) || !(R.y == mul(y, R.z))) valid = false;
+    if (!equal(R.x, mul(x, R.z)) || !equal(R.y, mul(y, R.z))) valid = false;
     if (live && !half) {
-        store_fr_std(out_xy + (size_t)i * 16, from_mont(x));
-        store_fr_std(out_xy + (size_t)i * 16 + 8, from_mont(y));
+        store_fr_std(out_xy + (size_t)i * 16, fs_to_std(x));
+        store_fr_std(out_xy + (size_t)i * 16 + 8, fs_to_std(y));
         ok[i] = valid ? 1u : 0u;
     }
 }
@@ -317,16 +313,16 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_te_decode_points(const uint32_t* 
         valid = borrow != 0;
     }
     if (!valid) ys = Fr::zero();
-    const Fr one = Fr::one();
-    Fr y = to_mont(ys);
-    Fr y2 = sqr(y);
-    Fr den = sub(te_mul_a<CV>(one), mul(te_d_mont<CV>(), y2));
-    if (den.is_zero()) { valid = false; den = one; }
-    Fr x2 = mul(sub(one, y2), inv(den));
-    Fr x;
+    const Fs one = Fs::one();
+    Fs y = fs_from_std(ys);
+    Fs y2 = sqr(y);
+    Fs den = sub(te_mul_a<CV>(one), mul(te_d_mont<CV>(), y2));
+    if (is_zero(den)) { valid = false; den = one; }
+    Fs x2 = mul(sub(one, y2), inv(den));
+    Fs x;
     if (!fr_sqrt(x2, x)) { valid = false; x = one; }
     {
-        Fr xs = from_mont(x), nxs = from_mont(neg(x));
+        Fr xs = fs_to_std(x), nxs = fs_to_std(neg(x));
         bool x_larger = false;
 #pragma unroll
         for (int j = 7; j >= 0; j--) {
@@ -340,13 +336,13 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_te_decode_points(const uint32_t* 
     TePoint Q = P;
 #pragma unroll 1
     for (int j = 0; j < LOG2_H; j++) Q = te_dbl<true, CV>(Q);
-    if (Q.x.is_zero()) { valid = false; Q = P; }    // hP = O (x = 0 also covers the order-2 point (0,-1), which h kills anyway)
-    Fr zi = inv(Q.z.is_zero() ? one : Q.z);
-    Fr qx = mul(Q.x, zi), qy = mul(Q.y, zi);
+    if (is_zero(Q.x)) { valid = false; Q = P; }    // hP = O (x = 0 also covers the order-2 point (0,-1), which h kills anyway)
+    Fs zi = inv(is_zero(Q.z) ? one : Q.z);
+    Fs qx = mul(Q.x, zi), qy = mul(Q.y, zi);
     if (TAI) {
         if (live) {
-            store_fr_std(out_xy + (size_t)i * 16, from_mont(qx));
-            store_fr_std(out_xy + (size_t)i * 16 + 8, from_mont(qy));
+            store_fr_std(out_xy + (size_t)i * 16, fs_to_std(qx));
+            store_fr_std(out_xy + (size_t)i * 16 + 8, fs_to_std(qy));
             ok[i] = valid ? 1u : 0u;
         }
         return;
@@ -358,10 +354,10 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_te_decode_points(const uint32_t* 
 #pragma unroll
     for (int j = 0; j < 8; j++) k[j] = CV == CV_JUBJUB ? HINV_J[j] : HINV_B[j];
     TePoint R = bsn_scalar_mul_core<CV>(tab, lane, qx, qy, k);
-    if (!(R.x == mul(x, R.z)) || !(R.y == mul(y, R.z))) valid = false;
+    if (!equal(R.x, mul(x, R.z)) || !equal(R.y, mul(y, R.z))) valid = false;
     if (live) {
-        store_fr_std(out_xy + (size_t)i * 16, from_mont(x));
-        store_fr_std(out_xy + (size_t)i * 16 + 8, from_mont(y));
+        store_fr_std(out_xy + (size_t)i * 16, fs_to_std(x));
+        store_fr_std(out_xy + (size_t)i * 16 + 8, fs_to_std(y));
         ok[i] = valid ? 1u : 0u;
     }
 }

@@ -15,6 +15,15 @@
 
 namespace dr {
 
+// a*v on the saturated representation (the constraint and linearisation kernels): a = -5 (Bandersnatch) or -1 (JubJub)
+template <int CV>
+DR_DEV Fr te_mul_a_fr(const Fr& v) {
+    if (CV == CV_JUBJUB) return neg(v);
+    Fr t = dbl(v);
+    t = dbl(t);
+    t = add(t, v);
+    return neg(t);
+}
 DR_DEV Fr ld_std(const uint32_t* p) { return to_mont(gload_fr(p)); }
 DR_DEV void st_std(uint32_t* p, const Fr& v) { gstore_fr(p, from_mont(v)); }
 DR_DEV Fr fr_from_u32(uint32_t v) {       // small integer -> Montgomery
@@ -128,20 +137,22 @@ __global__ void k_ring_chain(const uint32_t* __restrict__ ring_pts_mont /* N*16:
     uint32_t* ext = chain_ext + (size_t)pid * RING_CHAIN * 32;
     uint32_t* pre = prefix + (size_t)pid * RING_CHAIN * 8;
     uint32_t* aff = chain_aff + (size_t)pid * RING_CHAIN * 16;
+    // (the curve arithmetic runs on Fs values, fr29.hip.h; the ring table, the seed and the affine results are in the 2^256
+    //  Montgomery form the column kernels read: one product per coordinate at the boundary.  The scratch keeps packed words.)
     auto put = [&](uint32_t idx, const TePoint& p) {
-        gstore_fr(ext + idx * 32, p.x); gstore_fr(ext + idx * 32 + 8, p.y);
-        gstore_fr(ext + idx * 32 + 16, p.z); gstore_fr(ext + idx * 32 + 24, p.t);
+        gstore_fr(ext + idx * 32, pack(p.x)); gstore_fr(ext + idx * 32 + 8, pack(p.y));
+        gstore_fr(ext + idx * 32 + 16, pack(p.z)); gstore_fr(ext + idx * 32 + 24, pack(p.t));
     };
     auto ring_point = [&](uint32_t row) {
         TePoint p;
-        p.x = gload_fr(ring_pts_mont + (size_t)row * 16);
-        p.y = gload_fr(ring_pts_mont + (size_t)row * 16 + 8);
-        p.z = Fr::one();
+        p.x = from_mont256(gload_fr(ring_pts_mont + (size_t)row * 16));
+        p.y = from_mont256(gload_fr(ring_pts_mont + (size_t)row * 16 + 8));
+        p.z = Fs::one();
         p.t = mul(p.x, p.y);
         return p;
     };
     TePoint acc;
-    acc.x = from_arg(rc.seed_x); acc.y = from_arg(rc.seed_y); acc.z = Fr::one(); acc.t = mul(acc.x, acc.y);
+    acc.x = from_mont256(from_arg(rc.seed_x)); acc.y = from_mont256(from_arg(rc.seed_y)); acc.z = Fs::one(); acc.t = mul(acc.x, acc.y);
     TePoint seed = acc;
     uint32_t cnt = 0;
     put(cnt++, acc);
@@ -164,20 +175,20 @@ __global__ void k_ring_chain(const uint32_t* __restrict__ ring_pts_mont /* N*16:
     put(cnt, te_add<CV>(acc, te_cneg(seed, true)));           // relation = result - seed
     const uint32_t total = cnt + 1;
     // batch inversion of the Z coordinates
-    Fr run = Fr::one();
+    Fs run = Fs::one();
 #pragma unroll 1
     for (uint32_t i = 0; i < total; i++) {
-        gstore_fr(pre + i * 8, run);
-        run = mul(run, gload_fr(ext + i * 32 + 16));
+        gstore_fr(pre + i * 8, pack(run));
+        run = mul(run, unpack(gload_fr(ext + i * 32 + 16)));
     }
-    Fr inv_run = inv(run);
+    Fs inv_run = inv(run);
 #pragma unroll 1
     for (int i = (int)total - 1; i >= 0; i--) {
-        Fr z = gload_fr(ext + i * 32 + 16);
-        Fr zi = mul(inv_run, gload_fr(pre + i * 8));
+        const Fs z = unpack(gload_fr(ext + i * 32 + 16));
+        const Fs zi = mul(inv_run, unpack(gload_fr(pre + i * 8)));
         inv_run = mul(inv_run, z);
-        gstore_fr(aff + i * 16, mul(gload_fr(ext + i * 32), zi));
-        gstore_fr(aff + i * 16 + 8, mul(gload_fr(ext + i * 32 + 8), zi));
+        gstore_fr(aff + i * 16, to_mont256(mul(unpack(gload_fr(ext + i * 32)), zi)));
+        gstore_fr(aff + i * 16 + 8, to_mont256(mul(unpack(gload_fr(ext + i * 32 + 8)), zi)));
     }
 }
 
@@ -188,7 +199,7 @@ __global__ void k_ring_chain(const uint32_t* __restrict__ ring_pts_mont /* N*16:
 DR_DEV TePoint te_shfl_up(const TePoint& p, unsigned delta) {
     TePoint o;
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
+    for (int t = 0; t < L29; t++) {
         o.x.l[t] = __shfl_up(p.x.l[t], delta, 64);
         o.y.l[t] = __shfl_up(p.y.l[t], delta, 64);
         o.z.l[t] = __shfl_up(p.z.l[t], delta, 64);
@@ -205,15 +216,17 @@ __global__ __launch_bounds__(64) void k_ring_chain_wave(const uint32_t* __restri
     if (pid >= batch) return;
     uint32_t* ext = chain_ext + (size_t)pid * RING_CHAIN * 32;
     uint32_t* aff = chain_aff + (size_t)pid * RING_CHAIN * 16;
+    // (the curve arithmetic runs on Fs values, fr29.hip.h; the ring table, the seed and the affine results are in the 2^256
+    //  Montgomery form the column kernels read: one product per coordinate at the boundary.  The scratch keeps packed words.)
     auto put = [&](uint32_t idx, const TePoint& p) {
-        gstore_fr(ext + idx * 32, p.x); gstore_fr(ext + idx * 32 + 8, p.y);
-        gstore_fr(ext + idx * 32 + 16, p.z); gstore_fr(ext + idx * 32 + 24, p.t);
+        gstore_fr(ext + idx * 32, pack(p.x)); gstore_fr(ext + idx * 32 + 8, pack(p.y));
+        gstore_fr(ext + idx * 32 + 16, pack(p.z)); gstore_fr(ext + idx * 32 + 24, pack(p.t));
     };
     auto ring_point = [&](uint32_t row) {
         TePoint p;
-        p.x = gload_fr(ring_pts_mont + (size_t)row * 16);
-        p.y = gload_fr(ring_pts_mont + (size_t)row * 16 + 8);
-        p.z = Fr::one();
+        p.x = from_mont256(gload_fr(ring_pts_mont + (size_t)row * 16));
+        p.y = from_mont256(gload_fr(ring_pts_mont + (size_t)row * 16 + 8));
+        p.z = Fs::one();
         p.t = mul(p.x, p.y);
         return p;
     };
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(64) void k_ring_chain_wave(const uint32_t* __restri
     if (lane == 0) exc = te_identity();
     // 3. seed, seed + PK_k, then this lane's own values
     TePoint seed;
-    seed.x = from_arg(rc.seed_x); seed.y = from_arg(rc.seed_y); seed.z = Fr::one(); seed.t = mul(seed.x, seed.y);
+    seed.x = from_mont256(from_arg(rc.seed_x)); seed.y = from_mont256(from_arg(rc.seed_y)); seed.z = Fs::one(); seed.t = mul(seed.x, seed.y);
     TePoint base = te_add<CV>(seed, ring_point(producer_idx[pid]));
     uint32_t idx[6];
     int nv = 0;
@@ -274,21 +287,21 @@ __global__ __launch_bounds__(64) void k_ring_chain_wave(const uint32_t* __restri
         cnt_out[pid] = cnt;
     }
     // 4. normalise this lane's values with one inversion
-    Fr pre[6];
-    Fr run = Fr::one();
+    Fs pre[6];
+    Fs run = Fs::one();
 #pragma unroll 1
     for (int i = 0; i < nv; i++) {
         pre[i] = run;
-        run = mul(run, gload_fr(ext + idx[i] * 32 + 16));
+        run = mul(run, unpack(gload_fr(ext + idx[i] * 32 + 16)));
     }
-    Fr inv_run = inv(run);                                 // lock-step across the wave (inv(1) on idle lanes)
+    Fs inv_run = inv(run);                                 // lock-step across the wave (inv(1) on idle lanes)
 #pragma unroll 1
     for (int i = nv - 1; i >= 0; i--) {
         const uint32_t* e = ext + idx[i] * 32;
-        Fr zi = mul(inv_run, pre[i]);
-        inv_run = mul(inv_run, gload_fr(e + 16));
-        gstore_fr(aff + idx[i] * 16, mul(gload_fr(e), zi));
-        gstore_fr(aff + idx[i] * 16 + 8, mul(gload_fr(e + 8), zi));
+        const Fs zi = mul(inv_run, pre[i]);
+        inv_run = mul(inv_run, unpack(gload_fr(e + 16)));
+        gstore_fr(aff + idx[i] * 16, to_mont256(mul(unpack(gload_fr(e)), zi)));
+        gstore_fr(aff + idx[i] * 16 + 8, to_mont256(mul(unpack(gload_fr(e + 8)), zi)));
     }
 }
 
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __rest
     // c1 = (accip' - accip - b*s) * nl          (the common factor nl of c1..c3 is applied once, after the alphas)
     Fr acc = mul(gload_fr(al + 0 * 8), sub(sub(ip_n, ip), mul(b, s)));
     // c2 = (b*(x3*(y1y2 + a x1x2) - (x1y1 + x2y2)) + (1-b)(x3 - x1)) * nl ,  a = the curve coefficient
-    Fr t2 = sub(mul(x3, add(y1y2, te_mul_a<CV>(x1x2))), add(x1y1, x2y2));
+    Fr t2 = sub(mul(x3, add(y1y2, te_mul_a_fr<CV>(x1x2))), add(x1y1, x2y2));
     Fr c2 = add(mul(b, t2), mul(omb, sub(x3, x1)));
     acc = add(acc, mul(gload_fr(al + 1 * 8), c2));
     // c3 = (b*(y3*(x1y2 - x2y1) - (x1y1 - x2y2)) + (1-b)(y3 - y1)) * nl
@@ -495,7 +508,7 @@ __global__ void k_ring_lin_scalars(const uint32_t* __restrict__ evals /* [B][8][
     Fr pxz = ld_std(e), pyz = ld_std(e + 8), bz = ld_std(e + 3 * 8), axz = ld_std(e + 5 * 8), ayz = ld_std(e + 6 * 8);
     Fr term = sub(ld_std(zetas + (size_t)pid * 8), from_arg(rc.last_x));
     Fr omb = sub(Fr::one(), bz);
-    Fr fx = mul(add(mul(bz, add(mul(ayz, pyz), te_mul_a<CV>(mul(axz, pxz)))), omb), term);
+    Fr fx = mul(add(mul(bz, add(mul(ayz, pyz), te_mul_a_fr<CV>(mul(axz, pxz)))), omb), term);
     Fr fy = mul(add(mul(bz, sub(mul(axz, pyz), mul(pxz, ayz))), omb), term);
     const uint32_t* al = alphas + (size_t)pid * 7 * 8;
     gstore_fr(ks + ((size_t)pid * 3 + 0) * 8, mul(gload_fr(al), term));          // alphas: Montgomery, see k_ring_constraints

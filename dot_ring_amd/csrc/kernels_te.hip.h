@@ -17,26 +17,31 @@ constexpr int BSN_BLOCK = 64;          // one wave per workgroup: 64 KiB of LDS 
 constexpr int BSN_TABLE = 8;           // entries 1P..8P
 constexpr int BSN_PT_WORDS = 32;       // X,Y,Z,T x 8 limbs
 
+// (the table keeps canonical 8-word coordinates: 64 KiB per wave as before; packing costs ~120 instructions per coordinate
+//  when the 8 entries are built, unpacking ~20 per coordinate per lookup — against ~2200 for the addition that follows)
 DR_DEV void lds_store_point(uint32_t* tab, int entry, int lane, const TePoint& p) {
     uint32_t* base = tab + (size_t)entry * BSN_PT_WORDS * BSN_BLOCK + lane;
+    const Fr x = pack(p.x), y = pack(p.y), z = pack(p.z), t = pack(p.t);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        base[(0 + i) * BSN_BLOCK] = p.x.l[i];
-        base[(8 + i) * BSN_BLOCK] = p.y.l[i];
-        base[(16 + i) * BSN_BLOCK] = p.z.l[i];
-        base[(24 + i) * BSN_BLOCK] = p.t.l[i];
+        base[(0 + i) * BSN_BLOCK] = x.l[i];
+        base[(8 + i) * BSN_BLOCK] = y.l[i];
+        base[(16 + i) * BSN_BLOCK] = z.l[i];
+        base[(24 + i) * BSN_BLOCK] = t.l[i];
     }
 }
 DR_DEV TePoint lds_load_point(const uint32_t* tab, int entry, int lane) {
     const uint32_t* base = tab + (size_t)entry * BSN_PT_WORDS * BSN_BLOCK + lane;
-    TePoint p;
+    Fr x, y, z, t;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        p.x.l[i] = base[(0 + i) * BSN_BLOCK];
-        p.y.l[i] = base[(8 + i) * BSN_BLOCK];
-        p.z.l[i] = base[(16 + i) * BSN_BLOCK];
-        p.t.l[i] = base[(24 + i) * BSN_BLOCK];
+        x.l[i] = base[(0 + i) * BSN_BLOCK];
+        y.l[i] = base[(8 + i) * BSN_BLOCK];
+        z.l[i] = base[(16 + i) * BSN_BLOCK];
+        t.l[i] = base[(24 + i) * BSN_BLOCK];
     }
+    TePoint p;
+    p.x = unpack(x); p.y = unpack(y); p.z = unpack(z); p.t = unpack(t);
     return p;
 }
 
@@ -52,6 +57,18 @@ DR_DEV void store_fr_std(uint32_t* p, const Fr& v) {
     uint4* q = reinterpret_cast<uint4*>(p);
     q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+DR_DEV TePoint te_shfl_down(const TePoint& p, unsigned delta) {
+    TePoint o;
+#pragma unroll
+    for (int t = 0; t < L29; t++) {
+        o.x.l[t] = __shfl_down(p.x.l[t], delta, 64);
+        o.y.l[t] = __shfl_down(p.y.l[t], delta, 64);
+        o.z.l[t] = __shfl_down(p.z.l[t], delta, 64);
+        o.t.l[t] = __shfl_down(p.t.l[t], delta, 64);
+    }
+    return o;
 }
 
 // k mod n for a 256-bit k by conditional subtractions: floor(2^256 / n) = 8 for Bandersnatch (n > 2^252), 17 for JubJub
@@ -75,9 +92,9 @@ DR_DEV void reduce_mod_order(uint32_t (&k)[8]) {
 
 // scalar multiplication core shared by the batch and the grouped-MSM kernels: returns k*P (extended coords)
 template <int CV = CV_BANDERSNATCH>
-DR_DEV TePoint bsn_scalar_mul_core(uint32_t* tab, int lane, const Fr& px, const Fr& py, uint32_t (&k)[8]) {
+DR_DEV TePoint bsn_scalar_mul_core(uint32_t* tab, int lane, const Fs& px, const Fs& py, uint32_t (&k)[8]) {
     TePoint P;
-    P.x = px; P.y = py; P.z = Fr::one(); P.t = mul(px, py);
+    P.x = px; P.y = py; P.z = Fs::one(); P.t = mul(px, py);
     // table 1P..8P
     lds_store_point(tab, 0, lane, P);
     TePoint Q = te_dbl<true, CV>(P);
@@ -120,9 +137,9 @@ DR_DEV TePoint bsn_scalar_mul_core(uint32_t* tab, int lane, const Fr& px, const 
 }
 
 DR_DEV void te_store_affine(uint32_t* out, const TePoint& acc) {
-    Fr zi = inv(acc.z);
-    store_fr_std(out, from_mont(mul(acc.x, zi)));
-    store_fr_std(out + 8, from_mont(mul(acc.y, zi)));
+    const Fs zi = inv(acc.z);
+    store_fr_std(out, fs_to_std(mul(acc.x, zi)));
+    store_fr_std(out + 8, fs_to_std(mul(acc.y, zi)));
 }
 
 // out[i] = k[i] * P[i].  pts: n x 16 u32 (x||y, standard form LE), ks: n x 8 u32, out: n x 16 u32.
@@ -135,8 +152,8 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_scalar_mul(const uint32_t* __
     uint32_t i = blockIdx.x * BSN_BLOCK + lane;
     const bool live = i < n;
     if (!live) i = n - 1;             // keep the wave converged; the duplicate result is not stored
-    Fr px = to_mont(load_fr_std(pts + (size_t)i * 16));
-    Fr py = to_mont(load_fr_std(pts + (size_t)i * 16 + 8));
+    Fs px = fs_from_std(load_fr_std(pts + (size_t)i * 16));
+    Fs py = fs_from_std(load_fr_std(pts + (size_t)i * 16 + 8));
     uint32_t k[8];
     {
         Fr kk = load_fr_std(ks + (size_t)i * 8);
@@ -163,9 +180,9 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_scalar_mul_w2(const uint32_t*
     const bool live = i < n;
     if (!live) i = n - 1;
     TePoint P;
-    P.x = to_mont(load_fr_std(pts + (size_t)i * 16));
-    P.y = to_mont(load_fr_std(pts + (size_t)i * 16 + 8));
-    P.z = Fr::one();
+    P.x = fs_from_std(load_fr_std(pts + (size_t)i * 16));
+    P.y = fs_from_std(load_fr_std(pts + (size_t)i * 16 + 8));
+    P.z = Fs::one();
     P.t = mul(P.x, P.y);
     uint32_t k[8];
     {
@@ -224,8 +241,8 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_msm_groups(const uint32_t* __
     TePoint acc = te_identity();
     // every lane runs the core (wave-uniform control flow); dead lanes recompute element 0 and are masked out
     size_t idx = live ? (size_t)g * m + j : 0;
-    Fr px = to_mont(load_fr_std(pts + idx * 16));
-    Fr py = to_mont(load_fr_std(pts + idx * 16 + 8));
+    Fs px = fs_from_std(load_fr_std(pts + idx * 16));
+    Fs py = fs_from_std(load_fr_std(pts + idx * 16 + 8));
     uint32_t k[8];
     {
         Fr kk = load_fr_std(ks + idx * 8);
@@ -238,15 +255,7 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_msm_groups(const uint32_t* __
     // fold within the group: lane j += lane j+s
 #pragma unroll 1
     for (uint32_t s = mpad >> 1; s > 0; s >>= 1) {
-        TePoint o;
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-            o.x.l[t] = __shfl_down(acc.x.l[t], s, 64);
-            o.y.l[t] = __shfl_down(acc.y.l[t], s, 64);
-            o.z.l[t] = __shfl_down(acc.z.l[t], s, 64);
-            o.t.l[t] = __shfl_down(acc.t.l[t], s, 64);
-        }
-        acc = te_add<CV>(acc, o);
+        acc = te_add<CV>(acc, te_shfl_down(acc, s));
     }
     if (g < groups && j == 0) te_store_affine(out + (size_t)g * 16, acc);
 }
@@ -256,14 +265,9 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_msm_groups(const uint32_t* __
 // (dot_ring/curve/twisted_edwards/te_affine_point.py:212-295, te_curve.py:48-95); hash_to_field stays on the host.
 // One lane per input.  Square roots: Tonelli-Shanks with p-1 = Q*2^32 and the non-residue 5, as the reference's
 // sqrt_mod_bls_scalar_cy (bandersnatch_te.pyx:421); which root comes out is irrelevant (the map fixes the sign).
-DR_DEV Fr fr_const(uint32_t l0, uint32_t l1, uint32_t l2, uint32_t l3, uint32_t l4, uint32_t l5, uint32_t l6, uint32_t l7) {
-    Fr r;
-    r.l[0] = l0; r.l[1] = l1; r.l[2] = l2; r.l[3] = l3; r.l[4] = l4; r.l[5] = l5; r.l[6] = l6; r.l[7] = l7;
-    return r;
-}
 // a^e for a 256-bit exponent given as plain limbs (MSB-first square and multiply)
-DR_DEV Fr fr_pow_limbs(const Fr& a, const uint32_t (&e)[8]) {
-    Fr r = Fr::one();
+DR_DEV Fs fr_pow_limbs(const Fs& a, const uint32_t (&e)[8]) {
+    Fs r = Fs::one();
     bool started = false;
 #pragma unroll 1
     for (int i = 7; i >= 0; i--) {
@@ -280,24 +284,13 @@ DR_DEV Fr fr_pow_limbs(const Fr& a, const uint32_t (&e)[8]) {
 }
 
 
-DR_DEV TePoint te_shfl_down(const TePoint& p, unsigned delta) {
-    TePoint o;
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        o.x.l[t] = __shfl_down(p.x.l[t], delta, 64);
-        o.y.l[t] = __shfl_down(p.y.l[t], delta, 64);
-        o.z.l[t] = __shfl_down(p.z.l[t], delta, 64);
-        o.t.l[t] = __shfl_down(p.t.l[t], delta, 64);
-    }
-    return o;
-}
 
 // acc + (x2, y2, d*t2) with Z2 = 1  (add-2008-hwcd: D = Z1, C = T1 * d t2)
 template <int CV>
-DR_DEV TePoint te_madd(const TePoint& p, const Fr& x2, const Fr& y2, const Fr& dt2) {
-    Fr A = mul(p.x, x2), B = mul(p.y, y2), C = mul(p.t, dt2);
-    Fr E = sub(sub(mul(add(p.x, p.y), add(x2, y2)), A), B);
-    Fr F = sub(p.z, C), G = add(p.z, C), H = sub(B, te_mul_a<CV>(A));
+DR_DEV TePoint te_madd(const TePoint& p, const Fs& x2, const Fs& y2, const Fs& dt2) {
+    const Fs A = mul(p.x, x2), B = mul(p.y, y2), C = mul(p.t, dt2);
+    const Fs E = mul2(p.x, y2, p.y, x2);
+    const Fs F = sub(p.z, C), G = add(p.z, C), H = te_b_minus_aA<CV>(A, B);      // bounds as in te_add (D = Z1)
     TePoint r;
     r.x = mul(E, F);
     r.y = mul(G, H);
@@ -311,7 +304,7 @@ DR_DEV TePoint te_madd(const TePoint& p, const Fr& x2, const Fr& y2, const Fr& d
 // The sigma protocols multiply two CONSTANT points all the time — the generator G and the Pedersen blinding base B
 // (vrf/pedersen/vrf.py:94,104,111: x*G + b*B, k*G + k_b*B; pk = sk*G) — and their launches are latency chains, not
 // throughput: a variable-base multiplication is ~250 dependent doublings.  With a table of every window multiple,
-//     table[w][e] = (e + 1) * 16^w * P   (w < 64, e < 8; affine, as (x, y, d x y) in Montgomery form: 48 KB per base),
+//     table[w][e] = (e + 1) * 16^w * P   (w < 64, e < 8; affine, as (x, y, d x y) in Montgomery form, canonical words: 48 KB per base),
 // k*P is the sum of 64 signed table entries — no doublings — and the sum splits over 4 lanes of 16 windows each plus two
 // shuffle additions: a dependent chain of 18 additions instead of ~320 operations.
 constexpr int TE_FIXED_WINDOWS = 64, TE_FIXED_ENTRIES = 8, TE_FIXED_LANES = 4;
@@ -322,19 +315,19 @@ template <int CV>
 __global__ __launch_bounds__(64) void k_te_fixed_table(const uint32_t* __restrict__ base_xy /* 16 words std */, uint32_t* __restrict__ table) {
     const int w = threadIdx.x;
     TePoint P;
-    P.x = to_mont(load_fr_std(base_xy)); P.y = to_mont(load_fr_std(base_xy + 8)); P.z = Fr::one(); P.t = mul(P.x, P.y);
+    P.x = fs_from_std(load_fr_std(base_xy)); P.y = fs_from_std(load_fr_std(base_xy + 8)); P.z = Fs::one(); P.t = mul(P.x, P.y);
 #pragma unroll 1
     for (int i = 0; i < 4 * w; i++) P = te_dbl<true, CV>(P);
     TePoint cur = P;
 #pragma unroll 1
     for (int e = 0; e < TE_FIXED_ENTRIES; e++) {
         if (e > 0) cur = te_add<CV>(cur, P);
-        const Fr zi = inv(cur.z);
-        const Fr x = mul(cur.x, zi), y = mul(cur.y, zi);
+        const Fs zi = inv(cur.z);
+        const Fs x = mul(cur.x, zi), y = mul(cur.y, zi);
         uint32_t* o = table + ((size_t)w * TE_FIXED_ENTRIES + e) * 24;
-        store_fr_std(o, x);
-        store_fr_std(o + 8, y);
-        store_fr_std(o + 16, mul(te_d_mont<CV>(), mul(x, y)));
+        store_fr_std(o, pack(x));
+        store_fr_std(o + 8, pack(y));
+        store_fr_std(o + 16, pack(mul(te_d_mont<CV>(), mul(x, y))));
     }
 }
 
@@ -387,8 +380,10 @@ __global__ __launch_bounds__(64) void k_te_fixed_base_groups(TeFixedTables tabs,
         if (d == 0) continue;
         const int mag = d < 0 ? -d : d;
         const uint32_t* e = table + ((size_t)(16 * q + i) * TE_FIXED_ENTRIES + (mag - 1)) * 24;
-        Fr x = load_fr_std(e), y = load_fr_std(e + 8), dt = load_fr_std(e + 16);
-        if (d < 0) { x = neg(x); dt = neg(dt); }
+        Fs x = unpack(load_fr_std(e)), dt = unpack(load_fr_std(e + 16));
+        const Fs y = unpack(load_fr_std(e + 8));
+        x = cneg(x, d < 0);
+        dt = cneg(dt, d < 0);
         acc = te_madd<CV>(acc, x, y, dt);
     }
     if (!live) acc = te_identity();

@@ -17,27 +17,27 @@
 
 namespace dr {
 
-// (load_fr_std / store_fr_std copy 8 words as they are: Montgomery values stay Montgomery)
+// (load_fr_std / store_fr_std copy 8 words as they are; pack / unpack keep the Montgomery form: canonical words in memory)
 DR_DEV TePoint load_te_ext(const uint32_t* arr, size_t idx) {
     const uint32_t* p = arr + idx * 32;
     TePoint r;
-    r.x = load_fr_std(p); r.y = load_fr_std(p + 8); r.z = load_fr_std(p + 16); r.t = load_fr_std(p + 24);
+    r.x = unpack(load_fr_std(p)); r.y = unpack(load_fr_std(p + 8)); r.z = unpack(load_fr_std(p + 16)); r.t = unpack(load_fr_std(p + 24));
     return r;
 }
 DR_DEV void store_te_ext(uint32_t* arr, size_t idx, const TePoint& v) {
     uint32_t* p = arr + idx * 32;
-    store_fr_std(p, v.x); store_fr_std(p + 8, v.y); store_fr_std(p + 16, v.z); store_fr_std(p + 24, v.t);
+    store_fr_std(p, pack(v.x)); store_fr_std(p + 8, pack(v.y)); store_fr_std(p + 16, pack(v.z)); store_fr_std(p + 24, pack(v.t));
 }
 
 template <int CV>
 __global__ void k_te_msm_prepare(const uint32_t* __restrict__ pts /* n*16 std */, uint32_t n, uint32_t* __restrict__ table /* n*24 */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr x = to_mont(load_fr_std(pts + (size_t)i * 16)), y = to_mont(load_fr_std(pts + (size_t)i * 16 + 8));
+    const Fs x = fs_from_std(load_fr_std(pts + (size_t)i * 16)), y = fs_from_std(load_fr_std(pts + (size_t)i * 16 + 8));
     uint32_t* o = table + (size_t)i * 24;
-    store_fr_std(o, x);
-    store_fr_std(o + 8, y);
-    store_fr_std(o + 16, mul(te_d_mont<CV>(), mul(x, y)));
+    store_fr_std(o, pack(x));
+    store_fr_std(o + 8, pack(y));
+    store_fr_std(o + 16, pack(mul(te_d_mont<CV>(), mul(x, y))));
 }
 
 // A bucket longer than this is not walked by one lane but by a whole wave (k_te_msm_accumulate_heavy): skewed scalars — many
@@ -53,8 +53,8 @@ DR_DEV TePoint te_msm_walk(const uint32_t* __restrict__ table, const uint32_t* _
     for (uint32_t p = first; p < len; p += stride) {
         const uint32_t e = sorted[beg + p];
         const uint32_t* q = table + (size_t)(e & 0x7fffffffu) * 24;
-        Fr x = load_fr_std(q), y = load_fr_std(q + 8), dt = load_fr_std(q + 16);
-        if (e >> 31) { x = neg(x); dt = neg(dt); }               // -(x, y) = (-x, y), t = x y changes sign with x
+        const bool minus = (e >> 31) != 0;                       // -(x, y) = (-x, y), t = x y changes sign with x
+        const Fs x = cneg(unpack(load_fr_std(q)), minus), y = unpack(load_fr_std(q + 8)), dt = cneg(unpack(load_fr_std(q + 16)), minus);
         acc = te_madd<CV>(acc, x, y, dt);
     }
     return acc;

@@ -10,6 +10,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FQ_P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+FR_P = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+FIELDS = {"fq": (FQ_P, 14, 28, 40), "fr": (FR_P, 9, 29, 26)}
 
 
 @pytest.fixture(scope="module")
@@ -20,32 +22,36 @@ def checker(tmp_path_factory):
     return str(exe)
 
 
-def _run(checker, xs):
-    out = subprocess.run([checker], input="".join(f"{x:x}\n" for x in xs), capture_output=True, text=True, check=True).stdout
+def _run(checker, xs, field="fq"):
+    out = subprocess.run([checker, field], input="".join(f"{x:x}\n" for x in xs), capture_output=True, text=True, check=True).stdout
     rows = [list(map(int, line.split())) for line in out.strip().splitlines()]
     assert len(rows) == len(xs)
     return rows
 
 
-def test_divstep_inversion_against_big_integers(checker):
+@pytest.mark.parametrize("field", ["fq", "fr"])
+def test_divstep_inversion_against_big_integers(checker, field):
+    p, n, bits, max_batches = FIELDS[field]
     rng = random.Random(381)
-    xs = [rng.randrange(1, FQ_P) for _ in range(4000)]
-    xs += [1, 2, 3, FQ_P - 1, FQ_P - 2, (FQ_P - 1) // 2, (FQ_P + 1) // 2, 1 << 380, (1 << 380) - 1, (1 << 28) - 1, 1 << 28,
-           (1 << 364) + 1, FQ_P >> 1, FQ_P - (1 << 200)]
-    xs += [pow(2, k, FQ_P) for k in range(0, 760, 19)]                       # powers of two: long runs of even steps
-    xs += [(FQ_P - pow(2, k, FQ_P)) % FQ_P for k in range(1, 380, 23)]
-    xs += [pow(3, -k, FQ_P) for k in range(1, 40)]
+    xs = [rng.randrange(1, p) for _ in range(4000)]
+    xs += [1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << (p.bit_length() - 2), (1 << (p.bit_length() - 2)) - 1, (1 << bits) - 1,
+           1 << bits, (1 << (bits * (n - 1))) + 1, p >> 1, p - (1 << 200)]
+    xs += [pow(2, k, p) for k in range(0, 2 * p.bit_length(), 19)]             # powers of two: long runs of even steps
+    xs += [(p - pow(2, k, p)) % p for k in range(1, p.bit_length(), 23)]
+    xs += [pow(3, -k, p) for k in range(1, 40)]
     worst = 0
-    for x, row in zip(xs, _run(checker, xs)):
-        limbs, batches = row[:14], row[14]
-        value = sum(l << (28 * i) for i, l in enumerate(limbs))
-        assert value * x % FQ_P == 1, hex(x)
-        assert abs(value) < 21 * FQ_P
-        assert all(abs(l) < (1 << 28) for l in limbs[:13]) and abs(limbs[13]) < (1 << 23)
+    for x, row in zip(xs, _run(checker, xs, field)):
+        limbs, batches = row[:n], row[n]
+        value = sum(l << (bits * i) for i, l in enumerate(limbs))
+        assert value * x % p == 1, hex(x)
+        assert abs(value) < (max_batches // 2 + 1) * p
+        assert all(abs(l) < (1 << bits) for l in limbs[: n - 1]) and abs(limbs[n - 1]) < (1 << 27)
         worst = max(worst, batches)
-    assert worst <= 40
+    assert worst <= max_batches
 
 
-def test_divstep_zero_maps_to_zero(checker):
-    (row,) = _run(checker, [0])
-    assert row[:14] == [0] * 14 and row[14] == 0
+@pytest.mark.parametrize("field", ["fq", "fr"])
+def test_divstep_zero_maps_to_zero(checker, field):
+    n = FIELDS[field][1]
+    (row,) = _run(checker, [0], field)
+    assert row[:n] == [0] * n and row[n] == 0

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "dot_ring_amd", "csrc")
 
 FQ_P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+FR_P = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 
 
 def _s32(v):
@@ -74,6 +75,8 @@ def _run(lines, out_ops, in_ops, values):
             wr(dst, full & ((1 << 64) - 1))
         elif mnem == "v_mul_lo_u32":
             wr(ops[0], (rd(ops[1]) * rd(ops[2])) & 0xFFFFFFFF)
+        elif mnem == "v_sub_u32":
+            wr(ops[0], (rd(ops[1]) - rd(ops[2])) & 0xFFFFFFFF)
         elif mnem == "v_and_b32":
             wr(ops[0], rd(ops[1]) & rd(ops[2]))
         elif mnem == "v_ashrrev_i64":
@@ -113,93 +116,105 @@ def _lazy(rng, n, bits, limb_bound, p, value_bound_p):
             return l, v
 
 
-CASES = [("montmul14x28_asm", "montsqr14x28_asm", 14, 28, FQ_P)]
+# per field: asm names, limbs, bits, modulus, the operand shapes the kernels use — (limb bound a, limb bound b, |a| / p, |b| / p):
+# the value bounds keep |a b| / R below p / 2 ("normal" result) — and the shapes of the squaring and of the fused product
+CASES = [
+    dict(mul="montmul14x28_asm", sqr="montsqr14x28_asm", mul2="montmul2_14x28_asm", n=14, bits=28, p=FQ_P,
+         shapes=[(1 << 28, 1 << 28, 2, 2), (1 << 30, 1 << 28, 31, 31), (1 << 29, 1 << 29, 31, 31), (1 << 28, 1 << 30, 8, 31)],
+         extreme=(1 << 30, 1 << 28), sqr_shape=(1 << 29, 31), mul2_shape=((1 << 29, 8), (1 << 28, 8), (1 << 28, 4), (1 << 28, 2))),
+    dict(mul="montmul9x29_asm", sqr="montsqr9x29_asm", mul2="montmul2_9x29_asm", n=9, bits=29, p=FR_P,
+         shapes=[(1 << 29, 1 << 29, 2, 2), (1 << 30, 1 << 29, 6, 5), (3 << 28, 3 << 28, 5, 5), (1 << 29, 1 << 30, 9, 3), (1 << 29, 1 << 29, 14, 1)],
+         extreme=(1 << 30, 1 << 29), sqr_shape=(3 << 28, 5), mul2_shape=((1 << 29, 4), (1 << 29, 4), (1 << 29, 4), (1 << 29, 4))),
+]
 
 
-@pytest.mark.parametrize("mul_name,sqr_name,n,bits,p", CASES)
-def test_generated_montgomery_sequences(header, mul_name, sqr_name, n, bits, p):
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["mul"])
+def test_generated_montgomery_sequences(header, case):
+    n, bits, p = case["n"], case["bits"], case["p"]
     rng = random.Random(2802)
     R = 1 << (bits * n)
     n0 = (-pow(p, -1, 1 << bits)) % (1 << bits)
     consts = {f"(int32_t)FP::P[{i}]": x for i, x in enumerate(_limbs(p, n, bits))}
     consts["FP::N0"] = n0
-    mul = _parse(header, mul_name)
-    sqr = _parse(header, sqr_name)
+    mul = _parse(header, case["mul"])
+    sqr = _parse(header, case["sqr"])
     assert sum(1 for l in mul[0] if l.startswith("v_mad")) == 2 * n * n
     assert sum(1 for l in sqr[0] if l.startswith("v_mad")) == n * n + n * (n + 1) // 2
 
-    def check(res, a_val, b_val, tag):
+    def check(res, prod, tag):
         limbs = [res[f"r[{i}]"] for i in range(n)]
         assert all(0 <= x < (1 << bits) for x in limbs[:-1]), tag
         got = sum(x << (bits * i) for i, x in enumerate(limbs))
-        assert (got * R - a_val * b_val) % p == 0, tag
+        assert (got * R - prod) % p == 0, tag
         assert -p // 2 < got < p + p // 2, tag                      # "normal": (-p/2, 1.5 p)
 
-    shapes = [((1 << bits), (1 << bits), 2, 2),          # two products
-              ((1 << 30), (1 << bits), 31, 31),          # lazy x normal at the stated bounds
-              ((1 << 29), (1 << 29), 31, 31),
-              ((1 << bits), (1 << 30), 8, 31)]
-    for la, lb, va, vb in shapes:
+    def value(l):
+        return sum(x << (bits * i) for i, x in enumerate(l))
+
+    for la, lb, va, vb in case["shapes"]:
         for _ in range(12):
             a, av = _lazy(rng, n, bits, la, p, va)
             b, bv = _lazy(rng, n, bits, lb, p, vb)
             vals = dict(consts)
             vals.update({f"a[{i}]": a[i] for i in range(n)})
             vals.update({f"b[{i}]": b[i] for i in range(n)})
-            check(_run(*mul, vals), av, bv, (la, lb))
-    # extreme limbs: every limb at +-(bound - 1)
+            check(_run(*mul, vals), av * bv, (la, lb))
+    # extreme limbs: every limb at +-(bound - 1) — the 64-bit column sums must hold (the interpreter asserts it); the value is
+    # far outside the lazy range, so only the congruence is checked
+    ea, eb = case["extreme"]
     for sa in (1, -1):
         for sb in (1, -1):
-            a = [sa * ((1 << 30) - 1)] * (n - 1) + [sa * 3]
-            b = [sb * ((1 << bits) - 1)] * (n - 1) + [sb * 3]
+            a = [sa * (ea - 1)] * (n - 1) + [sa * 3]
+            b = [sb * (eb - 1)] * (n - 1) + [sb * 3]
             vals = dict(consts)
             vals.update({f"a[{i}]": a[i] for i in range(n)})
             vals.update({f"b[{i}]": b[i] for i in range(n)})
             res = _run(*mul, vals)
-            av = sum(x << (bits * i) for i, x in enumerate(a))
-            bv = sum(x << (bits * i) for i, x in enumerate(b))
-            got = sum(res[f"r[{i}]"] << (bits * i) for i in range(n))
-            assert (got * R - av * bv) % p == 0
-    # squaring: |limb| <= 2^29
+            got = value([res[f"r[{i}]"] for i in range(n)])
+            assert (got * R - value(a) * value(b)) % p == 0
+    # squaring
+    sl, sv = case["sqr_shape"]
     for _ in range(24):
-        a, av = _lazy(rng, n, bits, 1 << 29, p, 31)
+        a, av = _lazy(rng, n, bits, sl, p, sv)
         vals = dict(consts)
         vals.update({f"a[{i}]": a[i] for i in range(n)})
-        check(_run(*sqr, vals), av, av, "sqr")
-    for s in (1, -1):
-        a = [s * (1 << 29)] * (n - 1) + [s * 3]
+        check(_run(*sqr, vals), av * av, "sqr")
+    for s_ in (1, -1):
+        a = [s_ * (sl - 1)] * (n - 1) + [s_ * 3]
         vals = dict(consts)
         vals.update({f"a[{i}]": a[i] for i in range(n)})
         res = _run(*sqr, vals)
-        av = sum(x << (bits * i) for i, x in enumerate(a))
-        got = sum(res[f"r[{i}]"] << (bits * i) for i in range(n))
-        assert (got * R - av * av) % p == 0
-    # fused a b + c d (one reduction): a with limbs up to 2^29, the others below 2^28, both signs
-    mul2 = _parse(header, "montmul2_14x28_asm")
+        got = value([res[f"r[{i}]"] for i in range(n)])
+        assert (got * R - value(a) ** 2) % p == 0
+    # fused a b + c d (one reduction), both signs
+    mul2 = _parse(header, case["mul2"])
     assert sum(1 for l in mul2[0] if l.startswith("v_mad")) == 3 * n * n
+    (la, va), (lb, vb), (lc, vc), (ld, vd) = case["mul2_shape"]
     for trial in range(24):
-        a, av = _lazy(rng, n, bits, 1 << 29, p, 8)
-        b, bv = _lazy(rng, n, bits, 1 << bits, p, 8)
-        c, cv_ = _lazy(rng, n, bits, 1 << bits, p, 4)
-        d_, dv = _lazy(rng, n, bits, 1 << bits, p, 2)
-        if trial == 0:
-            a = [(1 << 29) - 1] * (n - 1) + [3]; av = sum(x << (bits * i) for i, x in enumerate(a))
-            b = [(1 << bits) - 1] * (n - 1) + [3]; bv = sum(x << (bits * i) for i, x in enumerate(b))
-            c = [-((1 << bits) - 1)] * (n - 1) + [-3]; cv_ = sum(x << (bits * i) for i, x in enumerate(c))
-            d_ = [-((1 << bits) - 1)] * (n - 1) + [-3]; dv = sum(x << (bits * i) for i, x in enumerate(d_))
+        a, av = _lazy(rng, n, bits, la, p, va)
+        b, bv = _lazy(rng, n, bits, lb, p, vb)
+        c, cv_ = _lazy(rng, n, bits, lc, p, vc)
+        d_, dv = _lazy(rng, n, bits, ld, p, vd)
+        extreme = trial == 0
+        if extreme:
+            a = [la - 1] * (n - 1) + [3]; av = value(a)
+            b = [lb - 1] * (n - 1) + [3]; bv = value(b)
+            c = [-(lc - 1)] * (n - 1) + [-3]; cv_ = value(c)
+            d_ = [-(ld - 1)] * (n - 1) + [-3]; dv = value(d_)
         vals = dict(consts)
         for nm, arr in (("a", a), ("b", b), ("c", c), ("d", d_)):
             vals.update({f"{nm}[{i}]": arr[i] for i in range(n)})
         res = _run(*mul2, vals)
         limbs = [res[f"r[{i}]"] for i in range(n)]
         assert all(0 <= x < (1 << bits) for x in limbs[:-1])
-        got = sum(x << (bits * i) for i, x in enumerate(limbs))
+        got = value(limbs)
         assert (got * R - (av * bv + cv_ * dv)) % p == 0
-        assert -p // 2 < got < p + p // 2
+        if not extreme:
+            assert -p // 2 < got < p + p // 2
     # zero, one, p - 1 in canonical limbs
     for av in (0, 1, p - 1, R % p):
         for bv in (0, 1, p - 1):
             vals = dict(consts)
             vals.update({f"a[{i}]": x for i, x in enumerate(_limbs(av, n, bits))})
             vals.update({f"b[{i}]": x for i, x in enumerate(_limbs(bv, n, bits))})
-            check(_run(*mul, vals), av, bv, "canonical")
+            check(_run(*mul, vals), av * bv, "canonical")
