@@ -143,6 +143,11 @@ def _thread_buffer(name: str, nbytes: int):
     return have
 
 
+def wipe(buf) -> None:
+    """Zero a reused ctypes buffer that held secret material (the auxiliary records carry the blinding factors)."""
+    ctypes.memset(buf, 0, len(buf))
+
+
 def _ragged(items):
     """Concatenate byte strings -> (blob, uint64 offsets[count+1])."""
     off = (ctypes.c_uint64 * (len(items) + 1))()

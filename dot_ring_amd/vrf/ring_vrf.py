@@ -481,7 +481,9 @@ class RingVRF(VRF):
                 suite, alphas[lo:hi], additional_data[lo:hi], salts[lo:hi] if salts else None,
                 b"".join(bytes(sk) if len(sk) == 32 else le(int.from_bytes(sk, "little") % sp.subgroup_order) for sk in secret_keys[lo:hi]),
                 indices[lo:hi], prefix, zk)
-            return [cls._from_native(raw[784 * i : 784 * i + 784], aux[ab * i : ab * i + ab]) for i in range(hi - lo)]
+            proofs = [cls._from_native(raw[784 * i : 784 * i + 784], aux[ab * i : ab * i + ab]) for i in range(hi - lo)]
+            _native.wipe(aux)           # the per-thread buffer is reused: the blinding factors live on only in the proof objects
+            return proofs
 
         # Opt-in (DOTRING_PROVE_PARTS=2; default 1 = one call): large batches as two halves from two threads — while one half is in
         # its store-bound sort or its latency-bound bucket reduction / affine conversion, the other half's accumulate kernel fills
