@@ -43,6 +43,7 @@ _PROTOTYPES = {
     "dr_bsn_msm_groups": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, c_size_t, c_void_p]),
     "dr_bsn_encode_to_curve_batch": (c_int, [c_void_p, c_char_p, c_size_t, c_void_p]),
     "dr_fr_sqrt": (c_int, [c_char_p, c_void_p]),
+    "dr_fr_ops_selftest": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, c_void_p, c_void_p]),
     "dr_srs_load": (c_int, [c_void_p, c_char_p, c_size_t, POINTER(c_void_p)]),
     "dr_srs_synthetic": (c_int, [c_void_p, c_char_p, c_uint, c_size_t, POINTER(c_void_p)]),
     "dr_srs_precompute_comb": (c_int, [c_void_p, c_void_p]),
@@ -428,6 +429,15 @@ class Context:
         ms, cnt = c_double(0), c_int(0)
         _check(lib().dr_prof_get(self.handle, kernel.encode(), byref(ms), byref(cnt)))
         return ms.value, cnt.value
+
+    def fr_ops_selftest(self, a: bytes, b: bytes):
+        """dr_fr_ops_selftest: (n x 9 x 32 result bytes, n square flags) for n pairs of canonical 32-byte elements."""
+        n = len(a) // 32
+        if len(a) != 32 * n or len(b) != 32 * n:
+            raise ValueError("operands are 32 bytes each")
+        out, flags = ctypes.create_string_buffer(max(1, 288 * n)), ctypes.create_string_buffer(max(1, n))
+        _check(lib().dr_fr_ops_selftest(self.handle, a, b, n, out, flags))
+        return out.raw[: 288 * n], flags.raw[:n]
 
     # ---- seam A
     # (curve = CURVE_BANDERSNATCH / CURVE_JUBJUB; the default goes through the dr_bsn_* names of the original seam)

@@ -49,6 +49,30 @@ DR_DEV bool fr_sqrt(const Fs& x, Fs& root) {
     return true;
 }
 
+// Diagnostic (dr_fr_ops_selftest): the unsaturated field arithmetic of fr29.hip.h on its own, one lane per (a, b) pair of
+// standard-form elements.  out[i] = nine 32-byte standard-form records: a b, a^2, a + b, a - b, a^-1 (0 for 0),
+// (a + b)(a - b) through two lazy operands, a * (curve coefficient -5) through the shifted addition chain of the group
+// law (3p - 5a), a b + b a through the fused product, sqrt(a) (zero when a is not a square); flag[i] = 1 iff a is a square.
+__global__ void k_fr_ops_selftest(const uint32_t* __restrict__ a_std, const uint32_t* __restrict__ b_std, uint32_t n, uint32_t* __restrict__ out,
+                                  uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fs a = fs_from_std(load_fr_std(a_std + (size_t)i * 8)), b = fs_from_std(load_fr_std(b_std + (size_t)i * 8));
+    uint32_t* o = out + (size_t)i * 72;
+    store_fr_std(o, fs_to_std(mul(a, b)));
+    store_fr_std(o + 8, fs_to_std(sqr(a)));
+    store_fr_std(o + 16, fs_to_std(add(a, b)));
+    store_fr_std(o + 24, fs_to_std(sub(a, b)));
+    store_fr_std(o + 32, fs_to_std(inv(a)));
+    store_fr_std(o + 40, fs_to_std(mul(add(a, b), sub(a, b))));
+    store_fr_std(o + 48, fs_to_std(te_aA<CV_BANDERSNATCH>(a)));
+    store_fr_std(o + 56, fs_to_std(mul2(a, b, b, a)));
+    Fs r;
+    const bool square = fr_sqrt(a, r);
+    store_fr_std(o + 64, fs_to_std(square ? r : Fs::zero()));
+    flag[i] = square ? 1u : 0u;
+}
+
 // Elligator 2 onto the Montgomery model up to the point (s, t) = (x B_M, y B_M); the inversion 1/(1 + Z u^2) is
 // supplied by the caller so that the two maps of one input share ONE inversion (Montgomery's trick).
 struct EllHalf { Fs tv1, den; };

@@ -271,6 +271,29 @@ def test_g1_msm_synthetic_bases_closed_form(ctx, log2n, table):
     srs.close()
 
 
+def test_fr29_field_arithmetic_against_big_integers(ctx):
+    """the unsaturated Fr of the twisted Edwards kernels (csrc/fr29.hip.h: 9 signed limbs of 29 bits, lazy reduction) through
+    dr_fr_ops_selftest: products, squarings, sums, differences, inverses (division steps), a product of two lazy operands,
+    the -5 a addition chain of the group law, the fused two-product and Tonelli-Shanks, on the edges of the field (0, 1, 2,
+    p - 1, p - 2, values around 2^29 k and 2^255 - small, all-ones limb patterns) and 20 000 random pairs"""
+    p = coracle.FR_P
+    rng = random.Random(29)
+    edge = [0, 1, 2, 3, 5, p - 1, p - 2, p - 5, (p - 1) // 2, (p + 1) // 2, 1 << 29, (1 << 29) - 1, (1 << 58) + 1, (1 << 232) - 1, 1 << 232,
+            (1 << 254) - 1, 1 << 254, p - (1 << 29), p - (1 << 232), sum(((1 << 29) - 1) << (29 * i) for i in range(8)) % p,
+            pow(5, (p - 1) >> 32, p), pow(7, -1, p)]
+    pairs = [(x, y) for x in edge for y in edge] + [(rng.randrange(p), rng.randrange(p)) for _ in range(20000)]
+    a = b"".join(x.to_bytes(32, "little") for x, _ in pairs)
+    b = b"".join(y.to_bytes(32, "little") for _, y in pairs)
+    out, flags = ctx.fr_ops_selftest(a, b)
+    for i, (x, y) in enumerate(pairs):
+        rec = [int.from_bytes(out[288 * i + 32 * k : 288 * i + 32 * k + 32], "little") for k in range(9)]
+        want = [x * y % p, x * x % p, (x + y) % p, (x - y) % p, pow(x, -1, p) if x else 0, (x * x - y * y) % p, (-5 * x) % p, 2 * x * y % p]
+        assert rec[:8] == want, (hex(x), hex(y))
+        square = x == 0 or pow(x, (p - 1) // 2, p) == 1
+        assert flags[i] == (1 if square else 0), hex(x)
+        assert (rec[8] * rec[8] - x) % p == 0 if square else rec[8] == 0, hex(x)
+
+
 def test_g1_msm_partition_sort_skewed_and_ragged(ctx):
     """the two-pass partition sort of one huge table MSM (k_g1_part_scatter / k_g1_part_sort) away from uniformly random
     scalars: a ragged size (index groups of unequal length, a last tile of a few scalars), every scalar equal (one bucket per
