@@ -477,10 +477,22 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         TRY(g1_bases.reserve(n_g1 * 96));
         TRY(g1_in.reserve(7 * B * 48));
         TRY(g1_std.reserve(n_g1 * 96));
-        HIP_TRY(hipMemcpyAsync(g1_in.p, g1_enc.data(), 7 * B * 48, hipMemcpyHostToDevice, st));
-        TRY(launch(ctx, "k_g1_decompress", [&] {
-            g1_launch_decompress(st, g1_in.as<uint8_t>(), g1_bases.as<uint32_t>(), d_ok + n_te, 7 * B);
+        // the G1 decompression (a 380-squaring chain on ~100 waves) runs next to the Bandersnatch decoding (~1 ms on 128 waves) on
+        // the third stream; an event brings it back into this stream before anything reads the bases
+        if (!ctx->aux2) TRY(dr_ctx_create(ctx->device, &ctx->aux2));
+        hipStream_t st2 = ctx->aux2->stream;
+        ctx->aux2->prof = ctx->prof;
+        HIP_TRY(hipMemcpyAsync(g1_in.p, g1_enc.data(), 7 * B * 48, hipMemcpyHostToDevice, st2));
+        TRY(launch(ctx->aux2, "k_g1_decompress", [&] {
+            g1_launch_decompress(st2, g1_in.as<uint8_t>(), g1_bases.as<uint32_t>(), d_ok + n_te, 7 * B);
         }));
+        {
+            hipEvent_t done;
+            HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+            hipError_t e1 = hipEventRecord(done, st2), e2 = e1 == hipSuccess ? hipStreamWaitEvent(st, done, 0) : e1;
+            (void)hipEventDestroy(done);
+            HIP_TRY(e2);
+        }
         {
             uint8_t tail_be[4 * 96];
             std::memcpy(tail_be, vk->fixed_commitments, 3 * 96);
