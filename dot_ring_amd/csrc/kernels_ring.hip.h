@@ -194,7 +194,7 @@ __global__ void k_ring_chain(const uint32_t* __restrict__ ring_pts_mont /* N*16:
 
 // The same chain with one WAVE per proof: lane l owns blinding bits 4l..4l+3.  Local sums of the selected bit points,
 // an inclusive scan across the wave (6 shuffle steps), then every lane walks its own <= 4 additions from
-// seed + PK_k + (sum of all lower lanes) — 16 dependent additions instead of ~128, and one Fermat inversion per lane
+// seed + PK_k + (sum of all lower lanes) — 16 dependent additions instead of ~128, and one division-step inversion per lane
 // (lock-step, so it costs the time of one) to normalise the lane's own values.  Same outputs as k_ring_chain.
 DR_DEV TePoint te_shfl_up(const TePoint& p, unsigned delta) {
     TePoint o;

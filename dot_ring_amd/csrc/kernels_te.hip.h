@@ -5,7 +5,7 @@
 // k_bsn_scalar_mul: signed fixed 4-bit windows (digits in [-8,7], 64 windows over the 253-bit scalar),
 // the per-lane table {1..8}P in LDS laid out [entry][word][lane] so that a data-dependent entry index
 // still hits bank = lane (conflict-free ds_read_b32), 3 of every 4 doublings skip the T coordinate,
-// final affine conversion by a Fermat inversion per lane.  Replaces the reference's GLV + joint 2-bit
+// final affine conversion by one division-step inversion per lane (fr29.hip.h).  Replaces the reference's GLV + joint 2-bit
 // window kernel (dot_ring/curve/native_field/bandersnatch_te.pyx:480-554 via specs/bandersnatch.py:177-191):
 // the output is the canonical affine point, so the different window schedule is invisible in the bytes.
 #pragma once
