@@ -392,8 +392,8 @@ int msm_to_bytes(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars
 }
 
 // batch > 1: results were left in ctx->result (XYZZ).  The affine conversion is one 381-bit field inversion per
-// result: on the GPU a branch-free binary-Euclid chain (≈ 0.5 ms of pure latency per call, whatever the batch; 0.85 ms with
-// the Fermat power it replaced).  Measured alternative for whole batches (DOTRING_AFFINE_ON_HOST=1): download XYZZ and invert
+// result: on the GPU a division-step chain (divstep28.hip.h: ≈ 0.08 ms of pure latency per call, whatever the batch; 0.5 ms with
+// the binary Euclid, 0.85 ms with the Fermat power before that).  Measured alternative for whole batches (DOTRING_AFFINE_ON_HOST=1): download XYZZ and invert
 // on the worker threads — less GPU time but more wall time per 1024 proofs, so the kernel stays the default there.
 int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, int* is_inf) {
     static const bool on_host = std::getenv("DOTRING_AFFINE_ON_HOST") && std::atoi(std::getenv("DOTRING_AFFINE_ON_HOST")) != 0;
