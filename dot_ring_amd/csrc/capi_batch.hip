@@ -194,33 +194,60 @@ int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_
     tr_.mark("spawn+zk");
     TRY(dr_ring_prove_witness(p, B, producer_index, blind.data(), zk_random48 ? zk.data() : nullptr, relation.data(), wit.data(), wit_inf.data()));
     tr_.mark("witness");
-    drh::FsTranscript base;
-    base.sh.update(fs_prefix, fs_prefix_len);
-    std::vector<drh::FsTranscript> fs(B, base);
+    // transcripts in groups of four proofs (FsTranscript4: four Keccak states per vector instruction); the last group repeats
+    // proof B - 1 in its spare slots, whose (identical) results land on the same bytes
+    drh::FsTranscript4 base;
+    base.sh.update_same(fs_prefix, fs_prefix_len);
+    const size_t G = (B + 3) / 4;
+    std::vector<drh::FsTranscript4> fs(G, base);
+    auto member = [&](size_t g, int k) { return std::min(4 * g + (size_t)k, B - 1); };
     std::vector<uint8_t> alphas7(B * 7 * 32), zetas(B * 32), nus(B * 8 * 32);
-    drh::parallel_for(B, [&](size_t i) {
-        fs[i].absorb_labeled("instance", relation.data() + 64 * i, 64);
-        uint8_t ser[4 * 96];
-        for (int c = 0; c < 4; c++) drh::g1_serialized(wit.data() + 96 * (4 * i + c), wit_inf[4 * i + c], ser + 96 * c);
-        fs[i].absorb_labeled("committed_cols", ser, sizeof ser);
-        fs[i].challenges("constraints_aggregation", 7, alphas7.data() + 224 * i);
+    drh::parallel_for(G, [&](size_t g) {
+        const uint8_t* in[4];
+        uint8_t* out[4];
+        uint8_t ser[4][4 * 96];
+        for (int k = 0; k < 4; k++) in[k] = relation.data() + 64 * member(g, k);
+        fs[g].absorb_labeled("instance", in, 64);
+        for (int k = 0; k < 4; k++) {
+            const size_t i = member(g, k);
+            for (int c = 0; c < 4; c++) drh::g1_serialized(wit.data() + 96 * (4 * i + c), wit_inf[4 * i + c], ser[k] + 96 * c);
+            in[k] = ser[k];
+            out[k] = alphas7.data() + 224 * i;
+        }
+        fs[g].absorb_labeled("committed_cols", in, 4 * 96);
+        fs[g].challenges("constraints_aggregation", 7, out);
     });
     tr_.mark("fs1");
     TRY(dr_ring_prove_quotient(p, B, alphas7.data(), cq.data(), cq_inf.data()));
     tr_.mark("quotient");
-    drh::parallel_for(B, [&](size_t i) {
-        uint8_t ser[96];
-        drh::g1_serialized(cq.data() + 96 * i, cq_inf[i], ser);
-        fs[i].absorb_labeled("quotient", ser, 96);
-        fs[i].challenges("evaluation_point", 1, zetas.data() + 32 * i);
+    drh::parallel_for(G, [&](size_t g) {
+        const uint8_t* in[4];
+        uint8_t* out[4];
+        uint8_t ser[4][96];
+        for (int k = 0; k < 4; k++) {
+            const size_t i = member(g, k);
+            drh::g1_serialized(cq.data() + 96 * i, cq_inf[i], ser[k]);
+            in[k] = ser[k];
+            out[k] = zetas.data() + 32 * i;
+        }
+        fs[g].absorb_labeled("quotient", in, 96);
+        fs[g].challenges("evaluation_point", 1, out);
     });
     tr_.mark("fs2");
     TRY(dr_ring_prove_evals(p, B, zetas.data(), evals.data()));
     tr_.mark("evals");
-    drh::parallel_for(B, [&](size_t i) {
-        fs[i].absorb_labeled("register_evaluations", evals.data() + 256 * i, 224);
-        fs[i].absorb_labeled("shifted_linearization_evaluation", evals.data() + 256 * i + 224, 32);
-        fs[i].challenges("kzg_aggregation", 8, nus.data() + 256 * i);
+    drh::parallel_for(G, [&](size_t g) {
+        const uint8_t *in[4], *in2[4];
+        uint8_t* out[4];
+        for (int k = 0; k < 4; k++) {
+            const size_t i = member(g, k);
+            in[k] = evals.data() + 256 * i;
+            in2[k] = evals.data() + 256 * i + 224;
+            out[k] = nus.data() + 256 * i;
+        }
+        fs[g].absorb_labeled("register_evaluations", in, 224);
+        fs[g].absorb_labeled("shifted_linearization_evaluation", in2, 32);
+        fs[g].challenges("kzg_aggregation", 8, out);
     });
     tr_.mark("fs3");
     TRY(dr_ring_prove_openings(p, B, nus.data(), opens.data(), open_inf.data()));
@@ -518,8 +545,8 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
     // ---- 4. ring proofs: transcript replay + verifier scalar pass per proof, random linear combination of all claims
     drh::RingVerifierDomain dm;
     dm.init(vk->log2n, vk->omega_n, vk->seed_xy);
-    drh::FsTranscript base;
-    base.sh.update(vk->fs_prefix, vk->fs_prefix_len);
+    drh::FsTranscript4 base;
+    base.sh.update_same(vk->fs_prefix, vk->fs_prefix_len);
     std::vector<uint8_t> lhs_sc(n_g1 * 32), rhs_sc(2 * B * 32);
     std::vector<uint64_t> fixed_part(B * 16);           // per proof: r1*nu0, r1*nu1, r1*nu2, r1*agg + r2*l_zw
     std::vector<int> bad(B, 0);
@@ -530,22 +557,48 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         if (inf) { std::memset(out, 0, 96); out[0] = 0x40; return; }
         for (int j = 0; j < 48; j++) { out[j] = s[47 - j]; out[48 + j] = s[95 - j]; }
     };
+    // transcript replay, four proofs per sponge group (the spare slots of the last group repeat proof B - 1)
+    std::vector<uint8_t> al_all(B * 7 * 32), zeta_all(B * 32), nus_all(B * 8 * 32);
+    drh::parallel_for((B + 3) / 4, [&](size_t g) {
+        drh::FsTranscript4 t = base;
+        size_t idx[4];
+        const uint8_t *in[4], *in2[4];
+        uint8_t* out[4];
+        uint8_t ser[4][4 * 96];
+        for (int k = 0; k < 4; k++) {
+            idx[k] = std::min(4 * g + (size_t)k, B - 1);
+            in[k] = te_xy.data() + 64 * (4 * idx[k] + 1);                     // blinded public key
+        }
+        t.absorb_labeled("instance", in, 64);
+        for (int k = 0; k < 4; k++) {
+            for (int c = 0; c < 4; c++) be_rec(7 * idx[k] + c, ser[k] + 96 * c);
+            in[k] = ser[k];
+            out[k] = al_all.data() + 224 * idx[k];
+        }
+        t.absorb_labeled("committed_cols", in, 4 * 96);
+        t.challenges("constraints_aggregation", 7, out);
+        for (int k = 0; k < 4; k++) {
+            be_rec(7 * idx[k] + 4, ser[k]);
+            out[k] = zeta_all.data() + 32 * idx[k];
+        }
+        t.absorb_labeled("quotient", in, 96);
+        t.challenges("evaluation_point", 1, out);
+        for (int k = 0; k < 4; k++) {
+            const uint8_t* pl = proofs + 784 * idx[k] + 192;
+            in[k] = pl + 192;
+            in2[k] = pl + 464;
+            out[k] = nus_all.data() + 256 * idx[k];
+        }
+        t.absorb_labeled("register_evaluations", in, 224);
+        t.absorb_labeled("shifted_linearization_evaluation", in2, 32);
+        t.challenges("kzg_aggregation", 8, out);
+    });
     drh::parallel_for(B, [&](size_t i) {
         const uint8_t* pr = proofs + 784 * i;
         const uint8_t* pl = pr + 192;
-        drh::FsTranscript t = base;
-        uint8_t result_seed[64], ser[4 * 96], al[7 * 32], zeta[32], nus[8 * 32];
+        uint8_t result_seed[64];
+        const uint8_t *al = al_all.data() + 224 * i, *zeta = zeta_all.data() + 32 * i, *nus = nus_all.data() + 256 * i;
         const uint8_t* relation = te_xy.data() + 64 * (4 * i + 1);            // blinded public key
-        t.absorb_labeled("instance", relation, 64);
-        for (int k = 0; k < 4; k++) be_rec(7 * i + k, ser + 96 * k);
-        t.absorb_labeled("committed_cols", ser, sizeof ser);
-        t.challenges("constraints_aggregation", 7, al);
-        be_rec(7 * i + 4, ser);
-        t.absorb_labeled("quotient", ser, 96);
-        t.challenges("evaluation_point", 1, zeta);
-        t.absorb_labeled("register_evaluations", pl + 192, 224);
-        t.absorb_labeled("shifted_linearization_evaluation", pl + 464, 32);
-        t.challenges("kzg_aggregation", 8, nus);
         drh::te_add_affine(*su.cv, vk->seed_xy, relation, result_seed);
         drh::RingClaimScalars cl;
         if (!drh::ring_verifier_terms(*su.cv, dm, al, nus, zeta, pl + 192, pl + 464, result_seed, cl)) { bad[i] = 1; return; }

@@ -5,6 +5,7 @@
 // worker threads instead of one interpreter call each.  Checked against hashlib in tests/test_native_host.py.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <cstddef>
 
@@ -101,33 +102,39 @@ struct Sha512 {
 // ---------------------------------------------------------------- Keccak-f[1600] sponge (SHAKE128: rate 168, SHAKE256: rate 136)
 // Fully unrolled rounds on 25 local lanes (theta, rho + pi, chi, iota fused; rotation counts and lane moves are compile-time):
 // the transcript replay of a batch verifier is ~20 permutations per proof, i.e. this function is most of its host time.
-inline uint64_t keccak_rol(uint64_t v, int n) { return (v << n) | (v >> (64 - n)); }
-inline void keccak_f1600(uint64_t st[25]) {
+// The body is a template over the lane type: uint64_t for one state, a 4 x 64-bit vector for FOUR states in lockstep (the
+// transcripts of four proofs absorb the same lengths in the same order, so their sponges permute at the same moments; with
+// AVX2 one vector instruction serves four permutations, ~3.5x the throughput of the scalar code).
+typedef uint64_t u64x4 __attribute__((vector_size(32)));
+template <class V>
+__attribute__((always_inline)) inline V keccak_rol(V v, int n) { return (v << n) | (v >> (64 - n)); }
+template <class V>
+__attribute__((always_inline)) inline void keccak_f1600_t(V* st) {
     static const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
                                     0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
                                     0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
                                     0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
                                     0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
                                     0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-    uint64_t a00 = st[0], a01 = st[1], a02 = st[2], a03 = st[3], a04 = st[4], a05 = st[5], a06 = st[6], a07 = st[7], a08 = st[8], a09 = st[9],
+    V a00 = st[0], a01 = st[1], a02 = st[2], a03 = st[3], a04 = st[4], a05 = st[5], a06 = st[6], a07 = st[7], a08 = st[8], a09 = st[9],
              a10 = st[10], a11 = st[11], a12 = st[12], a13 = st[13], a14 = st[14], a15 = st[15], a16 = st[16], a17 = st[17], a18 = st[18],
              a19 = st[19], a20 = st[20], a21 = st[21], a22 = st[22], a23 = st[23], a24 = st[24];
     for (int round = 0; round < 24; round++) {
         // theta
-        const uint64_t c0 = a00 ^ a05 ^ a10 ^ a15 ^ a20, c1 = a01 ^ a06 ^ a11 ^ a16 ^ a21, c2 = a02 ^ a07 ^ a12 ^ a17 ^ a22,
+        const V c0 = a00 ^ a05 ^ a10 ^ a15 ^ a20, c1 = a01 ^ a06 ^ a11 ^ a16 ^ a21, c2 = a02 ^ a07 ^ a12 ^ a17 ^ a22,
                        c3 = a03 ^ a08 ^ a13 ^ a18 ^ a23, c4 = a04 ^ a09 ^ a14 ^ a19 ^ a24;
-        const uint64_t d0 = c4 ^ keccak_rol(c1, 1), d1 = c0 ^ keccak_rol(c2, 1), d2 = c1 ^ keccak_rol(c3, 1), d3 = c2 ^ keccak_rol(c4, 1),
+        const V d0 = c4 ^ keccak_rol(c1, 1), d1 = c0 ^ keccak_rol(c2, 1), d2 = c1 ^ keccak_rol(c3, 1), d3 = c2 ^ keccak_rol(c4, 1),
                        d4 = c3 ^ keccak_rol(c0, 1);
         // rho + pi: b[y][2x+3y] = rol(a[x][y] ^ d[x], r[x][y])   (lane index = x + 5y)
-        const uint64_t b00 = a00 ^ d0;
-        const uint64_t b10 = keccak_rol(a01 ^ d1, 1), b20 = keccak_rol(a02 ^ d2, 62), b05 = keccak_rol(a03 ^ d3, 28), b15 = keccak_rol(a04 ^ d4, 27);
-        const uint64_t b16 = keccak_rol(a05 ^ d0, 36), b01 = keccak_rol(a06 ^ d1, 44), b11 = keccak_rol(a07 ^ d2, 6), b21 = keccak_rol(a08 ^ d3, 55),
+        const V b00 = a00 ^ d0;
+        const V b10 = keccak_rol(a01 ^ d1, 1), b20 = keccak_rol(a02 ^ d2, 62), b05 = keccak_rol(a03 ^ d3, 28), b15 = keccak_rol(a04 ^ d4, 27);
+        const V b16 = keccak_rol(a05 ^ d0, 36), b01 = keccak_rol(a06 ^ d1, 44), b11 = keccak_rol(a07 ^ d2, 6), b21 = keccak_rol(a08 ^ d3, 55),
                        b06 = keccak_rol(a09 ^ d4, 20);
-        const uint64_t b07 = keccak_rol(a10 ^ d0, 3), b17 = keccak_rol(a11 ^ d1, 10), b02 = keccak_rol(a12 ^ d2, 43), b12 = keccak_rol(a13 ^ d3, 25),
+        const V b07 = keccak_rol(a10 ^ d0, 3), b17 = keccak_rol(a11 ^ d1, 10), b02 = keccak_rol(a12 ^ d2, 43), b12 = keccak_rol(a13 ^ d3, 25),
                        b22 = keccak_rol(a14 ^ d4, 39);
-        const uint64_t b23 = keccak_rol(a15 ^ d0, 41), b08 = keccak_rol(a16 ^ d1, 45), b18 = keccak_rol(a17 ^ d2, 15), b03 = keccak_rol(a18 ^ d3, 21),
+        const V b23 = keccak_rol(a15 ^ d0, 41), b08 = keccak_rol(a16 ^ d1, 45), b18 = keccak_rol(a17 ^ d2, 15), b03 = keccak_rol(a18 ^ d3, 21),
                        b13 = keccak_rol(a19 ^ d4, 8);
-        const uint64_t b14 = keccak_rol(a20 ^ d0, 18), b24 = keccak_rol(a21 ^ d1, 2), b09 = keccak_rol(a22 ^ d2, 61), b19 = keccak_rol(a23 ^ d3, 56),
+        const V b14 = keccak_rol(a20 ^ d0, 18), b24 = keccak_rol(a21 ^ d1, 2), b09 = keccak_rol(a22 ^ d2, 61), b19 = keccak_rol(a23 ^ d3, 56),
                        b04 = keccak_rol(a24 ^ d4, 14);
         // chi + iota
         a00 = b00 ^ (~b01 & b02) ^ RC[round]; a01 = b01 ^ (~b02 & b03); a02 = b02 ^ (~b03 & b04); a03 = b03 ^ (~b04 & b00); a04 = b04 ^ (~b00 & b01);
@@ -139,6 +146,14 @@ inline void keccak_f1600(uint64_t st[25]) {
     st[0] = a00; st[1] = a01; st[2] = a02; st[3] = a03; st[4] = a04; st[5] = a05; st[6] = a06; st[7] = a07; st[8] = a08; st[9] = a09;
     st[10] = a10; st[11] = a11; st[12] = a12; st[13] = a13; st[14] = a14; st[15] = a15; st[16] = a16; st[17] = a17; st[18] = a18; st[19] = a19;
     st[20] = a20; st[21] = a21; st[22] = a22; st[23] = a23; st[24] = a24;
+}
+
+inline void keccak_f1600(uint64_t st[25]) { keccak_f1600_t<uint64_t>(st); }
+__attribute__((target("avx2"))) inline void keccak_f1600_x4_avx2(u64x4* st) { keccak_f1600_t<u64x4>(st); }
+inline void keccak_f1600_x4_generic(u64x4* st) { keccak_f1600_t<u64x4>(st); }       // the compiler splits the vectors (SSE2)
+inline void keccak_f1600_x4(u64x4* st) {
+    static const bool avx2 = __builtin_cpu_supports("avx2") && std::getenv("DOTRING_KECCAK_GENERIC") == nullptr;   // (the knob: tests)
+    if (avx2) keccak_f1600_x4_avx2(st); else keccak_f1600_x4_generic(st);
 }
 
 template <int RATE>
@@ -182,5 +197,53 @@ struct Shake {
 };
 using Shake128 = Shake<168>;
 using Shake256 = Shake<136>;
+
+// four sponges in lockstep: every update gives each of them the same number of bytes
+template <int RATE>
+struct Shake4 {
+    u64x4 st[25];
+    uint8_t buf[4][RATE];    // the current block of each stream, XORed into the state when it is full
+    size_t pos = 0;
+
+    Shake4() { std::memset(st, 0, sizeof st); }
+    static void xor_block(u64x4* s, const uint8_t (*blk)[RATE]) {
+        for (size_t l = 0; l < RATE / 8; l++) {
+            uint64_t w[4];
+            for (int k = 0; k < 4; k++) std::memcpy(&w[k], blk[k] + 8 * l, 8);
+            s[l] ^= u64x4{w[0], w[1], w[2], w[3]};
+        }
+    }
+    void update(const uint8_t* const p[4], size_t len) {
+        size_t done = 0;
+        while (done < len) {
+            const size_t take = RATE - pos < len - done ? RATE - pos : len - done;
+            for (int k = 0; k < 4; k++) std::memcpy(buf[k] + pos, p[k] + done, take);
+            pos += take; done += take;
+            if (pos == RATE) { xor_block(st, buf); keccak_f1600_x4(st); pos = 0; }
+        }
+    }
+    void update_same(const void* data, size_t len) {
+        const uint8_t* q = (const uint8_t*)data;
+        const uint8_t* p[4] = {q, q, q, q};
+        update(p, len);
+    }
+    // digests of everything absorbed so far (n <= RATE bytes each); the absorbing state is left untouched
+    void digest(uint8_t* const out[4], size_t n) const {
+        u64x4 s[25];
+        std::memcpy(s, st, sizeof s);
+        uint8_t b[4][RATE];                                    // the partial blocks, padded
+        for (int k = 0; k < 4; k++) {
+            std::memcpy(b[k], buf[k], pos);
+            std::memset(b[k] + pos, 0, RATE - pos);
+            b[k][pos] ^= 0x1f;
+            b[k][RATE - 1] ^= 0x80;
+        }
+        xor_block(s, b);
+        keccak_f1600_x4(s);
+        for (int k = 0; k < 4; k++)
+            for (size_t i = 0; i < n; i++) out[k][i] = (uint8_t)(s[i >> 3][k] >> (8 * (i & 7)));
+    }
+};
+using Shake128x4 = Shake4<168>;
 
 }  // namespace drh

@@ -556,6 +556,44 @@ struct FsTranscript {
     }
 };
 
+// The transcripts of FOUR proofs side by side (Shake4): the ring proof's absorbs have the same lengths for every proof, so the
+// four sponges stay in lockstep.  Same call sequence as FsTranscript, data and outputs as arrays of four pointers.
+struct FsTranscript4 {
+    Shake128x4 sh;
+    void framed(const char* label) {
+        size_t n = std::strlen(label);
+        uint8_t l[4];
+        FsTranscript::be32((uint32_t)n, l);
+        sh.update_same(label, n);
+        sh.update_same(l, 4);
+    }
+    void absorb_labeled(const char* label, const uint8_t* const data[4], size_t len) {
+        framed(label);
+        uint8_t l[4];
+        FsTranscript::be32((uint32_t)len, l);
+        sh.update(data, len);
+        sh.update_same(l, 4);
+    }
+    // n challenges per proof; out[k] = n little-endian 32-byte values of proof k
+    void challenges(const char* label, int n, uint8_t* const out[4]) {
+        static const uint8_t footer[4] = {0, 0, 0, 9};
+        for (int i = 0; i < n; i++) {
+            if (i > 0) sh.update_same(footer, 4);
+            framed(label);
+            sh.update_same("challenge", 9);
+            uint8_t raw[4][48];
+            uint8_t* const rp[4] = {raw[0], raw[1], raw[2], raw[3]};
+            sh.digest(rp, 48);
+            for (int k = 0; k < 4; k++) {
+                uint64_t v[4];
+                mod_p().reduce_bytes(raw[k], 48, true, v);
+                store_le32(v, out[k] + 32 * i);
+            }
+        }
+        sh.update_same(footer, 4);
+    }
+};
+
 // ---------------------------------------------------------------- ring-proof verifier scalar pass (verify.py:51-210)
 struct RingVerifierDomain {
     unsigned log2n;

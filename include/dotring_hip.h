@@ -263,7 +263,10 @@ DR_API int dr_ring_prove_openings(dr_ring_prover *p, size_t batch, const uint8_t
  * they run on worker threads (DOTRING_HOST_THREADS, default min(16, cores)) inside ONE call per batch, with the GPU
  * phases above in between.  Results are byte-identical to prove() called per proof.
  */
-enum { DR_HASH_SHA512 = 0, DR_HASH_SHAKE128 = 1, DR_HASH_SHAKE256 = 2 };
+enum { DR_HASH_SHA512 = 0, DR_HASH_SHAKE128 = 1, DR_HASH_SHAKE256 = 2,
+       /* diagnostic: `data` = four messages of len / 4 bytes each, `out` = their four SHAKE128 digests of out_len / 4 bytes each
+        * (at most 168), computed by the four-in-lockstep sponge the batch transcripts use */
+       DR_HASH_SHAKE128_X4 = 3 };
 DR_API int dr_host_hash(int kind, const uint8_t *data, size_t len, uint8_t *out, size_t out_len);
 /* out = SHAKE256(seed || LE64(0))[0..576) || SHAKE256(seed || LE64(1))[0..576) || ... (len bytes), hashed on the worker threads.
  * dr_ringvrf_prove_batch's zk_random48 for a batch (12 x 48 bytes per proof: the hidden rows of columns/columns.py:139-146, drawn

@@ -17,6 +17,29 @@ def test_host_hashes_match_hashlib():
             assert _native.host_hash(2, data, ol) == hashlib.shake_256(data).digest(ol)
 
 
+def test_four_way_shake128_matches_hashlib():
+    """the four-in-lockstep SHAKE128 sponge of the batch transcripts (hosthash.hpp: Shake4, Keccak-f on 4 x 64-bit vectors) against
+    hashlib: message lengths around the 168-byte rate, four different messages per call, every digest length up to a block"""
+    rng = random.Random(4)
+    for ln in [0, 1, 7, 8, 9, 55, 166, 167, 168, 169, 170, 335, 336, 337, 500, 1000, 1700]:
+        msgs = [bytes(rng.randrange(256) for _ in range(ln)) for _ in range(4)]
+        for ol in (1, 16, 48, 64, 167, 168):
+            got = _native.host_hash(3, b"".join(msgs), 4 * ol)
+            assert [got[ol * k : ol * (k + 1)] for k in range(4)] == [hashlib.shake_128(m).digest(ol) for m in msgs], (ln, ol)
+
+
+def test_four_way_shake128_without_avx2():
+    """the same sponge through the code path for hosts without AVX2 (the vector type split by the compiler)"""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import hashlib; from dot_ring_amd import _native; m=[bytes([k])*300 for k in range(4)]; "
+            "g=_native.host_hash(3, b''.join(m), 4*64); assert [g[64*k:64*k+64] for k in range(4)] == [hashlib.shake_128(x).digest(64) for x in m]")
+    env = dict(os.environ, DOTRING_KECCAK_GENERIC="1")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
 def test_hash_to_field_batch_matches_oracle():
     le = lambda v: int(v).to_bytes(32, "little")
     msgs = [b"", b"abc", b"\x00" * 300] + [hashlib.sha256(bytes([i])).digest() * (i % 5) for i in range(40)]
