@@ -842,8 +842,13 @@ __global__ __launch_bounds__(RC_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))
     const uint32_t T = H / L;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= windows * T) return;
-    size_t win = gid / T;
-    uint32_t ch = (uint32_t)(gid % T), s = ch * L;
+    // few sets (one huge MSM in 16 index groups): neighbouring lanes take the SAME chunk of different sets, so a wave's chunk
+    // offsets s share all but two bits and the double-and-add below executes an addition only where that shared bit is set
+    // (~19 instead of ~25 operations for a 15-bit s); many sets: chunk-minor as before
+    const bool set_minor = windows <= 32;
+    size_t win = set_minor ? gid % windows : gid / T;
+    uint32_t ch = (uint32_t)(set_minor ? gid / windows : gid % T), s = ch * L;
+    gid = win * T + ch;                                          // index of this lane's result
     G1Xyzz run = g1_inf();
     park_put(park, run);                                         // sum = O
 #pragma unroll 1
