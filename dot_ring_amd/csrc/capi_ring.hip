@@ -53,7 +53,7 @@ struct dr_ring_prover {
     int root_inf[3];
     // per-batch state
     size_t batch = 0;
-    Scratch idx, blind, zk, chain_ext, prefix, chain_aff, cnt, relation, rps, cols, wit4, alphas, agg, q, zetas, evals, ks, lin,
+    Scratch idx, blind, zk, chain_ext, prefix, chain_aff, cnt, relation, rps, cols, wit4, alphas, alpha_aux, agg, q, zetas, evals, ks, lin,
         nus, aggo, chunkv, quot1, quot2, diffs;
 };
 
@@ -209,7 +209,7 @@ void dr_ring_prover_destroy(dr_ring_prover* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (Scratch* s : {&p->ring_pts_mont, &p->fixed_coef, &p->fixed4, &p->lag4, &p->not_last, &p->idx, &p->blind, &p->zk, &p->chain_ext,
-                       &p->prefix, &p->chain_aff, &p->cnt, &p->relation, &p->rps, &p->cols, &p->wit4, &p->alphas, &p->agg, &p->q, &p->zetas,
+                       &p->prefix, &p->chain_aff, &p->cnt, &p->relation, &p->rps, &p->cols, &p->wit4, &p->alphas, &p->alpha_aux, &p->agg, &p->q, &p->zetas,
                        &p->evals, &p->ks, &p->lin, &p->nus, &p->aggo, &p->chunkv, &p->quot1, &p->quot2, &p->diffs})
         s->release();
     if (p->aux_ctx) {
@@ -329,12 +329,15 @@ int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alpha
     HIP_TRY(hipMemcpyAsync(p->alphas.p, alphas, batch * 7 * 32, hipMemcpyHostToDevice, st));
     // 7 alphas per proof are read by every point of the 4N domain: convert them to Montgomery form once
     hipLaunchKernelGGL(dr::k_fr_to_mont, dim3(div_up(batch * 7, 256)), dim3(256), 0, st, p->alphas.as<uint32_t>(), batch * 7);
+    TRY(p->alpha_aux.reserve(batch * 2 * 32));
+    hipLaunchKernelGGL(dr::k_ring_alpha_aux, dim3(div_up(batch, 64)), dim3(64), 0, st, p->alphas.as<uint32_t>(), p->rps.as<uint32_t>(), rc,
+                       (uint32_t)batch, p->alpha_aux.as<uint32_t>());
     // N coefficients per column -> evaluations on the 4N domain: the NTT reads the columns directly (zero padding implied) and
     // leaves the evaluations in Montgomery form
     TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch * 4, false, false, true, p->cols.as<uint32_t>(), 2));
     TRY(launch(ctx, "k_ring_constraints", [&] {
         LAUNCH_CV(p->curve, dr::k_ring_constraints, dim3(div_up(batch * m, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(), p->fixed4.as<uint32_t>(),
-                           p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas.as<uint32_t>(), p->rps.as<uint32_t>(), rc,
+                           p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas.as<uint32_t>(), p->alpha_aux.as<uint32_t>(), rc,
                            (uint32_t)batch, p->agg.as<uint32_t>());
     }));
     // the constraint kernel wrote Montgomery form; the coefficients land in the (now free) wit4 buffer: the first pass cannot

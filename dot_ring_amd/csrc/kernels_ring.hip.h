@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __rest
                                                           const uint32_t* __restrict__ lag4 /* [2][m][8] mont: L0, Llast */,
                                                           const uint32_t* __restrict__ not_last /* [m][8] mont */,
                                                           const uint32_t* __restrict__ alphas /* [B][7][8] Montgomery (converted once per batch) */,
-                                                          const uint32_t* __restrict__ rps_mont /* [B][16] */,
+                                                          const uint32_t* __restrict__ alpha_aux /* [B][2][8] Montgomery: k_ring_alpha_aux */,
                                                           RingConsts rc, uint32_t batch, uint32_t* __restrict__ agg /* [B][m][8] Montgomery */) {
     const uint32_t m = rc.n * 4;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -403,28 +403,41 @@ __global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __rest
     Fr one = Fr::one();
     Fr omb = sub(one, b);
     Fr x1y1 = mul(x1, y1), x2y2 = mul(x2, y2), x1x2 = mul(x1, x2), y1y2 = mul(y1, y2);
+    // 23 products per point (29 when every constraint was evaluated as written): the selector form b*u + (1-b)*v is
+    // v + b*(u - v), and the three boundary constraints share their Lagrange factors (below).
     // c1 = (accip' - accip - b*s) * nl          (the common factor nl of c1..c3 is applied once, after the alphas)
     Fr acc = mul(gload_fr(al + 0 * 8), sub(sub(ip_n, ip), mul(b, s)));
     // c2 = (b*(x3*(y1y2 + a x1x2) - (x1y1 + x2y2)) + (1-b)(x3 - x1)) * nl ,  a = the curve coefficient
     Fr t2 = sub(mul(x3, add(y1y2, te_mul_a_fr<CV>(x1x2))), add(x1y1, x2y2));
-    Fr c2 = add(mul(b, t2), mul(omb, sub(x3, x1)));
+    Fr v2 = sub(x3, x1);
+    Fr c2 = add(v2, mul(b, sub(t2, v2)));
     acc = add(acc, mul(gload_fr(al + 1 * 8), c2));
     // c3 = (b*(y3*(x1y2 - x2y1) - (x1y1 - x2y2)) + (1-b)(y3 - y1)) * nl
     Fr t3 = sub(mul(y3, sub(mul(x1, y2), mul(x2, y1))), sub(x1y1, x2y2));
-    Fr c3 = add(mul(b, t3), mul(omb, sub(y3, y1)));
+    Fr v3 = sub(y3, y1);
+    Fr c3 = add(v3, mul(b, sub(t3, v3)));
     acc = add(acc, mul(gload_fr(al + 2 * 8), c3));
     acc = mul(acc, nl);
     // c4 = b(1-b)
     acc = add(acc, mul(gload_fr(al + 3 * 8), mul(b, omb)));
-    // c5/c6 = (acc - seed)*L0 + (acc - (result+seed))*Llast ; c7 = accip*L0 + (accip-1)*Llast
-    Fr rx = gload_fr(rps_mont + (size_t)pid * 16), ry = gload_fr(rps_mont + (size_t)pid * 16 + 8);
-    Fr c5 = add(mul(sub(x1, from_arg(rc.seed_x)), l0), mul(sub(x1, rx), ln));
-    Fr c6 = add(mul(sub(y1, from_arg(rc.seed_y)), l0), mul(sub(y1, ry), ln));
-    Fr c7 = add(mul(ip, l0), mul(sub(ip, one), ln));
-    acc = add(acc, mul(gload_fr(al + 4 * 8), c5));
-    acc = add(acc, mul(gload_fr(al + 5 * 8), c6));
-    acc = add(acc, mul(gload_fr(al + 6 * 8), c7));
+    // c5/c6 = (acc - seed)*L0 + (acc - (result+seed))*Llast ; c7 = accip*L0 + (accip-1)*Llast.  With A = a5 seed_x + a6 seed_y and
+    // B = a5 r_x + a6 r_y + a7 per proof (k_ring_alpha_aux):  a5 c5 + a6 c6 + a7 c7 = (L0 + Llast)(a5 x1 + a6 y1 + a7 accip) - L0 A - Llast B
+    const uint32_t* ax = alpha_aux + (size_t)pid * 2 * 8;
+    Fr lin = add(add(mul(gload_fr(al + 4 * 8), x1), mul(gload_fr(al + 5 * 8), y1)), mul(gload_fr(al + 6 * 8), ip));
+    acc = add(acc, sub(sub(mul(add(l0, ln), lin), mul(l0, gload_fr(ax))), mul(ln, gload_fr(ax + 8))));
     gstore_fr(agg + gid * 8, acc);
+}
+
+// per proof: A = a5 seed_x + a6 seed_y, B = a5 r_x + a6 r_y + a7 (Montgomery; alphas already converted) for k_ring_constraints
+__global__ void k_ring_alpha_aux(const uint32_t* __restrict__ alphas /* [B][7][8] Montgomery */, const uint32_t* __restrict__ rps_mont /* [B][16] */,
+                                 RingConsts rc, uint32_t batch, uint32_t* __restrict__ out /* [B][2][8] */) {
+    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= batch) return;
+    const uint32_t* al = alphas + (size_t)pid * 7 * 8;
+    const Fr a5 = gload_fr(al + 4 * 8), a6 = gload_fr(al + 5 * 8), a7 = gload_fr(al + 6 * 8);
+    const Fr rx = gload_fr(rps_mont + (size_t)pid * 16), ry = gload_fr(rps_mont + (size_t)pid * 16 + 8);
+    gstore_fr(out + (size_t)pid * 16, add(mul(a5, from_arg(rc.seed_x)), mul(a6, from_arg(rc.seed_y))));
+    gstore_fr(out + (size_t)pid * 16 + 8, add(add(mul(a5, rx), mul(a6, ry)), a7));
 }
 
 // ---- K8: coefficient-space passes ---------------------------------------------------------------------------
