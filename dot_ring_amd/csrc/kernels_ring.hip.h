@@ -453,15 +453,18 @@ __global__ void k_ring_quotient(const uint32_t* __restrict__ agg_poly /* [B][4N]
     if (gid >= (size_t)batch * qn) return;
     uint32_t pid = (uint32_t)(gid / qn), j = (uint32_t)(gid % qn);
     const uint32_t* a = agg_poly + (size_t)pid * m * 8;
+    // regrouped: q_j = sum_d tail[d] * (sum_i a[j + i N - d]) — the four foldings first, then 4 products instead of up to 16
     Fr acc = Fr::zero();
-#pragma unroll 1
-    for (uint32_t i = 1; i <= 4; i++) {
-        uint32_t kidx = j + i * n;                       // index into c_agg (length m + 3)
-        if (kidx >= m + 3) break;
 #pragma unroll
-        for (uint32_t d = 0; d < 4; d++) {
-            if (kidx >= d && kidx - d < m) acc = add(acc, mul(from_arg(rc.tail[d]), gload_fr(a + (size_t)(kidx - d) * 8)));
+    for (uint32_t d = 0; d < 4; d++) {
+        Fr fold = Fr::zero();
+#pragma unroll 1
+        for (uint32_t i = 1; i <= 4; i++) {
+            const uint32_t kidx = j + i * n;             // index into c_agg (length m + 3)
+            if (kidx >= m + 3) break;
+            if (kidx >= d && kidx - d < m) fold = add(fold, gload_fr(a + (size_t)(kidx - d) * 8));
         }
+        acc = add(acc, mul(from_arg(rc.tail[d]), fold));
     }
     gstore_fr(q + gid * 8, acc);
 }
