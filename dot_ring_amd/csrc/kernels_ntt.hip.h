@@ -103,8 +103,10 @@ __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_local(const uint32_t* __restr
             int j = t & (half - 1);
             int base = (t >> (s - 1)) << s;
             Fr u = lds_get(tile, base + j), v = lds_get(tile, base + j + half);
-            Fr w = gload_fr(tw + ((size_t)j << (k - s)) * 8);
-            v = mul(w, v);
+            if (s > 1) {                        // stage 1: every twiddle is w^0 = 1 (wave-uniform: no product at all)
+                Fr w = gload_fr(tw + ((size_t)j << (k - s)) * 8);
+                v = mul(w, v);
+            }
             lds_put(tile, base + j, add(u, v));
             lds_put(tile, base + j + half, sub(u, v));
         }
