@@ -2,6 +2,7 @@
 // batch_verify run the whole protocol in the library: GPU phases through the entry points of the other parts, the hashing
 // between them on worker threads (hosthash.hpp, hostproto.hpp).
 #include "capi_internal.hpp"
+#include <atomic>
 #include "hostsmall.hpp"
 
 using namespace dri;
@@ -387,21 +388,23 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
     PhaseTrace tr_("verify_batch");
     // ---- 1. canonical scalars; gather encoded points
     std::vector<uint8_t> te_enc(B * 4 * 32), g1_enc(B * 7 * 48);
-    bool canonical = true;
-    for (size_t i = 0; i < B; i++) {
+    std::atomic<bool> canonical{true};
+    drh::parallel_for(B, [&](size_t i) {
         const uint8_t* pr = proofs + 784 * i;
         std::memcpy(te_enc.data() + 128 * i, pr, 128);
         uint64_t v[4];
-        for (int k = 0; k < 2; k++) { drh::load_le32(pr + 128 + 32 * k, v); if (drh::Mod256::geq(v, mn.m)) canonical = false; }      // dec_scalar
+        bool ok_i = true;
+        for (int k = 0; k < 2; k++) { drh::load_le32(pr + 128 + 32 * k, v); if (drh::Mod256::geq(v, mn.m)) ok_i = false; }      // dec_scalar
         const uint8_t* pl = pr + 192;
-        for (int k = 0; k < 7; k++) { drh::load_le32(pl + 192 + 32 * k, v); if (drh::Mod256::geq(v, mp.m)) canonical = false; }
-        drh::load_le32(pl + 464, v); if (drh::Mod256::geq(v, mp.m)) canonical = false;
+        for (int k = 0; k < 7; k++) { drh::load_le32(pl + 192 + 32 * k, v); if (drh::Mod256::geq(v, mp.m)) ok_i = false; }
+        drh::load_le32(pl + 464, v); if (drh::Mod256::geq(v, mp.m)) ok_i = false;
+        if (!ok_i) canonical.store(false, std::memory_order_relaxed);
         uint8_t* g = g1_enc.data() + 336 * i;
         std::memcpy(g, pl, 192);                   // C_b, C_accip, C_accx, C_accy
         std::memcpy(g + 192, pl + 416, 48);        // C_q
         std::memcpy(g + 240, pl + 496, 96);        // Phi_zeta, Phi_zeta_omega
-    }
-    if (!canonical) return DR_OK;
+    });
+    if (!canonical.load()) return DR_OK;
 
     // ---- 2. GPU: decode + validate the 4B Bandersnatch points, decompress the 7B G1 points; meanwhile a helper thread
     // hashes the inputs to the curve on a second stream (all three kernels are latency-bound: a few dozen waves)
