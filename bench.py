@@ -20,12 +20,17 @@ Secondary measurements in the same JSON line (rank 0, one GPU):
   other_ring_sizes   the metric's other ring sizes: 256 (N = 1024) and 3000 (N = 4096, known-tau SRS: BASELINE configs[4]'s shape)
   distinct_signers   the headline workload with 1024 different signing keys instead of one
   single_call_ms     latency of one RingVRF.prove / one RingVRF.verify (the reference's own benchmark shape, docs/BENCHMARK.md:63-73)
-With N ranks (one per GPU) every rank proves and verifies its own 1024 proofs — independent units, no collective — and the
-base-sharded MSM leg (`g1_msm_sharded`) runs one MSM over bases sharded across the ranks with an RCCL all-gather of the partial
-points (dot_ring_amd/parallel.py, dr_comm_*).  No PyTorch anywhere: the launcher only has to export RANK / LOCAL_RANK /
-WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
+With N ranks (one per GPU) every rank proves and verifies its own 1024 proofs — independent units, no collective.  N > 1 adds
+  config5            BASELINE configs[4] at its per-GPU shape: ring 3839 (the largest ring of domain 4096, known-tau SRS),
+                     1024 proofs per rank, prove + verify, parity subset against the oracle on rank 0
+  g1_msm_sharded     one MSM over bases sharded across the ranks with an RCCL all-gather of the partial points
+                     (dot_ring_amd/parallel.py, dr_comm_*), `rccl_ranks` = ncclCommCount
+No PyTorch anywhere: a launcher only has to export RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
 
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 through torch.distributed.run (one rank per GPU).
+Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 either through torch.distributed.run (one rank per GPU) or as
+this bare command: with no RANK in the environment the process starts the N rank processes itself (fresh children, before any
+GPU call of its own — the shape of the reference's tests/benchmark/bench_ring_proof.py:168-182), relays rank 0's JSON line and
+exits with the worst child's code.  A collective that fails or stalls still prints the line, and the exit code is non-zero.
 """
 from __future__ import annotations
 
@@ -49,7 +54,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 # VALU ceiling of the bucket walk: one XYZZ mixed addition = 8 products (461 instructions each) + 2 squarings (383) over
 # 14 x 28-bit limbs + ~330 add / sub / carry / unpack instructions = ~4780 wave-instructions per 64 additions; 1024 SIMDs
 # x 2.4 GHz at ~4.2 cycles per instruction (profiles/r02_ubench_valu.txt: v_mad_i64_i32 4.2-4.4, VOP2 2.6)
-MADD_INSTRUCTIONS = 8 * 461 + 2 * 383 + 330
+MADD_INSTRUCTIONS_LITERAL = 8 * 461 + 2 * 383 + 330
+
+
+def _madd_instructions():
+    """wave-instructions of one pass of k_g1_accumulate's inner loop, counted from the built code object by
+    tools/count_kernel_insts.py (run by __graft_entry__.build()); the literal above only when that file is missing"""
+    try:
+        with open(os.path.join(ROOT, "dot_ring_amd", "kernel_counts.json")) as f:
+            rec = json.load(f)["k_g1_accumulate"]
+        return int(rec["loop_instructions"]), rec["source"]
+    except Exception:
+        return MADD_INSTRUCTIONS_LITERAL, "literal in bench.py (dot_ring_amd/kernel_counts.json missing)"
+
+
+MADD_INSTRUCTIONS, MADD_SOURCE = _madd_instructions()
 VALU_PEAK_GADD_S = 1024 * 2.4e9 / 4.2 * 64 / MADD_INSTRUCTIONS / 1e9
 # the same bucket walk in isolation (tools/ubench_limbs.hip: 2048 chained additions per lane over the prover's 13 MB table,
 # profiles/r02_ubench_limbs_fused.txt): an empirical ceiling for the kernel's inner loop on this chip
@@ -346,13 +365,21 @@ def single_call_leg(w: "RingWorkload", reps: int = 10):
             "verified": bool(ok and not bad), "reps": reps}
 
 
-def ring_size_leg(d, ring_size: int, batch: int, steps: int, parity_proofs: int):
-    w = RingWorkload(d, ring_size, batch)
-    elapsed, all_ok = w.run(steps, 1)
-    ok, _, _ = w.parity(parity_proofs) if parity_proofs else (True, None, 0.0)
-    out = {"ring_size": ring_size, "domain_size": w.ring.params.domain_size, "batch": batch, "steps": steps,
-           "proofs_per_s": batch * steps / elapsed, "prove_only_proofs_per_s": batch * steps / w.prove_s,
-           "verify_only_proofs_per_s": batch * steps / w.verify_s, "parity_ok": bool(ok and all_ok), "parity_proofs": parity_proofs,
+def ring_size_leg(d, ring_size: int, batch: int, steps: int, parity_proofs: int, rank: int = 0, ctl=None, barrier=lambda: None):
+    """prove_batch + batch_verify at another ring size.  With a control communicator every rank runs its own `batch` proofs
+    between two barriers, the time is the max over ranks and proofs_per_s the whole job's; parity (rank 0) against the oracle."""
+    world = 1 if ctl is None else ctl.world
+    w = RingWorkload(d, ring_size, batch, first_index=rank * batch)
+    elapsed, all_ok = w.run(steps, 1, barrier)
+    if ctl is not None:
+        stats = [struct.unpack("<dB", b) for b in ctl.all_gather(struct.pack("<dB", elapsed, 1 if all_ok else 0))]
+        elapsed, all_ok = max(s_[0] for s_ in stats), all(s_[1] for s_ in stats)
+    ok, _, _ = w.parity(parity_proofs) if parity_proofs and rank == 0 else (True, None, 0.0)
+    out = {"ring_size": ring_size, "domain_size": w.ring.params.domain_size, "max_ring_size": w.ring.params.max_ring_size,
+           "batch": batch, "steps": steps, "ranks": world,
+           "proofs_per_s": batch * world * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
+           "prove_only_proofs_per_s": batch * steps / w.prove_s, "verify_only_proofs_per_s": batch * steps / w.verify_s,
+           "parity_ok": bool(ok and all_ok), "parity_proofs": parity_proofs if rank == 0 else 0,
            "ring_root_s": w.ring_root_s, "srs": "known-tau, 12289 points" if w.big else "shipped 2^11 file"}
     del w
     return out
@@ -389,8 +416,69 @@ def sharded_msm_leg(ctx, comm, log2_total: int, steps: int, scaling: str):
     d_scalars.free()
     srs.close()
     return {"sharding": "bases", "scaling": scaling, "pairs_total": n, "pairs_per_rank": cnt, "ranks": comm.world,
-            "collective": type(comm).__name__, "scalar_muls_per_s": n * steps / elapsed, "ms_per_msm": elapsed / steps * 1e3,
+            "rccl_ranks": comm.rccl_ranks() if hasattr(comm, "rccl_ranks") else None, "collective": type(comm).__name__, "scalar_muls_per_s": n * steps / elapsed, "ms_per_msm": elapsed / steps * 1e3,
             "parity_closed_form_all_ranks": all(s[1] for s in stats)}
+
+
+def launch_ranks(n: int, argv, script: str | None = None) -> int:
+    """`python bench.py --gpus N` as a bare command: start the N rank processes — fresh children of this process, which itself
+    never touches the GPU (nothing of dot_ring_amd is imported here) and never execs — with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, relay rank 0's stdout (the JSON line) and return the worst child's exit code."""
+    import socket
+    import subprocess
+
+    port = None
+    for _ in range(64):                                 # MASTER_PORT and MASTER_PORT + 1 (the control star) both free
+        with socket.socket() as a:
+            a.bind(("127.0.0.1", 0))
+            cand = a.getsockname()[1]
+            with socket.socket() as b:
+                try:
+                    b.bind(("127.0.0.1", cand + 1))
+                except OSError:
+                    continue
+        port = cand
+        break
+    if port is None:
+        print("bench.py: no free port pair for the rank processes", file=sys.stderr)
+        return 2
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    import threading
+
+    def relay():                                        # rank 0 prints the one JSON line; anything else it says passes through too
+        for text in procs[0].stdout:
+            sys.stdout.write(text)
+            sys.stdout.flush()
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    deadline = None
+    try:
+        while any(p.poll() is None for p in procs):
+            if deadline is None and any(p.poll() not in (None, 0) for p in procs):
+                deadline = time.monotonic() + 60.0      # a rank failed: the others get a minute to notice, then are stopped
+            if deadline is not None and time.monotonic() > deadline:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+        th.join(timeout=10)
+    codes = [p.returncode for p in procs]
+    worst = max((c if c >= 0 else 128 - c) for c in codes)
+    if worst:
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+    return worst
 
 
 def main() -> int:
@@ -406,19 +494,21 @@ def main() -> int:
     ap.add_argument("--extras", type=int, default=1, help="0 = skip the secondary legs (bsn_scalar_mul, other ring sizes, distinct signers)")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            return 2
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: taking the launcher's {world} ranks", file=sys.stderr)
         args.gpus = world
 
     # rehearsal on a box with fewer GPUs than ranks (never used by the driver): DOTRING_BENCH_SHARE_GPU=1 puts every rank on
-    # device 0 and swaps the RCCL all-gather for the TCP one (RCCL refuses two ranks on one GPU)
-    share = os.environ.get("DOTRING_BENCH_SHARE_GPU") == "1"
-    if share:
+    # device 0 and swaps the RCCL all-gather for the TCP one (RCCL refuses two ranks on one GPU); =rccl shares the device but
+    # keeps the RCCL communicator (the test of the failure path)
+    share_mode = os.environ.get("DOTRING_BENCH_SHARE_GPU", "")
+    share = share_mode == "1"
+    if share_mode in ("1", "rccl"):
         local_rank = 0
     os.environ["DOTRING_DEVICE"] = str(local_rank)
     if world > 1 and "DOTRING_HOST_THREADS" not in os.environ:
@@ -539,8 +629,8 @@ def main() -> int:
                             "parity_ok": bool(ok_d and ok_p), "parity_proofs": 2}
                 parity_ok = parity_ok and distinct["parity_ok"]
                 others = {}
-                for rs in (256, 3000):
-                    leg = ring_size_leg(d, rs, batch, 3, 2)
+                for rs, st in ((256, 3), (3839, 5)):     # 3839 = the largest ring of domain 4096: BASELINE configs[4]'s per-GPU shape
+                    leg = ring_size_leg(d, rs, batch, st, 2)
                     others[str(rs)] = leg
                     parity_ok = parity_ok and leg["parity_ok"]
         line = {
@@ -571,7 +661,7 @@ def main() -> int:
                          # cost per instruction is measured, profiles/r02_ubench_valu.txt, the instruction count is the generated code's)
                          "valu": {"achieved_gadd_s": dense_adds / (acc_ms / 1e3) / 1e9 if acc_ms else None, "peak_gadd_s": VALU_PEAK_GADD_S,
                                   "frac": dense_adds / (acc_ms / 1e3) / 1e9 / VALU_PEAK_GADD_S if acc_ms else None,
-                                  "instructions_per_addition": MADD_INSTRUCTIONS,
+                                  "instructions_per_addition": MADD_INSTRUCTIONS, "instructions_source": MADD_SOURCE,
                                   "isolated_chain_gadd_s": MEASURED_CHAIN_GADD_S,
                                   "frac_of_isolated_chain": dense_adds / (acc_ms / 1e3) / 1e9 / MEASURED_CHAIN_GADD_S if acc_ms else None,
                                   "note": "dense bucket additions only (7N pairs x windows per proof); by-parts and verify-side additions not counted"},
@@ -598,20 +688,35 @@ def main() -> int:
             print("bench.py: PARITY FAILURE — GPU result differs from the oracle", file=sys.stderr)
             rc = 1
 
-    # ---- N > 1: the base-sharded MSM (BASELINE configs[4]'s MSM leg), the one place with an exchange step: ncclAllGather of one
-    # point per rank through dr_comm_* (TCP star when the ranks share a GPU).  Guarded: a collective library that fails or
-    # stalls on this node is reported in the line instead of taking the measured headline with it.
+    # ---- N > 1: BASELINE configs[4].  (a) its per-GPU shape — ring 3839 (domain 4096, known-tau SRS), `batch` proofs per rank,
+    # prove + verify, proofs sharded per rank with no collective, parity subset on rank 0; (b) the base-sharded MSM, the one
+    # place with an exchange step: ncclAllGather of one point per rank through dr_comm_* (TCP star when the ranks share a GPU).
+    # The collective part is guarded: a collective library that fails or stalls on this node is reported in the line instead
+    # of taking the measured headline with it — and the process then exits NON-ZERO (3 = error, 4 = stalled).
     hung = False
+    if ctl is not None and args.extras:
+        leg5 = ring_size_leg(d, 3839, batch, max(1, min(args.steps, 5)), 2 if args.cpu_proofs > 0 else 0, rank, ctl, barrier)
+        if line is not None:
+            leg5["config"] = (f"BASELINE configs[4]: RingVRF[Bandersnatch] prove_batch + batch_verify, ring 3839 (domain 4096), {batch} proofs per "
+                              f"rank = {batch * world} proofs per step on {world} GPUs; its sharded MSM: g1_msm_sharded")
+            line["config5"] = leg5
+            if not leg5["parity_ok"]:
+                print("bench.py: PARITY FAILURE — config5 leg", file=sys.stderr)
+                rc = 1
     if ctl is not None and args.msm_log2n > 0:
-        box = {}
+        box = {"stage": "start"}
 
         def sharded_legs():
+            box["stage"] = "ncclGetUniqueId / ncclCommInitRank"
             comm = ctl if share else parallel.RcclComm(ctx, rank, world, bootstrap=ctl)
             # strong: 2^msm_log2n pairs in total; weak: 2^msm_log2n pairs per rank (rounded up to a power of two of ranks)
+            box["stage"] = "ncclAllGather (strong-scaling MSM)"
             legs = [sharded_msm_leg(ctx, comm, args.msm_log2n, 10, "strong")]
             extra = max(0, (world - 1).bit_length())
             if extra:
+                box["stage"] = "ncclAllGather (weak-scaling MSM)"
                 legs.append(sharded_msm_leg(ctx, comm, args.msm_log2n + extra, 5, "weak"))
+            box["stage"] = "ncclCommDestroy"
             if comm is not ctl:
                 comm.close()
             box["legs"] = legs
@@ -627,18 +732,41 @@ def main() -> int:
         th.start()
         th.join(timeout=float(os.environ.get("DOTRING_BENCH_SHARDED_TIMEOUT", "300")))
         hung = th.is_alive()
-        sharded = box.get("legs") or {"error": box.get("error", "timed out"), "collective": "SocketComm" if share else "RcclComm"}
+        state = "timeout" if hung else ("error" if "error" in box else "ok")
+        if state != "ok":
+            rc = max(rc, 4 if hung else 3)
+            print(f"bench.py: rank {rank}: sharded MSM leg {state} in {box['stage']}: {box.get('error', 'no answer within the timeout')}", file=sys.stderr)
+        # every rank reaches this point (the guard has a timeout), so the outcome per rank travels over the control star; a
+        # rank whose peers failed in a SocketComm rehearsal would otherwise be the only witness
+        mine = json.dumps({"rank": rank, "state": state, "stage": box["stage"], "error": box.get("error")}).encode()[:480].ljust(480)
+        try:
+            reports = [json.loads(b.decode().strip()) for b in ctl.all_gather(mine)]
+        except Exception as exc:              # noqa: BLE001 — a peer that is gone: still print, still fail
+            reports = [{"rank": rank, "state": state, "stage": box["stage"], "error": box.get("error")},
+                       {"rank": None, "state": "error", "stage": "status exchange", "error": f"{type(exc).__name__}: {exc}"}]
+        failed = [r_ for r_ in reports if r_["state"] != "ok"]
+        if failed:
+            rc = max(rc, 3)
         if line is not None:
-            line["g1_msm_sharded"] = sharded
-            if isinstance(sharded, list) and not all(leg["parity_closed_form_all_ranks"] for leg in sharded):
-                print("bench.py: PARITY FAILURE — sharded MSM differs from the closed form", file=sys.stderr)
-                rc = 1
+            if failed:
+                line["g1_msm_sharded"] = {"error": "; ".join(f"rank {r_['rank']}: {r_['state']} in {r_['stage']}" + (f" ({r_['error']})" if r_["error"] else "")
+                                                             for r_ in failed),
+                                          "failed_ranks": [r_["rank"] for r_ in failed], "collective": "SocketComm" if share else "RcclComm",
+                                          "legs": box.get("legs")}
+            else:
+                line["g1_msm_sharded"] = box["legs"]
+                if not all(leg["parity_closed_form_all_ranks"] for leg in box["legs"]):
+                    print("bench.py: PARITY FAILURE — sharded MSM differs from the closed form", file=sys.stderr)
+                    rc = max(rc, 1)
     if line is not None:
         print(json.dumps(line), flush=True)
     if hung:
-        os._exit(rc)                           # a stalled collective holds its thread: leave without joining it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(rc)                           # a stalled collective holds its thread: leave without joining it — NON-ZERO
     if ctl is not None:
-        ctl.barrier()
+        if rc == 0:
+            ctl.barrier()
         ctl.close()
     return rc
 

@@ -125,6 +125,7 @@ _PROTOTYPES.update({
     "dr_comm_destroy": (None, [c_void_p]),
     "dr_comm_rank": (c_int, [c_void_p]),
     "dr_comm_world": (c_int, [c_void_p]),
+    "dr_comm_count": (c_int, [c_void_p, POINTER(c_int)]),
     "dr_comm_all_gather": (c_int, [c_void_p, c_char_p, c_size_t, c_char_p]),
     "dr_g1_msm_sharded_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, POINTER(c_int)]),
 })
@@ -224,6 +225,10 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = args
         _lib = cdll
     return _lib
+
+
+def last_error() -> str:
+    return (lib().dr_last_error() or b"").decode("utf-8", "replace")
 
 
 def _check(rc: int) -> None:

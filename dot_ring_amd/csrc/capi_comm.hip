@@ -21,6 +21,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) comm_init_rank = nullptr;
     decltype(&ncclAllGather) all_gather = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
     std::string error;
 };
@@ -29,9 +30,11 @@ Rccl& rccl() {
     static Rccl r = [] {
         Rccl x;
         const char* env = std::getenv("DOTRING_RCCL_LIB");
+        const bool forced = env && *env;                 // DOTRING_RCCL_LIB names THE library: no silent fallback to another one
         const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
             if (!n || !*n) continue;
+            if (forced && n != env) break;
             x.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (x.handle) break;
         }
@@ -49,6 +52,7 @@ Rccl& rccl() {
         x.comm_init_rank = reinterpret_cast<decltype(x.comm_init_rank)>(sym("ncclCommInitRank"));
         x.all_gather = reinterpret_cast<decltype(x.all_gather)>(sym("ncclAllGather"));
         x.comm_destroy = reinterpret_cast<decltype(x.comm_destroy)>(sym("ncclCommDestroy"));
+        x.comm_count = reinterpret_cast<decltype(x.comm_count)>(sym("ncclCommCount"));
         x.error_string = reinterpret_cast<decltype(x.error_string)>(sym("ncclGetErrorString"));
         return x;
     }();
@@ -122,6 +126,16 @@ void dr_comm_destroy(dr_comm* c) {
 int dr_comm_rank(const dr_comm* c) { return c ? c->rank : -1; }
 int dr_comm_world(const dr_comm* c) { return c ? c->world : 0; }
 
+// the number of ranks RCCL itself holds in this communicator (ncclCommCount): what a report should quote, not the caller's idea of it
+int dr_comm_count(const dr_comm* c, int* out_ranks) {
+    if (!c || !c->comm || !out_ranks) return fail(DR_ERR_INVALID, "null argument");
+    TRY(rccl_ready());
+    int n = 0;
+    NCCL_TRY(rccl().comm_count(c->comm, &n));
+    *out_ranks = n;
+    return DR_OK;
+}
+
 // all-gather of `bytes` bytes per rank between host buffers: staged through HBM, ncclAllGather on the context's stream
 int dr_comm_all_gather(dr_comm* c, const void* send, size_t bytes, void* recv /* world * bytes */) {
     if (!c || !c->ctx) return fail(DR_ERR_INVALID, "null communicator");
@@ -141,18 +155,29 @@ int dr_comm_all_gather(dr_comm* c, const void* send, size_t bytes, void* recv /*
 
 // One MSM whose bases are sharded over the ranks of `c`: this rank holds `n_local` of them (srs, from `offset`) with
 // their scalars; the result — identical on every rank — is the sum of all ranks' partial MSMs.
+// Every rank ALWAYS enters the all-gather: a rank whose local part fails (bad arguments, out of memory, a kernel error)
+// sends status 2 in byte 96 of its record instead of leaving the others blocked in the collective, and then every rank
+// returns an error — the failing one its own, the others DR_ERR_DEVICE naming the rank.
 int dr_g1_msm_sharded_dev(dr_ctx* ctx, dr_comm* c, const dr_srs* srs, size_t offset, const void* d_scalars, size_t n_local,
                           uint8_t out_be_xy[96], int* is_inf) {
-    if (!c || c->ctx != ctx) return fail(DR_ERR_INVALID, "communicator belongs to another context");
-    if (!out_be_xy) return fail(DR_ERR_INVALID, "null argument");
+    if (!c || c->ctx != ctx) return fail(DR_ERR_INVALID, "communicator belongs to another context");   // no communicator to enter
     uint8_t mine[97] = {0};
     int inf = 1;
-    if (n_local) TRY(dr_g1_msm_dev(ctx, srs, offset, d_scalars, n_local, mine, &inf));
-    mine[96] = inf ? 1 : 0;
+    int local_rc = out_be_xy ? DR_OK : fail(DR_ERR_INVALID, "null argument");
+    std::string local_msg = local_rc == DR_OK ? std::string() : std::string(dr_last_error());
+    if (local_rc == DR_OK && n_local) {
+        local_rc = dr_g1_msm_dev(ctx, srs, offset, d_scalars, n_local, mine, &inf);
+        if (local_rc != DR_OK) local_msg = dr_last_error();
+    }
+    mine[96] = local_rc != DR_OK ? 2 : (inf ? 1 : 0);
     std::vector<uint8_t> all((size_t)c->world * 97);
     TRY(dr_comm_all_gather(c, mine, 97, all.data()));
+    if (local_rc != DR_OK) return fail(local_rc, "local shard of the sharded MSM failed: " + local_msg);
     std::vector<uint8_t> pts;
-    for (int r = 0; r < c->world; r++)
-        if (!all[(size_t)r * 97 + 96]) pts.insert(pts.end(), all.begin() + (size_t)r * 97, all.begin() + (size_t)r * 97 + 96);
+    for (int r = 0; r < c->world; r++) {
+        uint8_t st = all[(size_t)r * 97 + 96];
+        if (st > 1) return fail(DR_ERR_DEVICE, "sharded MSM: the local shard of rank " + std::to_string(r) + " failed");
+        if (!st) pts.insert(pts.end(), all.begin() + (size_t)r * 97, all.begin() + (size_t)r * 97 + 96);
+    }
     return dr_g1_sum(pts.data(), pts.size() / 96, out_be_xy, is_inf);
 }

@@ -140,19 +140,42 @@ class RcclComm:
 
     def __init__(self, ctx: "_native.Context", rank: int, world: int, bootstrap: SocketComm | None = None):
         self.ctx, self.rank, self.world = ctx, rank, world
+        self.handle = None
         own_boot = bootstrap is None
         boot = bootstrap or SocketComm(rank, world)
         try:
+            # rank 0 ALWAYS broadcasts: one status byte (0 = id follows, 1 = ncclGetUniqueId failed) + the 128-byte id, so a
+            # failure on rank 0 reaches the peers as an exception instead of leaving them in recv
             uid = ctypes.create_string_buffer(_native.COMM_ID_BYTES)
+            status, err = 0, ""
             if rank == 0:
-                _native._check(_native.lib().dr_comm_unique_id(uid))
-            uid_bytes = boot.broadcast(uid.raw if rank == 0 else None, _native.COMM_ID_BYTES)
+                if _native.lib().dr_comm_unique_id(uid) != 0:
+                    status, err = 1, _native.last_error()
+            msg = boot.broadcast(bytes([status]) + uid.raw if rank == 0 else None, 1 + _native.COMM_ID_BYTES)
+            if msg[0]:
+                raise _native.DotRingHipError("rank 0 could not create the RCCL unique id" + (f": {err}" if err else ""))
+            uid_bytes = msg[1:]
+            handle = ctypes.c_void_p()
+            rc = _native.lib().dr_comm_create(ctx.handle, uid_bytes, rank, world, ctypes.byref(handle))
+            err = _native.last_error() if rc else ""
+            # every rank learns whether ncclCommInitRank succeeded everywhere before anyone enters a collective on it
+            oks = boot.all_gather(bytes([1 if rc == 0 else 0]))
         finally:
             if own_boot:
                 boot.close()
-        handle = ctypes.c_void_p()
-        _native._check(_native.lib().dr_comm_create(ctx.handle, uid_bytes, rank, world, ctypes.byref(handle)))
+        if rc != 0:
+            raise _native.DotRingHipError(f"ncclCommInitRank failed on rank {rank}: {err}")
         self.handle = handle
+        bad = [r for r, b in enumerate(oks) if not b[0]]
+        if bad:
+            self.close()
+            raise _native.DotRingHipError(f"ncclCommInitRank failed on rank(s) {bad}")
+
+    def rccl_ranks(self) -> int:
+        """ranks RCCL itself counts in the communicator (ncclCommCount)"""
+        n = ctypes.c_int(0)
+        _native._check(_native.lib().dr_comm_count(self.handle, ctypes.byref(n)))
+        return n.value
 
     def all_gather(self, mine: bytes) -> list[bytes]:
         n = len(mine)

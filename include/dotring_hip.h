@@ -188,10 +188,13 @@ DR_API int dr_comm_create(dr_ctx *ctx, const uint8_t id[DR_COMM_ID_BYTES], int r
 DR_API void dr_comm_destroy(dr_comm *comm);
 DR_API int dr_comm_rank(const dr_comm *comm);
 DR_API int dr_comm_world(const dr_comm *comm);
+/* ranks RCCL itself counts in the communicator (ncclCommCount) */
+DR_API int dr_comm_count(const dr_comm *comm, int *out_ranks);
 /* host-to-host all-gather of `bytes` bytes per rank (staged through HBM, ncclAllGather on the context's stream) */
 DR_API int dr_comm_all_gather(dr_comm *comm, const void *send, size_t bytes, void *recv /* world*bytes */);
 /* this rank's n_local pairs (srs[offset..], device-resident scalars) of one MSM sharded over the communicator;
- * the result is the whole MSM, identical on every rank */
+ * the result is the whole MSM, identical on every rank.  A rank whose local part fails still enters the all-gather
+ * (status byte in its 97-byte record), so the others return DR_ERR_DEVICE naming it instead of blocking in the collective */
 DR_API int dr_g1_msm_sharded_dev(dr_ctx *ctx, dr_comm *comm, const dr_srs *srs, size_t offset, const void *d_scalars, size_t n_local,
                                  uint8_t out_be_xy[96], int *is_inf);
 

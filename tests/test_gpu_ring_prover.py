@@ -166,6 +166,63 @@ def test_domain_4096_with_known_tau_srs_matches_oracle(ctx):
         vrf.prove_batch([b"x"], [b""], [sk], [pk], plain_ring, plain_root)
 
 
+def test_config5_per_gpu_shape_ring_3839_with_1024_proofs(ctx):
+    """BASELINE configs[4] at its per-GPU shape: "ring_size 4096" = domain 4096, whose largest ring is 4096 - 257 = 3839 keys
+    (params.py:172-173, 273-277; test_audit_regressions.py:112-114), 1024 proofs per GPU.  Known-tau SRS (the shipped file is too
+    short).  Two deterministic proofs byte for byte against the oracle (signer in the LAST row of the ring), then 1024
+    proofs with random hidden rows through the size-independent properties of the N = 2048 full-size test."""
+    import dot_ring_amd as d
+    from dot_ring_amd.ring_proof.pcs import SRS
+    from oracle.pyref import kzg as okzg
+
+    tau = int.from_bytes(hashlib.sha256(b"config5-tau").digest(), "little") % coracle.FR_P
+    srs = SRS.synthetic(tau, 3 * 4096 + 1)
+    o_srs = okzg.SRS.from_tau(tau, 3 * 4096 + 1)
+    o_srs.g2_raw = list(srs.g2_raw)
+    pcs = d.KZG.with_srs(srs)
+    keys = _keys(3839, b"c5")
+    sk = (987654321).to_bytes(32, "little")
+    pk = d.Bandersnatch.public_key_from_secret(sk)
+    keys[3838] = pk
+    with pytest.raises(ValueError):
+        d.Ring(keys + [keys[0]], d.RingProofParams(domain_size=4096, max_ring_size=3839, pcs=pcs))   # 3840 keys do not fit domain 4096
+    tv = d.RingProofParams.from_ring_size(3839, test_vectors=True, pcs=pcs)
+    assert (tv.domain_size, tv.max_ring_size) == (4096, 3839)
+    tv_ring = d.Ring(keys, tv)
+    tv_root = d.RingRoot.from_ring(tv_ring, tv)
+    o_ring = oring.Ring(keys, oring.Params.from_ring_size(3839, test_vectors=True, srs=o_srs))
+    o_root = oring.RingRoot(o_ring)
+    assert tv_root.encode() == o_root.encode()
+    vrf = d.RingVRF[d.Bandersnatch]
+    two = vrf.prove_batch([b"c5-a", b"c5-b"], [b"", b"ad"], [sk, sk], [pk, pk], tv_ring, tv_root)
+    assert two[0].encode() == oring.ring_vrf_prove(o_ring, o_root, b"c5-a", b"", sk)
+    assert two[1].encode() == oring.ring_vrf_prove(o_ring, o_root, b"c5-b", b"ad", sk)
+    # production mode, 1024 proofs
+    params = d.RingProofParams.from_ring_size(3839, pcs=pcs)
+    ring = d.Ring(keys, params)
+    root = d.RingRoot.from_ring(ring, params)
+    assert root.encode() == tv_root.encode()
+    n = 1024
+    als = [b"c5-in-%d" % (i % 300) for i in range(n)]
+    ads = [b"c5-ad-%d" % (i % 5) for i in range(n)]
+    a = vrf.prove_batch(als, ads, [sk] * n, [pk] * n, ring, root)
+    b = vrf.prove_batch(als, ads, [sk] * n, [pk] * n, ring, root)
+    ea, eb = [p.encode() for p in a], [p.encode() for p in b]
+    assert all(len(e) == 784 for e in ea)
+    assert [e[:192] for e in ea] == [e[:192] for e in eb]            # Pedersen part is deterministic
+    assert len({e[192:] for e in ea + eb}) == 2 * n                  # ring part is blinded by fresh randomness
+    assert vrf.batch_verify(a, als, ads, ring, root)
+    assert vrf.batch_verify(two, [b"c5-a", b"c5-b"], [b"", b"ad"], ring, root)   # deterministic and random rows share the root
+    assert a[1023].verify(als[1023], ads[1023], ring, root)
+    assert vrf.batch_verify(a[:300] + b[300:], als, ads, ring, root)
+    bad = list(a)
+    raw = bytearray(ea[640])
+    raw[500] ^= 0x10
+    bad[640] = vrf.decode(bytes(raw))
+    assert not vrf.batch_verify(bad, als, ads, ring, root)
+    assert not vrf.batch_verify(a, als, ads[1:] + ads[:1], ring, root)
+
+
 @pytest.mark.parametrize("suite", ["sha512", "shake128"])
 def test_device_elligator_matches_oracle(ctx, suite):
     import dot_ring_amd as d
