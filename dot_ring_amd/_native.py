@@ -120,6 +120,7 @@ _PROTOTYPES.update({
 _PROTOTYPES.update({
     "dr_te_fixed_base_msm_groups": (c_int, [c_void_p, c_int, c_char_p, c_size_t, c_char_p, c_size_t, c_void_p]),
     "dr_host_random_expand": (c_int, [c_char_p, c_void_p, c_size_t]),
+    "dr_ringvrf_aux_take_blindings": (c_int, [c_void_p, c_size_t, c_void_p]),
     "dr_comm_unique_id": (c_int, [c_char_p]),
     "dr_comm_create": (c_int, [c_void_p, c_char_p, c_int, c_int, POINTER(c_void_p)]),
     "dr_comm_destroy": (None, [c_void_p]),
@@ -150,6 +151,21 @@ def _thread_buffer(name: str, nbytes: int):
 def wipe(buf) -> None:
     """Zero a reused ctypes buffer that held secret material (the auxiliary records carry the blinding factors)."""
     ctypes.memset(buf, 0, len(buf))
+
+
+def wipe_thread_buffer(name: str) -> None:
+    """Zero the calling thread's reused buffer `name` if it exists (a native call that raised may have left secrets in it)."""
+    have = getattr(_buffers, name, None)
+    if have is not None:
+        wipe(have)
+
+
+def aux_take_blindings(aux_buf, batch: int):
+    """The blinding factors of a dr_ringvrf_prove_batch call, moved out of its auxiliary records (zeroed there): returns the
+    scratch buffer holding batch * 32 bytes; the caller slices each proof's own 32 bytes out and wipes it."""
+    out = _thread_buffer("prove_blind", 32 * batch)
+    _check(lib().dr_ringvrf_aux_take_blindings(aux_buf, batch, out))
+    return out
 
 
 def _ragged(items):

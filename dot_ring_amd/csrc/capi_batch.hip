@@ -408,7 +408,7 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
 
     // ---- 2. GPU: decode + validate the 4B Bandersnatch points, decompress the 7B G1 points; meanwhile a helper thread
     // hashes the inputs to the curve on a second stream (all three kernels are latency-bound: a few dozen waves)
-    if (!ctx->aux) TRY(dr_ctx_create(ctx->device, &ctx->aux));
+    if (!ctx->aux) TRY(ctx_create_role(ctx->device, 1, &ctx->aux));
     dr_ctx* actx = ctx->aux;
     actx->prof = ctx->prof;
     // One helper thread for the whole Pedersen side (second stream): hash the inputs to the curve right away, then wait at a
@@ -496,6 +496,10 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         TRY(ctx->io_a.reserve(n_te * 32));
         TRY(ctx->io_b.reserve(n_te * 64));
         TRY(ctx->io_c.reserve(n_te * 4 + n_g1 * 4));
+        // partitioned chip (DOTRING_SIDE_CUS): both decoders are latency chains and run one after the other on the side compute
+        // units, where another context's bucket walk cannot hold them up; `st` below is then the side stream
+        SideSection side_(ctx);
+        hipStream_t st = ctx->stream;
         HIP_TRY(hipMemcpyAsync(ctx->io_a.p, te_enc.data(), n_te * 32, hipMemcpyHostToDevice, st));
         uint32_t* d_ok = ctx->io_c.as<uint32_t>();
         TRY(launch(ctx, "k_bsn_decode_points", [&] {
@@ -509,11 +513,12 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         TRY(g1_std.reserve(n_g1 * 96));
         // the G1 decompression (a 380-squaring chain on ~100 waves) runs next to the Bandersnatch decoding (~1 ms on 128 waves) on
         // the third stream; an event brings it back into this stream before anything reads the bases
-        if (!ctx->aux2) TRY(dr_ctx_create(ctx->device, &ctx->aux2));
-        hipStream_t st2 = ctx->aux2->stream;
+        if (!ctx->aux2) TRY(ctx_create_role(ctx->device, 2, &ctx->aux2));
+        dr_ctx* dctx = side_.active ? ctx : ctx->aux2;
+        hipStream_t st2 = dctx->stream;
         ctx->aux2->prof = ctx->prof;
         HIP_TRY(hipMemcpyAsync(g1_in.p, g1_enc.data(), 7 * B * 48, hipMemcpyHostToDevice, st2));
-        TRY(launch(ctx->aux2, "k_g1_decompress", [&] {
+        TRY(launch(dctx, "k_g1_decompress", [&] {
             g1_launch_decompress(st2, g1_in.as<uint8_t>(), g1_bases.as<uint32_t>(), d_ok + n_te, 7 * B);
         }));
         {
@@ -678,7 +683,7 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         TRY(ctx->scalars.reserve(n_g1 * 32));
         // the two MSMs are independent and each is a short latency chain (sort, accumulate, reduce, fold): the rhs runs on
         // a third stream from a helper thread while this thread does the lhs
-        if (!ctx->aux2) TRY(dr_ctx_create(ctx->device, &ctx->aux2));
+        if (!ctx->aux2) TRY(ctx_create_role(ctx->device, 2, &ctx->aux2));
         dr_ctx* bctx = ctx->aux2;
         bctx->prof = ctx->prof;
         int rhs_rc = DR_OK;

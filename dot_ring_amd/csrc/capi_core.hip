@@ -94,7 +94,35 @@ int bsn_consts_init(hipStream_t st) {
 }
 }  // namespace
 
-int dr_ctx_create(int device_id, dr_ctx** out) {
+namespace {
+// DOTRING_SIDE_CUS=k (0 = off): compute units taken from the chip-filling kernels and given to the latency-bound ones.
+// Mask bits are interleaved over the XCDs by the driver (bit i -> XCD i mod 8), so the top k bits are k/8 units per XCD.
+int side_cus() {
+    static const int k = [] {
+        const char* e = std::getenv("DOTRING_SIDE_CUS");
+        int v = e ? std::atoi(e) : 0;
+        return v < 0 ? 0 : v;
+    }();
+    return k;
+}
+// role 0 / 2: all but the top k units; role 1: the top k units
+hipError_t create_masked_stream(hipStream_t* st, int device, bool side) {
+    const int k = side_cus();
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return e;
+    const int total = prop.multiProcessorCount;
+    if (k <= 0 || k >= total) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
+    for (int i = 0; i < total; i++)
+        if ((i >= total - k) == side) mask[(size_t)i / 32] |= 1u << (i % 32);
+    return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
+}
+}  // namespace
+
+int dr_ctx_create(int device_id, dr_ctx** out) { return ctx_create_role(device_id, 0, out); }
+
+int dri::ctx_create_role(int device_id, int role, dr_ctx** out) {
     if (!out) return fail(DR_ERR_INVALID, "null out pointer");
     *out = nullptr;
     int n = dr_device_count();
@@ -104,8 +132,17 @@ int dr_ctx_create(int device_id, dr_ctx** out) {
     dr_ctx* ctx = new (std::nothrow) dr_ctx();
     if (!ctx) return fail(DR_ERR_NOMEM, "out of host memory");
     ctx->device = device_id;
-    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    hipError_t e = create_masked_stream(&ctx->stream, device_id, role == 1);
+    if (e == hipSuccess && role == 0 && side_cus() > 0) {
+        e = create_masked_stream(&ctx->side, device_id, true);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_in, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_out, hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
+        if (ctx->side_in) (void)hipEventDestroy(ctx->side_in);
+        if (ctx->side_out) (void)hipEventDestroy(ctx->side_out);
+        if (ctx->side) (void)hipStreamDestroy(ctx->side);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return fail(DR_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
@@ -124,6 +161,9 @@ int dr_ctx_create(int device_id, dr_ctx** out) {
     if (const char* gl = std::getenv("DOTRING_BSN_GLV")) g_bsn_glv = std::atoi(gl) != 0;
     int rc = bsn_consts_init(ctx->stream);
     if (rc != DR_OK) {
+        if (ctx->side_in) (void)hipEventDestroy(ctx->side_in);
+        if (ctx->side_out) (void)hipEventDestroy(ctx->side_out);
+        if (ctx->side) (void)hipStreamDestroy(ctx->side);
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return rc;
@@ -156,6 +196,12 @@ void dr_ctx_destroy(dr_ctx* ctx) {
     }
     for (auto& e : ctx->twiddles.entries) (void)hipFree(e.d_tw);
     for (auto& fb : ctx->fixed_bases) (void)hipFree(fb.d_table);
+    if (ctx->side) {
+        (void)hipStreamSynchronize(ctx->side);
+        (void)hipStreamDestroy(ctx->side);
+        (void)hipEventDestroy(ctx->side_in);
+        (void)hipEventDestroy(ctx->side_out);
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -229,6 +275,21 @@ int te_scalar_mul_batch_dev(dr_ctx* ctx, int cv, const void* d_pts, const void* 
     // 4-bit windows (64 KiB of LDS per wave, 2 waves per CU) while the launch is latency-bound; 2-bit windows
     // (16 KiB, 10 waves per CU) once there are more waves than the 4-bit kernel can keep resident
     static const long w2_from = std::getenv("DOTRING_BSN_W2_FROM") ? std::atol(std::getenv("DOTRING_BSN_W2_FROM")) : 32768;
+    if (g_bsn_glv && drh::te_curve(cv) && drh::te_curve(cv)->glv && n < 16384) {
+        // latency-bound launch: GLV on lane pairs, the scalars reduced and decomposed by the lanes themselves (k_bsn_scalar_mul_glv<true>)
+        TRY(ctx->io_b.reserve(4));
+        HIP_TRY(hipMemsetAsync(ctx->io_b.p, 0, 4, ctx->stream));
+        TRY(launch(ctx, "k_bsn_scalar_mul", [&] {
+            hipLaunchKernelGGL(dr::k_bsn_scalar_mul_glv<true>, dim3(div_up(2 * n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
+                               (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t*)d_out, (uint32_t)n, ctx->io_b.as<uint32_t>());
+        }));
+        uint32_t bad = 0;
+        HIP_TRY(hipMemcpyAsync(&bad, ctx->io_b.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->prof) TRY(prof_collect(ctx));
+        if (bad) return fail(DR_ERR_DEVICE, "GLV decomposition out of range");
+        return DR_OK;
+    }
     TRY(launch(ctx, "k_bsn_scalar_mul", [&] {
         if (w2_from > 0 && n >= (size_t)w2_from)
             LAUNCH_CV(cv, dr::k_bsn_scalar_mul_w2, dim3(div_up(n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
@@ -292,10 +353,11 @@ int te_scalar_mul_batch(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_
         TRY(ctx->io_a.reserve(n * 64));
         TRY(ctx->io_b.reserve(n * 48));
         TRY(ctx->io_c.reserve(n * 64));
+        SideSection side_(ctx);
         HIP_TRY(hipMemcpyAsync(ctx->io_a.p, pts_xy, n * 64, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(ctx->io_b.p, split.data(), n * 48, hipMemcpyHostToDevice, ctx->stream));
         TRY(launch(ctx, "k_bsn_scalar_mul", [&] {
-            hipLaunchKernelGGL(dr::k_bsn_scalar_mul_glv, dim3(div_up(2 * n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
+            hipLaunchKernelGGL(dr::k_bsn_scalar_mul_glv<false>, dim3(div_up(2 * n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
                                ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>(), (uint32_t)n);
         }));
         HIP_TRY(hipMemcpyAsync(out_xy, ctx->io_c.p, n * 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -408,6 +470,7 @@ int te_fixed_base_groups(dr_ctx* ctx, int cv, const uint8_t* bases_xy, const uin
     const uint32_t per_block = 64 / (mpad * dr::TE_FIXED_LANES);
     TRY(ctx->io_b.reserve(groups * m * 32));
     TRY(ctx->io_c.reserve(groups * 64));
+    SideSection side_(groups * m < 65536 ? ctx : nullptr);
     HIP_TRY(hipMemcpyAsync(ctx->io_b.p, scalars, groups * m * 32, hipMemcpyHostToDevice, ctx->stream));
     TRY(launch(ctx, "k_bsn_fixed_base", [&] {
         LAUNCH_CV(cv, dr::k_te_fixed_base_groups, dim3(div_up(groups, per_block)), dim3(64), 0, ctx->stream, tabs, ctx->io_b.as<uint32_t>(),
@@ -512,6 +575,7 @@ int te_decode_points(dr_ctx* ctx, int cv, bool tai, const uint8_t* enc, size_t n
     TRY(ctx->io_a.reserve(n * 32));
     TRY(ctx->io_b.reserve(n * 64));
     TRY(ctx->io_c.reserve(n * 4));
+    SideSection side_(n <= 8192 ? ctx : nullptr);
     HIP_TRY(hipMemcpyAsync(ctx->io_a.p, enc, n * 32, hipMemcpyHostToDevice, ctx->stream));
     TRY(launch(ctx, "k_bsn_decode_points", [&] {
         launch_decode_points(ctx, ctx->stream, cv, tai, ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>(), n);
@@ -628,6 +692,16 @@ int dr_host_random_expand(const uint8_t seed[32], uint8_t* out, size_t len) {
     return DR_OK;
 }
 
+int dr_ringvrf_aux_take_blindings(uint8_t* aux, size_t batch, uint8_t* out_blind) {
+    if (batch && (!aux || !out_blind)) return fail(DR_ERR_INVALID, "null buffer");
+    for (size_t i = 0; i < batch; i++) {
+        uint8_t* b = aux + (size_t)DR_RINGVRF_AUX_BYTES * i + 256;
+        std::memcpy(out_blind + 32 * i, b, 32);
+        explicit_bzero(b, 32);
+    }
+    return DR_OK;
+}
+
 int load_suite(const dr_vrf_suite* s, drh::VrfSuite& out) {
     if (!s || !s->suite_id || s->suite_id_len == 0 || s->suite_id_len > 200) return fail(DR_ERR_INVALID, "bad VRF suite");
     out.suite_id.assign(s->suite_id, s->suite_id + s->suite_id_len);
@@ -735,6 +809,7 @@ int encode_and_mul(dr_ctx* ctx, const drh::VrfSuite& su, size_t B, const uint8_t
     TRY(ctx->io_a.reserve(B * 64));
     TRY(ctx->io_b.reserve(B * 48));
     TRY(ctx->io_c.reserve(2 * B * 64));
+    SideSection side_(ctx);                                // two latency chains of 16..32 waves: the side compute units
     uint32_t* d_in = ctx->io_c.as<uint32_t>();
     uint32_t* d_out = d_in + B * 16;
     HIP_TRY(hipMemcpyAsync(ctx->io_a.p, us.data(), B * 64, hipMemcpyHostToDevice, ctx->stream));
@@ -745,7 +820,7 @@ int encode_and_mul(dr_ctx* ctx, const drh::VrfSuite& su, size_t B, const uint8_t
     TRY(glv_split_scalars(xs, B, split));                  // on the host, while the Elligator kernel runs
     HIP_TRY(hipMemcpyAsync(ctx->io_b.p, split.data(), B * 48, hipMemcpyHostToDevice, ctx->stream));
     TRY(launch(ctx, "k_bsn_scalar_mul", [&] {
-        hipLaunchKernelGGL(dr::k_bsn_scalar_mul_glv, dim3(div_up(2 * B, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream, d_in,
+        hipLaunchKernelGGL(dr::k_bsn_scalar_mul_glv<false>, dim3(div_up(2 * B, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream, d_in,
                            ctx->io_b.as<uint32_t>(), d_out, (uint32_t)B);
     }));
     HIP_TRY(hipMemcpyAsync(inputs_xy, d_in, B * 64, hipMemcpyDeviceToHost, ctx->stream));

@@ -87,6 +87,11 @@ using dri::Scratch;
 struct dr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // DOTRING_SIDE_CUS=k: `stream` is confined to all but k compute units and `side` owns those k (hipExtStreamCreateWithCUMask):
+    // latency-bound kernels (a few dozen waves on a long dependent chain) go to `side` through SideSection, where another
+    // context's chip-filling bucket walk cannot starve them of workgroup slots.  nullptr = no partition (one plain stream).
+    hipStream_t side = nullptr;
+    hipEvent_t side_in = nullptr, side_out = nullptr;
     bool prof = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, ProfEntry> prof_data;
@@ -126,6 +131,31 @@ namespace dri {
 
 int use_ctx(dr_ctx* ctx);
 int prof_collect(dr_ctx* ctx);
+// dr_ctx_create with a role: 0 = a caller's context (wide stream + its own side stream when the chip is partitioned),
+// 1 = a helper context whose whole stream is latency-bound work (lives on the side compute units), 2 = a helper that runs
+// chip-filling kernels (wide stream only)
+int ctx_create_role(int device_id, int role, dr_ctx** out);
+
+// Everything enqueued on ctx->stream while a SideSection is alive goes to the context's side stream instead, ordered after
+// the work already enqueued on the main stream; on destruction the main stream waits for it.  A no-op without a partition.
+struct SideSection {
+    dr_ctx* ctx;
+    bool active;
+    explicit SideSection(dr_ctx* c) : ctx(c), active(c && c->side) {
+        if (!active) return;
+        (void)hipEventRecord(ctx->side_in, ctx->stream);
+        (void)hipStreamWaitEvent(ctx->side, ctx->side_in, 0);
+        std::swap(ctx->stream, ctx->side);
+    }
+    ~SideSection() {
+        if (!active) return;
+        std::swap(ctx->stream, ctx->side);
+        (void)hipEventRecord(ctx->side_out, ctx->side);
+        (void)hipStreamWaitEvent(ctx->stream, ctx->side_out, 0);
+    }
+    SideSection(const SideSection&) = delete;
+    SideSection& operator=(const SideSection&) = delete;
+};
 
 // kernel launch wrapper with optional hipEvent timing on the ctx stream
 template <class F>

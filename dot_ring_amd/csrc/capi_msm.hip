@@ -64,11 +64,32 @@ MsmPlan make_plan(size_t n, int force_c) {
 }
 }  // namespace
 
+namespace {
+// DOTRING_WIDE_TOKEN=1 (experiment): contexts of one process take turns with their chip-filling MSM pipelines — a
+// batched MSM holds the token from its sort to the end of its bucket reduction, so that another lane's wide kernels never queue
+// up behind this one's bucket walk (where they would wait for workgroup slots with their stream blocked).
+std::mutex g_wide_mutex;
+struct WideToken {
+    dr_ctx* ctx;
+    bool held;
+    WideToken(dr_ctx* c, bool want) : ctx(c), held(false) {
+        static const bool on = std::getenv("DOTRING_WIDE_TOKEN") && std::atoi(std::getenv("DOTRING_WIDE_TOKEN")) != 0;
+        if (on && want) { g_wide_mutex.lock(); held = true; }
+    }
+    ~WideToken() {
+        if (!held) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        g_wide_mutex.unlock();
+    }
+};
+}  // namespace
+
 int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch,
                std::vector<drh::G1>& results, const MsmTable* tbl) {
     results.assign(batch, drh::G1::inf());
     if (n == 0 || batch == 0) return DR_OK;
     if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "MSM size must be below 2^31");
+    WideToken token_(ctx, batch >= 64);
     const bool single = tbl != nullptr && tbl->table != nullptr;
     // comb table + many MSMs: a plain sum of looked-up points per MSM, nothing to sort or reduce
     if (single && tbl->comb && batch >= 32 && g_use_comb) {
@@ -193,14 +214,20 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
                 hipLaunchKernelGGL(dr::k_g1_sort_sets, dim3((unsigned)bsets), dim3(dr::SORT_BLOCK), 0, st, d_scalars, pl.wt, sp,
                                    ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
         }));
-    } else if (part_sort) {
+    }
+    // partition sort: every partition stream gets room for 4x its share of the set's entries (at least 64 k): 0.27 GB of streams
+    // at 2^20 pairs where room for ALL entries of the set in each of the 32 streams took 2.1 GB.  A distribution that overfills a
+    // stream (few distinct scalars) shows in the fill counters after pass A and takes the global-atomic path below instead.
+    bool sorted_done = lds_sort;
+    if (!sorted_done && part_sort) {
         dr::PartParams pp{};
         pp.n = (uint32_t)n; pp.H = pl.H; pp.groups = groups; pp.P = part_p; pp.pshift = part_shift;
         pp.tile = std::min<uint32_t>(2048, dr::PART_TILE_ENTRIES / (uint32_t)pl.W);
         pp.tiles_per_set = (uint32_t)((per_set_scalars + pp.tile - 1) / pp.tile);
-        pp.cap_part = (uint32_t)per_set_digits; pp.capacity = (uint32_t)per_set_digits;
+        pp.cap_part = (uint32_t)std::min<size_t>(per_set_digits, std::max<size_t>(4 * per_set_digits / part_p, 65536));
+        pp.capacity = (uint32_t)per_set_digits;
         pp.tbl_stride = tbl->stride; pp.tbl_offset = tbl->offset;
-        TRY(ctx->digits.reserve(bsets * (size_t)part_p * per_set_digits * 4));
+        TRY(ctx->digits.reserve(bsets * (size_t)part_p * pp.cap_part * 4));
         TRY(ctx->cursor.reserve(bsets * (size_t)part_p * 4));
         TRY(ctx->sorted.reserve(bsets * per_set_digits * 4));
         HIP_TRY(hipMemsetAsync(ctx->cursor.p, 0, bsets * (size_t)part_p * 4, st));
@@ -208,10 +235,20 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
             hipLaunchKernelGGL(dr::k_g1_part_scatter, dim3((unsigned)(bsets * pp.tiles_per_set)), dim3(dr::PART_BLOCK), 0, st, d_scalars, pl.wt, pp,
                                ctx->cursor.as<uint32_t>(), ctx->digits.as<uint32_t>());
         }));
-        TRY(launch(ctx, "k_g1_part_sort", [&] {
-            hipLaunchKernelGGL(dr::k_g1_part_sort, dim3((unsigned)(bsets * part_p)), dim3(dr::PART_BLOCK), 0, st, ctx->digits.as<uint32_t>(),
-                               ctx->cursor.as<uint32_t>(), pp, ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
-        }));
+        std::vector<uint32_t> fill(bsets * (size_t)part_p);
+        HIP_TRY(hipMemcpyAsync(fill.data(), ctx->cursor.p, fill.size() * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bool fits = true;
+        for (uint32_t f : fill) fits = fits && f <= pp.cap_part;
+        if (fits) {
+            TRY(launch(ctx, "k_g1_part_sort", [&] {
+                hipLaunchKernelGGL(dr::k_g1_part_sort, dim3((unsigned)(bsets * part_p)), dim3(dr::PART_BLOCK), 0, st, ctx->digits.as<uint32_t>(),
+                                   ctx->cursor.as<uint32_t>(), pp, ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
+            }));
+            sorted_done = true;
+        }
+    }
+    if (!sorted_done) {
     } else {
         TRY(ctx->digits.reserve(ndigits * 4));
         TRY(ctx->cursor.reserve(nbuckets * 4));
@@ -356,8 +393,9 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         results[0] = acc;
     } else {
         TRY(ctx->result.reserve(batch * 192));
+        SideSection side_(ctx);                            // a 255-doubling chain per MSM on batch / 64 waves
         TRY(launch(ctx, "k_g1_horner", [&] {
-            hipLaunchKernelGGL(dr::k_g1_horner, dim3(div_up(batch, 64)), dim3(64), 0, st, ctx->winsum.as<uint32_t>(),
+            hipLaunchKernelGGL(dr::k_g1_horner, dim3(div_up(batch, 64)), dim3(64), 0, ctx->stream, ctx->winsum.as<uint32_t>(),
                                (uint32_t)batch, pl.wt, ctx->result.as<uint32_t>());
         }));
         // results stay in ctx->result; msm_batch_results_to_bytes() finishes them on the device
@@ -410,6 +448,7 @@ int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, in
         return DR_OK;
     }
     TRY(ctx->io_c.reserve(batch * 96));
+    SideSection side_(ctx);                                // one inversion chain on batch / 64 waves
     TRY(launch(ctx, "k_g1_results_affine", [&] {
         hipLaunchKernelGGL(dr::k_g1_results_affine, dim3(div_up(batch, 64)), dim3(64), 0, ctx->stream, ctx->result.as<uint32_t>(),
                            (uint32_t)batch, ctx->io_c.as<uint32_t>());

@@ -444,7 +444,7 @@ dr_ctx* ring_prover_ctx(dr_ring_prover* p) { return p->ctx; }
 int ring_prover_curve(const dr_ring_prover* p) { return p->curve; }
 int ring_prover_aux_ctx(dr_ring_prover* p, dr_ctx** out) {
     if (!p->aux_ctx) {
-        TRY(dr_ctx_create(p->ctx->device, &p->aux_ctx));
+        TRY(ctx_create_role(p->ctx->device, 1, &p->aux_ctx));
         p->ctx->helpers.push_back(p->aux_ctx);
     }
     *out = p->aux_ctx;

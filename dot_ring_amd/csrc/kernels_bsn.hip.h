@@ -195,31 +195,116 @@ DR_DEV TePoint bsn_window_core(uint32_t* tab, int lane, const TePoint& P, const 
     }
     return acc;
 }
+// ---- GLV decomposition on the device (dot_ring/curve/glv.py:128-163; the host's glv_decompose of hostproto.hpp word for word):
+// k = k1 + k2 * lambda (mod n), |k1|, |k2| < 2^128, from the lattice basis v1 = (a1, b1), v2 = (a2, -a1):
+//   c1 = floor(k * G1 / 2^256), c2 = floor(k * G2 / 2^256)  (G1 = floor(2^256 a1 / n), G2 = floor(2^256 b1 / n)),
+//   k1 = k - (c1 a1 + c2 a2), k2 = c2 a1 - c1 b1 — 256-bit integers in 32-bit words with 64-bit multiply-adds.
+template <int NA, int NB>
+DR_DEV void mul_words(const uint32_t (&a)[NA], const uint32_t (&b)[NB], uint32_t (&out)[NA + NB]) {
+#pragma unroll
+    for (int i = 0; i < NA + NB; i++) out[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const uint64_t t = (uint64_t)a[i] * b[j] + out[i + j] + c;
+            out[i + j] = (uint32_t)t;
+            c = (uint32_t)(t >> 32);
+        }
+        out[i + NB] = c;
+    }
+}
+// signed 256-bit (d, borrow of the subtraction that produced it) -> 128-bit magnitude + sign; false when it does not fit
+DR_DEV bool glv_finish(uint32_t (&d)[8], uint32_t borrow, uint32_t (&mag)[4], uint32_t& neg) {
+    neg = borrow ? 1u : 0u;
+    if (borrow) {
+        uint32_t c = 1;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint64_t t = (uint64_t)(~d[i]) + c;
+            d[i] = (uint32_t)t;
+            c = (uint32_t)(t >> 32);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) mag[i] = d[i];
+    return (d[4] | d[5] | d[6] | d[7]) == 0;
+}
+// k < n in, (|k1|, |k2|, signs) out; false only if a half does not fit 128 bits (cannot happen for k < n with this basis)
+DR_DEV bool glv_split_dev(const uint32_t (&k)[8], uint32_t (&k1)[4], uint32_t (&k2)[4], uint32_t& neg1, uint32_t& neg2) {
+    constexpr uint32_t A1[4] = {0x9789181fu, 0x4b02f94au, 0x4be6928eu, 0x555fe200u};
+    constexpr uint32_t B1[4] = {0x23d61f44u, 0xf8e2591au, 0xe55e8f5du, 0x0814b3eeu};
+    constexpr uint32_t A2[4] = {0x47ac3e88u, 0xf1c4b234u, 0xcabd1ebbu, 0x102967ddu};
+    constexpr uint32_t G1[5] = {0x3f4747c1u, 0xdebac77au, 0x541cf632u, 0xf21df5b0u, 0x00000002u};   // floor(2^256 a1 / n)
+    constexpr uint32_t G2[4] = {0x547768aau, 0x993b75e7u, 0xd8767bdeu, 0x4760f127u};                // floor(2^256 b1 / n)
+    uint32_t t13[13], t12[12], c1[4], c2[4];
+    mul_words<8, 5>(k, G1, t13);
+    mul_words<8, 4>(k, G2, t12);
+    bool ok = t13[12] == 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { c1[i] = t13[8 + i]; c2[i] = t12[8 + i]; }
+    uint32_t p1[8], p2[8], s[8], d[8];
+    mul_words<4, 4>(c1, A1, p1);
+    mul_words<4, 4>(c2, A2, p2);
+    uint32_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = addc(p1[i], p2[i], cy);
+    ok = ok && cy == 0;
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = subb(k[i], s[i], bw);
+    ok = glv_finish(d, bw, k1, neg1) && ok;
+    mul_words<4, 4>(c2, A1, p1);
+    mul_words<4, 4>(c1, B1, p2);
+    bw = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = subb(p1[i], p2[i], bw);
+    ok = glv_finish(d, bw, k2, neg2) && ok;
+    return ok;
+}
+
 // one half of a GLV pair: the lane's base (P or psi(P), negated when its half-scalar is negative) times |k_half|
-// split: per term 12 words — |k1| (4), |k2| (4), neg1, neg2, 2 pad
-DR_DEV TePoint bsn_glv_half(uint32_t* tab, int lane, const uint32_t* __restrict__ pts, const uint32_t* __restrict__ split, size_t term, bool second) {
+// split: per term 12 words — |k1| (4), |k2| (4), neg1, neg2, 2 pad; RAW: `split` holds the n raw 8-word scalars instead and
+// every lane reduces its term's scalar mod n and decomposes it itself (both lanes of a pair: ~400 instructions against the
+// ~300 000 of the window chain — and no host pass over device-resident scalars)
+template <bool RAW = false>
+DR_DEV TePoint bsn_glv_half(uint32_t* tab, int lane, const uint32_t* __restrict__ pts, const uint32_t* __restrict__ split, size_t term, bool second,
+                            uint32_t* __restrict__ err = nullptr) {
     Fs px = fs_from_std(load_fr_std(pts + term * 16));
     Fs py = fs_from_std(load_fr_std(pts + term * 16 + 8));
     TePoint base;
     if (second) base = bsn_endomorphism(px, py);
     else { base.x = px; base.y = py; base.z = Fs::one(); base.t = mul(px, py); }
-    const uint32_t* s = split + term * 12;
-    base = te_cneg(base, s[8 + (second ? 1 : 0)] != 0);
     uint32_t k[5];
+    if constexpr (RAW) {
+        uint32_t kk[8], k1[4], k2[4], n1, n2;
 #pragma unroll
-    for (int j = 0; j < 4; j++) k[j] = s[(second ? 4 : 0) + j];
+        for (int j = 0; j < 8; j++) kk[j] = split[term * 8 + j];
+        reduce_mod_order<CV_BANDERSNATCH>(kk);
+        if (!glv_split_dev(kk, k1, k2, n1, n2) && err) atomicOr(err, 1u);
+        base = te_cneg(base, (second ? n2 : n1) != 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) k[j] = second ? k2[j] : k1[j];
+    } else {
+        const uint32_t* s = split + term * 12;
+        base = te_cneg(base, s[8 + (second ? 1 : 0)] != 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) k[j] = s[(second ? 4 : 0) + j];
+    }
     k[4] = 0;
     return bsn_window_core<33>(tab, lane, base, k);
 }
 // out[i] = k[i] * P[i] from the split scalars; lanes 2i, 2i+1 share one scalar multiplication
+template <bool RAW = false>
 __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_scalar_mul_glv(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ split,
-                                                                  uint32_t* __restrict__ out, uint32_t n) {
+                                                                  uint32_t* __restrict__ out, uint32_t n, uint32_t* __restrict__ err = nullptr) {
     __shared__ uint32_t tab[BSN_TABLE * BSN_PT_WORDS * BSN_BLOCK];
     const int lane = threadIdx.x;
     uint32_t i = (blockIdx.x * BSN_BLOCK + lane) >> 1;
     const bool live = i < n;
     if (!live) i = n - 1;
-    TePoint acc = bsn_glv_half(tab, lane, pts, split, i, (lane & 1) != 0);
+    TePoint acc = bsn_glv_half<RAW>(tab, lane, pts, split, i, (lane & 1) != 0, err);
     TePoint o = te_shfl_down(acc, 1);
     acc = te_add(acc, o);
     if (live && !(lane & 1)) te_store_affine(out + (size_t)i * 16, acc);

@@ -569,7 +569,8 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
 //   pass B (k_g1_part_sort): one workgroup per (set, partition) sorts its ~32 k entries by bucket entirely in LDS (histogram,
 //     scan, placement into a stage, coalesced copy-out — k_g1_sort_sets_staged's second half on a stream instead of digit
 //     rows), and writes counts / offsets / sorted in the layout the accumulate kernel reads.
-// Every partition stream has room for ALL entries of its set, so no scalar distribution can overflow one.
+// A partition stream has room for cap_part entries (4x an even share): pass A never writes past it, the host compares the fill
+// counters with cap_part after pass A and sorts with the global-atomic kernels when a stream was overfilled (few distinct scalars).
 constexpr int PART_BLOCK = 1024;
 constexpr uint32_t PART_TILE_ENTRIES = 32768, PART_MAX_P = 32, PART_MAX_HP = 1024, PART_STAGE = 36864, PART_SLACK = 2048;
 
@@ -646,7 +647,8 @@ __global__ __launch_bounds__(PART_BLOCK) void k_g1_part_scatter(const uint32_t* 
     for (uint32_t idx = tid; idx < total; idx += PART_BLOCK) {
         uint32_t lo = 0, hi = pp.P;                                 // largest p with pbase[p] <= idx
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pbase[mid] <= idx) lo = mid; else hi = mid; }
-        streams[((size_t)set * pp.P + lo) * pp.cap_part + gbase[lo] + (idx - pbase[lo])] = stage[idx];
+        const uint32_t at = gbase[lo] + (idx - pbase[lo]);
+        if (at < pp.cap_part) streams[((size_t)set * pp.P + lo) * pp.cap_part + at] = stage[idx];   // an overfull stream: the host sees its fill count
     }
 }
 

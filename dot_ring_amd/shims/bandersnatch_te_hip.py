@@ -37,7 +37,11 @@ def _xy(pt) -> bytes:
 
 
 def _msm(points_xy, scalars):
-    """sum k_i P_i for affine points and NON-NEGATIVE scalars of up to 256 bits -> extended projective tuple with Z = 1."""
+    """sum k_i P_i for affine points and NON-NEGATIVE scalars of up to 256 bits -> extended projective tuple with Z = 1.
+    Points must lie in the prime-order subgroup (every caller in the reference passes generators, public keys or hash-to-curve
+    outputs, glv.py:191-472): scalars are reduced mod n here and by the kernels, so for a point with a torsion component the
+    result would differ from the reference's plain integer multiplication by a torsion point.  Not checked (a subgroup test costs
+    a scalar multiplication per point)."""
     ks = [int(k) for k in scalars]
     if any(k < 0 or k >> 256 for k in ks):
         raise OverflowError("scalar out of range")      # as the reference's 4-limb conversion (bandersnatch_te.pyx:55-66)

@@ -22,6 +22,8 @@ from ..ring_proof.transcript import FiatShamirTranscript, serialize_verifier_key
 from ..ring_proof.verifier import batch_inverse, linear_pcs_verifications, replay_challenges, zeta_denominators
 from .base import VRF
 from .codec import point_len
+
+_PK_MEMO_LOCK = threading.Lock()          # guards every RingVRF class's _pk_memo (prove_batch)
 from .pedersen import PedersenVRF
 
 RING_SCALAR_LEN = 32
@@ -241,15 +243,17 @@ class RingVRF(VRF):
                "accx_zeta", "accy_zeta", "c_q", "l_zeta_omega", "open_agg_zeta", "open_l_zeta_omega")
 
     @classmethod
-    def _from_batch(cls, raw_blob: bytes, aux_blob: bytes, count: int) -> list:
+    def _from_batch(cls, raw_blob: bytes, aux_blob: bytes, count: int, blind_blob=None) -> list:
         """The proofs of one dr_ringvrf_prove_batch call: every object only points into the two shared byte strings; its own 784 +
         960 bytes are sliced out when something first asks for them (1024 objects: 0.35 ms instead of 1.2 ms), and batch_verify
-        of exactly these proofs, untouched and in order, hands the shared string to the library without re-assembling it."""
+        of exactly these proofs, untouched and in order, hands the shared string to the library without re-assembling it.
+        The shared auxiliary string holds NO secret: the blinding factors were moved out of it (dr_ringvrf_aux_take_blindings) and
+        each proof keeps its own 32 bytes only — holding or pickling one proof does not keep another proof's blinding factor alive."""
         new = object.__new__
         out = []
         for i in range(count):
             p = new(cls)
-            p.__dict__["_batch"] = (raw_blob, aux_blob, i)
+            p.__dict__["_batch"] = (raw_blob, aux_blob, i, None if blind_blob is None else blind_blob[32 * i : 32 * i + 32])
             out.append(p)
         return out
 
@@ -257,9 +261,12 @@ class RingVRF(VRF):
     def _unbatch(d) -> None:
         b = d.pop("_batch", None)
         if b is not None:
-            raw_blob, aux_blob, i = b
+            raw_blob, aux_blob, i, blind = b
             ab = _native.RINGVRF_AUX_BYTES
-            d["_raw"], d["_aux"] = raw_blob[784 * i : 784 * i + 784], aux_blob[ab * i : ab * i + ab]
+            aux = aux_blob[ab * i : ab * i + ab]
+            if blind is not None:
+                aux = aux[:256] + blind + aux[288:]
+            d["_raw"], d["_aux"] = raw_blob[784 * i : 784 * i + 784], aux
 
     def __getattr__(self, name):
         d = self.__dict__
@@ -436,23 +443,30 @@ class RingVRF(VRF):
         gen = cv.point_type.generator_point()
         # one scalar multiplication per distinct key not seen before (sk -> pk is deterministic; a small per-class memo
         # saves a latency-bound launch per call when a signer proves repeatedly)
-        memo = cls.__dict__.get("_pk_memo")
-        if memo is None:
-            memo = {}
-            cls._pk_memo = memo
         # the memo is keyed by a hash of the secret key: the process keeps no copy of secret material beyond the call
         tag = lambda sk: hashlib.blake2b(sk, digest_size=16, person=b"dotring-pk-memo").digest()
         sk_bytes = [bytes(sk) for sk in secret_keys]
         tag_of = {sk: tag(sk) for sk in dict.fromkeys(sk_bytes)}     # one hash per distinct key of THIS call (a local, not kept)
         tags = [tag_of[sk] for sk in sk_bytes]
-        distinct = {t: sk for sk, t in tag_of.items() if t not in memo}
+        # prove_batch may run on several threads at once (DOTRING_PROVE_PARTS, application lanes): lookups, the clear() at the size
+        # cap and the update all happen under one lock, and the comparison below uses this call's own snapshot
+        with _PK_MEMO_LOCK:
+            memo = cls.__dict__.get("_pk_memo")
+            if memo is None:
+                memo = {}
+                cls._pk_memo = memo
+            known = {t: memo[t] for t in tag_of.values() if t in memo}
+        distinct = {t: sk for sk, t in tag_of.items() if t not in known}
         if distinct:
             derived = scalar_mul_batch([gen] * len(distinct), [int.from_bytes(sk, "little") for sk in distinct.values()])
-            if len(memo) + len(distinct) > 4096:
-                memo.clear()
-            memo.update((t, pt.point_to_string()) for t, pt in zip(distinct, derived))
+            fresh = {t: pt.point_to_string() for t, pt in zip(distinct, derived)}
+            known.update(fresh)
+            with _PK_MEMO_LOCK:
+                if len(memo) + len(fresh) > 4096:
+                    memo.clear()
+                memo.update(fresh)
         for t, pk in zip(tags, producer_keys):
-            if pk != memo[t]:
+            if pk != known[t]:
                 raise ValueError("producer_key does not match secret_key")
         root = ring_root
         if root is None or root.px.coeffs is None or root.py.coeffs is None or root.s.coeffs is None or len(root.s.evals) < ring.params.domain_size:
@@ -493,14 +507,23 @@ class RingVRF(VRF):
             # hidden rows: 12 x 48 random bytes per proof, expanded from a fresh 32-byte OS seed by the library's worker threads
             # (SHAKE256 in counter mode; os.urandom alone took 1.5 ms per 1024 proofs on the calling thread)
             zk = None if ring.params.test_vectors else _native.random_expand(secrets.token_bytes(32), 48 * 12 * (hi - lo))
-            raw, aux = device_prover.get_device_prover(ring, 0).ringvrf_prove_batch(
-                suite, alphas[lo:hi], additional_data[lo:hi], salts[lo:hi] if salts else None,
-                b"".join(bytes(sk) if len(sk) == 32 else le(int.from_bytes(sk, "little") % sp.subgroup_order) for sk in secret_keys[lo:hi]),
-                indices[lo:hi], prefix, zk)
             n = hi - lo
-            proofs = cls._from_batch(ctypes.string_at(raw, 784 * n), ctypes.string_at(aux, ab * n), n)
-            _native.wipe(aux)           # the per-thread buffer is reused: the blinding factors live on only in the proofs' record
-            return proofs
+            prover = device_prover.get_device_prover(ring, 0)
+            aux = blind = None
+            try:
+                raw, aux = prover.ringvrf_prove_batch(
+                    suite, alphas[lo:hi], additional_data[lo:hi], salts[lo:hi] if salts else None,
+                    b"".join(bytes(sk) if len(sk) == 32 else le(int.from_bytes(sk, "little") % sp.subgroup_order) for sk in secret_keys[lo:hi]),
+                    indices[lo:hi], prefix, zk)
+                blind = _native.aux_take_blindings(aux, n)          # the shared auxiliary string below carries no secret
+                return cls._from_batch(ctypes.string_at(raw, 784 * n), ctypes.string_at(aux, ab * n), n, ctypes.string_at(blind, 32 * n))
+            finally:
+                # the per-thread buffers are reused: wiped whether or not the native call succeeded
+                for buf in (aux, blind):
+                    if buf is not None:
+                        _native.wipe(buf)
+                if aux is None:
+                    _native.wipe_thread_buffer("prove_aux")
 
         # Opt-in (DOTRING_PROVE_PARTS=2; default 1 = one call): large batches as two halves from two threads — while one half is in
         # its store-bound sort or its latency-bound bucket reduction / affine conversion, the other half's accumulate kernel fills

@@ -275,6 +275,10 @@ DR_API int dr_host_hash(int kind, const uint8_t *data, size_t len, uint8_t *out,
  * dr_ringvrf_prove_batch's zk_random48 for a batch (12 x 48 bytes per proof: the hidden rows of columns/columns.py:139-146, drawn
  * with `secrets` in the reference) comes from one 32-byte OS seed this way. */
 DR_API int dr_host_random_expand(const uint8_t seed[32], uint8_t *out, size_t len);
+/* moves the secret part of dr_ringvrf_prove_batch's auxiliary records out: the 32-byte blinding factor of record i (offset 256
+ * of its DR_RINGVRF_AUX_BYTES) is copied to out_blind + 32 i and zeroed in the record, so that what callers keep per batch holds
+ * no secret and what they keep per proof is that proof's own factor only */
+DR_API int dr_ringvrf_aux_take_blindings(uint8_t *aux, size_t batch, uint8_t *out_blind /* batch*32 */);
 
 typedef struct dr_vrf_suite {
     const uint8_t *suite_id;        /* e.g. "Bandersnatch-SHA512-ELL2-v1" (bandersnatch.py:74-87) */

@@ -62,6 +62,29 @@ def test_bsn_scalar_mul_config2_4096(ctx):
         b.free()
 
 
+def test_bsn_scalar_mul_device_resident_glv_split_on_device(ctx):
+    """The device-resident entry point decomposes every scalar on the device (k_bsn_scalar_mul_glv<true>: reduce mod n, the lattice
+    rounding of glv.py:128-163 in 32-bit words): edge scalars — 0, 1, n - 1, n, n + 1, 2^128 +- 1, lambda, values >= n up to
+    2^256 - 1, powers of two, all-ones halves — the identity as input, ragged sizes, against the oracle's plain and GLV kernels."""
+    lam = 0x13B4F3DC4A39A493EDF849562B38C72BCFC49DB970A5056ED13D21408783DF05
+    edge = [0, 1, 2, N - 1, N, N + 1, (1 << 128) - 1, 1 << 128, (1 << 128) + 1, lam, lam - 1, N - lam, (1 << 256) - 1, (1 << 255) + 12345,
+            (1 << 252), (1 << 253) - 1, 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF << 128, 0x8000000000000000 << 64, 4 * N - 1, 8 * N + 7]
+    edge += [1 << b for b in range(0, 256, 17)]
+    for n in (1, 2, 63, 64, 65, 700):
+        pts = _seeded_points(n, b"dv")
+        ks = (edge + _seeded_scalars(max(0, n - len(edge)), b"dvk", 1 << 256))[:n]
+        if n >= 3:
+            pts[2] = bsn.IDENTITY
+        raw_p, raw_k = coracle.te_pack(pts), b"".join(k.to_bytes(32, "little") for k in ks)
+        want = coracle.te_mul_batch_raw(raw_p, coracle.scalars_pack([k % N for k in ks]), n, glv=False)
+        assert want == coracle.te_mul_batch_raw(raw_p, coracle.scalars_pack([k % N for k in ks]), n, glv=True)
+        d_p, d_k, d_o = ctx.alloc(64 * n).upload(raw_p), ctx.alloc(32 * n).upload(raw_k), ctx.alloc(64 * n)
+        ctx.bsn_scalar_mul_batch_dev(d_p, d_k, n, d_o)
+        assert d_o.download() == want, n
+        for b in (d_p, d_k, d_o):
+            b.free()
+
+
 def test_bsn_scalar_mul_identity_and_kat(ctx):
     # identity input, and the reference KAT pk = sk*G (tests/golden/ark-vrf/bandersnatch_sha-512_ell2_tiny.json #1)
     sk = int.from_bytes(bytes.fromhex("c9922b7a9849b9928e15c655dd2f22ceef737cc355024f43d4b04bf4398c270d"), "little")

@@ -57,6 +57,7 @@ def test_rccl_communicator_world_1(ctx):
     from dot_ring_amd import parallel
 
     comm = parallel.RcclComm(ctx, 0, 1)
+    assert comm.rccl_ranks() == 1                                        # ncclCommCount, not the caller's idea of the world
     assert comm.all_gather(b"\x01\x02\x03") == [b"\x01\x02\x03"]
     comm.barrier()
     got, want = _shard_msm(ctx, comm, 5000, 0, 1, None, 12)
@@ -99,3 +100,45 @@ def test_sharded_msm_real_gpu_shards(world, n, zero_rank, table):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in results)
     assert len({got for _, _, got in results}) == 1                      # identical on every rank
+
+
+def _rccl_worker(rank, world, port, n, out_q):
+    sys.path.insert(0, ROOT)
+    from dot_ring_amd import _native, parallel
+
+    boot = parallel.SocketComm(rank, world, "127.0.0.1", port)
+    ctx = _native.Context(rank)                                          # one GPU per rank
+    comm = parallel.RcclComm(ctx, rank, world, bootstrap=boot)
+    try:
+        got, want = _shard_msm(ctx, comm, n, rank, world, None, 12)
+        out_q.put((rank, got == want, got, comm.rccl_ranks()))
+    finally:
+        comm.barrier()
+        comm.close()
+        ctx.close()
+        boot.close()
+
+
+def test_rccl_two_ranks_on_two_gpus():
+    """ncclCommInitRank / ncclAllGather across two processes on two devices, the fused dr_g1_msm_sharded_dev end to end.
+    Needs two GPUs: skipped on the one-GPU test boxes (there the multi-rank cases above use the TCP communicator)."""
+    from dot_ring_amd import _native
+
+    if _native.lib().dr_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    world, n = 2, (1 << 16) + 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mpx = mp.get_context("spawn")
+    q = mpx.Queue()
+    procs = [mpx.Process(target=_rccl_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in results)
+    assert len({got for _, _, got, _ in results}) == 1
+    assert all(cnt == 2 for _, _, _, cnt in results)
