@@ -249,7 +249,6 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         }
     }
     if (!sorted_done) {
-    } else {
         TRY(ctx->digits.reserve(ndigits * 4));
         TRY(ctx->cursor.reserve(nbuckets * 4));
         TRY(ctx->sorted.reserve(ndigits * 4));
