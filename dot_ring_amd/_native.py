@@ -450,13 +450,13 @@ class Context:
         return ms.value, cnt.value
 
     def fr_ops_selftest(self, a: bytes, b: bytes):
-        """dr_fr_ops_selftest: (n x 9 x 32 result bytes, n square flags) for n pairs of canonical 32-byte elements."""
+        """dr_fr_ops_selftest: (n x 12 x 32 result bytes, n square flags) for n pairs of canonical 32-byte elements."""
         n = len(a) // 32
         if len(a) != 32 * n or len(b) != 32 * n:
             raise ValueError("operands are 32 bytes each")
-        out, flags = ctypes.create_string_buffer(max(1, 288 * n)), ctypes.create_string_buffer(max(1, n))
+        out, flags = ctypes.create_string_buffer(max(1, 384 * n)), ctypes.create_string_buffer(max(1, n))
         _check(lib().dr_fr_ops_selftest(self.handle, a, b, n, out, flags))
-        return out.raw[: 288 * n], flags.raw[:n]
+        return out.raw[: 384 * n], flags.raw[:n]
 
     # ---- seam A
     # (curve = CURVE_BANDERSNATCH / CURVE_JUBJUB; the default goes through the dr_bsn_* names of the original seam)

@@ -622,7 +622,7 @@ int dr_fr_ops_selftest(dr_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n
     TRY(check_fr_elems(a, n, "field element"));
     TRY(check_fr_elems(b, n, "field element"));
     TRY(ctx->io_a.reserve(n * 64));
-    TRY(ctx->io_b.reserve(n * 288));
+    TRY(ctx->io_b.reserve(n * 384));
     TRY(ctx->io_c.reserve(n * 4));
     HIP_TRY(hipMemcpyAsync(ctx->io_a.p, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->io_a.as<uint8_t>() + n * 32, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
@@ -630,7 +630,7 @@ int dr_fr_ops_selftest(dr_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n
                        ctx->io_a.as<uint32_t>() + n * 8, (uint32_t)n, ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     std::vector<uint32_t> flags(n);
-    HIP_TRY(hipMemcpyAsync(out, ctx->io_b.p, n * 288, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, ctx->io_b.p, n * 384, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(flags.data(), ctx->io_c.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < n; i++) is_square[i] = flags[i] ? 1 : 0;

@@ -48,31 +48,33 @@ struct dr_ring_prover {
     // per-ring tables
     Scratch ring_pts_mont;              // [N][16]
     Scratch fixed_coef;                 // [3][N][8] std (px, py, s coefficients)
-    Scratch fixed4, lag4, not_last;     // Montgomery tables on the 4N domain
+    Scratch fixed4, lag4, not_last;     // tables on the 4N domain, FS9 records (raw 9-limb Montgomery 2^261)
     uint8_t root[3 * 96];
     int root_inf[3];
     // per-batch state
     size_t batch = 0;
-    Scratch idx, blind, zk, chain_ext, prefix, chain_aff, cnt, relation, rps, cols, wit4, alphas, alpha_aux, agg, q, zetas, evals, ks, lin,
-        nus, aggo, chunkv, quot1, quot2, diffs;
+    Scratch idx, blind, zk, chain_ext, prefix, chain_aff, cnt, relation, rps, cols, wit4, alphas, alphas9, alpha_aux, agg, q, zetas, evals, ks, lin,
+        nus, nus9, aggo, chunkv, quot1, quot2, diffs;
 };
 
 namespace {
 
-int ring_ntt(dr_ring_prover* p, uint32_t* d_data, unsigned log2n, size_t batch, bool inverse, bool in_mont = false, bool out_mont = false,
-             const uint32_t* d_src = nullptr, int pad = 0) {
+// fmt_in / fmt_out: dr::NTT_FMT_STD8 (8 canonical words, standard form) or dr::NTT_FMT_FS9 (raw 9-limb Montgomery records)
+int ring_ntt(dr_ring_prover* p, uint32_t* d_data, unsigned log2n, size_t batch, bool inverse, int fmt_in = dr::NTT_FMT_STD8,
+             int fmt_out = dr::NTT_FMT_STD8, const uint32_t* d_src = nullptr, int pad = 0) {
     dr_ctx* ctx = p->ctx;
     const drh::Fr& w = log2n == p->rc.log2n ? p->omega_n : p->omega_4n;
     drh::Fr wi = inverse ? w.inv() : w;
     drh::Fr scale;
     if (inverse) scale = drh::Fr::from_u64((uint64_t)1 << log2n).inv();
+    const size_t in_words = fmt_in == dr::NTT_FMT_FS9 ? dr::L29 : 8, out_words = fmt_out == dr::NTT_FMT_FS9 ? dr::L29 : 8;
     // dr_ntt limits one launch to 65535 transforms (grid.y): split larger batches
     for (size_t done = 0; done < batch;) {
         size_t take = std::min<size_t>(batch - done, 65535);
         int rc = dr::ntt_run(ctx->stream, [&](const char* name, auto&& f) { return launch(ctx, name, f); }, ctx->twiddles, ctx->io_b,
-                             d_data + done * ((size_t)8 << log2n), log2n, take, wi, inverse ? &scale : nullptr,
-                             [&]() -> int { return DR_OK; }, in_mont, out_mont,
-                             d_src ? d_src + done * ((size_t)8 << (log2n - pad)) : nullptr, pad);
+                             d_data + done * (out_words << log2n), log2n, take, wi, inverse ? &scale : nullptr,
+                             [&]() -> int { return DR_OK; }, fmt_in, fmt_out,
+                             d_src ? d_src + done * (in_words << (log2n - pad)) : nullptr, pad);
         if (rc != DR_OK) return rc == DR_ERR_NOMEM ? fail(rc, "out of device memory in NTT") : fail(rc, "NTT launch failed");
         done += take;
     }
@@ -168,6 +170,9 @@ int dr_ring_prover_create_te(dr_ctx* ctx, int curve, const dr_srs* srs, unsigned
     // tail(X) = (X - w^-1)(X - w^-2)(X - w^-3)
     drh::Fr e1 = w1 + w2 + w3, e2 = w1 * w2 + w1 * w3 + w2 * w3, e3 = w1 * w2 * w3;
     rc.tail[0] = arg_of(e3.neg()); rc.tail[1] = arg_of(e2); rc.tail[2] = arg_of(e1.neg()); rc.tail[3] = arg_of(drh::Fr::one());
+    rc.tail9[0] = dr::fs_arg_mont(e3.neg()); rc.tail9[1] = dr::fs_arg_mont(e2); rc.tail9[2] = dr::fs_arg_mont(e1.neg());
+    rc.tail9[3] = dr::fs_arg_mont(drh::Fr::one());
+    rc.omega9 = dr::fs_arg_mont(p->omega_n);
     hipStream_t st = ctx->stream;
     // ring points -> Montgomery table ; fixed evaluation columns
     TRY(p->ring_pts_mont.reserve((size_t)n * 64));
@@ -181,24 +186,27 @@ int dr_ring_prover_create_te(dr_ctx* ctx, int curve, const dr_srs* srs, unsigned
         MsmTable t = srs_table(srs, 0);
         TRY(msm_to_bytes(ctx, srs->d_bases, p->fixed_coef.as<uint32_t>(), n, 3, p->root, p->root_inf, &t));
     }
-    // 4N-domain tables (Montgomery)
-    TRY(p->fixed4.reserve((size_t)3 * m * 32));
+    // 4N-domain tables: zero-padded coefficients -> forward NTT with FS9 output (raw 9-limb Montgomery records)
+    Scratch pad4;
+    TRY(pad4.reserve((size_t)3 * m * 32));
+    TRY(p->fixed4.reserve((size_t)3 * m * dr::L29 * 4));
     hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up((size_t)3 * m, 256)), dim3(256), 0, st, p->fixed_coef.as<uint32_t>(), n,
-                       p->fixed4.as<uint32_t>(), m, (size_t)3);
-    TRY(ring_ntt(p, p->fixed4.as<uint32_t>(), log2n + 2, 3, false));
-    hipLaunchKernelGGL(dr::k_fr_to_mont, dim3(div_up((size_t)3 * m, 256)), dim3(256), 0, st, p->fixed4.as<uint32_t>(), (size_t)3 * m);
+                       pad4.as<uint32_t>(), m, (size_t)3);
+    TRY(ring_ntt(p, p->fixed4.as<uint32_t>(), log2n + 2, 3, false, dr::NTT_FMT_STD8, dr::NTT_FMT_FS9, pad4.as<uint32_t>(), 0));
     Scratch lagc;
     TRY(lagc.reserve((size_t)2 * n * 32));
     hipLaunchKernelGGL(dr::k_ring_lagrange, dim3(div_up(n, 256)), dim3(256), 0, st, lagc.as<uint32_t>(), n,
                        arg_of(drh::Fr::from_u64(n).inv()), arg_of(w4.inv()));
-    TRY(p->lag4.reserve((size_t)2 * m * 32));
-    hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up((size_t)2 * m, 256)), dim3(256), 0, st, lagc.as<uint32_t>(), n, p->lag4.as<uint32_t>(), m, (size_t)2);
-    TRY(ring_ntt(p, p->lag4.as<uint32_t>(), log2n + 2, 2, false));
-    hipLaunchKernelGGL(dr::k_fr_to_mont, dim3(div_up((size_t)2 * m, 256)), dim3(256), 0, st, p->lag4.as<uint32_t>(), (size_t)2 * m);
-    TRY(p->not_last.reserve((size_t)m * 32));
-    hipLaunchKernelGGL(dr::k_ring_not_last, dim3(div_up(m, 256)), dim3(256), 0, st, p->not_last.as<uint32_t>(), m, arg_of(p->omega_4n), arg_of(w4));
+    TRY(p->lag4.reserve((size_t)2 * m * dr::L29 * 4));
+    hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up((size_t)2 * m, 256)), dim3(256), 0, st, lagc.as<uint32_t>(), n, pad4.as<uint32_t>(), m, (size_t)2);
+    TRY(ring_ntt(p, p->lag4.as<uint32_t>(), log2n + 2, 2, false, dr::NTT_FMT_STD8, dr::NTT_FMT_FS9, pad4.as<uint32_t>(), 0));
+    TRY(p->not_last.reserve((size_t)m * dr::L29 * 4));
+    // x - w^(N-4) on the 4N domain: built in the 8-word Montgomery form (pad4 is free again), then converted
+    hipLaunchKernelGGL(dr::k_ring_not_last, dim3(div_up(m, 256)), dim3(256), 0, st, pad4.as<uint32_t>(), m, arg_of(p->omega_4n), arg_of(w4));
+    hipLaunchKernelGGL(dr::k_fr_mont_to_fs9, dim3(div_up(m, 256)), dim3(256), 0, st, pad4.as<uint32_t>(), p->not_last.as<uint32_t>(), (size_t)m);
     HIP_TRY(hipStreamSynchronize(st));
     lagc.release();
+    pad4.release();
     HIP_TRY(hipGetLastError());
     guard.release();
     *out = p;
@@ -209,8 +217,8 @@ void dr_ring_prover_destroy(dr_ring_prover* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     for (Scratch* s : {&p->ring_pts_mont, &p->fixed_coef, &p->fixed4, &p->lag4, &p->not_last, &p->idx, &p->blind, &p->zk, &p->chain_ext,
-                       &p->prefix, &p->chain_aff, &p->cnt, &p->relation, &p->rps, &p->cols, &p->wit4, &p->alphas, &p->alpha_aux, &p->agg, &p->q, &p->zetas,
-                       &p->evals, &p->ks, &p->lin, &p->nus, &p->aggo, &p->chunkv, &p->quot1, &p->quot2, &p->diffs})
+                       &p->prefix, &p->chain_aff, &p->cnt, &p->relation, &p->rps, &p->cols, &p->wit4, &p->alphas, &p->alphas9, &p->alpha_aux, &p->agg, &p->q, &p->zetas,
+                       &p->evals, &p->ks, &p->lin, &p->nus, &p->nus9, &p->aggo, &p->chunkv, &p->quot1, &p->quot2, &p->diffs})
         s->release();
     if (p->aux_ctx) {
         if (p->ctx && ctx_alive(p->ctx)) {
@@ -271,7 +279,7 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
     // the columns are built in evaluation form in the wit4 buffer (unused until the quotient phase, which needs 4x this size anyway)
     // and interpolated from there into `cols`: the inverse NTT's first pass cannot run in place, a separate source saves its
     // temporary and the copy back
-    TRY(p->wit4.reserve(batch * 4 * (size_t)n * 4 * 32));
+    TRY(p->wit4.reserve(batch * 4 * (size_t)n * 4 * dr::L29 * 4));
     uint32_t* col_evals = p->wit4.as<uint32_t>();
     HIP_TRY(hipMemcpyAsync(p->idx.p, producer_index, batch * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(p->blind.p, blinding, batch * 32, hipMemcpyHostToDevice, st));
@@ -303,11 +311,11 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
             hipLaunchKernelGGL(dr::k_ring_diff, dim3(div_up(batch * 4 * n, 256)), dim3(256), 0, st, col_evals, n, batch * 4,
                                p->diffs.as<uint32_t>());
         }));
-        TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true, false, false, col_evals, 0));
+        TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true, dr::NTT_FMT_STD8, dr::NTT_FMT_STD8, col_evals, 0));
         MsmTable t = srs_table(p->ps_srs, 0);
         return msm_to_bytes(ctx, p->ps_srs->d_bases, p->diffs.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t);
     }
-    TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true, false, false, col_evals, 0));
+    TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true, dr::NTT_FMT_STD8, dr::NTT_FMT_STD8, col_evals, 0));
     MsmTable t = srs_table(p->srs, 0);
     return msm_to_bytes(ctx, p->srs->d_bases, p->cols.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t);
 }
@@ -323,26 +331,28 @@ int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alpha
     const uint32_t n = rc.n, m = 4 * n, qn = 3 * n + 1;
     hipStream_t st = ctx->stream;
     TRY(p->alphas.reserve(batch * 7 * 32));
-    TRY(p->wit4.reserve(batch * 4 * (size_t)m * 32));
-    TRY(p->agg.reserve(batch * (size_t)m * 32));
+    TRY(p->alphas9.reserve(batch * 7 * dr::L29 * 4));
+    TRY(p->wit4.reserve(batch * 4 * (size_t)m * dr::L29 * 4));
+    TRY(p->agg.reserve(batch * (size_t)m * dr::L29 * 4));
     TRY(p->q.reserve(batch * (size_t)qn * 32));
     HIP_TRY(hipMemcpyAsync(p->alphas.p, alphas, batch * 7 * 32, hipMemcpyHostToDevice, st));
-    // 7 alphas per proof are read by every point of the 4N domain: convert them to Montgomery form once
+    // 7 alphas per proof are read by every point of the 4N domain: converted once per batch — FS9 records for the constraint
+    // kernel, the 8-word Montgomery form for the two small per-proof kernels (k_ring_alpha_aux, k_ring_lin_scalars)
+    hipLaunchKernelGGL(dr::k_fr_std_to_fs9, dim3(div_up(batch * 7, 256)), dim3(256), 0, st, p->alphas.as<uint32_t>(), p->alphas9.as<uint32_t>(), batch * 7);
     hipLaunchKernelGGL(dr::k_fr_to_mont, dim3(div_up(batch * 7, 256)), dim3(256), 0, st, p->alphas.as<uint32_t>(), batch * 7);
-    TRY(p->alpha_aux.reserve(batch * 2 * 32));
+    TRY(p->alpha_aux.reserve(batch * 2 * dr::L29 * 4));
     hipLaunchKernelGGL(dr::k_ring_alpha_aux, dim3(div_up(batch, 64)), dim3(64), 0, st, p->alphas.as<uint32_t>(), p->rps.as<uint32_t>(), rc,
                        (uint32_t)batch, p->alpha_aux.as<uint32_t>());
     // N coefficients per column -> evaluations on the 4N domain: the NTT reads the columns directly (zero padding implied) and
-    // leaves the evaluations in Montgomery form
-    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch * 4, false, false, true, p->cols.as<uint32_t>(), 2));
+    // leaves the evaluations as raw 9-limb records
+    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch * 4, false, dr::NTT_FMT_STD8, dr::NTT_FMT_FS9, p->cols.as<uint32_t>(), 2));
     TRY(launch(ctx, "k_ring_constraints", [&] {
         LAUNCH_CV(p->curve, dr::k_ring_constraints, dim3(div_up(batch * m, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(), p->fixed4.as<uint32_t>(),
-                           p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas.as<uint32_t>(), p->alpha_aux.as<uint32_t>(), rc,
+                           p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas9.as<uint32_t>(), p->alpha_aux.as<uint32_t>(), rc,
                            (uint32_t)batch, p->agg.as<uint32_t>());
     }));
-    // the constraint kernel wrote Montgomery form; the coefficients land in the (now free) wit4 buffer: the first pass cannot
-    // run in place, so a separate output saves the temporary and the copy back
-    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch, true, true, false, p->agg.as<uint32_t>(), 0));
+    // the constraint kernel wrote raw sums; the coefficients (standard form) land in the (now free) wit4 buffer
+    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch, true, dr::NTT_FMT_FS9, dr::NTT_FMT_STD8, p->agg.as<uint32_t>(), 0));
     TRY(launch(ctx, "k_ring_quotient", [&] {
         hipLaunchKernelGGL(dr::k_ring_quotient, dim3(div_up(batch * qn, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(), rc, (uint32_t)batch,
                            p->q.as<uint32_t>());
@@ -363,7 +373,7 @@ int dr_ring_prove_evals(dr_ring_prover* p, size_t batch, const uint8_t* zetas, u
     hipStream_t st = ctx->stream;
     TRY(p->zetas.reserve(batch * 32));
     TRY(p->evals.reserve(batch * 8 * 32));
-    TRY(p->ks.reserve(batch * 3 * 32));
+    TRY(p->ks.reserve(batch * 3 * dr::L29 * 4));
     TRY(p->lin.reserve(batch * (size_t)n * 32));
     HIP_TRY(hipMemcpyAsync(p->zetas.p, zetas, batch * 32, hipMemcpyHostToDevice, st));
     TRY(launch(ctx, "k_ring_eval", [&] {
@@ -404,11 +414,12 @@ int dr_ring_prove_openings(dr_ring_prover* p, size_t batch, const uint8_t* nus, 
     // zero-padded (zero scalars produce no digits) — one sort / accumulate / reduce / affine pipeline instead of two
     TRY(p->quot1.reserve(2 * batch * (size_t)(qn - 1) * 32));
     TRY(p->quot2.reserve(batch * (size_t)(n - 1) * 32));
+    TRY(p->nus9.reserve(batch * 8 * dr::L29 * 4));
     HIP_TRY(hipMemcpyAsync(p->nus.p, nus, batch * 8 * 32, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(dr::k_fr_to_mont, dim3(div_up(batch * 8, 256)), dim3(256), 0, st, p->nus.as<uint32_t>(), batch * 8);     // multipliers: Montgomery form
+    hipLaunchKernelGGL(dr::k_fr_std_to_fs9, dim3(div_up(batch * 8, 256)), dim3(256), 0, st, p->nus.as<uint32_t>(), p->nus9.as<uint32_t>(), batch * 8);     // multipliers: Montgomery form
     TRY(launch(ctx, "k_ring_aggpoly", [&] {
         hipLaunchKernelGGL(dr::k_ring_aggpoly, dim3(div_up(batch * qn, 256)), dim3(256), 0, st, p->fixed_coef.as<uint32_t>(), p->cols.as<uint32_t>(),
-                           p->q.as<uint32_t>(), p->nus.as<uint32_t>(), n, (uint32_t)batch, p->aggo.as<uint32_t>());
+                           p->q.as<uint32_t>(), p->nus9.as<uint32_t>(), n, (uint32_t)batch, p->aggo.as<uint32_t>());
     }));
     auto syndiv = [&](const uint32_t* poly, uint32_t len, int mul_omega, uint32_t* quot, uint32_t nch) -> int {
         return launch(ctx, "k_syndiv", [&] {

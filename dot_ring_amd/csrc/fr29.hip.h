@@ -172,6 +172,86 @@ DR_DEV void canon29(const Fs& a, uint32_t (&w)[8]) {
     for (int j = 0; j < 8; j++) w[j] = x[j];
 }
 
+// ---------------------------------------------------------------- raw 9-word records
+// Prover-internal buffers (NTT tiles, the 4N-domain evaluations between the NTT and the constraint kernel, per-proof scalars)
+// keep the nine limbs as they are — 36 bytes per element, no canonicalisation on either side.  What a record holds (normal,
+// carried, value bound) is part of the producing kernel's contract.
+DR_DEV Fs fs_load9(const uint32_t* p) {
+    Fs r;
+#pragma unroll
+    for (int i = 0; i < L29; i++) r.l[i] = (int32_t)p[i];
+    return r;
+}
+DR_DEV void fs_store9(uint32_t* p, const Fs& v) {
+#pragma unroll
+    for (int i = 0; i < L29; i++) p[i] = (uint32_t)v.l[i];
+}
+// kernel-argument copy of an Fs value
+struct FsArg {
+    int32_t l[L29];
+};
+DR_DEV Fs from_arg(const FsArg& a) {
+    Fs r;
+#pragma unroll
+    for (int i = 0; i < L29; i++) r.l[i] = a.l[i];
+    return r;
+}
+// Any lazy value with |value| < 30 p and limbs within int32 -> carried limbs (0..7 in [0, 2^29), signed top limb) and
+// |value| < 0.51 p: q = round(value / p) from the top limb (p / 2^232 = 7597479.33; the low limbs add less than one unit of it),
+// then value - q p with 64-bit limb arithmetic (|q| P[i] does not fit 32 bits).  ~75 instructions: where a growing sum leaves a
+// kernel without passing through a product (the forward NTT's last stage).
+DR_DEV Fs reduce_small(const Fs& a) {
+    const Fs c = carry(a);
+    const int32_t q = __float2int_rn((float)c.l[L29 - 1] * (1.0f / 7597479.5f));
+    Fs r;
+    int64_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < L29 - 1; i++) {
+        const int64_t t = (int64_t)c.l[i] - (int64_t)q * (int64_t)Fr29Params::P[i] + cy;
+        r.l[i] = (int32_t)(t & (int64_t)M29);
+        cy = t >> 29;
+    }
+    r.l[L29 - 1] = c.l[L29 - 1] - q * (int32_t)Fr29Params::P[L29 - 1] + (int32_t)cy;
+    return r;
+}
+
+// the same for a value known to lie in (-p, 3p) — every product of normal operands, and a product plus a canonical value: + p,
+// then 2p and p come off where they fit
+// (two conditional subtractions instead of four: ~70 instructions against ~120)
+DR_DEV void canon29_small(const Fs& a, uint32_t (&w)[8]) {
+    using FP = Fr29Params;
+    const Fs c = carry(a);
+    uint32_t u[L29], cy = 0;
+#pragma unroll
+    for (int i = 0; i < L29; i++) {
+        u[i] = (uint32_t)c.l[i] + FP::P[i] + cy;
+        if (i < L29 - 1) { cy = u[i] >> 29; u[i] &= M29; }
+    }
+    uint32_t x[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) x[j] = 0;
+#pragma unroll
+    for (int i = 0; i < L29; i++) {
+        const int bit = 29 * i, j = bit >> 5, sh = bit & 31;
+        x[j] |= u[i] << sh;
+        if (sh > 3 && j + 1 < 9) x[j + 1] |= u[i] >> (32 - sh);
+    }
+#pragma unroll
+    for (int s = 1; s >= 0; s--) {
+        uint32_t d[9], borrow = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            uint32_t pw = j < 8 ? FrParams::P[j] << s : 0u;
+            if (s > 0 && j > 0) pw |= FrParams::P[j - 1] >> (32 - s);
+            d[j] = subb(x[j], pw, borrow);
+        }
+#pragma unroll
+        for (int j = 0; j < 9; j++) x[j] = borrow ? x[j] : d[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) w[j] = x[j];
+}
+
 // The 8-word containers of field.hip.h (Fr = Fe<FrParams>) carry values between lanes, LDS and memory; which form the words
 // are in is said by the function: pack / unpack keep the Montgomery form (2^261), fs_from_std / fs_to_std convert standard form.
 DR_DEV Fr pack(const Fs& a) {

@@ -50,15 +50,17 @@ DR_DEV bool fr_sqrt(const Fs& x, Fs& root) {
 }
 
 // Diagnostic (dr_fr_ops_selftest): the unsaturated field arithmetic of fr29.hip.h on its own, one lane per (a, b) pair of
-// standard-form elements.  out[i] = nine 32-byte standard-form records: a b, a^2, a + b, a - b, a^-1 (0 for 0),
+// standard-form elements.  out[i] = twelve 32-byte standard-form records: a b, a^2, a + b, a - b, a^-1 (0 for 0),
 // (a + b)(a - b) through two lazy operands, a * (curve coefficient -5) through the shifted addition chain of the group
-// law (3p - 5a), a b + b a through the fused product, sqrt(a) (zero when a is not a square); flag[i] = 1 iff a is a square.
+// law (3p - 5a), a b + b a through the fused product, sqrt(a) (zero when a is not a square); flag[i] = 1 iff a is a square;
+// then the helpers of the NTT / polynomial kernels: a b + a through canon29_small, a + 27 b and a - 28 b through reduce_small
+// (lazy sums of up to 28 p) and canon29_small.
 __global__ void k_fr_ops_selftest(const uint32_t* __restrict__ a_std, const uint32_t* __restrict__ b_std, uint32_t n, uint32_t* __restrict__ out,
                                   uint32_t* __restrict__ flag) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Fs a = fs_from_std(load_fr_std(a_std + (size_t)i * 8)), b = fs_from_std(load_fr_std(b_std + (size_t)i * 8));
-    uint32_t* o = out + (size_t)i * 72;
+    uint32_t* o = out + (size_t)i * 96;
     store_fr_std(o, fs_to_std(mul(a, b)));
     store_fr_std(o + 8, fs_to_std(sqr(a)));
     store_fr_std(o + 16, fs_to_std(add(a, b)));
@@ -71,6 +73,21 @@ __global__ void k_fr_ops_selftest(const uint32_t* __restrict__ a_std, const uint
     const bool square = fr_sqrt(a, r);
     store_fr_std(o + 64, fs_to_std(square ? r : Fs::zero()));
     flag[i] = square ? 1u : 0u;
+    // records 9..11 are written in the Montgomery form they are computed in (the host divides by 2^261)
+    Fr w;
+    canon29_small(add(mul(a, b), a), w.l);
+    store_fr_std(o + 72, w);
+    Fs up = a, down = a;
+#pragma unroll 1
+    for (int k = 0; k < 28; k++) {
+        if (k < 27) up = add(up, b);
+        down = sub(down, b);
+        if ((k & 1) == 1) { up = carry(up); down = carry(down); }
+    }
+    canon29_small(reduce_small(up), w.l);
+    store_fr_std(o + 80, w);
+    canon29_small(reduce_small(down), w.l);
+    store_fr_std(o + 88, w);
 }
 
 // Elligator 2 onto the Montgomery model up to the point (s, t) = (x B_M, y B_M); the inversion 1/(1 + Z u^2) is

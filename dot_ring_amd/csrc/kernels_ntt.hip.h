@@ -2,32 +2,49 @@
 // (dot_ring/ring_proof/polynomial/ntt.pyx:116-163) + bls_scalar_ntt_round (bls12_381_scalar.c:333-356):
 // out[i] = sum_j in[j] * omega^(i*j), natural order in and out, optional scaling of every output.
 //
-// Structure: decimation in time over the bit-reversed input, exactly the butterfly network of the reference,
-// but staged through LDS: pass A loads a tile of 2^10 consecutive positions of the bit-reversed array (a gather
-// of 32-B elements), runs stages 1..10 in LDS (limb-major layout: lane i touches word [limb][i], conflict-free),
-// and streams the tile out; each later pass takes the next <= 4 index bits as "rows" of a (rows x 64 columns)
-// tile so that global accesses stay 2 KiB-contiguous.  Twiddles omega^j, j < n/2, are a per-(n, omega) table in
-// HBM (Montgomery form), cached in the context.  Elements are converted to Montgomery form on the first load
-// and back (fused with the optional scale) on the last store, so a transform moves 2 x 32 B per element per pass.
+// Structure: decimation in time over the bit-reversed input, exactly the butterfly network of the reference, staged through
+// LDS: pass A loads a tile of 2^10 consecutive positions of the bit-reversed array (a gather of whole elements), runs stages
+// 1..10 in LDS (limb-major layout: lane i touches word [limb][i], conflict-free) and streams the tile out; each later pass takes
+// the next <= 4 index bits as "rows" of a (rows x 64 columns) tile so that global accesses stay 2 KiB-contiguous.
+//
+// Arithmetic (round 3): the UNSATURATED field of fr29.hip.h — nine signed 29-bit limbs, Montgomery R = 2^261, lazy reduction.
+// A butterfly is one 206-instruction product, nine additions, nine subtractions and ~1.5 carry passes (25 instructions each)
+// where the saturated 8 x 32-bit field needed a 305-instruction product and two ~24-instruction modular add / sub: ~262
+// against ~353 instructions.  Nothing is canonicalised between stages:
+//   * LDS tiles and the intermediate arrays between passes hold the nine limbs RAW (36 bytes per element);
+//   * values grow by at most 1.04 p per stage along a run of "upper" butterfly inputs — after 24 stages still below 26 p, and a
+//     product takes operands up to 33 p (|a| |b| <= 35 p^2 with a normal twiddle);
+//   * limbs: the operand of the twiddle product is carried on load in every stage, the other operand in every second stage, so a
+//     limb is the sum of at most three 29-bit values and a carried one (|limb| < 2^31);
+//   * the last stage's outputs leave through a product (scaled / standard-form output: mul by the factor, then the canonical
+//     8 words) or through reduce_small (raw 9-limb output for the constraint kernel: |value| < 0.51 p).
+// Element formats at the kernel boundary: STD8 = 8 canonical words, standard form (the C ABI, coefficient arrays); FS9 = raw
+// 9-limb records in Montgomery form (prover-internal: the 4N-domain evaluations).  Twiddles omega^j, j < n/2, are a per-(n, omega)
+// table of 48-byte records (9 limbs + padding, three 16-byte loads) in HBM, cached in the context.
+// Radix-4 butterflies would not save products here: a prime field has no free multiplication by the fourth root of unity, so the
+// four points of two fused stages cost four products either way; what fusing saves is LDS traffic, which is not the bound.
 #pragma once
 #include "dev_types.hpp"
 #include "curve.hip.h"
 #include "hostmath.hpp"
+#include "ring_body.hip.h"
 
 namespace dr {
 
 constexpr int NTT_LOG_TILE = 10, NTT_TILE = 1 << NTT_LOG_TILE, NTT_BLOCK = 256;
 constexpr int NTT_COLS = 64, NTT_MAX_ROW_BITS = 4;
+constexpr int NTT_TW_WORDS = 12;                     // a twiddle record: 9 limbs + 3 words of padding (16-byte loads)
+enum { NTT_FMT_STD8 = 0, NTT_FMT_FS9 = 1 };
 
-DR_DEV Fr lds_get(const uint32_t* t, int i) {
-    Fr r;
+DR_DEV Fs lds_get9(const int32_t* t, int i) {
+    Fs r;
 #pragma unroll
-    for (int l = 0; l < 8; l++) r.l[l] = t[l * NTT_TILE + i];
+    for (int l = 0; l < L29; l++) r.l[l] = t[l * NTT_TILE + i];
     return r;
 }
-DR_DEV void lds_put(uint32_t* t, int i, const Fr& v) {
+DR_DEV void lds_put9(int32_t* t, int i, const Fs& v) {
 #pragma unroll
-    for (int l = 0; l < 8; l++) t[l * NTT_TILE + i] = v.l[l];
+    for (int l = 0; l < L29; l++) t[l * NTT_TILE + i] = v.l[l];
 }
 DR_DEV Fr gload_fr(const uint32_t* p) {
     Fr r;
@@ -41,8 +58,17 @@ DR_DEV void gstore_fr(uint32_t* p, const Fr& v) {
     q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
+DR_DEV Fs tw_load(const uint32_t* p) {              // a 48-byte twiddle record
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    Fs r;
+    r.l[0] = (int32_t)a.x; r.l[1] = (int32_t)a.y; r.l[2] = (int32_t)a.z; r.l[3] = (int32_t)a.w;
+    r.l[4] = (int32_t)b.x; r.l[5] = (int32_t)b.y; r.l[6] = (int32_t)b.z; r.l[7] = (int32_t)b.w;
+    r.l[8] = (int32_t)c.x;
+    return r;
+}
 
-struct FrArg {   // kernel-argument copy of a field element
+struct FrArg {   // kernel-argument copy of a field element (8 words: whatever form the caller says)
     uint32_t l[8];
 };
 DR_DEV Fr from_arg(const FrArg& a) {
@@ -52,36 +78,62 @@ DR_DEV Fr from_arg(const FrArg& a) {
     return r;
 }
 
-// tw[j] = omega^j (Montgomery), j < count
-__global__ void k_ntt_twiddles(uint32_t* tw, uint32_t count, FrArg omega_mont) {
+// an element of the input array in the given format -> Fs, Montgomery form (STD8: one product with R^2; FS9: as it lies)
+DR_DEV Fs ntt_load(const uint32_t* base, size_t idx, int fmt) {
+    if (fmt == NTT_FMT_FS9) return fs_load9(base + idx * L29);
+    return fs_from_std(gload_fr(base + idx * 8));
+}
+// the value a pass leaves behind.  final == 0: raw limbs for the next pass.  final == 1: the transform's output — STD8: v * factor
+// with the factor in STANDARD form (Montgomery x standard -> standard), canonical words; FS9 with a factor: v * factor (Montgomery),
+// FS9 without: reduce_small.
+DR_DEV void ntt_store(uint32_t* base, size_t idx, const Fs& v, int final, int fmt, int has_factor, const Fs& factor) {
+    if (!final) { fs_store9(base + idx * L29, v); return; }
+    if (fmt == NTT_FMT_STD8) {
+        Fr o;
+        canon29_small(mul(carry(v), factor), o.l);
+        gstore_fr(base + idx * 8, o);
+        return;
+    }
+    fs_store9(base + idx * L29, has_factor ? mul(carry(v), factor) : reduce_small(v));
+}
+
+// tw[j] = omega^j (Montgomery 2^261), j < count, as 12-word records
+__global__ void k_ntt_twiddles(uint32_t* tw, uint32_t count, FsArg omega_mont) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
-    Fr w = from_arg(omega_mont), r = Fr::one();
+    Fs w = from_arg(omega_mont), r = Fs::one();
     for (uint32_t e = j; e; e >>= 1) {
         if (e & 1) r = mul(r, w);
         w = sqr(w);
     }
-    gstore_fr(tw + (size_t)j * 8, r);
+    uint32_t* o = tw + (size_t)j * NTT_TW_WORDS;
+#pragma unroll
+    for (int i = 0; i < L29; i++) o[i] = (uint32_t)r.l[i];
+    o[9] = o[10] = o[11] = 0;
 }
 
+// one butterfly on (u, v) with twiddle w (trivial: w = 1, no product); carry_u: also carry the upper operand (every second
+// stage) — ring_body.hip.h: body_butterfly, whose limb and value bounds the host interval check walks through 24 stages
+DR_DEV void ntt_butterfly(Fs& u, Fs& v, const Fs& w, bool trivial, bool carry_u) { body_butterfly(u, v, w, trivial, carry_u); }
+
 // Pass A: stages 1..S (S = min(k, 10)) on tile `blockIdx.x` of transform `blockIdx.y`.
-// src is read at bit-reversed positions, dst written contiguously (src == dst is allowed only when S == k,
-// where one workgroup owns the whole transform).
-__global__ __launch_bounds__(NTT_BLOCK) void k_ntt_local(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
-                                                         const uint32_t* __restrict__ tw, int k, int S, int final_pass,
-                                                         FrArg out_factor, int in_mont, int pad) {
-    __shared__ uint32_t tile[8 * NTT_TILE];
+// src is read at bit-reversed positions, dst written contiguously (src == dst is allowed only when S == k, where one workgroup
+// owns the whole transform and the formats have the same element size or the whole tile is loaded before anything is stored).
+__global__ __launch_bounds__(NTT_BLOCK) void k_ntt_local(const uint32_t* src, uint32_t* dst,
+                                                         const uint32_t* __restrict__ tw, int k, int S, int final_pass, int fmt_in, int fmt_out,
+                                                         int has_factor, FsArg out_factor, int pad) {
+    __shared__ int32_t tile[L29 * NTT_TILE];
     const size_t n = (size_t)1 << k;
     const int tsize = 1 << S;
     const size_t xform = blockIdx.y, tbase = (size_t)blockIdx.x * tsize;
-    const uint32_t* in = src + xform * (n >> pad) * 8;
-    uint32_t* out = dst + xform * n * 8;
+    const size_t in_elem = fmt_in == NTT_FMT_FS9 ? L29 : 8;
+    const uint32_t* in = src + xform * (n >> pad) * in_elem;
+    uint32_t* out = dst + xform * n * (final_pass && fmt_out == NTT_FMT_STD8 ? 8 : L29);
     if (pad == 0) {
         for (int i = threadIdx.x; i < tsize; i += NTT_BLOCK) {
             size_t pos = tbase + i;
             size_t rev = (size_t)(__brevll((unsigned long long)pos) >> (64 - k));
-            Fr v = gload_fr(in + rev * 8);
-            lds_put(tile, i, in_mont ? v : to_mont(v));     // in_mont: the producer already wrote Montgomery form
+            lds_put9(tile, i, ntt_load(in, rev, fmt_in));
         }
     } else {
         // the input is a polynomial of n / 2^pad coefficients, zero-padded to n: in bit-reversed order only every 2^pad-th
@@ -91,73 +143,69 @@ __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_local(const uint32_t* __restr
         for (int i = threadIdx.x; i < (tsize >> pad); i += NTT_BLOCK) {
             size_t grp = (tbase >> pad) + i;
             size_t rev = (size_t)(__brevll((unsigned long long)grp) >> (64 - (k - pad)));
-            Fr v = gload_fr(in + rev * 8);
-            if (!in_mont) v = to_mont(v);
-            for (int c = 0; c < (1 << pad); c++) lds_put(tile, (i << pad) + c, v);
+            const Fs v = ntt_load(in, rev, fmt_in);
+            for (int c = 0; c < (1 << pad); c++) lds_put9(tile, (i << pad) + c, v);
         }
     }
     __syncthreads();
     for (int s = 1 + pad; s <= S; s++) {
         const int half = 1 << (s - 1);
+        const bool cu = ((s - pad) & 1) != 0;       // the first stage run here and every second one after it carry both operands
         for (int t = threadIdx.x; t < tsize / 2; t += NTT_BLOCK) {
             int j = t & (half - 1);
             int base = (t >> (s - 1)) << s;
-            Fr u = lds_get(tile, base + j), v = lds_get(tile, base + j + half);
-            if (s > 1) {                        // stage 1: every twiddle is w^0 = 1 (wave-uniform: no product at all)
-                Fr w = gload_fr(tw + ((size_t)j << (k - s)) * 8);
-                v = mul(w, v);
-            }
-            lds_put(tile, base + j, add(u, v));
-            lds_put(tile, base + j + half, sub(u, v));
+            Fs u = lds_get9(tile, base + j), v = lds_get9(tile, base + j + half);
+            Fs w = Fs::zero();
+            if (s > 1) w = tw_load(tw + ((size_t)j << (k - s)) * NTT_TW_WORDS);   // stage 1: every twiddle is w^0 = 1 (wave-uniform: no product at all)
+            ntt_butterfly(u, v, w, s == 1, cu);
+            lds_put9(tile, base + j, u);
+            lds_put9(tile, base + j + half, v);
         }
         __syncthreads();
     }
-    Fr f = from_arg(out_factor);
-    for (int i = threadIdx.x; i < tsize; i += NTT_BLOCK) {
-        Fr v = lds_get(tile, i);
-        if (final_pass) v = mul(v, f);          // Montgomery * standard-form factor -> standard form of v*factor
-        gstore_fr(out + (tbase + i) * 8, v);
-    }
+    const Fs f = from_arg(out_factor);
+    for (int i = threadIdx.x; i < tsize; i += NTT_BLOCK) ntt_store(out, tbase + i, lds_get9(tile, i), final_pass, fmt_out, has_factor, f);
 }
 
-// Later passes: stages lo+1..hi (hi - lo <= 4) in place.  Tile = 2^(hi-lo) rows x 64 columns; element position
-// p = (high * 2^(hi-lo) + r) * 2^lo + low, the workgroup owns a fixed `high`, 64 consecutive `low` values.
-__global__ __launch_bounds__(NTT_BLOCK) void k_ntt_strided(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw,
-                                                           int k, int lo, int hi, int final_pass, FrArg out_factor) {
-    __shared__ uint32_t tile[8 * NTT_TILE];
+// Later passes: stages lo+1..hi (hi - lo <= 4).  Tile = 2^(hi-lo) rows x 64 columns; element position
+// p = (high * 2^(hi-lo) + r) * 2^lo + low, the workgroup owns a fixed `high`, 64 consecutive `low` values.  Reads raw 9-limb
+// records from `src`, writes the same positions of `dst` (src == dst unless this is the final pass of a STD8 transform).
+__global__ __launch_bounds__(NTT_BLOCK) void k_ntt_strided(const uint32_t* src, uint32_t* dst, const uint32_t* __restrict__ tw,
+                                                           int k, int lo, int hi, int final_pass, int fmt_out, int has_factor, FsArg out_factor) {
+    __shared__ int32_t tile[L29 * NTT_TILE];
     const size_t n = (size_t)1 << k;
     const int rb = hi - lo, rows = 1 << rb;
     const size_t low_blocks = ((size_t)1 << lo) / NTT_COLS;
     const size_t high = blockIdx.x / low_blocks, low0 = (blockIdx.x % low_blocks) * NTT_COLS;
-    uint32_t* d = data + (size_t)blockIdx.y * n * 8;
+    const uint32_t* in = src + (size_t)blockIdx.y * n * L29;
+    uint32_t* out = dst + (size_t)blockIdx.y * n * (final_pass && fmt_out == NTT_FMT_STD8 ? 8 : L29);
     auto pos_of = [&](int r, int c) -> size_t { return (((high << rb) + r) << lo) + low0 + c; };
     for (int e = threadIdx.x; e < rows * NTT_COLS; e += NTT_BLOCK) {
         int r = e / NTT_COLS, c = e % NTT_COLS;
-        lds_put(tile, e, gload_fr(d + pos_of(r, c) * 8));
+        lds_put9(tile, e, fs_load9(in + pos_of(r, c) * L29));
     }
     __syncthreads();
     for (int s = lo + 1; s <= hi; s++) {
         const int hb = s - 1 - lo;                 // row bit that this stage pairs
+        const bool cu = ((s - lo) & 1) != 0;
         for (int t = threadIdx.x; t < rows * NTT_COLS / 2; t += NTT_BLOCK) {
             int c = t % NTT_COLS, rr = t / NTT_COLS;            // rr enumerates rows with bit hb cleared
             int r0 = ((rr >> hb) << (hb + 1)) | (rr & ((1 << hb) - 1));
             int r1 = r0 | (1 << hb);
             size_t p0 = pos_of(r0, c);
             size_t j = p0 & (((size_t)1 << (s - 1)) - 1);
-            Fr u = lds_get(tile, r0 * NTT_COLS + c), v = lds_get(tile, r1 * NTT_COLS + c);
-            Fr w = gload_fr(tw + (j << (k - s)) * 8);
-            v = mul(w, v);
-            lds_put(tile, r0 * NTT_COLS + c, add(u, v));
-            lds_put(tile, r1 * NTT_COLS + c, sub(u, v));
+            Fs u = lds_get9(tile, r0 * NTT_COLS + c), v = lds_get9(tile, r1 * NTT_COLS + c);
+            const Fs w = tw_load(tw + (j << (k - s)) * NTT_TW_WORDS);
+            ntt_butterfly(u, v, w, false, cu);
+            lds_put9(tile, r0 * NTT_COLS + c, u);
+            lds_put9(tile, r1 * NTT_COLS + c, v);
         }
         __syncthreads();
     }
-    Fr f = from_arg(out_factor);
+    const Fs f = from_arg(out_factor);
     for (int e = threadIdx.x; e < rows * NTT_COLS; e += NTT_BLOCK) {
         int r = e / NTT_COLS, c = e % NTT_COLS;
-        Fr v = lds_get(tile, e);
-        if (final_pass) v = mul(v, f);
-        gstore_fr(d + pos_of(r, c) * 8, v);
+        ntt_store(out, pos_of(r, c), lds_get9(tile, e), final_pass, fmt_out, has_factor, f);
     }
 }
 
@@ -170,17 +218,44 @@ inline FrArg to_arg(const drh::Fr& v) {   // raw limbs (whatever form v is in)
     }
     return a;
 }
+// 256-bit little-endian limbs (a canonical value below p) -> the nine 29-bit limbs of an Fs
+inline FsArg fs_limbs_of(const uint64_t (&w)[4]) {
+    FsArg a;
+    for (int i = 0; i < L29; i++) {
+        const int bit = 29 * i, j = bit >> 6, sh = bit & 63;
+        uint64_t v = w[j] >> sh;
+        if (sh > 35 && j + 1 < 4) v |= w[j + 1] << (64 - sh);
+        a.l[i] = (int32_t)(v & M29);
+    }
+    return a;
+}
+// a host field element -> kernel argument in the device's Montgomery form (2^261): the host keeps x 2^256, and (32 x) 2^256 has
+// the words of x 2^261
+inline FsArg fs_arg_mont(const drh::Fr& v) {
+    const drh::Fr t = v * drh::Fr::from_u64(32);
+    uint64_t w[4] = {t.l[0], t.l[1], t.l[2], t.l[3]};
+    return fs_limbs_of(w);
+}
+// ... and as the plain integer (standard form) in limbs
+inline FsArg fs_arg_std(const drh::Fr& v) {
+    const drh::Fr t = v.from_mont();
+    uint64_t w[4] = {t.l[0], t.l[1], t.l[2], t.l[3]};
+    return fs_limbs_of(w);
+}
 
-// in_mont / out_mont: the data is (left) in Montgomery form instead of standard form — producers and consumers inside the
-// prover that work in Montgomery form anyway save the two conversions (one product per element each).
+// One batched transform.  fmt_in / fmt_out: element format of the input and of the output (NTT_FMT_STD8: 8 canonical words in
+// standard form — the C ABI and the coefficient arrays; NTT_FMT_FS9: raw 9-limb Montgomery records — what the constraint kernel
+// reads and writes).  d_src (optional): the input lives in another buffer, n / 2^pad elements per transform (zero-padded to n in
+// effect); without it the transform runs on d_data in place.  Intermediate arrays between passes are raw 9-limb records: they
+// live in d_data when the output is FS9 and the input comes from d_src, in `tmp` otherwise.
 template <class Launch, class ScratchT, class Sync>
 int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp, uint32_t* d_data, unsigned k, size_t batch,
-            const drh::Fr& omega_mont, const drh::Fr* scale_mont, Sync&& sync, bool in_mont = false, bool out_mont = false,
+            const drh::Fr& omega_mont, const drh::Fr* scale_mont, Sync&& sync, int fmt_in = NTT_FMT_STD8, int fmt_out = NTT_FMT_STD8,
             const uint32_t* d_src = nullptr, int pad = 0) {
-    // d_src (optional): the input lives in another buffer, n / 2^pad coefficients per transform (zero-padded to n in effect);
-    // the first pass then writes straight into d_data and no temporary / copy back is needed
     const size_t n = (size_t)1 << k;
     if (batch > 65535) return DR_ERR_INVALID;
+    // value growth (ring_bounds_check.cpp): raw sums as input, or raw output without a final product, are covered up to 16 stages
+    if ((fmt_in == NTT_FMT_FS9 || (fmt_out == NTT_FMT_FS9 && !scale_mont)) && k > 16) return DR_ERR_INVALID;
     uint32_t* d_tw = nullptr;
     for (auto& e : cache.entries)
         if (e.log2n == k && e.omega == omega_mont) d_tw = e.d_tw;
@@ -190,50 +265,49 @@ int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp,
             cache.entries.erase(cache.entries.begin());
         }
         size_t cnt = n / 2;
-        if (hipMalloc((void**)&d_tw, cnt * 32) != hipSuccess) return DR_ERR_NOMEM;
-        FrArg wa = to_arg(omega_mont);
+        if (hipMalloc((void**)&d_tw, cnt * NTT_TW_WORDS * 4) != hipSuccess) return DR_ERR_NOMEM;
+        FsArg wa = fs_arg_mont(omega_mont);
         int rc = launch("k_ntt_twiddles", [&] {
             hipLaunchKernelGGL(k_ntt_twiddles, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, d_tw, (uint32_t)cnt, wa);
         });
         if (rc != DR_OK) return rc;
         cache.entries.push_back({k, omega_mont, d_tw});
     }
-    // output factor in STANDARD form: Montgomery value * standard factor = standard(value * factor)
-    // (Montgomery output: Montgomery value * Montgomery factor = Montgomery(value * factor); without a scale the final
-    // product is skipped altogether)
-    drh::Fr factor_std = out_mont ? (scale_mont ? *scale_mont : drh::Fr::one()) : (scale_mont ? scale_mont->from_mont() : drh::Fr::one().from_mont());
-    FrArg fa = to_arg(factor_std);
-    const int do_final = (out_mont && !scale_mont) ? 0 : 1;
-    const int im = in_mont ? 1 : 0;
+    // STD8 output: the factor in STANDARD form (Montgomery value x standard factor = standard(value x factor)), 1 without a scale;
+    // FS9 output: the factor in Montgomery form, or none
+    const int has_factor = (fmt_out == NTT_FMT_STD8 || scale_mont) ? 1 : 0;
+    const FsArg fa = fmt_out == NTT_FMT_STD8 ? fs_arg_std(scale_mont ? *scale_mont : drh::Fr::one())
+                                             : fs_arg_mont(scale_mont ? *scale_mont : drh::Fr::one());
     const int S = (int)std::min<unsigned>(k, NTT_LOG_TILE);
+    const uint32_t* src = d_src ? d_src : d_data;
     if ((int)k == S) {
         int rc = launch("k_ntt_local", [&] {
-            hipLaunchKernelGGL(k_ntt_local, dim3(1, (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_src ? d_src : d_data, d_data, d_tw, (int)k, S, do_final, fa, im, pad);
+            hipLaunchKernelGGL(k_ntt_local, dim3(1, (unsigned)batch), dim3(NTT_BLOCK), 0, st, src, d_data, d_tw, (int)k, S, 1, fmt_in, fmt_out, has_factor, fa, pad);
         });
         if (rc != DR_OK) return rc;
         return sync();
     }
-    int rc = DR_OK;
-    uint32_t* d_tmp = d_data;
-    if (!d_src) {
-        rc = tmp.reserve(n * batch * 32);
+    // several passes: where do the raw intermediates live?
+    uint32_t* d_mid = d_data;
+    if (fmt_out == NTT_FMT_STD8 || !d_src) {
+        int rc = tmp.reserve(n * batch * (size_t)L29 * 4);
         if (rc != DR_OK) return rc;
-        d_tmp = reinterpret_cast<uint32_t*>(tmp.p);
+        d_mid = reinterpret_cast<uint32_t*>(tmp.p);
     }
-    rc = launch("k_ntt_local", [&] {
-        hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> S), (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_src ? d_src : d_data, d_tmp, d_tw, (int)k, S, 0, fa, im, pad);
+    int rc = launch("k_ntt_local", [&] {
+        hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> S), (unsigned)batch), dim3(NTT_BLOCK), 0, st, src, d_mid, d_tw, (int)k, S, 0, fmt_in, fmt_out, has_factor, fa, pad);
     });
     if (rc != DR_OK) return rc;
     for (int lo = S; lo < (int)k; lo += NTT_MAX_ROW_BITS) {
         int hi = std::min<int>((int)k, lo + NTT_MAX_ROW_BITS);
-        int fin = hi == (int)k ? do_final : 0;
+        int fin = hi == (int)k ? 1 : 0;
         unsigned blocks = (unsigned)(n >> (hi - lo) >> 6);    // tiles per transform
+        uint32_t* d_out = fin ? d_data : d_mid;
         rc = launch("k_ntt_strided", [&] {
-            hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_tmp, d_tw, (int)k, lo, hi, fin, fa);
+            hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_mid, d_out, d_tw, (int)k, lo, hi, fin, fmt_out, has_factor, fa);
         });
         if (rc != DR_OK) return rc;
     }
-    if (d_tmp != d_data && hipMemcpyAsync(d_data, d_tmp, n * batch * 32, hipMemcpyDeviceToDevice, st) != hipSuccess) return DR_ERR_DEVICE;
     return sync();
 }
 

@@ -6,9 +6,12 @@
 //   Horner evaluations         dot_ring/ring_proof/polynomial/ops.py:170-176 (proof_builder.py:235-250)
 //   linearisation / nu-aggregation  proof_builder.py:197-233, 288-315
 //   synthetic division         dot_ring/ring_proof/pcs/utils.py:27-35
-// Conventions: per-proof data arrays cross kernel boundaries in STANDARD form (32-byte little-endian field
-// elements — what the NTT and MSM kernels consume); per-ring tables (fixed columns on the 4N domain, Lagrange
-// rows, x - w^(N-4), ring points) are kept in MONTGOMERY form.  Batch-major layouts: [proof][column][index].
+// Conventions: coefficient arrays cross kernel boundaries in STANDARD form (32-byte little-endian field elements — what the
+// MSM kernels consume).  The hot kernels compute on the unsaturated field of fr29.hip.h (round 3: K7 constraints, K8 quotient /
+// evaluation / linearisation / aggregation; bodies and their bounds: ring_body.hip.h): the 4N-domain evaluations between the
+// forward NTT, the constraint kernel and the inverse NTT, the per-ring tables on the 4N domain and the per-proof scalars that
+// multiply whole vectors are raw 9-limb records in Montgomery form (2^261) — "FS9", 36 bytes.  Witness generation, the setup
+// kernels and synthetic division keep the saturated 8-word field (Montgomery 2^256).  Batch-major layouts: [proof][column][index].
 #pragma once
 #include "kernels_te.hip.h"
 #include "kernels_ntt.hip.h"
@@ -74,6 +77,16 @@ __global__ void k_fr_to_mont(uint32_t* data, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) gstore_fr(data + i * 8, to_mont(gload_fr(data + i * 8)));
 }
+// standard-form 8-word elements -> FS9 records (Montgomery 2^261, normal limbs): per-ring tables once per ring, alphas / nus once per batch
+__global__ void k_fr_std_to_fs9(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) fs_store9(dst + i * L29, fs_from_std(gload_fr(src + i * 8)));
+}
+// 8-word Montgomery (2^256) elements -> FS9 records
+__global__ void k_fr_mont_to_fs9(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) fs_store9(dst + i * L29, from_mont256(gload_fr(src + i * 8)));
+}
 // not_last[i] = w4^i - w_N^(N-4)   (Montgomery), i < m
 __global__ void k_ring_not_last(uint32_t* __restrict__ out, uint32_t m, FrArg w4_mont, FrArg last_root_mont) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,6 +133,8 @@ struct RingConsts {
     FrArg tail[4];                       // (X - w^-1)(X - w^-2)(X - w^-3) coefficients, Montgomery, low first
     FrArg omega;                         // w_N, Montgomery
     FrArg last_x;                        // w_N^(N-4), Montgomery
+    FsArg tail9[4];                      // the tail coefficients and w_N again as FS9 arguments (Montgomery 2^261)
+    FsArg omega9;
 };
 
 // One lane per proof: the conditional-sum accumulator visits at most 255 distinct values (seed, then one addition
@@ -376,75 +391,72 @@ __global__ void k_ring_relations(const uint32_t* __restrict__ chain_aff, const u
 // ---- K7: the seven constraints, fused with the alpha aggregation ------------------------------------------------
 // One lane per (proof, point of the 4N domain).  Reads the four witness columns at i and at i + 4 (the w_N shift),
 // the per-ring tables at i, and writes sum_k alpha_k * c_k(i)   (constraints.py:83-151, proof_builder.py:175-180).
+// Arithmetic: ring_body.hip.h body_constraints on the unsaturated field — 23 products of 206 instructions (two of them fused),
+// additions and subtractions of 9, five carry passes: ~5.2 k instructions per point where the saturated field took ~7.7 k.
 template <int CV>
-__global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __restrict__ wit4 /* [B][4][m][8] Montgomery (NTT output): b, accip, accx, accy */,
-                                                          const uint32_t* __restrict__ fixed4 /* [3][m][8] mont: px, py, s */,
-                                                          const uint32_t* __restrict__ lag4 /* [2][m][8] mont: L0, Llast */,
-                                                          const uint32_t* __restrict__ not_last /* [m][8] mont */,
-                                                          const uint32_t* __restrict__ alphas /* [B][7][8] Montgomery (converted once per batch) */,
-                                                          const uint32_t* __restrict__ alpha_aux /* [B][2][8] Montgomery: k_ring_alpha_aux */,
-                                                          RingConsts rc, uint32_t batch, uint32_t* __restrict__ agg /* [B][m][8] Montgomery */) {
+__global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __restrict__ wit4 /* [B][4][m] FS9 (forward NTT output): b, accip, accx, accy */,
+                                                          const uint32_t* __restrict__ fixed4 /* [3][m] FS9: px, py, s */,
+                                                          const uint32_t* __restrict__ lag4 /* [2][m] FS9: L0, Llast */,
+                                                          const uint32_t* __restrict__ not_last /* [m] FS9 */,
+                                                          const uint32_t* __restrict__ alphas /* [B][7] FS9 (converted once per batch) */,
+                                                          const uint32_t* __restrict__ alpha_aux /* [B][2] FS9: k_ring_alpha_aux */,
+                                                          RingConsts rc, uint32_t batch, uint32_t* __restrict__ agg /* [B][m] FS9, raw sums */) {
     const uint32_t m = rc.n * 4;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)batch * m) return;
     uint32_t pid = (uint32_t)(gid / m), i = (uint32_t)(gid % m);
     uint32_t k = i + 4;
     if (k >= m) k -= m;
-    const uint32_t* w = wit4 + (size_t)pid * 4 * m * 8;
-    Fr b = gload_fr(w + ((size_t)0 * m + i) * 8);
-    Fr ip = gload_fr(w + ((size_t)1 * m + i) * 8), ip_n = gload_fr(w + ((size_t)1 * m + k) * 8);
-    Fr x1 = gload_fr(w + ((size_t)2 * m + i) * 8), x3 = gload_fr(w + ((size_t)2 * m + k) * 8);
-    Fr y1 = gload_fr(w + ((size_t)3 * m + i) * 8), y3 = gload_fr(w + ((size_t)3 * m + k) * 8);
-    Fr x2 = gload_fr(fixed4 + ((size_t)0 * m + i) * 8), y2 = gload_fr(fixed4 + ((size_t)1 * m + i) * 8);
-    Fr s = gload_fr(fixed4 + ((size_t)2 * m + i) * 8);
-    Fr l0 = gload_fr(lag4 + (size_t)i * 8), ln = gload_fr(lag4 + ((size_t)m + i) * 8);
-    Fr nl = gload_fr(not_last + (size_t)i * 8);
-    const uint32_t* al = alphas + (size_t)pid * 7 * 8;
-    Fr one = Fr::one();
-    Fr omb = sub(one, b);
-    Fr x1y1 = mul(x1, y1), x2y2 = mul(x2, y2), x1x2 = mul(x1, x2), y1y2 = mul(y1, y2);
-    // 23 products per point (29 when every constraint was evaluated as written): the selector form b*u + (1-b)*v is
-    // v + b*(u - v), and the three boundary constraints share their Lagrange factors (below).
-    // c1 = (accip' - accip - b*s) * nl          (the common factor nl of c1..c3 is applied once, after the alphas)
-    Fr acc = mul(gload_fr(al + 0 * 8), sub(sub(ip_n, ip), mul(b, s)));
-    // c2 = (b*(x3*(y1y2 + a x1x2) - (x1y1 + x2y2)) + (1-b)(x3 - x1)) * nl ,  a = the curve coefficient
-    Fr t2 = sub(mul(x3, add(y1y2, te_mul_a_fr<CV>(x1x2))), add(x1y1, x2y2));
-    Fr v2 = sub(x3, x1);
-    Fr c2 = add(v2, mul(b, sub(t2, v2)));
-    acc = add(acc, mul(gload_fr(al + 1 * 8), c2));
-    // c3 = (b*(y3*(x1y2 - x2y1) - (x1y1 - x2y2)) + (1-b)(y3 - y1)) * nl
-    Fr t3 = sub(mul(y3, sub(mul(x1, y2), mul(x2, y1))), sub(x1y1, x2y2));
-    Fr v3 = sub(y3, y1);
-    Fr c3 = add(v3, mul(b, sub(t3, v3)));
-    acc = add(acc, mul(gload_fr(al + 2 * 8), c3));
-    acc = mul(acc, nl);
-    // c4 = b(1-b)
-    acc = add(acc, mul(gload_fr(al + 3 * 8), mul(b, omb)));
-    // c5/c6 = (acc - seed)*L0 + (acc - (result+seed))*Llast ; c7 = accip*L0 + (accip-1)*Llast.  With A = a5 seed_x + a6 seed_y and
-    // B = a5 r_x + a6 r_y + a7 per proof (k_ring_alpha_aux):  a5 c5 + a6 c6 + a7 c7 = (L0 + Llast)(a5 x1 + a6 y1 + a7 accip) - L0 A - Llast B
-    const uint32_t* ax = alpha_aux + (size_t)pid * 2 * 8;
-    Fr lin = add(add(mul(gload_fr(al + 4 * 8), x1), mul(gload_fr(al + 5 * 8), y1)), mul(gload_fr(al + 6 * 8), ip));
-    acc = add(acc, sub(sub(mul(add(l0, ln), lin), mul(l0, gload_fr(ax))), mul(ln, gload_fr(ax + 8))));
-    gstore_fr(agg + gid * 8, acc);
+    const uint32_t* w = wit4 + (size_t)pid * 4 * m * L29;
+    const Fs b = fs_load9(w + ((size_t)0 * m + i) * L29);
+    const Fs ip = fs_load9(w + ((size_t)1 * m + i) * L29), ip_n = fs_load9(w + ((size_t)1 * m + k) * L29);
+    const Fs x1 = fs_load9(w + ((size_t)2 * m + i) * L29), x3 = fs_load9(w + ((size_t)2 * m + k) * L29);
+    const Fs y1 = fs_load9(w + ((size_t)3 * m + i) * L29), y3 = fs_load9(w + ((size_t)3 * m + k) * L29);
+    const Fs x2 = fs_load9(fixed4 + ((size_t)0 * m + i) * L29), y2 = fs_load9(fixed4 + ((size_t)1 * m + i) * L29);
+    const Fs s = fs_load9(fixed4 + ((size_t)2 * m + i) * L29);
+    const Fs l0 = fs_load9(lag4 + (size_t)i * L29), ln = fs_load9(lag4 + ((size_t)m + i) * L29);
+    const Fs nl = fs_load9(not_last + (size_t)i * L29);
+    const uint32_t* al = alphas + (size_t)pid * 7 * L29;
+    const uint32_t* ax = alpha_aux + (size_t)pid * 2 * L29;
+    const Fs acc = body_constraints<CV>(b, ip, ip_n, x1, x3, y1, y3, x2, y2, s, l0, ln, nl, fs_load9(al), fs_load9(al + L29), fs_load9(al + 2 * L29),
+                                        fs_load9(al + 3 * L29), fs_load9(al + 4 * L29), fs_load9(al + 5 * L29), fs_load9(al + 6 * L29), fs_load9(ax),
+                                        fs_load9(ax + L29));
+    fs_store9(agg + gid * L29, acc);
 }
 
-// per proof: A = a5 seed_x + a6 seed_y, B = a5 r_x + a6 r_y + a7 (Montgomery; alphas already converted) for k_ring_constraints
+// per proof: A = a5 seed_x + a6 seed_y, B = a5 r_x + a6 r_y + a7 for k_ring_constraints (computed on the 8-word field from the
+// Montgomery-256 alphas, written as FS9 records)
 __global__ void k_ring_alpha_aux(const uint32_t* __restrict__ alphas /* [B][7][8] Montgomery */, const uint32_t* __restrict__ rps_mont /* [B][16] */,
-                                 RingConsts rc, uint32_t batch, uint32_t* __restrict__ out /* [B][2][8] */) {
+                                 RingConsts rc, uint32_t batch, uint32_t* __restrict__ out /* [B][2] FS9 */) {
     const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= batch) return;
     const uint32_t* al = alphas + (size_t)pid * 7 * 8;
     const Fr a5 = gload_fr(al + 4 * 8), a6 = gload_fr(al + 5 * 8), a7 = gload_fr(al + 6 * 8);
     const Fr rx = gload_fr(rps_mont + (size_t)pid * 16), ry = gload_fr(rps_mont + (size_t)pid * 16 + 8);
-    gstore_fr(out + (size_t)pid * 16, add(mul(a5, from_arg(rc.seed_x)), mul(a6, from_arg(rc.seed_y))));
-    gstore_fr(out + (size_t)pid * 16 + 8, add(add(mul(a5, rx), mul(a6, ry)), a7));
+    fs_store9(out + (size_t)pid * 2 * L29, from_mont256(add(mul(a5, from_arg(rc.seed_x)), mul(a6, from_arg(rc.seed_y)))));
+    fs_store9(out + ((size_t)pid * 2 + 1) * L29, from_mont256(add(add(mul(a5, rx), mul(a6, ry)), a7)));
 }
 
 // ---- K8: coefficient-space passes ---------------------------------------------------------------------------
 // These kernels combine standard-form coefficient vectors with a few per-proof scalars.  A Montgomery product of a
 // Montgomery-form scalar with a STANDARD-form value is the standard form of the product (x R * c / R = x c), and sums of
 // standard-form values are standard-form: so the scalars (tail, k_i, nu_i, the evaluation point) are kept in Montgomery
-// form and the coefficients are used exactly as they lie in memory — no conversion per coefficient, none per result.
+// form — FS9 records or kernel arguments — and the coefficients are used exactly as they lie in memory: their 8 canonical words
+// unpacked into limbs (20 instructions), no conversion per coefficient; a result is packed once (canon29_small / canon29).
+DR_DEV Fs ld_coef(const uint32_t* p) { return unpack29(gload_fr(p).l); }            // a standard-form coefficient as limbs
+DR_DEV void st_coef_small(uint32_t* p, const Fs& v) {                               // value in (-p, 3p) -> canonical words
+    Fr o;
+    canon29_small(v, o.l);
+    gstore_fr(p, o);
+}
+DR_DEV Fs fs_pow_u32(Fs base, uint32_t e) {
+    Fs r = Fs::one();
+    for (; e; e >>= 1) {
+        if (e & 1) r = mul(r, base);
+        base = sqr(base);
+    }
+    return r;
+}
 // quotient: c_agg = tail (cubic) * agg_poly ;  q_j = sum_{i>=1} c_agg[j + i*N],  j < 3N+1
 __global__ void k_ring_quotient(const uint32_t* __restrict__ agg_poly /* [B][4N][8] std */, RingConsts rc, uint32_t batch,
                                 uint32_t* __restrict__ q /* [B][3N+1][8] std */) {
@@ -453,71 +465,77 @@ __global__ void k_ring_quotient(const uint32_t* __restrict__ agg_poly /* [B][4N]
     if (gid >= (size_t)batch * qn) return;
     uint32_t pid = (uint32_t)(gid / qn), j = (uint32_t)(gid % qn);
     const uint32_t* a = agg_poly + (size_t)pid * m * 8;
-    // regrouped: q_j = sum_d tail[d] * (sum_i a[j + i N - d]) — the four foldings first, then 4 products instead of up to 16
-    Fr acc = Fr::zero();
+    // regrouped: q_j = sum_d tail[d] * (sum_i a[j + i N - d]) — the four foldings first, then 4 products (two fused pairs)
+    // instead of up to 16
+    Fs fold[4];
 #pragma unroll
     for (uint32_t d = 0; d < 4; d++) {
-        Fr fold = Fr::zero();
+        fold[d] = Fs::zero();
 #pragma unroll 1
         for (uint32_t i = 1; i <= 4; i++) {
             const uint32_t kidx = j + i * n;             // index into c_agg (length m + 3)
             if (kidx >= m + 3) break;
-            if (kidx >= d && kidx - d < m) fold = add(fold, gload_fr(a + (size_t)(kidx - d) * 8));
+            if (kidx >= d && kidx - d < m) fold[d] = add(fold[d], ld_coef(a + (size_t)(kidx - d) * 8));
         }
-        acc = add(acc, mul(from_arg(rc.tail[d]), fold));
     }
-    gstore_fr(q + gid * 8, acc);
+    st_coef_small(q + gid * 8, body_quotient(from_arg(rc.tail9[0]), fold[0], from_arg(rc.tail9[1]), fold[1], from_arg(rc.tail9[2]), fold[2],
+                                             from_arg(rc.tail9[3]), fold[3]));
 }
 
 // Horner evaluation of `npoly` polynomials per proof at that proof's point: one workgroup per (proof, poly).
 // poly p < nfixed comes from the per-ring array `fixed` (std, [nfixed][len]); the others from `perproof`
-// ([B][nper][len] std).  out[pid*out_stride + out_off + p] (std).
+// ([B][nper][len] std).  out[pid*out_stride + out_off + p] (std).  A lane runs Horner over its slice with a lazy accumulator
+// (one product + 29 instructions per coefficient), scales by x^lo, and the 256 partial values are added up in a tree through
+// LDS (a carry per level, reduce_small after the fourth and the last level: ring_body / ring_bounds_check).
 constexpr int EV_BLOCK = 256;
 __global__ __launch_bounds__(EV_BLOCK) void k_ring_eval(const uint32_t* __restrict__ fixed, uint32_t nfixed,
                                                         const uint32_t* __restrict__ perproof, uint32_t nper, uint32_t len,
                                                         const uint32_t* __restrict__ points /* [B][8] std */, int mul_omega, RingConsts rc,
                                                         uint32_t* __restrict__ out, uint32_t out_stride, uint32_t out_off) {
-    __shared__ uint32_t red[EV_BLOCK * 8];
+    __shared__ int32_t red[EV_BLOCK * L29];
     const uint32_t pid = blockIdx.y, p = blockIdx.x;
     const uint32_t* src = p < nfixed ? fixed + (size_t)p * len * 8 : perproof + ((size_t)pid * nper + (p - nfixed)) * len * 8;
-    Fr x = ld_std(points + (size_t)pid * 8);
-    if (mul_omega) x = mul(x, from_arg(rc.omega));
+    Fs x = fs_from_std(gload_fr(points + (size_t)pid * 8));
+    if (mul_omega) x = mul(x, from_arg(rc.omega9));
     const uint32_t per = (len + EV_BLOCK - 1) / EV_BLOCK;
     const uint32_t lo = threadIdx.x * per;
-    Fr acc = Fr::zero();
+    Fs acc = Fs::zero();
     if (lo < len) {
         uint32_t hi = lo + per < len ? lo + per : len;
 #pragma unroll 1
-        for (int j = (int)hi - 1; j >= (int)lo; j--) acc = add(mul(acc, x), gload_fr(src + (size_t)j * 8));     // acc in standard form, x Montgomery
-        acc = mul(acc, fr_pow_u32(x, lo));
+        for (int j = (int)hi - 1; j >= (int)lo; j--) acc = body_horner(acc, x, ld_coef(src + (size_t)j * 8));     // acc in standard form, x Montgomery
+        acc = mul(acc, fs_pow_u32(x, lo));
     }
 #pragma unroll
-    for (int l = 0; l < 8; l++) red[l * EV_BLOCK + threadIdx.x] = acc.l[l];
+    for (int l = 0; l < L29; l++) red[l * EV_BLOCK + threadIdx.x] = acc.l[l];
     __syncthreads();
-    for (int s = EV_BLOCK / 2; s > 0; s >>= 1) {
+    int level = 0;
+    for (int s = EV_BLOCK / 2; s > 0; s >>= 1, level++) {
         if ((int)threadIdx.x < s) {
-            Fr a, b;
+            Fs a, b;
 #pragma unroll
-            for (int l = 0; l < 8; l++) { a.l[l] = red[l * EV_BLOCK + threadIdx.x]; b.l[l] = red[l * EV_BLOCK + threadIdx.x + s]; }
-            a = add(a, b);
+            for (int l = 0; l < L29; l++) { a.l[l] = red[l * EV_BLOCK + threadIdx.x]; b.l[l] = red[l * EV_BLOCK + threadIdx.x + s]; }
+            a = carry(add(a, b));
+            if (level == 3 || level == 7) a = reduce_small(a);
 #pragma unroll
-            for (int l = 0; l < 8; l++) red[l * EV_BLOCK + threadIdx.x] = a.l[l];
+            for (int l = 0; l < L29; l++) red[l * EV_BLOCK + threadIdx.x] = a.l[l];
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        Fr r;
+        Fs r;
 #pragma unroll
-        for (int l = 0; l < 8; l++) r.l[l] = red[l * EV_BLOCK];
-        gstore_fr(out + ((size_t)pid * out_stride + out_off + p) * 8, r);
+        for (int l = 0; l < L29; l++) r.l[l] = red[l * EV_BLOCK];
+        st_coef_small(out + ((size_t)pid * out_stride + out_off + p) * 8, r);
     }
 }
 
-// linearisation scalars per proof (proof_builder.py:253-286): k0 = a0*term, k1 = a1*fx*term, k2 = a2*fy*term
+// linearisation scalars per proof (proof_builder.py:253-286): k0 = a0*term, k1 = a1*fx*term, k2 = a2*fy*term (computed on the
+// 8-word field, written as FS9 records for k_ring_linpoly)
 template <int CV>
 __global__ void k_ring_lin_scalars(const uint32_t* __restrict__ evals /* [B][8][8] std: px,py,s,b,accip,accx,accy,(l) */,
                                    const uint32_t* __restrict__ alphas, const uint32_t* __restrict__ zetas, RingConsts rc,
-                                   uint32_t batch, uint32_t* __restrict__ ks /* [B][3][8] mont */) {
+                                   uint32_t batch, uint32_t* __restrict__ ks /* [B][3] FS9 */) {
     uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= batch) return;
     const uint32_t* e = evals + (size_t)pid * 8 * 8;
@@ -527,40 +545,47 @@ __global__ void k_ring_lin_scalars(const uint32_t* __restrict__ evals /* [B][8][
     Fr fx = mul(add(mul(bz, add(mul(ayz, pyz), te_mul_a_fr<CV>(mul(axz, pxz)))), omb), term);
     Fr fy = mul(add(mul(bz, sub(mul(axz, pyz), mul(pxz, ayz))), omb), term);
     const uint32_t* al = alphas + (size_t)pid * 7 * 8;
-    gstore_fr(ks + ((size_t)pid * 3 + 0) * 8, mul(gload_fr(al), term));          // alphas: Montgomery, see k_ring_constraints
-    gstore_fr(ks + ((size_t)pid * 3 + 1) * 8, mul(gload_fr(al + 8), fx));
-    gstore_fr(ks + ((size_t)pid * 3 + 2) * 8, mul(gload_fr(al + 16), fy));
+    fs_store9(ks + ((size_t)pid * 3 + 0) * L29, from_mont256(mul(gload_fr(al), term)));          // alphas: Montgomery 256 (k_fr_to_mont)
+    fs_store9(ks + ((size_t)pid * 3 + 1) * L29, from_mont256(mul(gload_fr(al + 8), fx)));
+    fs_store9(ks + ((size_t)pid * 3 + 2) * L29, from_mont256(mul(gload_fr(al + 16), fy)));
 }
 // lin[j] = k0*accip[j] + k1*accx[j] + k2*accy[j]
 __global__ void k_ring_linpoly(const uint32_t* __restrict__ cols /* [B][4][n][8] std coefficient columns */,
-                               const uint32_t* __restrict__ ks, uint32_t n, uint32_t batch, uint32_t* __restrict__ lin /* [B][n][8] */) {
+                               const uint32_t* __restrict__ ks /* [B][3] FS9 */, uint32_t n, uint32_t batch, uint32_t* __restrict__ lin /* [B][n][8] */) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)batch * n) return;
     uint32_t pid = (uint32_t)(gid / n), j = (uint32_t)(gid % n);
     const uint32_t* c = cols + (size_t)pid * 4 * n * 8;
-    Fr v = mul(gload_fr(ks + ((size_t)pid * 3 + 0) * 8), gload_fr(c + ((size_t)1 * n + j) * 8));
-    v = add(v, mul(gload_fr(ks + ((size_t)pid * 3 + 1) * 8), gload_fr(c + ((size_t)2 * n + j) * 8)));
-    v = add(v, mul(gload_fr(ks + ((size_t)pid * 3 + 2) * 8), gload_fr(c + ((size_t)3 * n + j) * 8)));
-    gstore_fr(lin + gid * 8, v);
+    const uint32_t* k = ks + (size_t)pid * 3 * L29;
+    st_coef_small(lin + gid * 8, body_lin3(fs_load9(k), ld_coef(c + ((size_t)1 * n + j) * 8), fs_load9(k + L29), ld_coef(c + ((size_t)2 * n + j) * 8),
+                                           fs_load9(k + 2 * L29), ld_coef(c + ((size_t)3 * n + j) * 8)));
 }
 // aggregated opening polynomial: sum of nu_i * poly_i over (px, py, s, b, accip, accx, accy, q)
 __global__ void k_ring_aggpoly(const uint32_t* __restrict__ fixed /* [3][n][8] std */, const uint32_t* __restrict__ cols,
-                               const uint32_t* __restrict__ q /* [B][3n+1][8] */, const uint32_t* __restrict__ nus /* [B][8][8] Montgomery (converted once per batch) */,
+                               const uint32_t* __restrict__ q /* [B][3n+1][8] */, const uint32_t* __restrict__ nus /* [B][8] FS9 (converted once per batch) */,
                                uint32_t n, uint32_t batch, uint32_t* __restrict__ out /* [B][3n+1][8] */) {
     const uint32_t qn = 3 * n + 1;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)batch * qn) return;
     uint32_t pid = (uint32_t)(gid / qn), j = (uint32_t)(gid % qn);
-    const uint32_t* nu = nus + (size_t)pid * 8 * 8;
-    Fr v = mul(gload_fr(nu + 7 * 8), gload_fr(q + gid * 8));
-    if (j < n) {
-#pragma unroll 1
-        for (uint32_t p = 0; p < 3; p++) v = add(v, mul(gload_fr(nu + p * 8), gload_fr(fixed + ((size_t)p * n + j) * 8)));
-        const uint32_t* c = cols + (size_t)pid * 4 * n * 8;
-#pragma unroll 1
-        for (uint32_t p = 0; p < 4; p++) v = add(v, mul(gload_fr(nu + (3 + p) * 8), gload_fr(c + ((size_t)p * n + j) * 8)));
+    const uint32_t* nu = nus + (size_t)pid * 8 * L29;
+    const Fs qj = ld_coef(q + gid * 8);
+    if (j >= n) {                                    // beyond degree N - 1 only the quotient contributes
+        st_coef_small(out + gid * 8, mul(fs_load9(nu + 7 * L29), qj));
+        return;
     }
-    gstore_fr(out + gid * 8, v);
+    const uint32_t* c = cols + (size_t)pid * 4 * n * 8;
+    Fs nv[8], cv[8];
+#pragma unroll
+    for (uint32_t t = 0; t < 8; t++) nv[t] = fs_load9(nu + t * L29);
+#pragma unroll
+    for (uint32_t t = 0; t < 3; t++) cv[t] = ld_coef(fixed + ((size_t)t * n + j) * 8);
+#pragma unroll
+    for (uint32_t t = 0; t < 4; t++) cv[3 + t] = ld_coef(c + ((size_t)t * n + j) * 8);
+    cv[7] = qj;
+    Fr o;
+    canon29(body_agg8(nv, cv), o.l);
+    gstore_fr(out + gid * 8, o);
 }
 
 // Synthetic division by (X - x): quotient Q_{i-1} = S_i with S_i = a_i + x*S_{i+1} (suffix Horner values).

@@ -118,10 +118,11 @@ DR_API int dr_te_fixed_base_msm_groups(dr_ctx *ctx, int curve, const uint8_t *ba
 
 /* Diagnostic: the device's field arithmetic on the base field of the twisted Edwards curves (the 9 x 29-bit representation of
  * csrc/fr29.hip.h that every kernel of this seam computes in), one lane per pair of canonical little-endian elements.
- * out: n x 9 x 32 bytes — a b, a^2, a + b, a - b, a^-1 (0 for 0), (a + b)(a - b), -5 a, 2 a b (fused product), sqrt(a) or 0;
- * is_square[i] = 1 iff a[i] is a square.  The reference has no counterpart: its field is Python / C big integers
+ * out: n x 12 x 32 bytes — a b, a^2, a + b, a - b, a^-1 (0 for 0), (a + b)(a - b), -5 a, 2 a b (fused product), sqrt(a) or 0;
+ * then, each times 2^261 (the form the kernels compute in): a b + a, a + 27 b, a - 28 b through the lazy-sum helpers of the NTT /
+ * polynomial kernels (canon29_small, reduce_small).  is_square[i] = 1 iff a[i] is a square.  The reference has no counterpart: its field is Python / C big integers
  * (dot_ring/curve/native_field/scalar.pyx); the tests check this entry point against the same integers. */
-DR_API int dr_fr_ops_selftest(dr_ctx *ctx, const uint8_t *a /* n*32 */, const uint8_t *b /* n*32 */, size_t n, uint8_t *out /* n*288 */,
+DR_API int dr_fr_ops_selftest(dr_ctx *ctx, const uint8_t *a /* n*32 */, const uint8_t *b /* n*32 */, size_t n, uint8_t *out /* n*384 */,
                               uint8_t *is_square /* n */);
 
 /* square root in the Bandersnatch base field; DR_ERR_NOTSQUARE if none exists. Host-side, no ctx. */

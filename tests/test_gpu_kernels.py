@@ -305,16 +305,19 @@ def test_fr29_field_arithmetic_against_big_integers(ctx):
             (1 << 254) - 1, 1 << 254, p - (1 << 29), p - (1 << 232), sum(((1 << 29) - 1) << (29 * i) for i in range(8)) % p,
             pow(5, (p - 1) >> 32, p), pow(7, -1, p)]
     pairs = [(x, y) for x in edge for y in edge] + [(rng.randrange(p), rng.randrange(p)) for _ in range(20000)]
+    r261 = pow(2, 261, p)
     a = b"".join(x.to_bytes(32, "little") for x, _ in pairs)
     b = b"".join(y.to_bytes(32, "little") for _, y in pairs)
     out, flags = ctx.fr_ops_selftest(a, b)
     for i, (x, y) in enumerate(pairs):
-        rec = [int.from_bytes(out[288 * i + 32 * k : 288 * i + 32 * k + 32], "little") for k in range(9)]
+        rec = [int.from_bytes(out[384 * i + 32 * k : 384 * i + 32 * k + 32], "little") for k in range(12)]
         want = [x * y % p, x * x % p, (x + y) % p, (x - y) % p, pow(x, -1, p) if x else 0, (x * x - y * y) % p, (-5 * x) % p, 2 * x * y % p]
         assert rec[:8] == want, (hex(x), hex(y))
         square = x == 0 or pow(x, (p - 1) // 2, p) == 1
         assert flags[i] == (1 if square else 0), hex(x)
         assert (rec[8] * rec[8] - x) % p == 0 if square else rec[8] == 0, hex(x)
+        # the lazy-sum helpers of the NTT / polynomial kernels (records in the device's Montgomery form, R = 2^261)
+        assert rec[9:] == [(x * y + x) * r261 % p, (x + 27 * y) * r261 % p, (x - 28 * y) * r261 % p], (hex(x), hex(y))
 
 
 def test_g1_msm_partition_sort_skewed_and_ragged(ctx):
