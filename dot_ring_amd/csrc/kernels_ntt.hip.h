@@ -32,19 +32,21 @@
 namespace dr {
 
 constexpr int NTT_LOG_TILE = 10, NTT_TILE = 1 << NTT_LOG_TILE, NTT_BLOCK = 256;
-constexpr int NTT_COLS = 64, NTT_MAX_ROW_BITS = 4;
+constexpr int NTT_STRIDED_TILE = 1024, NTT_MIN_COLS = 64, NTT_MAX_ROW_BITS = 4;
 constexpr int NTT_TW_WORDS = 12;                     // a twiddle record: 9 limbs + 3 words of padding (16-byte loads)
 enum { NTT_FMT_STD8 = 0, NTT_FMT_FS9 = 1 };
 
+template <int STRIDE = NTT_TILE>
 DR_DEV Fs lds_get9(const int32_t* t, int i) {
     Fs r;
 #pragma unroll
-    for (int l = 0; l < L29; l++) r.l[l] = t[l * NTT_TILE + i];
+    for (int l = 0; l < L29; l++) r.l[l] = t[l * STRIDE + i];
     return r;
 }
+template <int STRIDE = NTT_TILE>
 DR_DEV void lds_put9(int32_t* t, int i, const Fs& v) {
 #pragma unroll
-    for (int l = 0; l < L29; l++) t[l * NTT_TILE + i] = v.l[l];
+    for (int l = 0; l < L29; l++) t[l * STRIDE + i] = v.l[l];
 }
 DR_DEV Fr gload_fr(const uint32_t* p) {
     Fr r;
@@ -83,19 +85,16 @@ DR_DEV Fs ntt_load(const uint32_t* base, size_t idx, int fmt) {
     if (fmt == NTT_FMT_FS9) return fs_load9(base + idx * L29);
     return fs_from_std(gload_fr(base + idx * 8));
 }
-// the value a pass leaves behind.  final == 0: raw limbs for the next pass.  final == 1: the transform's output — STD8: v * factor
-// with the factor in STANDARD form (Montgomery x standard -> standard), canonical words; FS9 with a factor: v * factor (Montgomery),
-// FS9 without: reduce_small.
-DR_DEV void ntt_store(uint32_t* base, size_t idx, const Fs& v, int final, int fmt, int has_factor, const Fs& factor) {
-    if (!final) { fs_store9(base + idx * L29, v); return; }
-    if (fmt == NTT_FMT_STD8) {
-        Fr o;
-        canon29_small(mul(carry(v), factor), o.l);
-        gstore_fr(base + idx * 8, o);
-        return;
-    }
-    fs_store9(base + idx * L29, has_factor ? mul(carry(v), factor) : reduce_small(v));
+// What a pass leaves behind.  Not the last pass: the raw limbs.  The last pass — STD8: v * factor with the factor in STANDARD form
+// (Montgomery x standard -> standard), canonical words; FS9: v * factor (Montgomery) or, without a factor, reduce_small(v).
+// (Staging the 36-byte records through the tile as whole 16-byte chunks per lane was measured and dropped: the strided pass went
+// from 1.26 to 1.40 ms per 1024 proofs — the limb-major scatter in LDS costs more than nine 4-byte accesses per record.)
+DR_DEV void ntt_store_std8(uint32_t* base, size_t idx, const Fs& v, const Fs& factor) {
+    Fr o;
+    canon29_small(mul(carry(v), factor), o.l);
+    gstore_fr(base + idx * 8, o);
 }
+DR_DEV Fs ntt_final_fs9(const Fs& v, int has_factor, const Fs& factor) { return has_factor ? mul(carry(v), factor) : reduce_small(v); }
 
 // tw[j] = omega^j (Montgomery 2^261), j < count, as 12-word records
 __global__ void k_ntt_twiddles(uint32_t* tw, uint32_t count, FsArg omega_mont) {
@@ -116,7 +115,10 @@ __global__ void k_ntt_twiddles(uint32_t* tw, uint32_t count, FsArg omega_mont) {
 // stage) — ring_body.hip.h: body_butterfly, whose limb and value bounds the host interval check walks through 24 stages
 DR_DEV void ntt_butterfly(Fs& u, Fs& v, const Fs& w, bool trivial, bool carry_u) { body_butterfly(u, v, w, trivial, carry_u); }
 
-// Pass A: stages 1..S (S = min(k, 10)) on tile `blockIdx.x` of transform `blockIdx.y`.
+// columns of a strided-pass tile: 1024 / rows, at least 64 (host and device agree through this one function)
+__host__ __device__ inline int ntt_strided_col_bits(int row_bits) { return row_bits >= 4 ? 6 : 10 - row_bits; }
+
+// Pass A: stages 1..S (S = min(k, NTT_LOG_TILE)) on tile `blockIdx.x` of transform `blockIdx.y`.
 // src is read at bit-reversed positions, dst written contiguously (src == dst is allowed only when S == k, where one workgroup
 // owns the whole transform and the formats have the same element size or the whole tile is loaded before anything is stored).
 __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_local(const uint32_t* src, uint32_t* dst,
@@ -164,48 +166,57 @@ __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_local(const uint32_t* src, ui
         __syncthreads();
     }
     const Fs f = from_arg(out_factor);
-    for (int i = threadIdx.x; i < tsize; i += NTT_BLOCK) ntt_store(out, tbase + i, lds_get9(tile, i), final_pass, fmt_out, has_factor, f);
+    if (final_pass && fmt_out == NTT_FMT_STD8) {
+        for (int i = threadIdx.x; i < tsize; i += NTT_BLOCK) ntt_store_std8(out, tbase + i, lds_get9(tile, i), f);
+        return;
+    }
+    for (int i = threadIdx.x; i < tsize; i += NTT_BLOCK) {
+        const Fs v = lds_get9(tile, i);
+        fs_store9(out + (tbase + i) * L29, final_pass ? ntt_final_fs9(v, has_factor, f) : v);
+    }
 }
 
-// Later passes: stages lo+1..hi (hi - lo <= 4).  Tile = 2^(hi-lo) rows x 64 columns; element position
-// p = (high * 2^(hi-lo) + r) * 2^lo + low, the workgroup owns a fixed `high`, 64 consecutive `low` values.  Reads raw 9-limb
-// records from `src`, writes the same positions of `dst` (src == dst unless this is the final pass of a STD8 transform).
+// Later passes: stages lo+1..hi (hi - lo <= 4).  Tile = 2^(hi-lo) rows x `cols` columns (cols = 1024 / rows, at least 64); element
+// position p = (high * 2^(hi-lo) + r) * 2^lo + low, the workgroup owns a fixed `high` and `cols` consecutive `low` values.  Reads
+// raw 9-limb records from `src`, writes the same positions of `dst` (src == dst unless this is the final pass of a STD8 transform).
 __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_strided(const uint32_t* src, uint32_t* dst, const uint32_t* __restrict__ tw,
                                                            int k, int lo, int hi, int final_pass, int fmt_out, int has_factor, FsArg out_factor) {
-    __shared__ int32_t tile[L29 * NTT_TILE];
+    __shared__ int32_t tile[L29 * NTT_STRIDED_TILE];
     const size_t n = (size_t)1 << k;
     const int rb = hi - lo, rows = 1 << rb;
-    const size_t low_blocks = ((size_t)1 << lo) / NTT_COLS;
-    const size_t high = blockIdx.x / low_blocks, low0 = (blockIdx.x % low_blocks) * NTT_COLS;
+    const int cb = ntt_strided_col_bits(rb), cols = 1 << cb;
+    const size_t low_blocks = ((size_t)1 << lo) >> cb;
+    const size_t high = blockIdx.x / low_blocks, low0 = (blockIdx.x % low_blocks) << cb;
     const uint32_t* in = src + (size_t)blockIdx.y * n * L29;
     uint32_t* out = dst + (size_t)blockIdx.y * n * (final_pass && fmt_out == NTT_FMT_STD8 ? 8 : L29);
     auto pos_of = [&](int r, int c) -> size_t { return (((high << rb) + r) << lo) + low0 + c; };
-    for (int e = threadIdx.x; e < rows * NTT_COLS; e += NTT_BLOCK) {
-        int r = e / NTT_COLS, c = e % NTT_COLS;
-        lds_put9(tile, e, fs_load9(in + pos_of(r, c) * L29));
-    }
+    for (int e = threadIdx.x; e < rows * cols; e += NTT_BLOCK) lds_put9<NTT_STRIDED_TILE>(tile, e, fs_load9(in + pos_of(e >> cb, e & (cols - 1)) * L29));
     __syncthreads();
     for (int s = lo + 1; s <= hi; s++) {
         const int hb = s - 1 - lo;                 // row bit that this stage pairs
         const bool cu = ((s - lo) & 1) != 0;
-        for (int t = threadIdx.x; t < rows * NTT_COLS / 2; t += NTT_BLOCK) {
-            int c = t % NTT_COLS, rr = t / NTT_COLS;            // rr enumerates rows with bit hb cleared
+        for (int t = threadIdx.x; t < rows * cols / 2; t += NTT_BLOCK) {
+            int c = t & (cols - 1), rr = t >> cb;               // rr enumerates rows with bit hb cleared
             int r0 = ((rr >> hb) << (hb + 1)) | (rr & ((1 << hb) - 1));
             int r1 = r0 | (1 << hb);
             size_t p0 = pos_of(r0, c);
             size_t j = p0 & (((size_t)1 << (s - 1)) - 1);
-            Fs u = lds_get9(tile, r0 * NTT_COLS + c), v = lds_get9(tile, r1 * NTT_COLS + c);
+            Fs u = lds_get9<NTT_STRIDED_TILE>(tile, r0 * cols + c), v = lds_get9<NTT_STRIDED_TILE>(tile, r1 * cols + c);
             const Fs w = tw_load(tw + (j << (k - s)) * NTT_TW_WORDS);
             ntt_butterfly(u, v, w, false, cu);
-            lds_put9(tile, r0 * NTT_COLS + c, u);
-            lds_put9(tile, r1 * NTT_COLS + c, v);
+            lds_put9<NTT_STRIDED_TILE>(tile, r0 * cols + c, u);
+            lds_put9<NTT_STRIDED_TILE>(tile, r1 * cols + c, v);
         }
         __syncthreads();
     }
     const Fs f = from_arg(out_factor);
-    for (int e = threadIdx.x; e < rows * NTT_COLS; e += NTT_BLOCK) {
-        int r = e / NTT_COLS, c = e % NTT_COLS;
-        ntt_store(out, pos_of(r, c), lds_get9(tile, e), final_pass, fmt_out, has_factor, f);
+    if (final_pass && fmt_out == NTT_FMT_STD8) {
+        for (int e = threadIdx.x; e < rows * cols; e += NTT_BLOCK) ntt_store_std8(out, pos_of(e >> cb, e & (cols - 1)), lds_get9<NTT_STRIDED_TILE>(tile, e), f);
+        return;
+    }
+    for (int e = threadIdx.x; e < rows * cols; e += NTT_BLOCK) {
+        const Fs v = lds_get9<NTT_STRIDED_TILE>(tile, e);
+        fs_store9(out + pos_of(e >> cb, e & (cols - 1)) * L29, final_pass ? ntt_final_fs9(v, has_factor, f) : v);
     }
 }
 
@@ -301,7 +312,7 @@ int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp,
     for (int lo = S; lo < (int)k; lo += NTT_MAX_ROW_BITS) {
         int hi = std::min<int>((int)k, lo + NTT_MAX_ROW_BITS);
         int fin = hi == (int)k ? 1 : 0;
-        unsigned blocks = (unsigned)(n >> (hi - lo) >> 6);    // tiles per transform
+        unsigned blocks = (unsigned)(n >> (hi - lo) >> ntt_strided_col_bits(hi - lo));    // tiles per transform
         uint32_t* d_out = fin ? d_data : d_mid;
         rc = launch("k_ntt_strided", [&] {
             hipLaunchKernelGGL(k_ntt_strided, dim3(blocks, (unsigned)batch), dim3(NTT_BLOCK), 0, st, d_mid, d_out, d_tw, (int)k, lo, hi, fin, fmt_out, has_factor, fa);
