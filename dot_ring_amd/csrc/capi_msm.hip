@@ -290,6 +290,11 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     // per set scans and folds its <= 128 chunk results (DOTRING_MSM_SETSCAN=0: the chunk + double-and-add kernels below)
     static const bool setscan_on = std::getenv("DOTRING_MSM_SETSCAN") == nullptr || std::atoi(std::getenv("DOTRING_MSM_SETSCAN")) != 0;
     const bool setscan = setscan_on && pl.L == 16 && pl.T >= 8 && pl.T <= 256 && bsets >= 256;
+    // a single MSM over a wide window table (H >= 8192 buckets per index group): workgroup scan, (V, S) pairs to the host
+    // (DOTRING_MSM_WGSCAN=0: chunk sums + double-and-add + fold, as in round 2)
+    static const bool wgscan_on = std::getenv("DOTRING_MSM_WGSCAN") == nullptr || std::atoi(std::getenv("DOTRING_MSM_WGSCAN")) != 0;
+    const bool wgscan = wgscan_on && !setscan && !leveled && single && batch == 1 && pl.H >= 8192 && pl.H % dr::WS_SPAN == 0;
+    const size_t wg_per_set = pl.H / dr::WS_SPAN, wg_count = bsets * wg_per_set;
     if (setscan) {
         const size_t cnt = bsets * pl.T;
         TRY(ctx->partial.reserve(2 * cnt * 192));
@@ -333,6 +338,14 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         TRY(launch(ctx, "k_g1_reduce_windows", [&] {
             hipLaunchKernelGGL(dr::k_g1_reduce_final, dim3(div_up(bsets, 64)), dim3(64), 0, st, in_s, in_c, bsets, n, level, ctx->winsum.as<uint32_t>());
         }));
+    } else if (wgscan) {
+        // one huge bucket set per index group: workgroups of 2048 buckets scan and fold themselves (k_g1_reduce_wg_scan); their
+        // (V, S) pairs are combined on the host below
+        TRY(ctx->partial.reserve(2 * wg_count * 192));
+        TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
+            hipLaunchKernelGGL(dr::k_g1_reduce_wg_scan, dim3((unsigned)wg_count), dim3(dr::WS_BLOCK), 0, st, ctx->buckets.as<uint32_t>(),
+                               ctx->partial.as<uint32_t>());
+        }));
     } else {
         TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
             hipLaunchKernelGGL(dr::k_g1_reduce_chunks, dim3(div_up(bsets * pl.T, 128)), dim3(128), 0, st,
@@ -354,7 +367,31 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     }
 
     static_assert(sizeof(drh::G1) == 192, "XYZZ layout");
-    if (single) {
+    if (single && wgscan) {
+        // set value = sum_g (V_g + 2048 g S_g) over the set's workgroups: a running sum (descending g) on the worker threads, one
+        // bucket set per task; then the index groups are added up
+        std::vector<drh::G1> vs(2 * wg_count);
+        HIP_TRY(hipMemcpyAsync(vs.data(), ctx->partial.p, vs.size() * 192, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<drh::G1> per_set(bsets);
+        const std::function<void(size_t)> one_set = [&](size_t set) {
+            drh::G1* p = vs.data() + 2 * set * wg_per_set;
+            g1_dev_to_host(p, 2 * wg_per_set);
+            drh::G1 run = drh::G1::inf(), w = drh::G1::inf(), v = drh::G1::inf();
+            for (size_t g = wg_per_set; g-- > 0;) {
+                v = drh::g1_add(v, p[2 * g]);
+                if (g >= 1) { run = drh::g1_add(run, p[2 * g + 1]); w = drh::g1_add(w, run); }    // w = sum_g g S_g
+            }
+            for (int k = 0; k < 11; k++) w = drh::g1_dbl(w);                                        // x 2048
+            per_set[set] = drh::g1_add(v, w);
+        };
+        // a task is ~60 group operations (~50 us): one per worker thread (parallel_for would keep so few items on one thread)
+        if (drh::WorkerPool* pool = drh::worker_pool()) pool->run(bsets, (unsigned)std::min<size_t>(bsets, drh::host_threads()), one_set);
+        else for (size_t set = 0; set < bsets; set++) one_set(set);
+        drh::G1 acc = drh::G1::inf();
+        for (size_t set = 0; set < bsets; set++) acc = drh::g1_add(acc, per_set[set]);
+        results[0] = acc;
+    } else if (single) {
         // the bucket-set sum IS the MSM value: no window combination
         if (groups > 1 || batch == 1) {
             // few MSMs: fetch the per-group sums and add them on the host (<= 64 additions per MSM)

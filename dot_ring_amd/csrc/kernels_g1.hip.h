@@ -1037,6 +1037,58 @@ __global__ __launch_bounds__(RS_BLOCK) void k_g1_reduce_set_scan(const uint32_t*
     if (live && l == 0) store_xyzz(winsum, set, v);
 }
 
+// ---- 5d. one huge bucket set per index group (a single 2^18 .. 2^22-point MSM over a 16-bit window table: 16 sets of 32768
+// buckets).  The chunk kernel's per-lane chain there is 32 running-sum additions + a 15-bit double-and-add (~22 operations), then
+// a fold of 2048 chunk results per set: 0.80 + 0.22 ms at 2^20, pure latency on half a wave per SIMD.  Here a workgroup of 256 lanes
+// takes 2048 consecutive buckets of one set, 8 per lane:
+//     lane l:   R_l = sum_i B_i,  w_l = sum_i (i + 1) B_i          (16 additions, buckets descending)
+//     bucket j = 2048 g + 8 l + i of the set has weight j + 1:  sum = sum_l w_l + 8 sum_l l R_l + 2048 g sum_l R_l
+//     sum_l l R_l = sum_{k >= 1} X_k,  X_k = sum_{l >= k} R_l:  a suffix scan of R over the 256 lanes (8 log steps through LDS),
+//     Y_l = w_l + 8 X_l [l >= 1] (three doublings, one addition), a tree sum of Y (8 steps).
+// Per workgroup out: V = sum_l Y_l and S = X_0 = sum_l R_l; the host adds V + 2048 g S over the H / 2048 workgroups of a set (a
+// running sum of a few dozen points on the worker threads) — 33 additions + 3 doublings deep where the chunk kernel and its fold
+// are ~66.  One inlined addition, operands muxed per step, like k_g1_reduce_set_scan.
+constexpr int WS_BLOCK = 256, WS_PER_LANE = 8, WS_SPAN = WS_BLOCK * WS_PER_LANE;
+__global__ __launch_bounds__(WS_BLOCK) void k_g1_reduce_wg_scan(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out /* [workgroup][2]: V, S */) {
+    __shared__ uint32_t sm[WS_BLOCK * XYZZ_RAW_WORDS];
+    const uint32_t l = threadIdx.x;
+    const size_t b0 = ((size_t)blockIdx.x * WS_BLOCK + l) * WS_PER_LANE;      // first bucket of this lane (sets are multiples of 2048 buckets)
+    G1Xyzz run = g1_inf(), w = g1_inf(), v = g1_inf();
+    constexpr int n_local = 2 * WS_PER_LANE, lg = 8, s_scan = n_local, s_comb = s_scan + lg, s_tree = s_comb + 1, s_end = s_tree + lg;
+#pragma unroll 1
+    for (int step = 0; step < s_end; step++) {
+        G1Xyzz a, b = g1_inf();
+        int dst;                                            // 0: run, 1: w, 2: v
+        if (step < n_local) {
+            if ((step & 1) == 0) { a = run; b = load_xyzz(buckets, b0 + (WS_PER_LANE - 1 - (step >> 1))); dst = 0; }
+            else { a = w; b = run; dst = 1; }
+        } else if (step < s_comb) {                         // suffix scan: run_l += run_{l + 2^k}
+            const uint32_t dist = 1u << (step - s_scan);
+            put_raw(sm + l, WS_BLOCK, run);
+            __syncthreads();
+            if (l + dist < WS_BLOCK) b = get_raw(sm + l + dist, WS_BLOCK);
+            __syncthreads();
+            a = run; dst = 0;
+        } else if (step == s_comb) {                        // v = 8 X_l (lanes >= 1) + w_l
+            if (l >= 1) { v = g1_dbl(run); v = g1_dbl(v); v = g1_dbl(v); }
+            a = v; b = w; dst = 2;
+        } else {                                            // tree over the workgroup
+            const uint32_t dist = WS_BLOCK >> (step - s_tree + 1);
+            put_raw(sm + l, WS_BLOCK, v);
+            __syncthreads();
+            if (l < dist) b = get_raw(sm + l + dist, WS_BLOCK);
+            __syncthreads();
+            a = v; dst = 2;
+        }
+        const G1Xyzz r = g1_add(a, b);
+        if (dst == 0) run = r; else if (dst == 1) w = r; else v = r;
+    }
+    if (l == 0) {
+        store_xyzz(out, (size_t)blockIdx.x * 2, v);
+        store_xyzz(out, (size_t)blockIdx.x * 2 + 1, run);   // after the scan lane 0 holds the sum of all R_l
+    }
+}
+
 // one lane per set: direct running sum over the last n <= 16 entries, then value = L^levels * W - sum C
 __global__ __launch_bounds__(64) void k_g1_reduce_final(const uint32_t* __restrict__ in_s, const uint32_t* __restrict__ in_c, size_t sets, uint32_t n, int levels,
                                   uint32_t* __restrict__ winsum) {
