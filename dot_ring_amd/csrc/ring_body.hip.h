@@ -1,5 +1,5 @@
 // Arithmetic bodies of the ring prover's hot kernels, written once over an abstract field type F with the operations of
-// fr29.hip.h (add, sub, mul, mul2, carry, carry_u, sub_3p, dbl, neg, F::one()).  On the device F = dr::Fs.  On the host
+// fr29.hip.h (add, sub, mul, mul2, carry, carry_u, dbl, neg, F::one()).  On the device F = dr::Fs.  On the host
 // tests/native/ring_bounds_check.cpp instantiates the same bodies with an INTERVAL type that tracks, for every intermediate, the
 // range of its low limbs and of its value in units of p, and asserts the preconditions of each operation (a product needs limb
 // bounds whose product is at most 2^59.3 and value bounds whose product is at most 35; a carry needs limbs within int32; ...):
@@ -16,20 +16,11 @@
 
 namespace dr {
 
-// a * A for the curve coefficient a = -5 (Bandersnatch, cv = 0) or -1 (JubJub, cv = 1), A a product of normal operands:
-// 3p - 5A by additions and one unsigned carry pass (curve.hip.h: te_aA), limbs within (-2^29, 2^29), value in (-2.2 p, 3.2 p)
-template <int CV, class F>
-DR_BODY_FN F body_aA(const F& A) {
-    if (CV == 1) return neg(A);
-    const F t = add(dbl(dbl(A)), A);                 // < 5 * 2^29 as unsigned
-    return neg(sub_3p(carry_u(t)));
-}
-
 // K7: sum_k alpha_k c_k at one point of the 4N domain (constraints.py:83-151, proof_builder.py:175-180).
 //   witness values b, ip, ip_n (accip at i and i + 4), x1, x3, y1, y3: the forward NTT's raw output (carried, |value| < 0.51 p)
 //   per-ring tables x2, y2, s (px, py, selector), l0, ln (Lagrange rows), nl (x - w^(N-4)): canonical limbs (value in [0, p))
 //   a0..a6: the alphas, A and B: k_ring_alpha_aux's two per-proof scalars — normal (products)
-// 23 products.  The selector form b u + (1 - b) v is v + b (u - v); the three boundary constraints share
+// 23 products, ten of them as five fused a b + c d (one reduction each).  The selector form b u + (1 - b) v is v + b (u - v); the three boundary constraints share
 // (L0 + Llast)(a5 x + a6 y + a7 accip) - L0 A - Llast B.  Result: limbs within (-2^30, 2^30 + 2^29), |value| < 3.3 p — the
 // inverse NTT carries both operands of its first stage on load.
 template <int CV, class F>
@@ -37,25 +28,27 @@ DR_BODY_FN F body_constraints(const F& b, const F& ip, const F& ip_n, const F& x
                               const F& y2, const F& s, const F& l0, const F& ln, const F& nl, const F& a0, const F& a1, const F& a2,
                               const F& a3, const F& a4, const F& a5, const F& a6, const F& A, const F& B) {
     const F omb = sub(F::one(), b);
-    const F x1y1 = mul(x1, y1), x2y2 = mul(x2, y2), x1x2 = mul(x1, x2), y1y2 = mul(y1, y2);
+    const F x1y1 = mul(x1, y1), x2y2 = mul(x2, y2);
     // c1 = (accip' - accip - b s) nl        (the common factor nl of c1..c3 is applied once, after the alphas)
-    F acc = mul(a0, sub(sub(ip_n, ip), mul(b, s)));
-    // c2 = (b (x3 (y1 y2 + a x1 x2) - (x1 y1 + x2 y2)) + (1 - b)(x3 - x1)) nl
-    const F t2 = sub(mul(x3, add(y1y2, body_aA<CV>(x1x2))), add(x1y1, x2y2));
+    const F c1 = sub(sub(ip_n, ip), mul(b, s));
+    // c2 = (b (x3 (y1 y2 + a x1 x2) - (x1 y1 + x2 y2)) + (1 - b)(x3 - x1)) nl;  y1 y2 + a x1 x2 is ONE fused product with (a x1) as
+    // an operand: a = -5: -(4 x1 + x1), carried (limbs back below 2^29, |value| < 2.6 p); a = -1: -x1
+    const F ax1 = CV == 1 ? neg(x1) : neg(carry_u(add(dbl(dbl(x1)), x1)));
+    const F t2 = sub(mul(x3, mul2(y1, y2, ax1, x2)), add(x1y1, x2y2));
     const F v2 = sub(x3, x1);
     const F c2 = add(v2, mul(b, carry(sub(t2, v2))));
-    acc = add(acc, mul(a1, c2));
-    // c3 = (b (y3 (x1 y2 - x2 y1) - (x1 y1 - x2 y2)) + (1 - b)(y3 - y1)) nl
-    const F t3 = sub(mul(y3, sub(mul(x1, y2), mul(x2, y1))), sub(x1y1, x2y2));
+    // c3 = (b (y3 (x1 y2 - x2 y1) - (x1 y1 - x2 y2)) + (1 - b)(y3 - y1)) nl;  x1 y2 - x2 y1 fused
+    const F t3 = sub(mul(y3, mul2(x1, y2, neg(x2), y1)), sub(x1y1, x2y2));
     const F v3 = sub(y3, y1);
     const F c3 = add(v3, mul(b, carry(sub(t3, v3))));
-    acc = add(acc, mul(a2, c3));
-    acc = mul(carry(acc), nl);
+    // (a0 c1 + a1 c2 + a2 c3) nl: the first two products fused (operands carried: limbs below 2^29)
+    F acc = add(mul2(a0, carry(c1), a1, carry(c2)), mul(a2, c3));
+    acc = mul(acc, nl);
     // c4 = b (1 - b)
     acc = add(acc, mul(a3, mul(b, omb)));
-    // a5 c5 + a6 c6 + a7 c7 = (L0 + Llast)(a5 x1 + a6 y1 + a7 accip) - L0 A - Llast B
+    // a5 c5 + a6 c6 + a7 c7 = (L0 + Llast)(a5 x1 + a6 y1 + a7 accip) - (L0 A + Llast B), the last two products fused
     const F lin = add(mul2(a4, x1, a5, y1), mul(a6, ip));
-    return add(acc, sub(sub(mul(add(l0, ln), carry(lin)), mul(l0, A)), mul(ln, B)));
+    return add(acc, sub(mul(add(l0, ln), carry(lin)), mul2(l0, A, ln, B)));
 }
 
 // K8 quotient coefficient: sum_d tail_d fold_d, fold_d = the sum of up to four STANDARD-form coefficients (canonical limbs), tail_d
