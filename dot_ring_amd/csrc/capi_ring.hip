@@ -48,7 +48,11 @@ struct dr_ring_prover {
     // per-ring tables
     Scratch ring_pts_mont;              // [N][16]
     Scratch fixed_coef;                 // [3][N][8] std (px, py, s coefficients)
-    Scratch fixed4, lag4, not_last;     // tables on the 4N domain, FS9 records (raw 9-limb Montgomery 2^261)
+    Scratch fixed4, lag4, not_last;     // tables on the 4N domain, FS9 records (raw 9-limb Montgomery 2^261); with `cosets`: on the three
+                                        // non-trivial cosets only, coset-major ([poly][c - 1][j])
+    bool cosets = true;                 // DOTRING_NTT_COSETS=0: the full 4N-point transforms and constraint evaluation of round 2
+    Scratch coset_scale;                // [3][N] FS9: zeta^(c m) R^2, the multipliers of the scaled N-point NTT input
+    Scratch special;                    // [B][3] FS9: the aggregated constraint polynomial at the three hidden rows of coset 0
     uint8_t root[3 * 96];
     int root_inf[3];
     // per-batch state
@@ -61,20 +65,26 @@ namespace {
 
 // fmt_in / fmt_out: dr::NTT_FMT_STD8 (8 canonical words, standard form) or dr::NTT_FMT_FS9 (raw 9-limb Montgomery records)
 int ring_ntt(dr_ring_prover* p, uint32_t* d_data, unsigned log2n, size_t batch, bool inverse, int fmt_in = dr::NTT_FMT_STD8,
-             int fmt_out = dr::NTT_FMT_STD8, const uint32_t* d_src = nullptr, int pad = 0) {
+             int fmt_out = dr::NTT_FMT_STD8, const uint32_t* d_src = nullptr, int pad = 0, uint32_t src_div = 1,
+             const uint32_t* d_in_scale = nullptr, const uint32_t* d_special = nullptr) {
     dr_ctx* ctx = p->ctx;
     const drh::Fr& w = log2n == p->rc.log2n ? p->omega_n : p->omega_4n;
     drh::Fr wi = inverse ? w.inv() : w;
     drh::Fr scale;
     if (inverse) scale = drh::Fr::from_u64((uint64_t)1 << log2n).inv();
-    const size_t in_words = fmt_in == dr::NTT_FMT_FS9 ? dr::L29 : 8, out_words = fmt_out == dr::NTT_FMT_FS9 ? dr::L29 : 8;
-    // dr_ntt limits one launch to 65535 transforms (grid.y): split larger batches
+    const size_t out_words = fmt_out == dr::NTT_FMT_FS9 ? dr::L29 : 8;
+    // source words per TRANSFORM (the source pointer advances by whole launches): a scaled source is shared by src_div transforms,
+    // a coset-major source holds 3/4 of the points
+    const size_t in_words_x4 = fmt_in == dr::NTT_FMT_FS9 ? 4 * dr::L29 : fmt_in == dr::NTT_FMT_FS9_COSETS ? 3 * dr::L29 : 32;
+    // dr_ntt limits one launch to 65535 transforms (grid.y): split larger batches (in multiples of src_div)
+    const size_t per_launch = 65535 / src_div * src_div;
     for (size_t done = 0; done < batch;) {
-        size_t take = std::min<size_t>(batch - done, 65535);
+        size_t take = std::min<size_t>(batch - done, per_launch);
         int rc = dr::ntt_run(ctx->stream, [&](const char* name, auto&& f) { return launch(ctx, name, f); }, ctx->twiddles, ctx->io_b,
                              d_data + done * (out_words << log2n), log2n, take, wi, inverse ? &scale : nullptr,
                              [&]() -> int { return DR_OK; }, fmt_in, fmt_out,
-                             d_src ? d_src + done * (in_words << (log2n - pad)) : nullptr, pad);
+                             d_src ? d_src + (done / src_div) * ((in_words_x4 << (log2n - pad)) / 4) : nullptr, pad, src_div, d_in_scale,
+                             d_special ? d_special + done * 3 * dr::L29 : nullptr);
         if (rc != DR_OK) return rc == DR_ERR_NOMEM ? fail(rc, "out of device memory in NTT") : fail(rc, "NTT launch failed");
         done += take;
     }
@@ -173,6 +183,8 @@ int dr_ring_prover_create_te(dr_ctx* ctx, int curve, const dr_srs* srs, unsigned
     rc.tail9[0] = dr::fs_arg_mont(e3.neg()); rc.tail9[1] = dr::fs_arg_mont(e2); rc.tail9[2] = dr::fs_arg_mont(e1.neg());
     rc.tail9[3] = dr::fs_arg_mont(drh::Fr::one());
     rc.omega9 = dr::fs_arg_mont(p->omega_n);
+    rc.nl_hidden[0] = dr::fs_arg_mont(w3 - w4); rc.nl_hidden[1] = dr::fs_arg_mont(w2 - w4); rc.nl_hidden[2] = dr::fs_arg_mont(w1 - w4);
+    p->cosets = std::getenv("DOTRING_NTT_COSETS") == nullptr || std::atoi(std::getenv("DOTRING_NTT_COSETS")) != 0;
     hipStream_t st = ctx->stream;
     // ring points -> Montgomery table ; fixed evaluation columns
     TRY(p->ring_pts_mont.reserve((size_t)n * 64));
@@ -186,24 +198,39 @@ int dr_ring_prover_create_te(dr_ctx* ctx, int curve, const dr_srs* srs, unsigned
         MsmTable t = srs_table(srs, 0);
         TRY(msm_to_bytes(ctx, srs->d_bases, p->fixed_coef.as<uint32_t>(), n, 3, p->root, p->root_inf, &t));
     }
-    // 4N-domain tables: zero-padded coefficients -> forward NTT with FS9 output (raw 9-limb Montgomery records)
-    Scratch pad4;
-    TRY(pad4.reserve((size_t)3 * m * 32));
-    TRY(p->fixed4.reserve((size_t)3 * m * dr::L29 * 4));
-    hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up((size_t)3 * m, 256)), dim3(256), 0, st, p->fixed_coef.as<uint32_t>(), n,
-                       pad4.as<uint32_t>(), m, (size_t)3);
-    TRY(ring_ntt(p, p->fixed4.as<uint32_t>(), log2n + 2, 3, false, dr::NTT_FMT_STD8, dr::NTT_FMT_FS9, pad4.as<uint32_t>(), 0));
-    Scratch lagc;
+    Scratch pad4, lagc;
     TRY(lagc.reserve((size_t)2 * n * 32));
     hipLaunchKernelGGL(dr::k_ring_lagrange, dim3(div_up(n, 256)), dim3(256), 0, st, lagc.as<uint32_t>(), n,
                        arg_of(drh::Fr::from_u64(n).inv()), arg_of(w4.inv()));
-    TRY(p->lag4.reserve((size_t)2 * m * dr::L29 * 4));
-    hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up((size_t)2 * m, 256)), dim3(256), 0, st, lagc.as<uint32_t>(), n, pad4.as<uint32_t>(), m, (size_t)2);
-    TRY(ring_ntt(p, p->lag4.as<uint32_t>(), log2n + 2, 2, false, dr::NTT_FMT_STD8, dr::NTT_FMT_FS9, pad4.as<uint32_t>(), 0));
-    TRY(p->not_last.reserve((size_t)m * dr::L29 * 4));
-    // x - w^(N-4) on the 4N domain: built in the 8-word Montgomery form (pad4 is free again), then converted
-    hipLaunchKernelGGL(dr::k_ring_not_last, dim3(div_up(m, 256)), dim3(256), 0, st, pad4.as<uint32_t>(), m, arg_of(p->omega_4n), arg_of(w4));
-    hipLaunchKernelGGL(dr::k_fr_mont_to_fs9, dim3(div_up(m, 256)), dim3(256), 0, st, pad4.as<uint32_t>(), p->not_last.as<uint32_t>(), (size_t)m);
+    if (p->cosets) {
+        // tables on the three non-trivial cosets, coset-major: per polynomial three N-point NTTs of its coefficients scaled by zeta^(c m)
+        TRY(p->coset_scale.reserve((size_t)3 * n * dr::L29 * 4));
+        hipLaunchKernelGGL(dr::k_ring_coset_scale, dim3(div_up((size_t)3 * n, 256)), dim3(256), 0, st, p->coset_scale.as<uint32_t>(), n,
+                           dr::fs_arg_mont(p->omega_4n));
+        TRY(p->fixed4.reserve((size_t)3 * 3 * n * dr::L29 * 4));
+        TRY(ring_ntt(p, p->fixed4.as<uint32_t>(), log2n, 9, false, dr::NTT_FMT_STD8_SCALED, dr::NTT_FMT_FS9, p->fixed_coef.as<uint32_t>(), 0, 3,
+                     p->coset_scale.as<uint32_t>()));
+        TRY(p->lag4.reserve((size_t)2 * 3 * n * dr::L29 * 4));
+        TRY(ring_ntt(p, p->lag4.as<uint32_t>(), log2n, 6, false, dr::NTT_FMT_STD8_SCALED, dr::NTT_FMT_FS9, lagc.as<uint32_t>(), 0, 3,
+                     p->coset_scale.as<uint32_t>()));
+        TRY(p->not_last.reserve((size_t)3 * n * dr::L29 * 4));
+        hipLaunchKernelGGL(dr::k_ring_not_last3, dim3(div_up((size_t)3 * n, 256)), dim3(256), 0, st, p->not_last.as<uint32_t>(), n, arg_of(p->omega_4n),
+                           arg_of(w4));
+    } else {
+        // 4N-domain tables: zero-padded coefficients -> forward NTT with FS9 output (raw 9-limb Montgomery records)
+        TRY(pad4.reserve((size_t)3 * m * 32));
+        TRY(p->fixed4.reserve((size_t)3 * m * dr::L29 * 4));
+        hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up((size_t)3 * m, 256)), dim3(256), 0, st, p->fixed_coef.as<uint32_t>(), n,
+                           pad4.as<uint32_t>(), m, (size_t)3);
+        TRY(ring_ntt(p, p->fixed4.as<uint32_t>(), log2n + 2, 3, false, dr::NTT_FMT_STD8, dr::NTT_FMT_FS9, pad4.as<uint32_t>(), 0));
+        TRY(p->lag4.reserve((size_t)2 * m * dr::L29 * 4));
+        hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up((size_t)2 * m, 256)), dim3(256), 0, st, lagc.as<uint32_t>(), n, pad4.as<uint32_t>(), m, (size_t)2);
+        TRY(ring_ntt(p, p->lag4.as<uint32_t>(), log2n + 2, 2, false, dr::NTT_FMT_STD8, dr::NTT_FMT_FS9, pad4.as<uint32_t>(), 0));
+        TRY(p->not_last.reserve((size_t)m * dr::L29 * 4));
+        // x - w^(N-4) on the 4N domain: built in the 8-word Montgomery form (pad4 is free again), then converted
+        hipLaunchKernelGGL(dr::k_ring_not_last, dim3(div_up(m, 256)), dim3(256), 0, st, pad4.as<uint32_t>(), m, arg_of(p->omega_4n), arg_of(w4));
+        hipLaunchKernelGGL(dr::k_fr_mont_to_fs9, dim3(div_up(m, 256)), dim3(256), 0, st, pad4.as<uint32_t>(), p->not_last.as<uint32_t>(), (size_t)m);
+    }
     HIP_TRY(hipStreamSynchronize(st));
     lagc.release();
     pad4.release();
@@ -216,7 +243,7 @@ int dr_ring_prover_create_te(dr_ctx* ctx, int curve, const dr_srs* srs, unsigned
 void dr_ring_prover_destroy(dr_ring_prover* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    for (Scratch* s : {&p->ring_pts_mont, &p->fixed_coef, &p->fixed4, &p->lag4, &p->not_last, &p->idx, &p->blind, &p->zk, &p->chain_ext,
+    for (Scratch* s : {&p->ring_pts_mont, &p->fixed_coef, &p->fixed4, &p->lag4, &p->not_last, &p->coset_scale, &p->special, &p->idx, &p->blind, &p->zk, &p->chain_ext,
                        &p->prefix, &p->chain_aff, &p->cnt, &p->relation, &p->rps, &p->cols, &p->wit4, &p->alphas, &p->alphas9, &p->alpha_aux, &p->agg, &p->q, &p->zetas,
                        &p->evals, &p->ks, &p->lin, &p->nus, &p->nus9, &p->aggo, &p->chunkv, &p->quot1, &p->quot2, &p->diffs})
         s->release();
@@ -343,6 +370,26 @@ int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alpha
     TRY(p->alpha_aux.reserve(batch * 2 * dr::L29 * 4));
     hipLaunchKernelGGL(dr::k_ring_alpha_aux, dim3(div_up(batch, 64)), dim3(64), 0, st, p->alphas.as<uint32_t>(), p->rps.as<uint32_t>(), rc,
                        (uint32_t)batch, p->alpha_aux.as<uint32_t>());
+    if (p->cosets) {
+        // coset 0 first: the three hidden rows from the N-domain evaluations the witness phase left in wit4 (about to be overwritten)
+        TRY(p->special.reserve(batch * 3 * dr::L29 * 4));
+        TRY(launch(ctx, "k_ring_constraints", [&] {
+            LAUNCH_CV(p->curve, dr::k_ring_hidden_rows, dim3(div_up(batch * 3, 64)), dim3(64), 0, st, p->wit4.as<uint32_t>(), p->ring_pts_mont.as<uint32_t>(),
+                      p->alphas9.as<uint32_t>(), rc, (uint32_t)batch, p->special.as<uint32_t>());
+        }));
+        // N coefficients per column -> evaluations on the cosets zeta^c H, c = 1..3: three N-point NTTs of the coefficients scaled by
+        // zeta^(c m) (the scaling rides on the product that converts the input to Montgomery form), raw 9-limb records, coset-major
+        TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n, batch * 12, false, dr::NTT_FMT_STD8_SCALED, dr::NTT_FMT_FS9, p->cols.as<uint32_t>(), 0, 3,
+                     p->coset_scale.as<uint32_t>()));
+        TRY(launch(ctx, "k_ring_constraints", [&] {
+            LAUNCH_CV(p->curve, dr::k_ring_constraints3, dim3(div_up(batch * 3 * (size_t)n, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(),
+                      p->fixed4.as<uint32_t>(), p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas9.as<uint32_t>(),
+                      p->alpha_aux.as<uint32_t>(), rc, (uint32_t)batch, p->agg.as<uint32_t>());
+        }));
+        // inverse 4N-point transform of (zeros and the hidden rows on coset 0, the three evaluated cosets): standard-form coefficients
+        TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch, true, dr::NTT_FMT_FS9_COSETS, dr::NTT_FMT_STD8, p->agg.as<uint32_t>(), 0, 1, nullptr,
+                     p->special.as<uint32_t>()));
+    } else {
     // N coefficients per column -> evaluations on the 4N domain: the NTT reads the columns directly (zero padding implied) and
     // leaves the evaluations as raw 9-limb records
     TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch * 4, false, dr::NTT_FMT_STD8, dr::NTT_FMT_FS9, p->cols.as<uint32_t>(), 2));
@@ -353,6 +400,7 @@ int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alpha
     }));
     // the constraint kernel wrote raw sums; the coefficients (standard form) land in the (now free) wit4 buffer
     TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch, true, dr::NTT_FMT_FS9, dr::NTT_FMT_STD8, p->agg.as<uint32_t>(), 0));
+    }
     TRY(launch(ctx, "k_ring_quotient", [&] {
         hipLaunchKernelGGL(dr::k_ring_quotient, dim3(div_up(batch * qn, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(), rc, (uint32_t)batch,
                            p->q.as<uint32_t>());

@@ -34,7 +34,22 @@ namespace dr {
 constexpr int NTT_LOG_TILE = 10, NTT_TILE = 1 << NTT_LOG_TILE, NTT_BLOCK = 256;
 constexpr int NTT_STRIDED_TILE = 1024, NTT_MIN_COLS = 64, NTT_MAX_ROW_BITS = 4;
 constexpr int NTT_TW_WORDS = 12;                     // a twiddle record: 9 limbs + 3 words of padding (16-byte loads)
-enum { NTT_FMT_STD8 = 0, NTT_FMT_FS9 = 1 };
+enum { NTT_FMT_STD8 = 0, NTT_FMT_FS9 = 1, NTT_FMT_STD8_SCALED = 2, NTT_FMT_FS9_COSETS = 3 };
+// Where pass A finds element `idx` (natural order) of transform `xform`:
+//   STD8 / FS9       base[xform][idx]                                           (n >> pad elements per transform)
+//   STD8_SCALED      base[xform / div][idx] * scale[xform % div][idx]           — `div` transforms read ONE coefficient vector, each with
+//                    its own table of multipliers (FS9, premultiplied by R^2: the product that converts to Montgomery form applies
+//                    it): the evaluations of a polynomial on the cosets zeta^c H are NTT_N(a_m zeta^(c m))
+//   FS9_COSETS       the 4N-point vector whose coset c = idx mod 4, row j = idx / 4 lives coset-major in base[xform][c - 1][j] for
+//                    c = 1..3; coset 0 is zero except its last three rows, special[xform][0..2] (the aggregated constraint polynomial
+//                    vanishes on H outside the hidden rows)
+struct NttSource {
+    const uint32_t* base;
+    const uint32_t* scale;
+    const uint32_t* special;
+    int fmt;
+    uint32_t div;
+};
 
 template <int STRIDE = NTT_TILE>
 DR_DEV Fs lds_get9(const int32_t* t, int i) {
@@ -80,10 +95,19 @@ DR_DEV Fr from_arg(const FrArg& a) {
     return r;
 }
 
-// an element of the input array in the given format -> Fs, Montgomery form (STD8: one product with R^2; FS9: as it lies)
-DR_DEV Fs ntt_load(const uint32_t* base, size_t idx, int fmt) {
-    if (fmt == NTT_FMT_FS9) return fs_load9(base + idx * L29);
-    return fs_from_std(gload_fr(base + idx * 8));
+// element `idx` of transform `xform` (n_src elements per source vector) -> Fs, Montgomery form
+DR_DEV Fs ntt_load(const NttSource& in, size_t xform, size_t idx, size_t n_src) {
+    if (in.fmt == NTT_FMT_FS9) return fs_load9(in.base + (xform * n_src + idx) * L29);
+    if (in.fmt == NTT_FMT_STD8) return fs_from_std(gload_fr(in.base + (xform * n_src + idx) * 8));
+    if (in.fmt == NTT_FMT_STD8_SCALED) {
+        const size_t poly = xform / in.div, c = xform % in.div;
+        return mul(unpack29(gload_fr(in.base + (poly * n_src + idx) * 8).l), fs_load9(in.scale + (c * n_src + idx) * L29));
+    }
+    // NTT_FMT_FS9_COSETS
+    const size_t c = idx & 3, j = idx >> 2, nq = n_src >> 2;
+    if (c != 0) return fs_load9(in.base + ((xform * 3 + (c - 1)) * nq + j) * L29);
+    if (j + 3 >= nq) return fs_load9(in.special + (xform * 3 + (j + 3 - nq)) * L29);
+    return Fs::zero();
 }
 // What a pass leaves behind.  Not the last pass: the raw limbs.  The last pass — STD8: v * factor with the factor in STANDARD form
 // (Montgomery x standard -> standard), canonical words; FS9: v * factor (Montgomery) or, without a factor, reduce_small(v).
@@ -121,21 +145,20 @@ __host__ __device__ inline int ntt_strided_col_bits(int row_bits) { return row_b
 // Pass A: stages 1..S (S = min(k, NTT_LOG_TILE)) on tile `blockIdx.x` of transform `blockIdx.y`.
 // src is read at bit-reversed positions, dst written contiguously (src == dst is allowed only when S == k, where one workgroup
 // owns the whole transform and the formats have the same element size or the whole tile is loaded before anything is stored).
-__global__ __launch_bounds__(NTT_BLOCK) void k_ntt_local(const uint32_t* src, uint32_t* dst,
-                                                         const uint32_t* __restrict__ tw, int k, int S, int final_pass, int fmt_in, int fmt_out,
+__global__ __launch_bounds__(NTT_BLOCK) void k_ntt_local(NttSource in, uint32_t* dst,
+                                                         const uint32_t* __restrict__ tw, int k, int S, int final_pass, int fmt_out,
                                                          int has_factor, FsArg out_factor, int pad) {
     __shared__ int32_t tile[L29 * NTT_TILE];
     const size_t n = (size_t)1 << k;
     const int tsize = 1 << S;
     const size_t xform = blockIdx.y, tbase = (size_t)blockIdx.x * tsize;
-    const size_t in_elem = fmt_in == NTT_FMT_FS9 ? L29 : 8;
-    const uint32_t* in = src + xform * (n >> pad) * in_elem;
+    const size_t n_src = n >> pad;
     uint32_t* out = dst + xform * n * (final_pass && fmt_out == NTT_FMT_STD8 ? 8 : L29);
     if (pad == 0) {
         for (int i = threadIdx.x; i < tsize; i += NTT_BLOCK) {
             size_t pos = tbase + i;
             size_t rev = (size_t)(__brevll((unsigned long long)pos) >> (64 - k));
-            lds_put9(tile, i, ntt_load(in, rev, fmt_in));
+            lds_put9(tile, i, ntt_load(in, xform, rev, n_src));
         }
     } else {
         // the input is a polynomial of n / 2^pad coefficients, zero-padded to n: in bit-reversed order only every 2^pad-th
@@ -145,7 +168,7 @@ __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_local(const uint32_t* src, ui
         for (int i = threadIdx.x; i < (tsize >> pad); i += NTT_BLOCK) {
             size_t grp = (tbase >> pad) + i;
             size_t rev = (size_t)(__brevll((unsigned long long)grp) >> (64 - (k - pad)));
-            const Fs v = ntt_load(in, rev, fmt_in);
+            const Fs v = ntt_load(in, xform, rev, n_src);
             for (int c = 0; c < (1 << pad); c++) lds_put9(tile, (i << pad) + c, v);
         }
     }
@@ -262,11 +285,14 @@ inline FsArg fs_arg_std(const drh::Fr& v) {
 template <class Launch, class ScratchT, class Sync>
 int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp, uint32_t* d_data, unsigned k, size_t batch,
             const drh::Fr& omega_mont, const drh::Fr* scale_mont, Sync&& sync, int fmt_in = NTT_FMT_STD8, int fmt_out = NTT_FMT_STD8,
-            const uint32_t* d_src = nullptr, int pad = 0) {
+            const uint32_t* d_src = nullptr, int pad = 0, uint32_t src_div = 1, const uint32_t* d_in_scale = nullptr,
+            const uint32_t* d_special = nullptr) {
     const size_t n = (size_t)1 << k;
     if (batch > 65535) return DR_ERR_INVALID;
     // value growth (ring_bounds_check.cpp): raw sums as input, or raw output without a final product, are covered up to 16 stages
-    if ((fmt_in == NTT_FMT_FS9 || (fmt_out == NTT_FMT_FS9 && !scale_mont)) && k > 16) return DR_ERR_INVALID;
+    if ((fmt_in == NTT_FMT_FS9 || fmt_in == NTT_FMT_FS9_COSETS || (fmt_out == NTT_FMT_FS9 && !scale_mont)) && k > 16) return DR_ERR_INVALID;
+    if ((fmt_in == NTT_FMT_STD8_SCALED && (!d_in_scale || !d_src || src_div == 0 || pad)) || (fmt_in == NTT_FMT_FS9_COSETS && (!d_special || !d_src || k < 4 || pad)))
+        return DR_ERR_INVALID;
     uint32_t* d_tw = nullptr;
     for (auto& e : cache.entries)
         if (e.log2n == k && e.omega == omega_mont) d_tw = e.d_tw;
@@ -290,10 +316,10 @@ int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp,
     const FsArg fa = fmt_out == NTT_FMT_STD8 ? fs_arg_std(scale_mont ? *scale_mont : drh::Fr::one())
                                              : fs_arg_mont(scale_mont ? *scale_mont : drh::Fr::one());
     const int S = (int)std::min<unsigned>(k, NTT_LOG_TILE);
-    const uint32_t* src = d_src ? d_src : d_data;
+    NttSource src{d_src ? d_src : d_data, d_in_scale, d_special, fmt_in, src_div ? src_div : 1u};
     if ((int)k == S) {
         int rc = launch("k_ntt_local", [&] {
-            hipLaunchKernelGGL(k_ntt_local, dim3(1, (unsigned)batch), dim3(NTT_BLOCK), 0, st, src, d_data, d_tw, (int)k, S, 1, fmt_in, fmt_out, has_factor, fa, pad);
+            hipLaunchKernelGGL(k_ntt_local, dim3(1, (unsigned)batch), dim3(NTT_BLOCK), 0, st, src, d_data, d_tw, (int)k, S, 1, fmt_out, has_factor, fa, pad);
         });
         if (rc != DR_OK) return rc;
         return sync();
@@ -306,7 +332,7 @@ int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp,
         d_mid = reinterpret_cast<uint32_t*>(tmp.p);
     }
     int rc = launch("k_ntt_local", [&] {
-        hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> S), (unsigned)batch), dim3(NTT_BLOCK), 0, st, src, d_mid, d_tw, (int)k, S, 0, fmt_in, fmt_out, has_factor, fa, pad);
+        hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> S), (unsigned)batch), dim3(NTT_BLOCK), 0, st, src, d_mid, d_tw, (int)k, S, 0, fmt_out, has_factor, fa, pad);
     });
     if (rc != DR_OK) return rc;
     for (int lo = S; lo < (int)k; lo += NTT_MAX_ROW_BITS) {

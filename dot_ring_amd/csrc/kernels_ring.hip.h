@@ -43,6 +43,15 @@ DR_DEV Fr fr_pow_u32(Fr base, uint32_t e) {
     return r;
 }
 
+DR_DEV Fs fs_pow_u32_early(Fs base, uint32_t e) {          // base^e on the unsaturated field (Montgomery in and out)
+    Fs r = Fs::one();
+    for (; e; e >>= 1) {
+        if (e & 1) r = mul(r, base);
+        base = sqr(base);
+    }
+    return r;
+}
+
 // ---- per-ring setup ------------------------------------------------------------------------------------------
 // split the ring points into the px / py evaluation columns (standard form) and the selector column
 __global__ void k_ring_fixed_evals(const uint32_t* __restrict__ pts_std /* N*16 */, uint32_t n, uint32_t max_ring,
@@ -94,6 +103,26 @@ __global__ void k_ring_not_last(uint32_t* __restrict__ out, uint32_t m, FrArg w4
     gstore_fr(out + (size_t)i * 8, sub(fr_pow_u32(from_arg(w4_mont), i), from_arg(last_root_mont)));
 }
 
+// ---- the three non-trivial cosets of H in the 4N domain (round 3) ---------------------------------------------------
+// The 4N-domain point i = 4 j + c is w^j zeta^c (zeta = w_4N).  Everything the constraint kernel touches is kept coset-major,
+// [c - 1][j] for c = 1..3: a polynomial's evaluations on coset c are ONE N-point NTT of its coefficients scaled by zeta^(c m), the
+// row shift i -> i + 4 is j -> j + 1 within a coset, and coset 0 — H itself, where the aggregated constraint polynomial vanishes
+// outside the three hidden rows — is never transformed or evaluated at all.
+// multipliers of the scaled NTT input: out[c - 1][m] = zeta^(c m) R^2 (FS9), so that unpack(a_m) * out = Montgomery(a_m zeta^(c m))
+__global__ void k_ring_coset_scale(uint32_t* __restrict__ out /* [3][n] FS9 */, uint32_t n, FsArg zeta_mont) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 3 * n) return;
+    const uint32_t c = gid / n + 1, m = gid % n;
+    fs_store9(out + (size_t)gid * L29, mul(fs_pow_u32_early(from_arg(zeta_mont), c * m), Fs::constant<Fr29Params::R2>()));
+}
+// not_last on the three cosets: out[c - 1][j] = zeta^(4 j + c) - w^(N-4)   (FS9)
+__global__ void k_ring_not_last3(uint32_t* __restrict__ out /* [3][n] FS9 */, uint32_t n, FrArg zeta_mont256, FrArg last_root_mont256) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 3 * n) return;
+    const uint32_t c = gid / n + 1, j = gid % n;
+    fs_store9(out + (size_t)gid * L29, from_mont256(sub(fr_pow_u32(from_arg(zeta_mont256), 4 * j + c), from_arg(last_root_mont256))));
+}
+
 // ---- summation-by-parts commitments of the witness columns ------------------------------------------------------
 // The witness columns are piecewise constant in EVALUATION form (one-hot / bit rows, an accumulator that changes at
 // <= 254 rows), so   sum_j e_j * L_j(tau) G  =  sum_j (e_j - e_{j+1}) * PS_j   with  PS_j = sum_{i<=j} L_i(tau) G
@@ -135,6 +164,7 @@ struct RingConsts {
     FrArg last_x;                        // w_N^(N-4), Montgomery
     FsArg tail9[4];                      // the tail coefficients and w_N again as FS9 arguments (Montgomery 2^261)
     FsArg omega9;
+    FsArg nl_hidden[3];                  // w^(N-3+r) - w^(N-4), r = 0..2: the factor (x - w^(N-4)) at the three hidden rows
 };
 
 // One lane per proof: the conditional-sum accumulator visits at most 255 distinct values (seed, then one addition
@@ -437,6 +467,51 @@ __global__ void k_ring_alpha_aux(const uint32_t* __restrict__ alphas /* [B][7][8
     fs_store9(out + ((size_t)pid * 2 + 1) * L29, from_mont256(add(add(mul(a5, rx), mul(a6, ry)), a7)));
 }
 
+// K7 on the three cosets (coset-major layouts, see above): one lane per (proof, coset, row); the shifted row is j + 1 of the same coset
+template <int CV>
+__global__ __launch_bounds__(256) void k_ring_constraints3(const uint32_t* __restrict__ wit3 /* [B][4][3][n] FS9: b, accip, accx, accy */,
+                                                           const uint32_t* __restrict__ fixed3 /* [3][3][n] FS9: px, py, s */,
+                                                           const uint32_t* __restrict__ lag3 /* [2][3][n] FS9: L0, Llast */,
+                                                           const uint32_t* __restrict__ nl3 /* [3][n] FS9 */, const uint32_t* __restrict__ alphas,
+                                                           const uint32_t* __restrict__ alpha_aux, RingConsts rc, uint32_t batch,
+                                                           uint32_t* __restrict__ agg3 /* [B][3][n] FS9, raw sums */) {
+    const uint32_t n = rc.n, m3 = 3 * n;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)batch * m3) return;
+    const uint32_t pid = (uint32_t)(gid / m3), r = (uint32_t)(gid % m3), c = r / n, j = r % n, jn = j + 1 == n ? 0 : j + 1;
+    const uint32_t* w = wit3 + (size_t)pid * 4 * m3 * L29;
+    auto at = [&](uint32_t col, uint32_t row) { return fs_load9(w + (((size_t)col * 3 + c) * n + row) * L29); };
+    auto tab = [&](const uint32_t* t, uint32_t k) { return fs_load9(t + (((size_t)k * 3 + c) * n + j) * L29); };
+    const uint32_t* al = alphas + (size_t)pid * 7 * L29;
+    const uint32_t* ax = alpha_aux + (size_t)pid * 2 * L29;
+    const Fs acc = body_constraints<CV>(at(0, j), at(1, j), at(1, jn), at(2, j), at(2, jn), at(3, j), at(3, jn), tab(fixed3, 0), tab(fixed3, 1),
+                                        tab(fixed3, 2), tab(lag3, 0), tab(lag3, 1), fs_load9(nl3 + ((size_t)c * n + j) * L29), fs_load9(al),
+                                        fs_load9(al + L29), fs_load9(al + 2 * L29), fs_load9(al + 3 * L29), fs_load9(al + 4 * L29), fs_load9(al + 5 * L29),
+                                        fs_load9(al + 6 * L29), fs_load9(ax), fs_load9(ax + L29));
+    fs_store9(agg3 + gid * L29, acc);
+}
+// coset 0 = H: the aggregated constraint polynomial is zero there except at the three hidden rows N-3 .. N-1 (the quotient's tail
+// factor takes care of those).  One lane per (proof, hidden row): the same body on the N-domain evaluations — witness columns as the
+// witness phase left them (standard form), the ring point of that row, selector 0, L0 = Llast = 0.
+template <int CV>
+__global__ void k_ring_hidden_rows(const uint32_t* __restrict__ col_evals /* [B][4][n][8] std */, const uint32_t* __restrict__ ring_pts_mont /* [n][16] Montgomery 256 */,
+                                   const uint32_t* __restrict__ alphas /* [B][7] FS9 */, RingConsts rc, uint32_t batch,
+                                   uint32_t* __restrict__ special /* [B][3] FS9 */) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= batch * 3) return;
+    const uint32_t pid = gid / 3, r = gid % 3, n = rc.n, j = n - 3 + r, jn = j + 1 == n ? 0 : j + 1;
+    const uint32_t* w = col_evals + (size_t)pid * 4 * n * 8;
+    // reduce_small: the body's witness inputs are the forward NTT's outputs elsewhere (|value| < 0.51 p)
+    auto at = [&](uint32_t col, uint32_t row) { return reduce_small(fs_from_std(gload_fr(w + ((size_t)col * n + row) * 8))); };
+    const Fs x2 = from_mont256(gload_fr(ring_pts_mont + (size_t)j * 16)), y2 = from_mont256(gload_fr(ring_pts_mont + (size_t)j * 16 + 8));
+    const Fs zero = Fs::zero();
+    const uint32_t* al = alphas + (size_t)pid * 7 * L29;
+    const Fs acc = body_constraints<CV>(at(0, j), at(1, j), at(1, jn), at(2, j), at(2, jn), at(3, j), at(3, jn), carry(x2), carry(y2), zero, zero, zero,
+                                        from_arg(rc.nl_hidden[r]), fs_load9(al), fs_load9(al + L29), fs_load9(al + 2 * L29), fs_load9(al + 3 * L29),
+                                        fs_load9(al + 4 * L29), fs_load9(al + 5 * L29), fs_load9(al + 6 * L29), zero, zero);
+    fs_store9(special + (size_t)gid * L29, acc);
+}
+
 // ---- K8: coefficient-space passes ---------------------------------------------------------------------------
 // These kernels combine standard-form coefficient vectors with a few per-proof scalars.  A Montgomery product of a
 // Montgomery-form scalar with a STANDARD-form value is the standard form of the product (x R * c / R = x c), and sums of
@@ -449,14 +524,7 @@ DR_DEV void st_coef_small(uint32_t* p, const Fs& v) {                           
     canon29_small(v, o.l);
     gstore_fr(p, o);
 }
-DR_DEV Fs fs_pow_u32(Fs base, uint32_t e) {
-    Fs r = Fs::one();
-    for (; e; e >>= 1) {
-        if (e & 1) r = mul(r, base);
-        base = sqr(base);
-    }
-    return r;
-}
+DR_DEV Fs fs_pow_u32(const Fs& base, uint32_t e) { return fs_pow_u32_early(base, e); }
 // quotient: c_agg = tail (cubic) * agg_poly ;  q_j = sum_{i>=1} c_agg[j + i*N],  j < 3N+1
 __global__ void k_ring_quotient(const uint32_t* __restrict__ agg_poly /* [B][4N][8] std */, RingConsts rc, uint32_t batch,
                                 uint32_t* __restrict__ q /* [B][3N+1][8] std */) {

@@ -126,6 +126,12 @@ int main() {
                                                    canonical, canonical, canonical, normal, normal, normal, normal, normal, normal, normal, normal, normal);
         expect_within(dr::g_where, r, dr::TWO29 * 3, 3.3);
     }
+    {   // the hidden rows of coset 0 (k_ring_hidden_rows): ring point converted from the 2^256 form (normal, not canonical), zero selector / Lagrange rows
+        dr::g_where = "constraints (hidden rows)";
+        const FsB zero = FsB::make(0, 0, 0, 0);
+        expect_within(dr::g_where, dr::body_constraints<0>(reduced, reduced, reduced, reduced, reduced, reduced, reduced, normal, normal, zero, zero, zero, canonical,
+                                                           normal, normal, normal, normal, normal, normal, normal, zero, zero), dr::TWO29 * 3, 3.3);
+    }
     dr::g_where = "quotient";
     {
         const FsB fold = FsB::make(0, 4 * (dr::TWO29 - 1), 0, 4);            // up to four canonical coefficients added

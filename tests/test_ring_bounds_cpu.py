@@ -16,6 +16,6 @@ def test_ring_kernel_bodies_keep_their_bounds(tmp_path):
     proc = subprocess.run([str(exe)], capture_output=True, text=True)
     assert proc.returncode == 0, proc.stderr
     assert "all bounds hold" in proc.stdout
-    for name in ("constraints (Bandersnatch)", "constraints (JubJub)", "quotient", "horner", "agg8", "lin3", "ntt (normal input)",
+    for name in ("constraints (Bandersnatch)", "constraints (JubJub)", "constraints (hidden rows)", "quotient", "horner", "agg8", "lin3", "ntt (normal input)",
                  "ntt (constraint-kernel input)", "ntt (16 stages, raw output)"):
         assert name in proc.stdout
