@@ -93,7 +93,7 @@ for cv, suite in ((d.Bandersnatch, bsn.SHA512), (d.Bandersnatch_SHAKE128, bsn.SH
         t0 = time.perf_counter()
         wrong = total = 0
         for _ in range(max(1, int(2 * scale))):
-            size = rng.choice([1, 2, 9, 100, 255, 256, 300, 700])
+            size = rng.choice([1, 2, 9, 100, 255, 256, 300, 700, 767, 768, 1500] if cv is not d.JubJub else [1, 2, 9, 100, 255, 256, 300, 700])
             sks = [rng.randrange(1, bsn.N).to_bytes(32, "little") for _ in range(size)]
             keys = [cv.public_key_from_secret(sk) for sk in sks]
             params = d.RingProofParams.from_ring_size(size, test_vectors=True, cv=cv)
@@ -166,6 +166,41 @@ raw = b"".join(k.to_bytes(32, "little") for k in ks)
 got = coracle.te_unpack(ctx.te_fixed_base_msm_groups(coracle.te_pack([bsn.G, bsn.SHA512.blinding_base]), raw))
 want = [bsn.add(coracle.te_mul(bsn.G, ks[2 * i] % bsn.N), coracle.te_mul(bsn.SHA512.blinding_base, ks[2 * i + 1] % bsn.N)) for i in range(n)]
 report("fixed-base x*G + b*B", n, sum(g != w for g, w in zip(got, want)), t0)
+
+# 9. round 3: the NTT on the unsaturated field — random sizes, batches, scales, forward and inverse roots — against the oracle's radix-2 network
+t0 = time.perf_counter()
+wrong = total = 0
+root_2_32 = pow(7, (coracle.FR_P - 1) >> 32, coracle.FR_P)
+for _ in range(max(4, int(12 * scale))):
+    k = rng.choice([1, 2, 3, 6, 9, 10, 11, 12, 13, 14, 15])
+    n, batch = 1 << k, rng.choice([1, 1, 2, 5])
+    omega = pow(root_2_32, 1 << (32 - k), coracle.FR_P)
+    if rng.random() < 0.5:
+        omega = pow(omega, -1, coracle.FR_P)
+    scale_by = rng.choice([None, pow(n, -1, coracle.FR_P), rng.randrange(1, coracle.FR_P)])
+    rows = [[rng.choice([0, 1, coracle.FR_P - 1, rng.randrange(coracle.FR_P)]) if rng.random() < 0.2 else rng.randrange(coracle.FR_P) for _ in range(n)] for _ in range(batch)]
+    data = b"".join(v.to_bytes(32, "little") for row in rows for v in row)
+    got = ctx.ntt(data, k, omega, scale=scale_by)
+    for b, row in enumerate(rows):
+        want = coracle.ntt_raw(b"".join(v.to_bytes(32, "little") for v in row), n, omega)
+        if scale_by is not None:
+            want = b"".join((int.from_bytes(want[32 * i : 32 * i + 32], "little") * scale_by % coracle.FR_P).to_bytes(32, "little") for i in range(n))
+        wrong += got[32 * n * b : 32 * n * (b + 1)] != bytes(want)
+        total += 1
+report("ntt shapes", total, wrong, t0)
+
+# 10. round 3: the device-resident scalar multiplication (GLV decomposition in the kernel), full-width scalars
+t0 = time.perf_counter()
+n = int(3000 * scale)
+base = [coracle.te_mul(bsn.G, rng.randrange(1, bsn.N)) for _ in range(200)]
+pts = [base[rng.randrange(200)] for _ in range(n)]
+ks = [rng.choice([0, 1, bsn.N - 1, bsn.N, (1 << 256) - 1]) if rng.random() < 0.02 else rng.randrange(1 << 256) for _ in range(n)]
+raw_p, raw_k = coracle.te_pack(pts), b"".join(k.to_bytes(32, "little") for k in ks)
+d_p, d_k, d_o = ctx.alloc(64 * n).upload(raw_p), ctx.alloc(32 * n).upload(raw_k), ctx.alloc(64 * n)
+ctx.bsn_scalar_mul_batch_dev(d_p, d_k, n, d_o)
+got = d_o.download()
+want = coracle.te_mul_batch_raw(raw_p, coracle.scalars_pack([k % bsn.N for k in ks]), n, glv=True)
+report("bsn scalar_mul device-resident (GLV split on device)", n, sum(got[64 * i : 64 * i + 64] != bytes(want[64 * i : 64 * i + 64]) for i in range(n)), t0)
 
 print("FUZZ", "FAILED" if bad else "OK")
 sys.exit(1 if bad else 0)
