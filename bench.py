@@ -666,6 +666,16 @@ def main() -> int:
             parity_ok = parity_ok and single["verified"]
             pipelined = pipelined_leg(w, max(3, args.steps))
             parity_ok = parity_ok and pipelined["all_verified"]
+            if args.ring_size == 1024 and batch == 1024:
+                # the same step at other batch sizes per call: the fixed latencies of a call (head, decoding, host phases) against its batch
+                sweep = {}
+                for b in (512, 2048):
+                    wb = RingWorkload(d, args.ring_size, b)
+                    el, okb = wb.run(3, 1)
+                    sweep[str(b)] = {"proofs_per_s": b * 3 / el, "ms_per_step": el / 3 * 1e3, "all_verified": bool(okb)}
+                    parity_ok = parity_ok and okb
+                    del wb
+                pipelined["batch_sweep"] = sweep
             if args.ring_size == 1024 and batch >= 2:
                 # 1024 different signing keys (the reference bench — and the headline — sign every proof with one key)
                 w.distinct_signers()
