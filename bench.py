@@ -21,6 +21,7 @@ Secondary measurements in the same JSON line (rank 0, one GPU):
   distinct_signers   the headline workload with 1024 different signing keys instead of one
   single_call_ms     latency of one RingVRF.prove / one RingVRF.verify (the reference's own benchmark shape, docs/BENCHMARK.md:63-73)
   pipelined_prove_verify  the headline's work with batch_verify of batch k on a helper thread beside prove_batch of batch k + 1
+  batch_sweep        the headline's step at 512 and 2048 proofs per call
 With N ranks (one per GPU) every rank proves and verifies its own 1024 proofs — independent units, no collective.  N > 1 adds
   config5            BASELINE configs[4] at its per-GPU shape: ring 3839 (the largest ring of domain 4096, known-tau SRS),
                      1024 proofs per rank, prove + verify, parity subset against the oracle on rank 0
@@ -651,7 +652,7 @@ def main() -> int:
                                                     "NOT measured in this run)") if traffic else None
             except Exception:
                 traffic = None
-        g1 = bsn = others = distinct = single = pipelined = None
+        g1 = bsn = others = distinct = single = pipelined = sweep = None
         if world == 1 and args.msm_log2n > 0:
             g1 = g1_msm_measurement(ctx, args.msm_log2n, 10, 17, True)
             parity_ok = parity_ok and g1.get("parity_closed_form", True) and g1.get("parity_sample", True)
@@ -675,7 +676,7 @@ def main() -> int:
                     sweep[str(b)] = {"proofs_per_s": b * 3 / el, "ms_per_step": el / 3 * 1e3, "all_verified": bool(okb)}
                     parity_ok = parity_ok and okb
                     del wb
-                pipelined["batch_sweep"] = sweep
+
             if args.ring_size == 1024 and batch >= 2:
                 # 1024 different signing keys (the reference bench — and the headline — sign every proof with one key)
                 w.distinct_signers()
@@ -738,6 +739,7 @@ def main() -> int:
             "distinct_signers": distinct,
             "single_call_ms": single,
             "pipelined_prove_verify": pipelined,
+            "batch_sweep": sweep,
             "ring_root_s": w.ring_root_s,
             "setup_s": setup_s,
         }
