@@ -24,7 +24,7 @@ struct PedersenBatch {
     }
 
     int head(dr_ctx* ctx, const uint8_t* alphas, const uint64_t* alpha_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts,
-             const uint64_t* salt_off, const uint8_t* secret_scalars, PhaseTrace& tr_) {
+             const uint64_t* salt_off, const uint8_t* secret_scalars, PhaseTrace& tr_, const std::function<void()>* while_waiting = nullptr) {
         const drh::Mod256& mn = su.cv->n;
         // 1. secrets mod n
         xs.resize(B * 32);
@@ -35,7 +35,7 @@ struct PedersenBatch {
         }
         // 2. I_i = encode_to_curve(salt || alpha), O_i = x_i * I_i
         inputs.resize(B * 64); outs.resize(B * 64);
-        TRY(encode_and_mul(ctx, su, B, alphas, alpha_off, salts, salt_off, xs.data(), inputs.data(), outs.data()));
+        TRY(encode_and_mul(ctx, su, B, alphas, alpha_off, salts, salt_off, xs.data(), inputs.data(), outs.data(), while_waiting));
         tr_.mark("encode+x*I");
         // 3. transcripts, blinding factors
         tr.assign(B, drh::Bytes());
@@ -157,8 +157,20 @@ int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_
     const size_t B = batch;
     PhaseTrace tr_("prove_batch");
 
+    // hidden rows of the ring proof: 12 x 48 random bytes per proof reduced mod p — needs nothing from the GPU, so it runs on this
+    // thread (and the pool) while the Elligator and x*I kernels of the Pedersen head are in flight
+    std::vector<uint8_t> zk;
+    const std::function<void()> reduce_zk = [&] {
+        if (!zk_random48) return;
+        zk.resize(B * 12 * 32);
+        drh::parallel_for(B * 12, [&](size_t j) {
+            uint64_t v[4];
+            drh::mod_p().reduce_bytes(zk_random48 + 48 * j, 48, false, v);
+            drh::store_le32(v, zk.data() + 32 * j);
+        });
+    };
     PedersenBatch ped(su, B);
-    TRY(ped.head(ctx, alphas, alpha_off, ads, ad_off, salts, salt_off, secret_scalars, tr_));
+    TRY(ped.head(ctx, alphas, alpha_off, ads, ad_off, salts, salt_off, secret_scalars, tr_, &reduce_zk));
     std::vector<uint8_t>& blind = ped.blind;
     // 4.-6. the rest of the Pedersen part needs nothing from the ring proof and the ring proof needs only the blinding
     // factors: it runs on a second stream (own context: scratch + stream) from a helper thread while this thread drives
@@ -181,15 +193,6 @@ int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_
     } joiner{ped_thread};
 
     // 7. ring proof: witness columns
-    std::vector<uint8_t> zk;
-    if (zk_random48) {
-        zk.resize(B * 12 * 32);
-        drh::parallel_for(B * 12, [&](size_t j) {
-            uint64_t v[4];
-            drh::mod_p().reduce_bytes(zk_random48 + 48 * j, 48, false, v);
-            drh::store_le32(v, zk.data() + 32 * j);
-        });
-    }
     std::vector<uint8_t> relation(B * 64), wit(B * 4 * 96), cq(B * 96), evals(B * 256), opens(B * 192);
     std::vector<int> wit_inf(B * 4), cq_inf(B), open_inf(B * 2);
     tr_.mark("spawn+zk");

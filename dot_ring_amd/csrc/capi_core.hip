@@ -793,8 +793,9 @@ int dr_encode_to_curve_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const uint8
 // the first kernel runs) reads them from there; ONE synchronisation and download for both.  Other cases (try-and-increment
 // suites, batches beyond the GLV kernel's range) take the two separate calls.
 int encode_and_mul(dr_ctx* ctx, const drh::VrfSuite& su, size_t B, const uint8_t* data, const uint64_t* off, const uint8_t* salts,
-                   const uint64_t* salt_off, const uint8_t* xs, uint8_t* inputs_xy, uint8_t* outs_xy) {
+                   const uint64_t* salt_off, const uint8_t* xs, uint8_t* inputs_xy, uint8_t* outs_xy, const std::function<void()>* while_waiting) {
     if (su.cv->tai || !su.cv->glv || !g_bsn_glv || B == 0 || B >= 16384) {
+        if (while_waiting) (*while_waiting)();
         TRY(encode_to_curve_msgs(ctx, su, B, data, off, salts, salt_off, inputs_xy));
         return te_scalar_mul_batch(ctx, su.cv->id, inputs_xy, xs, B, outs_xy);
     }
@@ -823,6 +824,7 @@ int encode_and_mul(dr_ctx* ctx, const drh::VrfSuite& su, size_t B, const uint8_t
         hipLaunchKernelGGL(dr::k_bsn_scalar_mul_glv<false>, dim3(div_up(2 * B, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream, d_in,
                            ctx->io_b.as<uint32_t>(), d_out, (uint32_t)B);
     }));
+    if (while_waiting) (*while_waiting)();                 // the two latency chains above run ~1.7 ms: host work that does not need them goes here
     HIP_TRY(hipMemcpyAsync(inputs_xy, d_in, B * 64, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(outs_xy, d_out, B * 64, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -271,8 +271,10 @@ void launch_decode_points(dr_ctx* ctx, hipStream_t st, int cv, bool tai, const u
 int load_suite(const dr_vrf_suite* s, drh::VrfSuite& out);
 int encode_to_curve_msgs(dr_ctx* ctx, const drh::VrfSuite& su, size_t B, const uint8_t* data, const uint64_t* off, const uint8_t* salts,
                          const uint64_t* salt_off, uint8_t* out_xy);
+// while_waiting (optional): host work that needs nothing from these kernels, run on the calling thread after the launches and before the wait
 int encode_and_mul(dr_ctx* ctx, const drh::VrfSuite& su, size_t B, const uint8_t* data, const uint64_t* off, const uint8_t* salts,
-                   const uint64_t* salt_off, const uint8_t* xs, uint8_t* inputs_xy, uint8_t* outs_xy);
+                   const uint64_t* salt_off, const uint8_t* xs, uint8_t* inputs_xy, uint8_t* outs_xy,
+                   const std::function<void()>* while_waiting = nullptr);
 
 // DOTRING_TRACE=1: wall-clock phase breakdown of the native batch calls on stderr
 struct PhaseTrace {
