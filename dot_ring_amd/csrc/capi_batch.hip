@@ -408,6 +408,7 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         std::memcpy(g + 240, pl + 496, 96);        // Phi_zeta, Phi_zeta_omega
     });
     if (!canonical.load()) return DR_OK;
+    tr_.mark("gather");
 
     // ---- 2. GPU: decode + validate the 4B Bandersnatch points, decompress the 7B G1 points; meanwhile a helper thread
     // hashes the inputs to the curve on a second stream (all three kernels are latency-bound: a few dozen waves)
@@ -540,6 +541,7 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
             TRY(g1_be_to_le_limbs(tail_be, 4, le, true));
             HIP_TRY(hipMemcpyAsync(g1_bases.as<uint32_t>() + 7 * B * 24, le.data(), 4 * 96, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));          // `le` is a stack-lifetime staging buffer
+            tr_.mark("decode kernels");
             g1_launch_bases_to_mont(st, g1_bases.as<uint32_t>() + 7 * B * 24, 4);
         }
         g1_launch_bases_from_mont(st, g1_bases.as<uint32_t>(), g1_std.as<uint32_t>(), 7 * B);

@@ -158,6 +158,8 @@ class RcclComm:
             handle = ctypes.c_void_p()
             rc = _native.lib().dr_comm_create(ctx.handle, uid_bytes, rank, world, ctypes.byref(handle))
             err = _native.last_error() if rc else ""
+            if rc == 0:
+                self.handle = handle          # owned from here on: close() / __del__ destroy it whatever happens below
             # every rank learns whether ncclCommInitRank succeeded everywhere before anyone enters a collective on it
             oks = boot.all_gather(bytes([1 if rc == 0 else 0]))
         finally:
@@ -165,7 +167,6 @@ class RcclComm:
                 boot.close()
         if rc != 0:
             raise _native.DotRingHipError(f"ncclCommInitRank failed on rank {rank}: {err}")
-        self.handle = handle
         bad = [r for r, b in enumerate(oks) if not b[0]]
         if bad:
             self.close()
