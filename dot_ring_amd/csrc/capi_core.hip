@@ -88,6 +88,8 @@ int bsn_consts_init(hipStream_t st) {
     Fr c = five.pow(Q, 4);
     for (int j = 0; j < 32; j++) { put(h.c_pow[j], c); c = c.sqr(); }
     if (!(c == Fr::one())) return fail(DR_ERR_DEVICE, "bad Tonelli-Shanks constants");
+    static const uint64_t QP1H[4] = {0x7fff2dff80000000ULL, 0x04d0ec02a9ded201ULL, 0x94cebea4199cec04ULL, 0x0000000039f6d3a9ULL};   // (Q + 1) / 2
+    put(h.z_q1h, five.pow(QP1H, 4));
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(dr::g_bsn_consts), &h, sizeof h, 0, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     return DR_OK;

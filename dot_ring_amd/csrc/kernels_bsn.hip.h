@@ -12,6 +12,7 @@ struct BsnConsts {
     uint32_t mont_b[8], a_over_b[8], inv_b2[8];
     uint32_t c_pow[32][8];
     uint32_t glv_b[8], glv_c[8];         // endomorphism coefficients (bandersnatch.py:58-67), Montgomery form
+    uint32_t z_q1h[8];                   // 5^((Q+1)/2): turns x^((Q+1)/2) into (5 x)^((Q+1)/2) (fr_sqrt_or_5x)
 };
 __device__ BsnConsts g_bsn_consts;
 DR_DEV Fs bsn_const(const uint32_t (&w)[8]) { return unpack29(w); }
@@ -47,6 +48,49 @@ DR_DEV bool fr_sqrt(const Fs& x, Fs& root) {
     }
     root = R;
     return true;
+}
+
+// Elligator 2 needs sqrt(g) when g is a square and sqrt(Z u^2 g) = u sqrt(Z g) otherwise, with Z = 5 — the non-residue the
+// Tonelli-Shanks constants are built on.  ONE exponentiation serves both: with w = g^((Q-1)/2), R = w g, t = R w = g^Q, g is a
+// square iff t^(2^31) = 1; if it is not, (R, t) <- (R 5^((Q+1)/2), t 5^Q) are the same quantities for 5 g, which is one.  The
+// correction loop then runs once, on the same code path in every lane (the two calls of fr_sqrt this replaces diverged: a wave
+// with both kinds of lanes paid for two exponentiations and two loops).  Returns whether g was a square; root = sqrt(g) or sqrt(5 g).
+DR_DEV bool fr_sqrt_or_5x(const Fs& x, Fs& root) {
+    root = x;
+    if (is_zero(x)) return true;
+    constexpr uint32_t QM1H[8] = {0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u, 0u};   // (Q-1)/2
+    uint32_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = QM1H[i];
+    const Fs w = fr_pow_limbs(x, e);
+    Fs R = mul(w, x);
+    Fs t = mul(R, w);
+    const Fs one = Fs::one();
+    Fs probe = t;
+#pragma unroll 1
+    for (int k = 0; k < 31; k++) probe = sqr(probe);
+    const bool square = equal(probe, one);
+    if (!square) {
+        R = mul(R, bsn_const(g_bsn_consts.z_q1h));
+        t = mul(t, bsn_const(g_bsn_consts.c_pow[0]));
+    }
+    int M = 32, j = 0;             // current c = c_pow[j], of order 2^M
+#pragma unroll 1
+    for (int guard = 0; guard < 34; guard++) {
+        if (equal(t, one)) break;
+        int i = 1;
+        Fs tmp = sqr(t);
+#pragma unroll 1
+        while (!equal(tmp, one) && i < M) { tmp = sqr(tmp); i++; }
+        if (i == M) break;                             // cannot happen: t has order at most 2^31 here
+        const Fs b = bsn_const(g_bsn_consts.c_pow[j + M - i - 1]);
+        j += M - i;
+        M = i;
+        t = mul(t, bsn_const(g_bsn_consts.c_pow[j]));  // c <- b^2
+        R = mul(R, b);
+    }
+    root = R;
+    return square;
 }
 
 // Diagnostic (dr_fr_ops_selftest): the unsaturated field arithmetic of fr29.hip.h on its own, one lane per (a, b) pair of
@@ -92,11 +136,12 @@ __global__ void k_fr_ops_selftest(const uint32_t* __restrict__ a_std, const uint
 
 // Elligator 2 onto the Montgomery model up to the point (s, t) = (x B_M, y B_M); the inversion 1/(1 + Z u^2) is
 // supplied by the caller so that the two maps of one input share ONE inversion (Montgomery's trick).
-struct EllHalf { Fs tv1, den; };
+struct EllHalf { Fs u, tv1, den; };
 DR_DEV EllHalf ell2_prepare(const Fs& u) {
     Fr five_std = Fr::zero(); five_std.l[0] = 5;
     const Fs five = fs_from_std(five_std);
     EllHalf h;
+    h.u = u;
     h.tv1 = mul(five, sqr(u));                         // Z = 5
     if (is_zero(add(h.tv1, Fs::one()))) h.tv1 = Fs::zero();
     h.den = carry(add(h.tv1, Fs::one()));              // carried: it meets the partner's denominator in a product
@@ -108,11 +153,11 @@ DR_DEV TePoint ell2_finish(const EllHalf& h, const Fs& inv_den) {
     Fs x1 = neg(mul(aob, inv_den));
     Fs gx1 = mul(add(mul(add(x1, aob), x1), inv_b2), x1);
     Fs y;
-    bool e2 = fr_sqrt(gx1, y);
+    const bool e2 = fr_sqrt_or_5x(gx1, y);             // sqrt(g(x1)), or sqrt(Z g(x1)) when g(x1) is not a square
     Fs x = x1;
     if (!e2) {
         x = sub(neg(x1), aob);
-        (void)fr_sqrt(mul(h.tv1, gx1), y);             // Z u^2 g(x1) is a square when g(x1) is not
+        y = is_zero(h.tv1) ? Fs::zero() : mul(h.u, y); // sqrt(Z u^2 g(x1)) = u sqrt(Z g(x1)); tv1 = 0 (u = 0, or Z u^2 = -1 mapped to 0): the root of 0
     }
     bool odd = (fs_to_std(y).l[0] & 1u) != 0;
     if (e2 != odd) y = neg(y);                          // e2 XOR e3 -> negate
