@@ -720,6 +720,7 @@ def main() -> int:
                                   "frac": dense_adds / (acc_ms / 1e3) / 1e9 / VALU_PEAK_GADD_S if acc_ms else None,
                                   "instructions_per_addition": MADD_INSTRUCTIONS, "instructions_source": MADD_SOURCE,
                                   "isolated_chain_gadd_s": MEASURED_CHAIN_GADD_S,
+                                  "isolated_chain_source": "profiles/r02_ubench_limbs_fused.txt (tools/ubench_limbs.hip on another box; not re-measured in this run)",
                                   "frac_of_isolated_chain": dense_adds / (acc_ms / 1e3) / 1e9 / MEASURED_CHAIN_GADD_S if acc_ms else None,
                                   "note": "dense bucket additions only (7N pairs x windows per proof); by-parts and verify-side additions not counted"},
                          # per-proof unique traffic (11N scalars + 14 NTT passes' data + 784 B out), 3.17 KB per
