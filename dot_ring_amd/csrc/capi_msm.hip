@@ -23,6 +23,24 @@ int pick_window(size_t n) {
     return best;
 }
 
+// One small MSM over plain bases (the verifier's two folds of ~7 k and ~2 k points, KZG commits of a few thousand coefficients) is a
+// latency chain, not a throughput problem: the lanes of a launch are far fewer than the chip holds, so what counts is the longest
+// dependent chain — the bucket walk's ~(m + 3 sqrt(m)) mixed additions for m points per bucket, then the 4-bucket chunks' running sums
+// and (c - 3)-bit double-and-add, then the fold.  In units of one dependent addition (~11 us mixed, ~15 us full on a lone wave):
+int pick_window_latency(size_t n) {
+    int best = 7;
+    double best_t = 1e300;
+    for (int c = 7; c <= 13; c++) {
+        const int W = (256 + c - 1) / c;
+        const double H = (double)(1u << (c - 1));
+        if ((double)W * H > 131072.0) continue;
+        const double m = (double)n / H;
+        const double t = 11.0 * (m + 3.0 * std::sqrt(m) + 1.0) + 15.0 * (8.0 + 1.5 * (c - 3)) + 15.0 * (std::log2(std::max(H / 4.0, 2.0)) + 4.0);
+        if (t < best_t) { best_t = t; best = c; }
+    }
+    return best;
+}
+
 struct MsmPlan {
     dr::WindowTable wt;
     int W;
@@ -43,9 +61,9 @@ dr::WindowTable make_window_table(int c, int bits = 256) {      // `bits` scalar
     return wt;
 }
 
-MsmPlan make_plan(size_t n, int force_c) {
+MsmPlan make_plan(size_t n, int force_c, bool latency_bound = false) {
     MsmPlan p;
-    int c = window_ok(force_c) ? force_c : pick_window(n);
+    int c = window_ok(force_c) ? force_c : (latency_bound ? pick_window_latency(n) : pick_window(n));
     p.W = (256 + c - 1) / c;
     int base = 256 / p.W, rem = 256 % p.W;       // `rem` windows of width base+1 (placed on top), the rest base
     p.wt.W = p.W;
@@ -110,7 +128,9 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         }));
         return DR_OK;
     }
-    MsmPlan pl = make_plan(n, g_force_c);
+    // (DOTRING_MSM_LATENCY_WINDOW=0: the throughput model for every size)
+    static const bool latency_on = std::getenv("DOTRING_MSM_LATENCY_WINDOW") == nullptr || std::atoi(std::getenv("DOTRING_MSM_LATENCY_WINDOW")) != 0;
+    MsmPlan pl = make_plan(n, g_force_c, latency_on && !single && batch == 1 && n <= 32768);
     if (single) {
         pl.wt = tbl->wt;
         pl.W = tbl->wt.W;
