@@ -53,6 +53,9 @@ struct dr_ring_prover {
     bool cosets = true;                 // DOTRING_NTT_COSETS=0: the full 4N-point transforms and constraint evaluation of round 2
     Scratch coset_scale;                // [3][N] FS9: zeta^(c m) R^2, the multipliers of the scaled N-point NTT input
     Scratch special;                    // [B][3] FS9: the aggregated constraint polynomial at the three hidden rows of coset 0
+    Scratch hid;                        // [B][4][4][8] std: rows N-3, N-2, N-1, 0 of the witness columns' evaluations (saved by the witness phase)
+    bool fwd_pending = false;           // the witness phase has launched the coset transforms of this batch (they run beside the host's hashing)
+    bool quot2_pending = false;         // the evaluation phase has launched the synthetic division of the linearisation polynomial
     uint8_t root[3 * 96];
     int root_inf[3];
     // per-batch state
@@ -243,7 +246,7 @@ int dr_ring_prover_create_te(dr_ctx* ctx, int curve, const dr_srs* srs, unsigned
 void dr_ring_prover_destroy(dr_ring_prover* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
-    for (Scratch* s : {&p->ring_pts_mont, &p->fixed_coef, &p->fixed4, &p->lag4, &p->not_last, &p->coset_scale, &p->special, &p->idx, &p->blind, &p->zk, &p->chain_ext,
+    for (Scratch* s : {&p->ring_pts_mont, &p->fixed_coef, &p->fixed4, &p->lag4, &p->not_last, &p->coset_scale, &p->special, &p->hid, &p->idx, &p->blind, &p->zk, &p->chain_ext,
                        &p->prefix, &p->chain_aff, &p->cnt, &p->relation, &p->rps, &p->cols, &p->wit4, &p->alphas, &p->alphas9, &p->alpha_aux, &p->agg, &p->q, &p->zetas,
                        &p->evals, &p->ks, &p->lin, &p->nus, &p->nus9, &p->aggo, &p->chunkv, &p->quot1, &p->quot2, &p->diffs})
         s->release();
@@ -293,6 +296,7 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
     }
     if (zk_rows) TRY(check_fr_elems(zk_rows, batch * 12, "hidden row"));
     p->batch = batch;
+    p->quot2_pending = false;
     hipStream_t st = ctx->stream;
     TRY(p->idx.reserve(batch * 4));
     TRY(p->blind.reserve(batch * 32));
@@ -340,11 +344,25 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
         }));
         TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true, dr::NTT_FMT_STD8, dr::NTT_FMT_STD8, col_evals, 0));
         MsmTable t = srs_table(p->ps_srs, 0);
-        return msm_to_bytes(ctx, p->ps_srs->d_bases, p->diffs.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t);
+        TRY(msm_to_bytes(ctx, p->ps_srs->d_bases, p->diffs.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t));
+    } else {
+        TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true, dr::NTT_FMT_STD8, dr::NTT_FMT_STD8, col_evals, 0));
+        MsmTable t = srs_table(p->srs, 0);
+        TRY(msm_to_bytes(ctx, p->srs->d_bases, p->cols.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t));
     }
-    TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true, dr::NTT_FMT_STD8, dr::NTT_FMT_STD8, col_evals, 0));
-    MsmTable t = srs_table(p->srs, 0);
-    return msm_to_bytes(ctx, p->srs->d_bases, p->cols.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t);
+    p->fwd_pending = false;
+    if (p->cosets) {
+        // The commitments are on the host; the caller now hashes them into the transcript (0.3 - 0.45 ms for 1024 proofs).  What the
+        // quotient phase does first needs no challenge: the four columns on the three cosets.  Launched here and NOT waited for, the
+        // transforms run beside that hashing; the hidden rows of coset 0 are saved first, the transforms overwrite the evaluation columns.
+        TRY(p->hid.reserve(batch * 16 * 32));
+        hipLaunchKernelGGL(dr::k_ring_save_rows, dim3(div_up(batch * 16, 256)), dim3(256), 0, st, col_evals, n, (uint32_t)batch, p->hid.as<uint32_t>());
+        TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n, batch * 12, false, dr::NTT_FMT_STD8_SCALED, dr::NTT_FMT_FS9, p->cols.as<uint32_t>(), 0, 3,
+                     p->coset_scale.as<uint32_t>()));
+        HIP_TRY(hipGetLastError());
+        p->fwd_pending = true;
+    }
+    return DR_OK;
 }
 
 // phase B: constraints on the 4N domain, aggregation with the alphas, quotient polynomial and its commitment
@@ -371,16 +389,16 @@ int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alpha
     hipLaunchKernelGGL(dr::k_ring_alpha_aux, dim3(div_up(batch, 64)), dim3(64), 0, st, p->alphas.as<uint32_t>(), p->rps.as<uint32_t>(), rc,
                        (uint32_t)batch, p->alpha_aux.as<uint32_t>());
     if (p->cosets) {
-        // coset 0 first: the three hidden rows from the N-domain evaluations the witness phase left in wit4 (about to be overwritten)
+        // coset 0: the three hidden rows from the N-domain evaluations the witness phase saved
         TRY(p->special.reserve(batch * 3 * dr::L29 * 4));
+        if (!p->fwd_pending) return fail(DR_ERR_INVALID, "quotient phase without a witness phase for this batch");
+        p->fwd_pending = false;
+        // (the forward transforms — N coefficients per column -> evaluations on the cosets zeta^c H, c = 1..3: three N-point NTTs of the
+        //  coefficients scaled by zeta^(c m), raw 9-limb records, coset-major — were launched by the witness phase and are in this stream)
         TRY(launch(ctx, "k_ring_constraints", [&] {
-            LAUNCH_CV(p->curve, dr::k_ring_hidden_rows, dim3(div_up(batch * 3, 64)), dim3(64), 0, st, p->wit4.as<uint32_t>(), p->ring_pts_mont.as<uint32_t>(),
+            LAUNCH_CV(p->curve, dr::k_ring_hidden_rows, dim3(div_up(batch * 3, 64)), dim3(64), 0, st, p->hid.as<uint32_t>(), p->ring_pts_mont.as<uint32_t>(),
                       p->alphas9.as<uint32_t>(), rc, (uint32_t)batch, p->special.as<uint32_t>());
         }));
-        // N coefficients per column -> evaluations on the cosets zeta^c H, c = 1..3: three N-point NTTs of the coefficients scaled by
-        // zeta^(c m) (the scaling rides on the product that converts the input to Montgomery form), raw 9-limb records, coset-major
-        TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n, batch * 12, false, dr::NTT_FMT_STD8_SCALED, dr::NTT_FMT_FS9, p->cols.as<uint32_t>(), 0, 3,
-                     p->coset_scale.as<uint32_t>()));
         TRY(launch(ctx, "k_ring_constraints", [&] {
             LAUNCH_CV(p->curve, dr::k_ring_constraints3, dim3(div_up(batch * 3 * (size_t)n, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(),
                       p->fixed4.as<uint32_t>(), p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas9.as<uint32_t>(),
@@ -407,6 +425,32 @@ int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alpha
     }));
     MsmTable t = srs_table(p->srs, 0);
     return msm_to_bytes(ctx, p->srs->d_bases, p->q.as<uint32_t>(), qn, batch, out_cq, is_inf, &t);
+}
+
+// synthetic division of [batch] polynomials of len coefficients by (X - zeta) or (X - zeta*omega): chunk-local pass, link, write
+static int ring_syndiv(dr_ring_prover* p, size_t batch, const uint32_t* poly, uint32_t len, int mul_omega, uint32_t* quot) {
+    dr_ctx* ctx = p->ctx;
+    hipStream_t st = ctx->stream;
+    const dr::RingConsts& rc = p->rc;
+    const uint32_t nch = (len + dr::SD_CHUNK - 1) / dr::SD_CHUNK;
+    return launch(ctx, "k_syndiv", [&] {
+        hipLaunchKernelGGL(dr::k_syndiv_local, dim3(div_up(batch * nch, 128)), dim3(128), 0, st, poly, len, p->zetas.as<uint32_t>(), mul_omega, rc,
+                           (uint32_t)batch, p->chunkv.as<uint32_t>());
+        hipLaunchKernelGGL(dr::k_syndiv_link, dim3(div_up(batch, 64)), dim3(64), 0, st, p->chunkv.as<uint32_t>(), len, p->zetas.as<uint32_t>(),
+                           mul_omega, rc, (uint32_t)batch);
+        hipLaunchKernelGGL(dr::k_syndiv_write, dim3(div_up(batch * nch, 128)), dim3(128), 0, st, poly, len, p->zetas.as<uint32_t>(), mul_omega, rc,
+                           (uint32_t)batch, p->chunkv.as<uint32_t>(), quot);
+    });
+}
+
+// the second opening quotient, lin / (X - zeta*omega), zero-padded into the second half of the shared MSM's scalar vectors; needs no nu
+static int ring_quot2(dr_ring_prover* p, size_t batch) {
+    const uint32_t n = p->rc.n, qn = 3 * n + 1;
+    TRY(ring_syndiv(p, batch, p->lin.as<uint32_t>(), n, 1, p->quot2.as<uint32_t>()));
+    return launch(p->ctx, "k_ring_pad", [&] {
+        hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up(batch * (size_t)(qn - 1), 256)), dim3(256), 0, p->ctx->stream, p->quot2.as<uint32_t>(), n - 1,
+                           p->quot1.as<uint32_t>() + batch * (size_t)(qn - 1) * 8, qn - 1, batch);
+    });
 }
 
 // phase C1: register evaluations at zeta, linearisation polynomial and its value at zeta*omega
@@ -441,6 +485,16 @@ int dr_ring_prove_evals(dr_ring_prover* p, size_t batch, const uint8_t* zetas, u
     HIP_TRY(hipMemcpyAsync(out_evals, p->evals.p, batch * 8 * 32, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (ctx->prof) TRY(prof_collect(ctx));
+    // The caller hashes the evaluations into the transcript to draw the nus; the second opening quotient needs none of them: launched
+    // here and not waited for, it runs beside that hashing.  Both quotients of all proofs share ONE batched MSM: [2*batch][3N] scalar
+    // vectors, the short second quotient zero-padded (zero scalars produce no digits) — one sort / accumulate / reduce / affine pipeline.
+    const uint32_t qn = 3 * n + 1;
+    TRY(p->chunkv.reserve(batch * (size_t)((qn + dr::SD_CHUNK - 1) / dr::SD_CHUNK) * 32));
+    TRY(p->quot1.reserve(2 * batch * (size_t)(qn - 1) * 32));
+    TRY(p->quot2.reserve(batch * (size_t)(n - 1) * 32));
+    TRY(ring_quot2(p, batch));
+    HIP_TRY(hipGetLastError());
+    p->quot2_pending = true;
     return DR_OK;
 }
 
@@ -456,12 +510,6 @@ int dr_ring_prove_openings(dr_ring_prover* p, size_t batch, const uint8_t* nus, 
     hipStream_t st = ctx->stream;
     TRY(p->nus.reserve(batch * 8 * 32));
     TRY(p->aggo.reserve(batch * (size_t)qn * 32));
-    const uint32_t nch1 = (qn + dr::SD_CHUNK - 1) / dr::SD_CHUNK, nch2 = (n + dr::SD_CHUNK - 1) / dr::SD_CHUNK;
-    TRY(p->chunkv.reserve(batch * (size_t)nch1 * 32));
-    // both quotients of all proofs share ONE batched MSM: [2*batch][3N] scalar vectors, the short second quotient
-    // zero-padded (zero scalars produce no digits) — one sort / accumulate / reduce / affine pipeline instead of two
-    TRY(p->quot1.reserve(2 * batch * (size_t)(qn - 1) * 32));
-    TRY(p->quot2.reserve(batch * (size_t)(n - 1) * 32));
     TRY(p->nus9.reserve(batch * 8 * dr::L29 * 4));
     HIP_TRY(hipMemcpyAsync(p->nus.p, nus, batch * 8 * 32, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(dr::k_fr_std_to_fs9, dim3(div_up(batch * 8, 256)), dim3(256), 0, st, p->nus.as<uint32_t>(), p->nus9.as<uint32_t>(), batch * 8);     // multipliers: Montgomery form
@@ -469,22 +517,9 @@ int dr_ring_prove_openings(dr_ring_prover* p, size_t batch, const uint8_t* nus, 
         hipLaunchKernelGGL(dr::k_ring_aggpoly, dim3(div_up(batch * qn, 256)), dim3(256), 0, st, p->fixed_coef.as<uint32_t>(), p->cols.as<uint32_t>(),
                            p->q.as<uint32_t>(), p->nus9.as<uint32_t>(), n, (uint32_t)batch, p->aggo.as<uint32_t>());
     }));
-    auto syndiv = [&](const uint32_t* poly, uint32_t len, int mul_omega, uint32_t* quot, uint32_t nch) -> int {
-        return launch(ctx, "k_syndiv", [&] {
-            hipLaunchKernelGGL(dr::k_syndiv_local, dim3(div_up(batch * nch, 128)), dim3(128), 0, st, poly, len, p->zetas.as<uint32_t>(), mul_omega, rc,
-                               (uint32_t)batch, p->chunkv.as<uint32_t>());
-            hipLaunchKernelGGL(dr::k_syndiv_link, dim3(div_up(batch, 64)), dim3(64), 0, st, p->chunkv.as<uint32_t>(), len, p->zetas.as<uint32_t>(),
-                               mul_omega, rc, (uint32_t)batch);
-            hipLaunchKernelGGL(dr::k_syndiv_write, dim3(div_up(batch * nch, 128)), dim3(128), 0, st, poly, len, p->zetas.as<uint32_t>(), mul_omega, rc,
-                               (uint32_t)batch, p->chunkv.as<uint32_t>(), quot);
-        });
-    };
-    TRY(syndiv(p->aggo.as<uint32_t>(), qn, 0, p->quot1.as<uint32_t>(), nch1));
-    TRY(syndiv(p->lin.as<uint32_t>(), n, 1, p->quot2.as<uint32_t>(), nch2));
-    TRY(launch(ctx, "k_ring_pad", [&] {
-        hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up(batch * (size_t)(qn - 1), 256)), dim3(256), 0, st, p->quot2.as<uint32_t>(), n - 1,
-                           p->quot1.as<uint32_t>() + batch * (size_t)(qn - 1) * 8, qn - 1, batch);
-    }));
+    if (!p->quot2_pending) return fail(DR_ERR_INVALID, "openings phase without an evaluation phase for this batch");
+    p->quot2_pending = false;               // (lin's quotient was launched by the evaluation phase and is in this stream)
+    TRY(ring_syndiv(p, batch, p->aggo.as<uint32_t>(), qn, 0, p->quot1.as<uint32_t>()));
     std::vector<uint8_t> o(2 * batch * 96);
     std::vector<int> inf(2 * batch);
     MsmTable t = srs_table(p->srs, 0);

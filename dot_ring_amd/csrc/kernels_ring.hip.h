@@ -491,22 +491,30 @@ __global__ __launch_bounds__(256) void k_ring_constraints3(const uint32_t* __res
     fs_store9(agg3 + gid * L29, acc);
 }
 // coset 0 = H: the aggregated constraint polynomial is zero there except at the three hidden rows N-3 .. N-1 (the quotient's tail
-// factor takes care of those).  One lane per (proof, hidden row): the same body on the N-domain evaluations — witness columns as the
-// witness phase left them (standard form), the ring point of that row, selector 0, L0 = Llast = 0.
+// factor takes care of those).  k_ring_save_rows keeps the N-domain evaluations of rows N-3, N-2, N-1 and 0 of the four witness
+// columns (standard form) before the coset transforms overwrite the evaluation columns; k_ring_hidden_rows, one lane per (proof,
+// hidden row), runs the same body on them — the ring point of that row, selector 0, L0 = Llast = 0.
+__global__ void k_ring_save_rows(const uint32_t* __restrict__ col_evals /* [B][4][n][8] std */, uint32_t n, uint32_t batch,
+                                 uint32_t* __restrict__ hid /* [B][4][4][8]: rows n-3, n-2, n-1, 0 */) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= batch * 16) return;
+    const uint32_t pid = gid / 16, col = (gid / 4) % 4, r = gid % 4, row = r == 3 ? 0 : n - 3 + r;
+    gstore_fr(hid + (size_t)gid * 8, gload_fr(col_evals + (((size_t)pid * 4 + col) * n + row) * 8));
+}
 template <int CV>
-__global__ void k_ring_hidden_rows(const uint32_t* __restrict__ col_evals /* [B][4][n][8] std */, const uint32_t* __restrict__ ring_pts_mont /* [n][16] Montgomery 256 */,
+__global__ void k_ring_hidden_rows(const uint32_t* __restrict__ hid /* [B][4][4][8] std */, const uint32_t* __restrict__ ring_pts_mont /* [n][16] Montgomery 256 */,
                                    const uint32_t* __restrict__ alphas /* [B][7] FS9 */, RingConsts rc, uint32_t batch,
                                    uint32_t* __restrict__ special /* [B][3] FS9 */) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= batch * 3) return;
-    const uint32_t pid = gid / 3, r = gid % 3, n = rc.n, j = n - 3 + r, jn = j + 1 == n ? 0 : j + 1;
-    const uint32_t* w = col_evals + (size_t)pid * 4 * n * 8;
+    const uint32_t pid = gid / 3, r = gid % 3, n = rc.n, j = n - 3 + r;
+    const uint32_t* w = hid + (size_t)pid * 16 * 8;
     // reduce_small: the body's witness inputs are the forward NTT's outputs elsewhere (|value| < 0.51 p)
-    auto at = [&](uint32_t col, uint32_t row) { return reduce_small(fs_from_std(gload_fr(w + ((size_t)col * n + row) * 8))); };
+    auto at = [&](uint32_t col, uint32_t idx) { return reduce_small(fs_from_std(gload_fr(w + ((size_t)col * 4 + idx) * 8))); };
     const Fs x2 = from_mont256(gload_fr(ring_pts_mont + (size_t)j * 16)), y2 = from_mont256(gload_fr(ring_pts_mont + (size_t)j * 16 + 8));
     const Fs zero = Fs::zero();
     const uint32_t* al = alphas + (size_t)pid * 7 * L29;
-    const Fs acc = body_constraints<CV>(at(0, j), at(1, j), at(1, jn), at(2, j), at(2, jn), at(3, j), at(3, jn), carry(x2), carry(y2), zero, zero, zero,
+    const Fs acc = body_constraints<CV>(at(0, r), at(1, r), at(1, r + 1), at(2, r), at(2, r + 1), at(3, r), at(3, r + 1), carry(x2), carry(y2), zero, zero, zero,
                                         from_arg(rc.nl_hidden[r]), fs_load9(al), fs_load9(al + L29), fs_load9(al + 2 * L29), fs_load9(al + 3 * L29),
                                         fs_load9(al + 4 * L29), fs_load9(al + 5 * L29), fs_load9(al + 6 * L29), zero, zero);
     fs_store9(special + (size_t)gid * L29, acc);
