@@ -634,7 +634,9 @@ def main() -> int:
                 cpu_all = cpu_baseline_all_cores(w.keys, args.ring_size, w.signer_sk, max(2, m // 4), args.cpu_workers, cpu_proofs)
 
         # bucket additions of the dense MSMs in the profiled pass: pairs x windows of the SRS table (non-zero digit rate ~1)
-        table_windows = -(-256 // int(os.environ.get("DOTRING_SRS_WINDOW", "12") or 12))
+        # (asked of the library: an SRS with a row per bit tiles the scalars of a batched MSM by windows one bit wider, dr_srs_table_info)
+        tinfo = w.pcs._srs().device().table_info()
+        table_windows = tinfo["batched_windows"] if batch >= 256 else -(-256 // max(1, tinfo["window_bits"]))
         dense_adds = float(batch) * pairs_per_proof * table_windows * args.steps
         total = batch * world * args.steps
         value = total / elapsed
@@ -722,6 +724,7 @@ def main() -> int:
                                   "isolated_chain_gadd_s": MEASURED_CHAIN_GADD_S,
                                   "isolated_chain_source": "profiles/r02_ubench_limbs_fused.txt (tools/ubench_limbs.hip on another box; not re-measured in this run)",
                                   "frac_of_isolated_chain": dense_adds / (acc_ms / 1e3) / 1e9 / MEASURED_CHAIN_GADD_S if acc_ms else None,
+                                  "table": tinfo, "windows_per_scalar": table_windows,
                                   "note": "dense bucket additions only (7N pairs x windows per proof); by-parts and verify-side additions not counted"},
                          # per-proof unique traffic (11N scalars + 14 NTT passes' data + 784 B out), 3.17 KB per
                          # domain point = 6.5 MB per proof at N = 2048, over the whole job

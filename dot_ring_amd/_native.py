@@ -52,6 +52,7 @@ _PROTOTYPES = {
     "dr_srs_powers": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, POINTER(c_void_p)]),
     "dr_g2_mul": (c_int, [c_char_p, c_char_p, c_char_p]),
     "dr_srs_precompute": (c_int, [c_void_p, c_void_p, c_int]),
+    "dr_srs_table_info": (c_int, [c_void_p, POINTER(c_int)]),
     "dr_srs_download": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "dr_srs_destroy": (None, [c_void_p]),
     "dr_srs_size": (c_size_t, [c_void_p]),
@@ -312,6 +313,12 @@ class Srs:
         """Build (or with 0 drop) the fixed-base window table in HBM."""
         _check(lib().dr_srs_precompute(self.ctx.handle, self.handle, window_bits))
         return self
+
+    def table_info(self) -> dict:
+        """Shape of the fixed-base table (dr_srs_table_info): window_bits, rows, windows per scalar and odd-multiple buckets in batched MSMs."""
+        info = (c_int * 4)()
+        _check(lib().dr_srs_table_info(self.handle, info))
+        return {"window_bits": info[0], "rows": info[1], "batched_windows": info[2], "odd_buckets": bool(info[3])}
 
     def precompute_comb(self) -> "Srs":
         """Comb table over the window table (see dr_srs_precompute_comb); MemoryError if it does not fit."""

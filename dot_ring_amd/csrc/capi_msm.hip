@@ -56,8 +56,10 @@ dr::WindowTable make_window_table(int c, int bits = 256) {      // `bits` scalar
         int width = base + (w >= wt.W - rem ? 1 : 0);
         wt.start[w] = (uint8_t)bit;
         wt.width[w] = (uint8_t)width;
+        wt.row[w] = (uint8_t)w;
         bit += width;
     }
+    wt.odd = 0;
     return wt;
 }
 
@@ -73,8 +75,10 @@ MsmPlan make_plan(size_t n, int force_c, bool latency_bound = false) {
         int width = base + (w >= p.W - rem ? 1 : 0);
         p.wt.start[w] = (uint8_t)bit;
         p.wt.width[w] = (uint8_t)width;
+        p.wt.row[w] = (uint8_t)w;
         bit += width;
     }
+    p.wt.odd = 0;
     p.H = 1u << (p.wt.cmax - 1);
     p.L = std::min<uint32_t>(p.H, g_chunk_len);
     p.T = p.H / p.L;
@@ -131,14 +135,21 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     // (DOTRING_MSM_LATENCY_WINDOW=0: the throughput model for every size)
     static const bool latency_on = std::getenv("DOTRING_MSM_LATENCY_WINDOW") == nullptr || std::atoi(std::getenv("DOTRING_MSM_LATENCY_WINDOW")) != 0;
     MsmPlan pl = make_plan(n, g_force_c, latency_on && !single && batch == 1 && n <= 32768);
+    static const bool setscan_on = std::getenv("DOTRING_MSM_SETSCAN") == nullptr || std::atoi(std::getenv("DOTRING_MSM_SETSCAN")) != 0;
     if (single) {
-        pl.wt = tbl->wt;
-        pl.W = tbl->wt.W;
-        pl.H = 1u << (tbl->wt.cmax - 1);
+        // A table with a row per bit and hundreds of MSMs (the batched prover): one more bit per window, buckets for odd multiples only
+        // — as many buckets as before, a window less per scalar.  Needs the per-set LDS sort and the set-scan reduction (below).
+        const dr::WindowTable& wo = tbl->wt_odd;
+        const bool odd = wo.W != 0 && setscan_on && g_chunk_len == 16 && batch >= 256 && wo.cmax >= 9 && (1u << (wo.cmax - 2)) <= 4096 &&
+                         batch * (size_t)((1u << (wo.cmax - 2)) / 16) >= ((size_t)1 << 17) &&      // (fewer: the L = 4 chunk reduction below)
+                         (n + 64) * (size_t)wo.W <= (1u << 20) && batch * (n + 64) * (size_t)wo.W < (1ull << 32);
+        pl.wt = odd ? wo : tbl->wt;
+        pl.W = pl.wt.W;
+        pl.H = odd ? 1u << (pl.wt.cmax - 2) : 1u << (pl.wt.cmax - 1);
         pl.L = std::min<uint32_t>(pl.H, g_chunk_len);
         pl.T = pl.H / pl.L;
         d_bases = tbl->table;
-        if ((uint64_t)pl.W * tbl->stride >= (1ull << 31)) return fail(DR_ERR_INVALID, "window table too large");
+        if (((uint64_t)pl.wt.row[pl.W - 1] + pl.wt.cmax + 1) * tbl->stride >= (1ull << 31)) return fail(DR_ERR_INVALID, "window table too large");
     }
     // table mode: split the points of each MSM into index groups when one bucket set per MSM would leave lanes idle
     uint32_t groups = 1;
@@ -163,7 +174,9 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         pl.L = 4;
         pl.T = pl.H / 4;
     }
-    const size_t nbuckets = bsets * pl.H;
+    // odd-multiple buckets: every set has a few twin buckets besides its H (kernels_g1.hip.h: digit_bin), kept after all sets' buckets
+    const uint32_t aux = pl.wt.odd ? (dr::odd_twin_count(pl.H) + 15u) & ~15u : 0u;
+    const size_t nbuckets = bsets * (size_t)(pl.H + aux);
     const size_t ndigits = windows * n;
     if (nbuckets >= (1ull << 32) || ndigits >= (1ull << 32))
         return fail(DR_ERR_INVALID, "MSM batch too large for one launch (split the batch)");
@@ -209,6 +222,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         sp.capacity = (uint32_t)per_set_digits;
         sp.short_from = single ? tbl->short_from : 0xffffffffu;
         sp.n_short = single ? std::min<uint32_t>(tbl->n_short, (uint32_t)n) : 0;
+        sp.aux = aux; sp.sets = (uint32_t)bsets;
         TRY(ctx->sorted.reserve(bsets * per_set_digits * 4));
         // sets of more than a few thousand entries: the sorted segment is assembled in LDS and written in whole lines
         // (k_g1_sort_sets_staged; DOTRING_MSM_SORT_STAGED=0: scattered 4-byte stores as in round 1)
@@ -247,6 +261,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         pp.cap_part = (uint32_t)std::min<size_t>(per_set_digits, std::max<size_t>(4 * per_set_digits / part_p, 65536));
         pp.capacity = (uint32_t)per_set_digits;
         pp.tbl_stride = tbl->stride; pp.tbl_offset = tbl->offset;
+        for (int w = 0; w < pl.W; w++) pp.row[w] = pl.wt.row[w];
         TRY(ctx->digits.reserve(bsets * (size_t)part_p * pp.cap_part * 4));
         TRY(ctx->cursor.reserve(bsets * (size_t)part_p * 4));
         TRY(ctx->sorted.reserve(bsets * per_set_digits * 4));
@@ -281,7 +296,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         TRY(launch(ctx, "k_scan", [&] { exclusive_scan(ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), nbuckets); }));
         TRY(launch(ctx, "k_g1_scatter", [&] {
             hipLaunchKernelGGL(dr::k_g1_scatter, dim3(div_up(ndigits, 256)), dim3(256), 0, st, ctx->digits.as<int32_t>(),
-                               (uint32_t)n, windows, pl.H, single ? pl.W : 0, single ? tbl->stride : 0u, single ? tbl->offset : 0u, groups,
+                               (uint32_t)n, windows, pl.H, single ? pl.W : 0, pl.wt, single ? tbl->stride : 0u, single ? tbl->offset : 0u, groups,
                                ctx->offsets.as<uint32_t>(), ctx->cursor.as<uint32_t>(),
                                ctx->sorted.as<uint32_t>());
         }));
@@ -298,18 +313,28 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         hipLaunchKernelGGL(dr::k_g1_accumulate, dim3(div_up(nbuckets, 256)), dim3(256), 0, st, d_bases,
                            ctx->sorted.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(),
                            ctx->buckets.as<uint32_t>(), nbuckets);
-        // buckets of >= 255 entries (skewed scalars only): a wave each; returns at once when there are none
-        hipLaunchKernelGGL(dr::k_g1_accumulate_heavy, dim3(2048), dim3(64), 0, st, d_bases, ctx->sorted.as<uint32_t>(),
+        // lists of 256 entries or more (the lowest odd-multiple buckets of every set; skewed scalars): 16 lanes or a wave each; both
+        // launches return at once when there are none
+        hipLaunchKernelGGL(dr::k_g1_accumulate_long<16>, dim3(2048), dim3(64), 0, st, d_bases, ctx->sorted.as<uint32_t>(),
+                           ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(), ctx->cell_off.as<uint32_t>(),
+                           szblocks, ctx->buckets.as<uint32_t>());
+        hipLaunchKernelGGL(dr::k_g1_accumulate_long<64>, dim3(2048), dim3(64), 0, st, d_bases, ctx->sorted.as<uint32_t>(),
                            ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(), ctx->cell_off.as<uint32_t>(),
                            szblocks, ctx->buckets.as<uint32_t>());
     }));
+    if (aux) {
+        const size_t lanes = bsets * (size_t)std::max<uint32_t>(1, pl.H >> 4);
+        TRY(launch(ctx, "k_g1_merge_twins", [&] {
+            hipLaunchKernelGGL(dr::k_g1_merge_twins, dim3(div_up(lanes, 128)), dim3(128), 0, st, ctx->buckets.as<uint32_t>(), (uint32_t)bsets, pl.H, aux);
+        }));
+    }
     // many bucket sets (batched prover): level-wise reduction, 2 additions per entry and no scalar multiplications;
     // few sets (single MSMs): chunk sums + double-and-add, whose latency is one short chain
     const bool leveled = g_reduce_levels && pl.L == 16 && pl.H >= 256 && bsets * (size_t)(pl.H / 16) >= g_level_threshold;
     // many sets of <= 2048 buckets (every batched MSM of the prover): first level with 2 additions per bucket, then one workgroup
     // per set scans and folds its <= 128 chunk results (DOTRING_MSM_SETSCAN=0: the chunk + double-and-add kernels below)
-    static const bool setscan_on = std::getenv("DOTRING_MSM_SETSCAN") == nullptr || std::atoi(std::getenv("DOTRING_MSM_SETSCAN")) != 0;
     const bool setscan = setscan_on && pl.L == 16 && pl.T >= 8 && pl.T <= 256 && bsets >= 256;
+    if (pl.wt.odd && !(setscan && lds_sort)) return fail(DR_ERR_DEVICE, "internal: odd-multiple buckets planned for a path that does not support them");
     // a single MSM over a wide window table (H >= 8192 buckets per index group): workgroup scan, (V, S) pairs to the host
     // (DOTRING_MSM_WGSCAN=0: chunk sums + double-and-add + fold, as in round 2)
     static const bool wgscan_on = std::getenv("DOTRING_MSM_WGSCAN") == nullptr || std::atoi(std::getenv("DOTRING_MSM_WGSCAN")) != 0;
@@ -327,7 +352,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         TRY(launch(ctx, "k_g1_reduce_windows", [&] {
             const uint32_t per_block = dr::RS_BLOCK / (pl.T / dr::RS_GROUP);
             hipLaunchKernelGGL(dr::k_g1_reduce_set_scan, dim3(div_up(bsets, per_block)), dim3(dr::RS_BLOCK), 0, st, out_s, out_c, bsets, pl.T,
-                               ctx->winsum.as<uint32_t>());
+                               pl.wt.odd, ctx->winsum.as<uint32_t>());
         }));
     } else if (leveled) {
         // level outputs live in ctx->partial: [S | C] per level, sizes sets * H/16, sets * H/256, ...
@@ -465,6 +490,7 @@ MsmTable srs_table(const dr_srs* srs, size_t offset) {
     if (srs->d_table) {
         t.table = srs->d_table;
         t.wt = srs->table_wt;
+        t.wt_odd = srs->table_wt_odd;
         t.stride = (uint32_t)srs->count;
         t.offset = (uint32_t)offset;
         t.comb = srs->d_comb;
@@ -823,7 +849,11 @@ int dr_srs_download(dr_ctx* ctx, const dr_srs* srs, size_t offset, size_t count,
     return DR_OK;
 }
 
-int dr_srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits) {
+int dr_srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits) { return srs_precompute(ctx, srs, window_bits, true); }
+
+// bit_rows = false: window rows only (the prover's summation-by-parts bases: a few hundred scalars per vector, most of them +-1 — short,
+// uneven lists that gain nothing from a window less and measured 0.7 ms per batch slower with odd-multiple buckets)
+int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_rows) {
     TRY(use_ctx(ctx));
     if (!srs) return fail(DR_ERR_INVALID, "null argument");
     if (srs->device != ctx->device) return fail(DR_ERR_INVALID, "SRS lives on another device");
@@ -838,9 +868,28 @@ int dr_srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits) {
     if ((uint64_t)wt.W * srs->count >= (1ull << 31)) return fail(DR_ERR_INVALID, "window table too large");
     if (srs->d_table) (void)hipFree(srs->d_table);
     srs->d_table = nullptr;
-    HIP_TRY(hipMalloc((void**)&srs->d_table, (size_t)wt.W * srs->count * 96));
-    hipLaunchKernelGGL(dr::k_g1_window_table, dim3(div_up(srs->count, 128)), dim3(128), 0, ctx->stream, srs->d_bases, (uint32_t)srs->count, wt,
-                       srs->d_table);
+    srs->table_wt_odd = dr::WindowTable{};
+    // A small SRS gets a row for every bit (24 KB per base: 151 MB for the 6145 points of a 2048-point domain) — the window rows are a
+    // subset of it, and batched MSMs may then tile the scalar differently (odd-multiple buckets, see msm_device).
+    // DOTRING_SRS_BIT_ROWS_MB (default 512, 0 = never) bounds the table; DOTRING_SRS_ODD_BITS (default 1) is how much wider those windows are.
+    static const size_t bit_rows_mb = std::getenv("DOTRING_SRS_BIT_ROWS_MB") ? (size_t)std::atol(std::getenv("DOTRING_SRS_BIT_ROWS_MB")) : 512;
+    static const int odd_bits = std::getenv("DOTRING_SRS_ODD_BITS") ? std::atoi(std::getenv("DOTRING_SRS_ODD_BITS")) : 1;
+    const bool bit_rows = allow_bit_rows && window_bits <= 16 && (size_t)256 * srs->count * 96 <= (bit_rows_mb << 20);
+    const size_t rows = bit_rows ? 256 : (size_t)wt.W;
+    HIP_TRY(hipMalloc((void**)&srs->d_table, rows * srs->count * 96));
+    if (bit_rows) {
+        for (int w = 0; w < wt.W; w++) wt.row[w] = wt.start[w];
+        hipLaunchKernelGGL(dr::k_g1_bit_table, dim3(div_up(srs->count, 128)), dim3(128), 0, ctx->stream, srs->d_bases, (uint32_t)srs->count, 256u,
+                           srs->d_table);
+        if (odd_bits >= 0 && table_window_ok(window_bits + odd_bits)) {
+            srs->table_wt_odd = make_window_table(window_bits + odd_bits);
+            for (int w = 0; w < srs->table_wt_odd.W; w++) srs->table_wt_odd.row[w] = srs->table_wt_odd.start[w];
+            srs->table_wt_odd.odd = 1;
+        }
+    } else {
+        hipLaunchKernelGGL(dr::k_g1_window_table, dim3(div_up(srs->count, 128)), dim3(128), 0, ctx->stream, srs->d_bases, (uint32_t)srs->count, wt,
+                           srs->d_table);
+    }
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         (void)hipFree(srs->d_table);
@@ -902,6 +951,18 @@ void dr_srs_destroy(dr_srs* srs) {
 }
 
 size_t dr_srs_size(const dr_srs* srs) { return srs ? srs->count : 0; }
+
+int dr_srs_table_info(const dr_srs* srs, int info[4]) {
+    if (!srs || !info) return fail(DR_ERR_INVALID, "null argument");
+    info[0] = info[1] = info[2] = info[3] = 0;
+    if (!srs->d_table) return DR_OK;
+    const bool odd = srs->table_wt_odd.W != 0;
+    info[0] = srs->table_wt.cmax;
+    info[1] = odd || srs->table_wt.row[srs->table_wt.W - 1] != srs->table_wt.W - 1 ? 256 : srs->table_wt.W;
+    info[2] = odd ? srs->table_wt_odd.W : srs->table_wt.W;
+    info[3] = odd ? 1 : 0;
+    return DR_OK;
+}
 
 int dr_g1_msm_batch_dev(dr_ctx* ctx, const dr_srs* srs, const void* d_scalars, size_t n, size_t batch, uint8_t* out_be_xy, int* is_inf) {
     TRY(use_ctx(ctx));

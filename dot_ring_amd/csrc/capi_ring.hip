@@ -128,7 +128,7 @@ int lagrange_prefix_srs(dr_ctx* ctx, const dr_srs* srs_c, unsigned log2n, const 
     // them the bucket reduction, small (DOTRING_PS_WINDOW, default 10)
     int ps_bits = 10;
     if (const char* e = std::getenv("DOTRING_PS_WINDOW")) { int v = std::atoi(e); if (v >= 7 && v <= 16) ps_bits = v; }
-    rc = dr_srs_precompute(ctx, ps, ps_bits);
+    rc = srs_precompute(ctx, ps, ps_bits, std::getenv("DOTRING_PS_BIT_ROWS") && std::atoi(std::getenv("DOTRING_PS_BIT_ROWS")) != 0);
     if (rc != DR_OK) { dr_srs_destroy(ps); return rc; }
     // the by-parts scalars are sparse: in the comb kernel a wave skips a slot only when all 64 lanes have a zero digit,
     // while the bucket method never sees zero digits at all — DOTRING_PS_COMB=1 builds the comb table anyway

@@ -10,10 +10,16 @@ namespace dr {
 // Window table: the 256 scalar bits are tiled by W windows of width cmax or cmax-1 (wider ones on top), so every
 // window has about the same number of live buckets.  A narrow top window would otherwise hold only a few bits
 // and funnel n/2^t points into each of its few buckets — one lane then walks a chain thousands of points long.
+// Fixed-base tables come in two shapes: one row per window (row[w] = w: table[w][i] = 2^(start_w) * base[i]) or one row per BIT
+// (row[w] = start[w]: table[s][i] = 2^s * base[i] for every s < 256; any tiling of the 256 bits can then be used per call).
+// `odd` (bit rows only): a digit of magnitude m = 2^k * u, u odd, takes the point of row start_w + k and goes to bucket (u - 1) / 2 —
+// only odd multiples have buckets, 2^(cmax-2) per set instead of 2^(cmax-1); a set's value is sum_j (2j + 1) B_j.
 struct WindowTable {
     int W, cmax;
     uint8_t start[40];   // first bit of window w   (W <= 40: widths >= 7 ... see make_plan)
     uint8_t width[40];
+    uint8_t row[40];     // table row of window w (fixed-base table mode)
+    int odd;
 };
 constexpr int MAX_WINDOWS = 40;
 

@@ -270,7 +270,7 @@ __global__ void k_scan_add(uint32_t* out, const uint32_t* tile_sums, size_t n) {
 
 // ---- 3. counting-sort scatter: group (index|sign) by bucket
 // W > 0 selects the fixed-base-table mode: the entry indexes table[w][tbl_offset + i] and the bucket set is per MSM.
-__global__ void k_g1_scatter(const int32_t* __restrict__ digits, uint32_t n, size_t windows, uint32_t H, int W, uint32_t tbl_stride,
+__global__ void k_g1_scatter(const int32_t* __restrict__ digits, uint32_t n, size_t windows, uint32_t H, int W, WindowTable wt, uint32_t tbl_stride,
                              uint32_t tbl_offset, uint32_t groups, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
                              uint32_t* __restrict__ sorted) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,7 +284,7 @@ __global__ void k_g1_scatter(const int32_t* __restrict__ digits, uint32_t n, siz
     uint32_t entry = i;
     if (W > 0) {
         bset = (win / W) * groups + (size_t)(((uint64_t)i * groups) / n);
-        entry = (uint32_t)(win % W) * tbl_stride + tbl_offset + i;
+        entry = (uint32_t)wt.row[win % W] * tbl_stride + tbl_offset + i;
     }
     size_t bucket = bset * H + (mag - 1);
     uint32_t pos = offsets[bucket] + atomicAdd(&cursor[bucket], 1u);
@@ -308,13 +308,55 @@ __global__ __launch_bounds__(256) void k_g1_window_table(const uint32_t* __restr
     }
 }
 
+// fixed-base table with one row per bit: table[s][i] = 2^s * base[i], s < rows (affine, Montgomery), one lane per base
+__global__ __launch_bounds__(128) void k_g1_bit_table(const uint32_t* __restrict__ bases, uint32_t n, uint32_t rows, uint32_t* __restrict__ table) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Affine a = load_affine(bases, i);
+#pragma unroll 1
+    for (uint32_t s = 0; s < rows; s++) {
+        if (s > 0 && !a.inf) a = g1_to_affine_dev(g1_dbl_affine(a));
+        store_affine(table, (size_t)s * n + i, a);
+    }
+}
+
+// Odd-multiple buckets and their twins.  m = 2^k u (u odd) goes to bucket (u - 1) / 2 with the point of row start_w + k; left at
+// that, bucket 0 would collect m = 1, 2, 4, ... — cmax lists in one, hundreds of entries in the lowest buckets of every set.  So the
+// shifts are taken in groups of four: k < 4 feeds the bucket itself, k in [4g, 4g + 4), g >= 1, feeds a TWIN of it (same weight,
+// its own list; only buckets below H / 16^g have one), and k_g1_merge_twins adds the twins back before the reduction.  No list is
+// then longer than four times the average digit count.  Bins of a set: [0, H) the buckets, then the twins of g = 1, 2, 3.
+DR_DEV uint32_t odd_twin_offset(uint32_t H, uint32_t g) {          // first bin of group g >= 1
+    uint32_t off = H;
+    for (uint32_t q = 1; q < g; q++) off += (H >> (4 * q)) ? (H >> (4 * q)) : 1u;
+    return off;
+}
+inline uint32_t odd_twin_count(uint32_t H) {                       // host: bins beyond H (groups 1 .. 3)
+    uint32_t n = 0;
+    for (uint32_t q = 1; q <= 3; q++) n += (H >> (4 * q)) ? (H >> (4 * q)) : 1u;
+    return n;
+}
+// a digit of magnitude mag in window w -> its bin within the set (bucket or twin); `row` = the table row its point comes from
+DR_DEV uint32_t digit_bin(const WindowTable& wt, uint32_t H, int w, uint32_t mag, uint32_t& row) {
+    if (wt.odd) {
+        const uint32_t k = (uint32_t)__builtin_ctz(mag), g = k >> 2, j = mag >> (k + 1);
+        row = (uint32_t)wt.row[w] + k;
+        return g == 0 ? j : odd_twin_offset(H, g) + j;
+    }
+    row = wt.row[w];
+    return mag - 1u;
+}
+// where the bin of a set lives in counts / offsets / buckets: the sets' H buckets first, then `aux` twin slots per set
+DR_DEV size_t bin_slot(uint32_t set, uint32_t H, uint32_t bin, uint32_t aux, size_t aux_base) {
+    return bin < H ? (size_t)set * H + bin : aux_base + (size_t)set * aux + (bin - H);
+}
+
 // ---- 1'-3'. LDS counting sort: ONE workgroup owns one bucket set.  When a bucket set is small (H <= 8192 counters =
 // 32 KiB of LDS) and fed by a bounded number of digits (the batched prover: 7k MSMs x 2048 buckets), the histogram,
 // its exclusive scan and the placement all happen in LDS: no digit array in HBM, no global atomics, no global scan.
 // Each set gets a fixed-capacity segment of `sorted` (capacity = the most digits it can receive), so segment bases
 // need no cross-set scan.  Pass 1 counts, pass 2 recomputes the digits and places them.
 constexpr int SORT_BLOCK = 256;
-constexpr uint32_t SORT_MAX_H = 8192;
+constexpr uint32_t SORT_MAX_H = 8192, SORT_MAX_AUX = 320;      // (twins of odd-multiple buckets: H <= 4096 there)
 
 struct SortSetParams {
     uint32_t n, batch, H, groups;      // groups: table-mode index groups per MSM (1 otherwise)
@@ -323,6 +365,8 @@ struct SortSetParams {
     uint32_t capacity;                  // entries reserved per set in `sorted`
     uint32_t short_from, n_short;       // scalar vectors b >= short_from are zero beyond n_short entries: not even read
     uint32_t n_pad, digits_per_set;     // staged variant: row length (a multiple of 8) and u16 digits reserved per set
+    uint32_t aux;                       // odd-multiple buckets: twin slots per set (0 otherwise); they live at [sets * H + set * aux, ...)
+    uint32_t sets;
 };
 
 DR_DEV void load_scalar_mod_r(const uint32_t* __restrict__ scalars, size_t idx, uint32_t (&k)[9]) {
@@ -367,9 +411,10 @@ DR_DEV void for_each_digit(const uint32_t (&k)[9], const WindowTable& wt, int w_
 __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __restrict__ scalars, WindowTable wt, SortSetParams sp,
                                                              uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
                                                              uint32_t* __restrict__ sorted) {
-    __shared__ uint32_t bins[SORT_MAX_H];
+    __shared__ uint32_t bins[SORT_MAX_H + SORT_MAX_AUX];
     __shared__ uint32_t smem[SORT_BLOCK / 64];
-    const uint32_t H = sp.H, set = blockIdx.x;
+    const uint32_t H = sp.H, HB = sp.H + sp.aux, set = blockIdx.x;      // HB bins: the buckets and their twins
+    const size_t aux_base = (size_t)sp.sets * H;
     // which scalars and windows feed this set
     uint32_t b, i_lo, i_hi;
     int w_lo, w_hi;
@@ -389,21 +434,24 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
         i_lo = (uint32_t)(((uint64_t)g * sp.n + sp.groups - 1) / sp.groups);
         i_hi = (uint32_t)(((uint64_t)(g + 1) * sp.n + sp.groups - 1) / sp.groups);
     }
-    for (uint32_t j = threadIdx.x; j < H; j += SORT_BLOCK) bins[j] = 0;
+    for (uint32_t j = threadIdx.x; j < HB; j += SORT_BLOCK) bins[j] = 0;
     __syncthreads();
     // pass 1: histogram
     for (uint32_t i = i_lo + threadIdx.x; i < i_hi; i += SORT_BLOCK) {
         uint32_t k[9];
         load_scalar_mod_r(scalars, (size_t)b * sp.n + i, k);
-        for_each_digit(k, wt, w_lo, w_hi, [&](int, int32_t d) { atomicAdd(&bins[(d < 0 ? -d : d) - 1], 1u); });
+        for_each_digit(k, wt, w_lo, w_hi, [&](int w, int32_t d) {
+            uint32_t row;
+            atomicAdd(&bins[digit_bin(wt, H, w, (uint32_t)(d < 0 ? -d : d), row)], 1u);
+        });
     }
     __syncthreads();
     // counts out; in-place exclusive scan of the H bins (each lane owns H/SORT_BLOCK consecutive bins)
-    const uint32_t per = (H + SORT_BLOCK - 1) / SORT_BLOCK, lo = threadIdx.x * per, hi = lo + per < H ? lo + per : H;
+    const uint32_t per = (HB + SORT_BLOCK - 1) / SORT_BLOCK, lo = threadIdx.x * per < HB ? threadIdx.x * per : HB, hi = lo + per < HB ? lo + per : HB;
     uint32_t local = 0;
     for (uint32_t j = lo; j < hi; j++) {
         uint32_t c = bins[j];
-        counts[(size_t)set * H + j] = c;
+        counts[bin_slot(set, H, j, sp.aux, aux_base)] = c;
         local += c;
     }
     uint32_t total;
@@ -412,7 +460,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
     for (uint32_t j = lo; j < hi; j++) {
         uint32_t c = bins[j];
         bins[j] = run;                                  // becomes the placement cursor
-        offsets[(size_t)set * H + j] = base + run;
+        offsets[bin_slot(set, H, j, sp.aux, aux_base)] = base + run;
         run += c;
     }
     __syncthreads();
@@ -421,8 +469,9 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
         uint32_t k[9];
         load_scalar_mod_r(scalars, (size_t)b * sp.n + i, k);
         for_each_digit(k, wt, w_lo, w_hi, [&](int w, int32_t d) {
-            uint32_t pos = atomicAdd(&bins[(d < 0 ? -d : d) - 1], 1u);
-            uint32_t entry = sp.single ? (uint32_t)w * sp.tbl_stride + sp.tbl_offset + i : i;
+            uint32_t row;
+            uint32_t pos = atomicAdd(&bins[digit_bin(wt, H, w, (uint32_t)(d < 0 ? -d : d), row)], 1u);
+            uint32_t entry = sp.single ? row * sp.tbl_stride + sp.tbl_offset + i : i;
             sorted[base + pos] = entry | (d < 0 ? 0x80000000u : 0u);
         });
     }
@@ -449,11 +498,12 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
                                                                     uint16_t* __restrict__ digits16, uint32_t* __restrict__ counts,
                                                                     uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
     constexpr uint32_t SORT2_CHUNK = SORT2_CAP - SORT2_SLACK;
-    __shared__ uint32_t bins[MAX_H];
+    __shared__ uint32_t bins[MAX_H + SORT_MAX_AUX];
     __shared__ uint32_t stage[SORT2_CAP];
     __shared__ uint32_t cs[SORT2_MAX_CHUNKS + 1], jb[SORT2_MAX_CHUNKS + 1];
     __shared__ uint32_t smem[SORT2_BLOCK / 64];
-    const uint32_t H = sp.H, set = blockIdx.x, tid = threadIdx.x;
+    const uint32_t HR = sp.H, H = sp.H + sp.aux, set = blockIdx.x, tid = threadIdx.x;      // H bins: HR buckets and their twins
+    const size_t aux_base = (size_t)sp.sets * HR;
     uint32_t b, i_lo, i_hi;
     int w_lo, w_hi;
     if (sp.single) {
@@ -482,8 +532,14 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
             load_scalar_mod_r(scalars, (size_t)b * sp.n + i_lo + ii, k);
             for_each_digit<true>(k, wt, w_lo, w_hi, [&](int w, int32_t d) {
                 const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-                dg[(size_t)(w - w_lo) * n_pad + ii] = (uint16_t)(mag | (d < 0 ? 0x8000u : 0u));
-                if (d != 0) atomicAdd(&bins[mag - 1], 1u);
+                uint32_t row, enc = mag;
+                if (d != 0) {
+                    const uint32_t bin = digit_bin(wt, HR, w, mag, row);
+                    atomicAdd(&bins[bin], 1u);
+                    // odd multiples: pass 2 runs once per chunk, so the bin is worked out here, once: bin + 1 | (k & 3) << 13
+                    if (wt.odd) enc = (bin + 1u) | (((uint32_t)__builtin_ctz(mag) & 3u) << 13);
+                }
+                dg[(size_t)(w - w_lo) * n_pad + ii] = (uint16_t)(enc | (d < 0 ? 0x8000u : 0u));
             });
         } else {
             for (uint32_t r = 0; r < rows; r++) dg[(size_t)r * n_pad + ii] = 0;
@@ -495,7 +551,7 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
     uint32_t local = 0;
     for (uint32_t j = lo; j < hi; j++) {
         uint32_t c = bins[j];
-        counts[(size_t)set * H + j] = c;
+        counts[bin_slot(set, HR, j, sp.aux, aux_base)] = c;
         local += c;
     }
     uint32_t total;
@@ -505,7 +561,7 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
     for (uint32_t j = lo; j < hi; j++) {
         uint32_t c = bins[j];
         bins[j] = run;                                  // becomes the placement cursor
-        offsets[(size_t)set * H + j] = base + run;
+        offsets[bin_slot(set, HR, j, sp.aux, aux_base)] = base + run;
         const uint32_t k = run / SORT2_CHUNK;           // chunk in which this bucket's segment starts (k <= K; k == K only for
         atomicMin(&jb[k], j);                           //  empty buckets at the very end)
         atomicMin(&cs[k], run);
@@ -532,17 +588,23 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
             uint32_t r = 0, v = tid;
             for (uint32_t idx = tid; idx < nvec; idx += SORT2_BLOCK, v += SORT2_BLOCK) {
                 while (v >= nv) { v -= nv; r++; }
-                const uint32_t row_entry = (sp.single ? (uint32_t)(w_lo + (int)r) * sp.tbl_stride : 0u) + tbl + i_lo;
+                const uint32_t row_entry = (sp.single ? (uint32_t)wt.row[w_lo + (int)r] * sp.tbl_stride : 0u) + tbl + i_lo;
                 {
                     const uint4 q = vecs[idx];
                     const uint32_t words[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                     for (int t = 0; t < 8; t++) {
                         const uint32_t dd = (words[t >> 1] >> (16 * (t & 1))) & 0xffffu;
-                        const uint32_t j = (dd & 0x7fffu) - 1u;              // dd == 0 -> 0xffffffff: outside every range
+                        const uint32_t j = (dd & (wt.odd ? 0x1fffu : 0x7fffu)) - 1u;   // dd == 0 -> 0xffffffff: outside every range
                         if (j >= j_lo && j < j_hi) {
+                            uint32_t up = 0;
+                            if (wt.odd) {                                     // row + k: k = 4 g + (k & 3), g from the bin's range (digit_bin)
+                                const uint32_t d1 = HR + ((HR >> 4) ? (HR >> 4) : 1u), d2 = d1 + ((HR >> 8) ? (HR >> 8) : 1u);
+                                const uint32_t g = j < HR ? 0u : j < d1 ? 1u : j < d2 ? 2u : 3u;
+                                up = (4u * g + ((dd >> 13) & 3u)) * sp.tbl_stride;
+                            }
                             const uint32_t pos = atomicAdd(&bins[j], 1u);
-                            const uint32_t entry = (row_entry + v * 8 + (uint32_t)t) | ((dd & 0x8000u) << 16);
+                            const uint32_t entry = (row_entry + up + v * 8 + (uint32_t)t) | ((dd & 0x8000u) << 16);
                             const uint32_t rel = pos - c0;
                             if (rel < SORT2_CAP) stage[rel] = entry;
                             else sorted[base + pos] = entry;
@@ -580,6 +642,7 @@ struct PartParams {
     uint32_t cap_part;                                    // entries reserved per partition stream
     uint32_t capacity;                                    // entries reserved per set in `sorted`
     uint32_t tbl_stride, tbl_offset;
+    uint8_t row[32];                                      // table row of window w (WindowTable::row; W <= 32 here)
 };
 
 DR_DEV void part_set_range(const PartParams& pp, uint32_t set, uint32_t& b, uint32_t& i_lo, uint32_t& i_hi) {
@@ -714,7 +777,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_g1_part_sort(const uint32_t* __r
                 const uint32_t e = src[idx], j = (e >> 21) & 0x3ffu;
                 if (j >= j_lo && j < j_hi) {
                     const uint32_t pos = atomicAdd(&bins[j], 1u);
-                    const uint32_t entry = (((e >> 16) & 31u) * pp.tbl_stride + entry0 + (e & 0xffffu)) | (e & 0x80000000u);
+                    const uint32_t entry = ((uint32_t)pp.row[(e >> 16) & 31u] * pp.tbl_stride + entry0 + (e & 0xffffu)) | (e & 0x80000000u);
                     const uint32_t rel = pos - c0;
                     if (rel < PART_STAGE) stage[rel] = entry;
                     else sorted[base + pos] = entry;
@@ -730,10 +793,15 @@ __global__ __launch_bounds__(PART_BLOCK) void k_g1_part_sort(const uint32_t* __r
 
 // ---- 3b. order buckets by size (descending) so that the 64 lanes of a wave walk chains of nearly equal length.
 // A wave otherwise waits for its longest bucket: with ~20 points per bucket (Poisson) a third of the lane-cycles idle.
-// Counting sort over 256 size classes (sizes >= 255 share the first class): per-workgroup histograms in LDS, a scan
+// Counting sort over 256 size classes (sizes >= 696 share the first class, see size_class): per-workgroup histograms in LDS, a scan
 // over (class-major, workgroup-minor) cells, then each workgroup places its buckets.  Order inside a class is free.
 constexpr int SZ_BLOCK = 256, SZ_ITEMS = 8, SZ_TILE = SZ_BLOCK * SZ_ITEMS, SZ_CLASSES = 256;
-DR_DEV uint32_t size_class(uint32_t count) { return 255u - (count > 255u ? 255u : count); }    // class 0 = largest
+// class 0 = largest.  One class per size up to 191 entries, then steps of 8 (lanes of a wave differ by < 4 % there) up to 695: lists
+// of G1_LONG_BUCKET entries or more are shared by 16 or 64 lanes (k_g1_accumulate_long), similar lengths side by side.
+DR_DEV uint32_t size_class(uint32_t count) {
+    const uint32_t idx = count < 192u ? count : 192u + (((count - 192u) >> 3) > 63u ? 63u : ((count - 192u) >> 3));
+    return 255u - idx;
+}
 
 __global__ __launch_bounds__(SZ_BLOCK) void k_size_hist(const uint32_t* __restrict__ counts, size_t nbuckets, uint32_t nblocks,
                                                         uint32_t* __restrict__ cells /* [SZ_CLASSES][nblocks] */) {
@@ -765,11 +833,14 @@ __global__ __launch_bounds__(SZ_BLOCK) void k_size_place(const uint32_t* __restr
 // ---- 4. bucket accumulation: one lane per bucket walks its segment with mixed additions.  DOMINANT KERNEL.
 // Algorithmic traffic: 96 B base + 32 B scalar per (base,scalar) pair; the gather of bases is the
 // only large stream, the segment lists are 4 B per entry.
-// A bucket of the largest size class (>= 255 entries; the size ordering puts those first in `perm`) is left to
-// k_g1_accumulate_heavy, where a whole wave walks it: skewed scalars — a 0/1 column, many equal values — put thousands of
-// points into one bucket, and one lane adding them one after the other would be the kernel's whole run time (6145 equal
-// scalars: 28 ms in one lane, 0.5 ms in a wave).  The prover's dense MSMs (~66 points per bucket, Poisson) never get there.
-constexpr uint32_t G1_HEAVY_BUCKET = 255;
+// Long lists are not walked by one lane: skewed scalars — a 0/1 column, many equal values — put thousands of points into one bucket,
+// and one lane adding them one after the other would be the kernel's whole run time (6145 equal scalars: 28 ms in one lane, 0.5 ms
+// in a wave); odd-multiple buckets put a few hundred into the lowest buckets of EVERY set.  Lists of G1_LONG_BUCKET (256) entries
+// or more — the size ordering puts them first in `perm` — are left to k_g1_accumulate_long: 16 lanes per bucket (four buckets per
+// wave) up to G1_HEAVY_BUCKET entries, a whole wave beyond.  The prover's dense MSMs over window rows (~66 points per bucket,
+// Poisson) never get there.
+constexpr uint32_t G1_LONG_BUCKET = 256, G1_LONG_CLASS_IDX = 192 + (G1_LONG_BUCKET - 192) / 8;    // size_class index 200: sizes 256 .. 263
+constexpr uint32_t G1_HEAVY_BUCKET = 4096;
 
 DR_DEV G1Xyzz g1_walk(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, uint32_t beg, uint32_t len, uint32_t first,
                       uint32_t stride) {
@@ -794,39 +865,65 @@ __global__ __launch_bounds__(256) void k_g1_accumulate(const uint32_t* __restric
     if (t >= nbuckets) return;
     const size_t b = perm[t];
     const uint32_t len = counts[b];
-    if (len >= G1_HEAVY_BUCKET) return;
+    if (len >= G1_LONG_BUCKET) return;
     store_xyzz(buckets, b, g1_walk(bases, sorted, offsets[b], len, 0, 1));
 }
 
+template <int WIDTH>
 DR_DEV G1Xyzz xyzz_shfl_down(const G1Xyzz& p, unsigned delta) {
     G1Xyzz o;
 #pragma unroll
     for (int t = 0; t < L28; t++) {
-        o.x.l[t] = __shfl_down(p.x.l[t], delta, 64);
-        o.y.l[t] = __shfl_down(p.y.l[t], delta, 64);
-        o.zz.l[t] = __shfl_down(p.zz.l[t], delta, 64);
-        o.zzz.l[t] = __shfl_down(p.zzz.l[t], delta, 64);
+        o.x.l[t] = __shfl_down(p.x.l[t], delta, WIDTH);
+        o.y.l[t] = __shfl_down(p.y.l[t], delta, WIDTH);
+        o.zz.l[t] = __shfl_down(p.zz.l[t], delta, WIDTH);
+        o.zzz.l[t] = __shfl_down(p.zzz.l[t], delta, WIDTH);
     }
-    o.inf = __shfl_down(p.inf, delta, 64);
+    o.inf = __shfl_down(p.inf, delta, WIDTH);
     return o;
 }
-// one wave per heavy bucket (perm[0 .. n_heavy), n_heavy = the exclusive scan's offset of size class 1): the lanes stride over
-// the list, a shuffle tree folds their 64 partial sums.  Grid-stride, so a fixed small grid serves any number of heavy buckets.
-__global__ __launch_bounds__(64) void k_g1_accumulate_heavy(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
-                                                            const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_offsets,
-                                                            uint32_t nblocks, uint32_t* __restrict__ buckets) {
-    const uint32_t n_heavy = cell_offsets[nblocks];                 // cells are [class][block]: class 1 starts where class 0 ends
+// LANES (16 or 64) lanes per long bucket: perm[0 .. n_long), n_long = where the size classes below G1_LONG_BUCKET begin in the
+// exclusive scan of the [class][block] cells.  The lanes stride over the list, a shuffle tree folds their partial sums.  The
+// 16-lane instance takes lists of [G1_LONG_BUCKET, G1_HEAVY_BUCKET) entries, four per wave; the 64-lane instance the rest.
+// Grid-stride, so a fixed small grid serves any number of them; returns at once when there are none.
+template <int LANES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_accumulate_long(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                           const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_offsets,
+                                                           uint32_t nblocks, uint32_t* __restrict__ buckets) {
+    constexpr uint32_t PER_WAVE = 64 / LANES;
+    // class index >= G1_LONG_CLASS_IDX  <=>  class <= 255 - G1_LONG_CLASS_IDX; the next class starts at cell (256 - idx) * nblocks
+    const uint32_t n_long = cell_offsets[(size_t)(256u - G1_LONG_CLASS_IDX) * nblocks];
+    const uint32_t sub = threadIdx.x / LANES, lane = threadIdx.x % LANES;
 #pragma unroll 1
-    for (uint32_t t = blockIdx.x; t < n_heavy; t += gridDim.x) {
-        const size_t b = perm[t];
-        const uint32_t len = counts[b];
-        if (len < G1_HEAVY_BUCKET) continue;
-        G1Xyzz acc = g1_walk(bases, sorted, offsets[b], len, threadIdx.x, 64);
+    for (uint32_t t0 = blockIdx.x * PER_WAVE; t0 < n_long; t0 += gridDim.x * PER_WAVE) {
+        const uint32_t t = t0 + sub;
+        const bool have = t < n_long;
+        const size_t b = have ? perm[t] : 0;
+        const uint32_t len = have ? counts[b] : 0;
+        const bool mine = have && (LANES == 64 ? len >= G1_HEAVY_BUCKET : (len >= G1_LONG_BUCKET && len < G1_HEAVY_BUCKET));
+        if (__ballot(mine) == 0) continue;
+        G1Xyzz acc = g1_walk(bases, sorted, have ? offsets[b] : 0u, mine ? len : 0u, lane, LANES);
 #pragma unroll 1
-        for (unsigned d = 32; d >= 1; d >>= 1) acc = g1_add(acc, xyzz_shfl_down(acc, d));
-        if (threadIdx.x == 0) store_xyzz(buckets, b, acc);
+        for (unsigned d = LANES / 2; d >= 1; d >>= 1) acc = g1_add(acc, xyzz_shfl_down<LANES>(acc, d));
+        if (mine && lane == 0) store_xyzz(buckets, b, acc);
     }
+}
+
+// twins of odd-multiple buckets (digit_bin) back into their buckets: one lane per bucket that has a twin (j < H / 16)
+__global__ __launch_bounds__(128) void k_g1_merge_twins(uint32_t* __restrict__ buckets, uint32_t sets, uint32_t H, uint32_t aux) {
+    const uint32_t D1 = (H >> 4) ? (H >> 4) : 1u;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)sets * D1) return;
+    const uint32_t set = (uint32_t)(gid / D1), j = (uint32_t)(gid % D1);
+    const size_t twin0 = (size_t)sets * H + (size_t)set * aux;
+    G1Xyzz acc = load_xyzz(buckets, (size_t)set * H + j);
+#pragma unroll 1
+    for (uint32_t g = 1; g <= 3; g++) {
+        const uint32_t Dg = (H >> (4 * g)) ? (H >> (4 * g)) : 1u;
+        if (j < Dg) acc = g1_add(acc, load_xyzz(buckets, twin0 + (odd_twin_offset(H, g) - H) + j));
+    }
+    store_xyzz(buckets, (size_t)set * H + j, acc);
 }
 
 // ---- 5. bucket reduction.  Window value = sum_j (j+1) * B_j.  Chunk [s, s+L): running sums give
@@ -984,8 +1081,10 @@ __global__ __launch_bounds__(128) void k_g1_reduce_level(const uint32_t* __restr
 constexpr int RS_BLOCK = 64, RS_GROUP = 4;
 // (no occupancy cap: three live accumulators need ~390 registers, and with T/4 lanes per set the launch is at most one wave
 // per SIMD anyway)
+// `odd`: bucket j holds the odd multiple 2j + 1 (WindowTable::odd): value = 2 * [sum_j (j + 1) B_j] - sum_j B_j — one more step, on
+// the tree's result and the set total that the suffix scan left in lane 0.
 __global__ __launch_bounds__(RS_BLOCK) void k_g1_reduce_set_scan(const uint32_t* __restrict__ in_s, const uint32_t* __restrict__ in_c, size_t sets,
-                                                                 uint32_t T /* power of two, 8 .. 256 */, uint32_t* __restrict__ winsum) {
+                                                                 uint32_t T /* power of two, 8 .. 256 */, int odd, uint32_t* __restrict__ winsum) {
     __shared__ uint32_t sm[RS_BLOCK * XYZZ_RAW_WORDS];
     const uint32_t LS = T / RS_GROUP;                       // lanes per set (a power of two <= 64)
     const uint32_t per_block = RS_BLOCK / LS;
@@ -1000,10 +1099,12 @@ __global__ __launch_bounds__(RS_BLOCK) void k_g1_reduce_set_scan(const uint32_t*
     G1Xyzz run = g1_inf(), w = g1_inf(), v = g1_inf();
     const int n_local = 2 * RS_GROUP, s_scan = n_local, s_comb = s_scan + lg, s_corr = s_comb + 1, s_tree = s_corr + RS_GROUP, s_end = s_tree + lg;
 #pragma unroll 1
-    for (int step = 0; step < s_end; step++) {
+    for (int step = 0; step < s_end + (odd ? 1 : 0); step++) {
         G1Xyzz a, b = g1_inf();
         int dst;                                            // 0: run, 1: w, 2: v
-        if (step < n_local) {
+        if (step == s_end) {                                // odd multiples: 2 v - (set total)
+            a = g1_dbl(v); b = run; b.y = neg(b.y); dst = 2;
+        } else if (step < n_local) {
             if ((step & 1) == 0) { a = run; if (live) b = load_xyzz(in_s, c0 + (RS_GROUP - 1 - (step >> 1))); dst = 0; }
             else { a = w; b = run; dst = 1; }
         } else if (step < s_comb) {                         // suffix scan of the block sums: run_l += run_{l + 2^k}
@@ -1153,7 +1254,7 @@ constexpr int COMB_STRIDE = 32;      // words per comb entry: 96 bytes of data p
 
 // Build: one lane per (base j, window w) row: d*B for d = 1..hw by repeated mixed addition (XYZZ, staged in tmp), then
 // one inversion per row (Montgomery's trick over the row's ZZZ) turns them into affine Montgomery entries.
-__global__ __launch_bounds__(128) void k_g1_comb_build(const uint32_t* __restrict__ wtable /* [W][count] affine */, uint32_t count, WindowTable wt,
+__global__ __launch_bounds__(128) void k_g1_comb_build(const uint32_t* __restrict__ wtable /* [rows][count] affine, row of window w = wt.row[w] */, uint32_t count, WindowTable wt,
                                                        uint32_t Hc, size_t row_lo, uint32_t rows, uint32_t* __restrict__ comb,
                                                        uint32_t* __restrict__ tmp_xyzz /* [Hc][rows][48] */, uint32_t* __restrict__ tmp_pre /* [Hc][rows][12] */) {
     uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1162,7 +1263,7 @@ __global__ __launch_bounds__(128) void k_g1_comb_build(const uint32_t* __restric
     const uint32_t j = (uint32_t)(row / wt.W), w = (uint32_t)(row % wt.W);
     const uint32_t hw = 1u << (wt.width[w] - 1);
     uint32_t* out = comb + row * Hc * COMB_STRIDE;
-    const G1Affine B = load_affine(wtable, (size_t)w * count + j);
+    const G1Affine B = load_affine(wtable, (size_t)wt.row[w] * count + j);
     if (B.inf) {
         uint32_t z[12] = {0};
         for (uint32_t d = 0; d < hw; d++) { store_words12(out + (size_t)d * COMB_STRIDE, z); store_words12(out + (size_t)d * COMB_STRIDE + 12, z); }

@@ -410,6 +410,44 @@ def test_g1_msm_fixed_base_table_matches_plain(ctx, srs_bytes, bits):
     tabled.close()
 
 
+@pytest.mark.parametrize("bits,n,batch", [(9, 96, 8192), (12, 1500, 1024)])
+def test_g1_msm_batched_odd_multiple_buckets(ctx, srs_bytes, bits, n, batch):
+    """A small SRS gets a table with a row per bit, and a batch of hundreds of MSMs over it takes the odd-multiple tiling
+    (one bit wider windows, buckets for odd digit multiples and their twins, dr_srs_table_info): the very same scalar vectors in
+    batches of 64 take the window rows — the results must agree, and a sample of them with the oracle.  Edge vectors: powers of
+    two (every shift k up to the window width, i.e. every twin group), r - 1, all equal, all zero, 2^c - 1 patterns."""
+    rng = random.Random(bits * 1000 + n)
+    tabled = ctx.srs_load(srs_bytes[: 96 * n]).precompute(bits)
+    info = tabled.table_info()
+    assert info["window_bits"] == bits and info["rows"] == 256 and info["odd_buckets"]
+    assert info["batched_windows"] == -(-256 // (bits + 1))
+    r = coracle.FR_P
+    vecs = []
+    for b in range(batch):
+        if b == 0:
+            v = [0] * n
+        elif b == 1:
+            v = [r - 1] * n
+        elif b == 2:
+            v = [(1 << (i % 255)) % r for i in range(n)]                       # single bits: every row, every shift
+        elif b == 3:
+            v = [((1 << (bits + 1)) - 1) << ((bits + 1) * (i % 16)) for i in range(n)]
+        elif b == 4:
+            v = [5] * n                                                        # one long list
+        elif b == 5:
+            v = [(1 << 255) % r if i % 2 else ((1 << (bits)) << (7 * (i % 30))) % r for i in range(n)]
+        else:
+            v = [rng.randrange(r) for _ in range(n)]
+        vecs.append(b"".join(x.to_bytes(32, "little") for x in v))
+    got = ctx.g1_msm_batch(tabled, b"".join(vecs), n)
+    assert len(got) == batch
+    for lo in range(0, batch, 64 * 16):                                        # window rows: 64 vectors per call, every 16th chunk
+        assert ctx.g1_msm_batch(tabled, b"".join(vecs[lo : lo + 64]), n) == got[lo : lo + 64], lo
+    for b in (0, 1, 2, 3, 4, 5, 6, batch - 1):
+        assert got[b] == _oracle_msm_be(srs_bytes, vecs[b], n), b
+    tabled.close()
+
+
 # ------------------------------------------------------------------ seam C
 @pytest.mark.parametrize("log2n", [1, 2, 5, 9, 10, 11, 13, 14])
 def test_ntt_matches_oracle(ctx, log2n):
