@@ -439,7 +439,11 @@ def test_g1_msm_batched_odd_multiple_buckets(ctx, srs_bytes, bits, n, batch):
         else:
             v = [rng.randrange(r) for _ in range(n)]
         vecs.append(b"".join(x.to_bytes(32, "little") for x in v))
+    ctx.prof_reset()
+    ctx.prof_enable(True)
     got = ctx.g1_msm_batch(tabled, b"".join(vecs), n)
+    assert ctx.prof_get("k_g1_merge_twins")[1] == 1                            # the odd-multiple path did run
+    ctx.prof_enable(False)
     assert len(got) == batch
     for lo in range(0, batch, 64 * 16):                                        # window rows: 64 vectors per call, every 16th chunk
         assert ctx.g1_msm_batch(tabled, b"".join(vecs[lo : lo + 64]), n) == got[lo : lo + 64], lo

@@ -125,6 +125,17 @@ def test_ring_1024_domain_2048_matches_oracle(ctx):
     assert proofs[1].encode() == oring.ring_vrf_prove(o_ring, o_root, b"b", b"ad", sk)
     assert proofs[1].verify(b"b", b"ad", ring, root)
     assert d.RingVRF[d.Bandersnatch].batch_verify(proofs, [b"a", b"b"], [b"", b"ad"], ring, root)
+    # BASELINE config 4's batch: 1024 deterministic proofs in ONE call.  At that size the KZG MSMs take the odd-multiple buckets over the
+    # bit-row SRS table (dr_srs_table_info) where the two proofs above took its window rows: same inputs, same bytes.
+    assert params.pcs._srs().device().table_info()["odd_buckets"]
+    n = 1024
+    als = [b"a", b"b"] + [b"in-%d" % i for i in range(n - 2)]
+    ads = [b"", b"ad"] + [b"ad-%d" % (i % 3) for i in range(n - 2)]
+    big = d.RingVRF[d.Bandersnatch].prove_batch(als, ads, [sk] * n, [pk] * n, ring, root)
+    assert big[0].encode() == proofs[0].encode() and big[1].encode() == proofs[1].encode()
+    for i in (2, 511, 1023):
+        assert big[i].encode() == oring.ring_vrf_prove(o_ring, o_root, als[i], ads[i], sk), i
+    assert d.RingVRF[d.Bandersnatch].batch_verify(big, als, ads, ring, root)
 
 
 def test_domain_4096_with_known_tau_srs_matches_oracle(ctx):

@@ -136,6 +136,39 @@ for table in (0, 9, 12, 14):
     srs.close()
 report("g1 msm shapes", total, wrong, t0)
 
+# 6b. round 3: large batches over a bit-row table (odd-multiple buckets and their twins) against the same vectors in batches of 32
+# (window rows) and a sample against the oracle; scalars dense, sparse, short, repeated
+t0 = time.perf_counter()
+wrong = total = 0
+for table, n, batch in ((9, 50, 8192), (10, 333, 4096), (12, 2047, 1024), (13, 700, 512)):
+    if scale < 1 and n > 400:
+        continue
+    srs = ctx.srs_load(srs_be[: 96 * n]).precompute(table)
+    assert srs.table_info()["odd_buckets"]
+    kinds = [rng.choice(["dense", "sparse", "short", "repeated"]) for _ in range(batch)]
+    rows = []
+    for kind in kinds:
+        if kind == "dense":
+            row = [rng.randrange(coracle.FR_P) for _ in range(n)]
+        elif kind == "sparse":
+            row = [rng.randrange(coracle.FR_P) if rng.random() < 0.1 else rng.choice([0, 0, 1, coracle.FR_P - 1]) for _ in range(n)]
+        elif kind == "short":
+            row = [rng.randrange(1 << rng.choice([1, 13, 14, 64, 200])) for _ in range(n)]
+        else:
+            vals = [rng.randrange(coracle.FR_P) for _ in range(2)] + [1 << rng.randrange(255)]
+            row = [rng.choice(vals) for _ in range(n)]
+        rows.append(b"".join(k.to_bytes(32, "little") for k in row))
+    got = ctx.g1_msm_batch(srs, b"".join(rows), n)
+    for lo in range(0, batch, 32 * 8):
+        wrong += ctx.g1_msm_batch(srs, b"".join(rows[lo : lo + 32]), n) != got[lo : lo + 32]
+        total += 1
+    for b in rng.sample(range(batch), 6):
+        w = coracle.g1_msm_raw(srs_le[: 96 * n], rows[b], n)
+        wrong += got[b] != (None if w == bytes(96) else w[:48][::-1] + w[48:][::-1])
+        total += 1
+    srs.close()
+report("g1 msm odd-multiple buckets", total, wrong, t0)
+
 # 7. Bandersnatch bucket Pippenger (K4, from 256 terms): random sizes, uniform / short / repeated scalars (heavy buckets)
 t0 = time.perf_counter()
 wrong = total = 0
