@@ -72,7 +72,8 @@ int bsn_consts_init(hipStream_t st) {
     Fr mont_a = (a + d).dbl() * inv_den, mont_b = Fr::from_u64(4) * inv_den;
     Fr aob = mont_a * mont_b.inv(), inv_b2 = mont_b.sqr().inv();
     static const uint64_t Q[4] = {0xfffe5bfeffffffffULL, 0x09a1d80553bda402ULL, 0x299d7d483339d808ULL, 0x0000000073eda753ULL};   // (p-1) / 2^32
-    dr::BsnConsts h;
+    auto h_owner = std::make_unique<dr::BsnConsts>();        // 200 KB: not on the stack
+    dr::BsnConsts& h = *h_owner;
     // the device's twisted Edwards kernels keep Fr in Montgomery form with R = 2^261 (fr29.hip.h), the host with R = 2^256:
     // (32 v) in the host's form has the words of v in the device's
     const Fr thirty_two = Fr::from_u64(32);
@@ -90,6 +91,57 @@ int bsn_consts_init(hipStream_t st) {
     if (!(c == Fr::one())) return fail(DR_ERR_DEVICE, "bad Tonelli-Shanks constants");
     static const uint64_t QP1H[4] = {0x7fff2dff80000000ULL, 0x04d0ec02a9ded201ULL, 0x94cebea4199cec04ULL, 0x0000000039f6d3a9ULL};   // (Q + 1) / 2
     put(h.z_q1h, five.pow(QP1H, 4));
+    // windows of the discrete logarithm in <c> (kernels_bsn.hip.h: fr_sqrt_core)
+    {
+        const Fr c0 = five.pow(Q, 4), c_inv = c0.inv();
+        Fr step = c_inv;                                     // c^(-2^(8j))
+        Fr half0 = c_inv;                                    // c^(-1): dl_half[0][k] = c^(-k/2) for even k
+        for (int j = 0; j < 4; j++) {
+            Fr hstep = j == 0 ? half0 : Fr::one();
+            if (j > 0) {                                     // c^(-2^(8j - 1))
+                hstep = c_inv;
+                for (int q = 0; q < 8 * j - 1; q++) hstep = hstep.sqr();
+            }
+            Fr m = Fr::one(), hh = Fr::one();
+            for (int k = 0; k < 256; k++) {
+                put(h.dl_mul[j][k], m);
+                if (j == 0) {
+                    put(h.dl_half[0][k], hh);                // entry k holds c^(-(k >> 1)): read for even k only
+                    if (k & 1) hh = hh * hstep;
+                } else {
+                    put(h.dl_half[j][k], hh);
+                    hh = hh * hstep;
+                }
+                m = m * step;
+            }
+            for (int q = 0; q < 8; q++) step = step.sqr();
+        }
+        Fr g3 = c0;
+        for (int q = 0; q < 24; q++) g3 = g3.sqr();          // order 2^8
+        std::vector<uint32_t> low(256);
+        Fr v = Fr::one();
+        for (int k = 0; k < 256; k++) {
+            uint32_t w[8];
+            put(w, v);
+            low[k] = w[0];
+            v = v * g3;
+        }
+        if (!(v == Fr::one())) return fail(DR_ERR_DEVICE, "bad discrete-logarithm constants");
+        bool found = false;
+        for (uint32_t a = 0x9e3779b1u; !found && a > 0x9e3779b1u - 200000u; a -= 2) {
+            std::memset(h.dl_map, 0xff, sizeof h.dl_map);
+            std::vector<uint8_t> used(65536, 0);
+            bool ok = true;
+            for (int k = 0; k < 256 && ok; k++) {
+                const uint32_t idx = (low[k] * a) >> 16;
+                if (used[idx]) ok = false;
+                used[idx] = 1;
+                h.dl_map[idx] = (uint8_t)k;
+            }
+            if (ok) { h.dl_hash_mul = a; found = true; }
+        }
+        if (!found) return fail(DR_ERR_DEVICE, "no perfect hash for the discrete-logarithm table");
+    }
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(dr::g_bsn_consts), &h, sizeof h, 0, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     return DR_OK;

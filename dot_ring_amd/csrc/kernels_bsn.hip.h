@@ -13,49 +13,31 @@ struct BsnConsts {
     uint32_t c_pow[32][8];
     uint32_t glv_b[8], glv_c[8];         // endomorphism coefficients (bandersnatch.py:58-67), Montgomery form
     uint32_t z_q1h[8];                   // 5^((Q+1)/2): turns x^((Q+1)/2) into (5 x)^((Q+1)/2) (fr_sqrt_or_5x)
+    // discrete logarithms in the 2-Sylow subgroup <c>, c = 5^Q of order 2^32, by 8-bit windows (fr_sqrt_core):
+    uint32_t dl_mul[4][256][8];          // c^(-k 2^(8j))
+    uint32_t dl_half[4][256][8];         // c^(-k 2^(8j) / 2)   (j = 0: even k only)
+    uint32_t dl_hash_mul;                // perfect hash of the 256 elements of <c^(2^24)>: map[(low word * dl_hash_mul) >> 16] = exponent
+    uint8_t dl_map[65536];
 };
 __device__ BsnConsts g_bsn_consts;
 DR_DEV Fs bsn_const(const uint32_t (&w)[8]) { return unpack29(w); }
 
-// Tonelli-Shanks (the reference's sqrt_mod_bls_scalar_cy, bandersnatch_te.pyx:421-477) with the squareness test folded
-// in: with w = x^((Q-1)/2), R = w x and t = R w = x^Q; x is a square iff t^(2^31) = 1, which the first pass of the
-// order search finds out anyway — no separate Legendre exponentiation.  Returns false for non-residues.
-DR_DEV bool fr_sqrt(const Fs& x, Fs& root) {
-    root = x;
-    if (is_zero(x)) return true;
-    constexpr uint32_t QM1H[8] = {0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u, 0u};   // (Q-1)/2
-    uint32_t e[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) e[i] = QM1H[i];
-    Fs w = fr_pow_limbs(x, e);
-    Fs R = mul(w, x);
-    Fs t = mul(R, w);
-    const Fs one = Fs::one();
-    int M = 32, j = 0;             // current c = c_pow[j], of order 2^M
-#pragma unroll 1
-    for (int guard = 0; guard < 34; guard++) {
-        if (equal(t, one)) break;
-        int i = 1;
-        Fs tmp = sqr(t);
-#pragma unroll 1
-        while (!equal(tmp, one) && i < M) { tmp = sqr(tmp); i++; }
-        if (i == M) return false;                      // order of t is 2^M: not a square
-        const Fs b = bsn_const(g_bsn_consts.c_pow[j + M - i - 1]);
-        j += M - i;
-        M = i;
-        t = mul(t, bsn_const(g_bsn_consts.c_pow[j]));  // c <- b^2
-        R = mul(R, b);
-    }
-    root = R;
-    return true;
+// Square roots in Fr, p - 1 = Q 2^32.  The reference's sqrt_mod_bls_scalar_cy (bandersnatch_te.pyx:421-477) is Tonelli-Shanks: with
+// w = x^((Q-1)/2), R = w x, t = R w = x^Q  (R^2 = x t), it walks t down to 1 with ~250 squarings on average and 500 at worst, a
+// different number in every lane.  t lies in the cyclic group <c> of order 2^32, c = 5^Q, so here its logarithm e (t = c^e) is read
+// off in four 8-bit windows instead: t^(2^24) is one of the 256 elements of <c^(2^24)> — a perfect-hash table gives e mod 2^8 —,
+// t c^(-e0) raised to 2^16 the next window, and so on: 48 squarings, 7 products, 4 table look-ups, the same in every lane.
+// x is a square iff e is even, and then x = (R c^(-e/2))^2.  Which of the two roots comes out differs from Tonelli-Shanks in general;
+// every caller fixes the sign itself (Elligator: sgn0; point decoding: the sign bit; dr_fr_sqrt: host code).
+// OR_5X (Elligator 2 needs sqrt(g) when g is a square and sqrt(Z u^2 g) = u sqrt(Z g) otherwise, Z = 5 — the non-residue c is built
+// on): when e is odd, (R, t) <- (R 5^((Q+1)/2), t c) are the same quantities for 5 g, whose logarithm e + 1 is even.  ONE
+// exponentiation serves both cases.  Returns whether x was a square; root = sqrt(x), or sqrt(5 x) (OR_5X), else unspecified.
+DR_DEV uint32_t fr_dlog_window(const Fs& v) {
+    const Fr c = pack(v);
+    return g_bsn_consts.dl_map[(c.l[0] * g_bsn_consts.dl_hash_mul) >> 16];
 }
-
-// Elligator 2 needs sqrt(g) when g is a square and sqrt(Z u^2 g) = u sqrt(Z g) otherwise, with Z = 5 — the non-residue the
-// Tonelli-Shanks constants are built on.  ONE exponentiation serves both: with w = g^((Q-1)/2), R = w g, t = R w = g^Q, g is a
-// square iff t^(2^31) = 1; if it is not, (R, t) <- (R 5^((Q+1)/2), t 5^Q) are the same quantities for 5 g, which is one.  The
-// correction loop then runs once, on the same code path in every lane (the two calls of fr_sqrt this replaces diverged: a wave
-// with both kinds of lanes paid for two exponentiations and two loops).  Returns whether g was a square; root = sqrt(g) or sqrt(5 g).
-DR_DEV bool fr_sqrt_or_5x(const Fs& x, Fs& root) {
+template <bool OR_5X>
+DR_DEV bool fr_sqrt_core(const Fs& x, Fs& root) {
     root = x;
     if (is_zero(x)) return true;
     constexpr uint32_t QM1H[8] = {0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u, 0u};   // (Q-1)/2
@@ -65,33 +47,28 @@ DR_DEV bool fr_sqrt_or_5x(const Fs& x, Fs& root) {
     const Fs w = fr_pow_limbs(x, e);
     Fs R = mul(w, x);
     Fs t = mul(R, w);
-    const Fs one = Fs::one();
-    Fs probe = t;
+    bool square = true;
 #pragma unroll 1
-    for (int k = 0; k < 31; k++) probe = sqr(probe);
-    const bool square = equal(probe, one);
-    if (!square) {
-        R = mul(R, bsn_const(g_bsn_consts.z_q1h));
-        t = mul(t, bsn_const(g_bsn_consts.c_pow[0]));
-    }
-    int M = 32, j = 0;             // current c = c_pow[j], of order 2^M
+    for (int j = 0; j < 4; j++) {
+        Fs v = t;
 #pragma unroll 1
-    for (int guard = 0; guard < 34; guard++) {
-        if (equal(t, one)) break;
-        int i = 1;
-        Fs tmp = sqr(t);
-#pragma unroll 1
-        while (!equal(tmp, one) && i < M) { tmp = sqr(tmp); i++; }
-        if (i == M) break;                             // cannot happen: t has order at most 2^31 here
-        const Fs b = bsn_const(g_bsn_consts.c_pow[j + M - i - 1]);
-        j += M - i;
-        M = i;
-        t = mul(t, bsn_const(g_bsn_consts.c_pow[j]));  // c <- b^2
-        R = mul(R, b);
+        for (int k = 0; k < 24 - 8 * j; k++) v = sqr(v);
+        uint32_t ej = fr_dlog_window(v);
+        if (j == 0 && (ej & 1u)) {
+            square = false;
+            if (!OR_5X) return false;
+            t = mul(t, bsn_const(g_bsn_consts.c_pow[0]));
+            R = mul(R, bsn_const(g_bsn_consts.z_q1h));
+            ej = (ej + 1u) & 255u;
+        }
+        if (j < 3) t = mul(t, bsn_const(g_bsn_consts.dl_mul[j][ej]));
+        R = mul(R, bsn_const(g_bsn_consts.dl_half[j][ej]));
     }
     root = R;
     return square;
 }
+DR_DEV bool fr_sqrt(const Fs& x, Fs& root) { return fr_sqrt_core<false>(x, root); }
+DR_DEV bool fr_sqrt_or_5x(const Fs& x, Fs& root) { return fr_sqrt_core<true>(x, root); }
 
 // Diagnostic (dr_fr_ops_selftest): the unsaturated field arithmetic of fr29.hip.h on its own, one lane per (a, b) pair of
 // standard-form elements.  out[i] = twelve 32-byte standard-form records: a b, a^2, a + b, a - b, a^-1 (0 for 0),

@@ -265,20 +265,33 @@ __global__ __launch_bounds__(BSN_BLOCK) void k_bsn_msm_groups(const uint32_t* __
 // (dot_ring/curve/twisted_edwards/te_affine_point.py:212-295, te_curve.py:48-95); hash_to_field stays on the host.
 // One lane per input.  Square roots: Tonelli-Shanks with p-1 = Q*2^32 and the non-residue 5, as the reference's
 // sqrt_mod_bls_scalar_cy (bandersnatch_te.pyx:421); which root comes out is irrelevant (the map fixes the sign).
-// a^e for a 256-bit exponent given as plain limbs (MSB-first square and multiply)
+// a^e for a 256-bit exponent given as plain limbs, the same for every lane (control flow is scalar): MSB-first with sliding windows
+// of up to three bits over the odd powers a, a^3, a^5, a^7 — one product per ~4 exponent bits instead of one per 2
 DR_DEV Fs fr_pow_limbs(const Fs& a, const uint32_t (&e)[8]) {
+    const Fs a2 = sqr(a), a3 = mul(a, a2), a5 = mul(a3, a2), a7 = mul(a5, a2);
+    auto bit = [&](int i) -> uint32_t { return (e[i >> 5] >> (i & 31)) & 1u; };
+    int i = 255;
+    while (i >= 0 && !bit(i)) i--;
+    if (i < 0) return Fs::one();
     Fs r = Fs::one();
     bool started = false;
 #pragma unroll 1
-    for (int i = 7; i >= 0; i--) {
+    while (i >= 0) {
+        if (!bit(i)) { r = sqr(r); i--; continue; }
+        int l = i >= 2 ? 3 : i + 1;
+        while (!bit(i - l + 1)) l--;
+        uint32_t v = 0;
+        for (int k = 0; k < l; k++) v = (v << 1) | bit(i - k);
+        if (started) {
 #pragma unroll 1
-        for (int b = 31; b >= 0; b--) {
-            if (started) r = sqr(r);
-            if ((e[i] >> b) & 1) {
-                r = started ? mul(r, a) : a;
-                started = true;
-            }
+            for (int k = 0; k < l; k++) r = sqr(r);
         }
+        Fs m;
+#pragma unroll
+        for (int t = 0; t < L29; t++) m.l[t] = v == 1 ? a.l[t] : v == 3 ? a3.l[t] : v == 5 ? a5.l[t] : a7.l[t];
+        r = started ? mul(r, m) : m;
+        started = true;
+        i -= l;
     }
     return r;
 }
