@@ -52,7 +52,7 @@ _PROTOTYPES = {
     "dr_srs_powers": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, POINTER(c_void_p)]),
     "dr_g2_mul": (c_int, [c_char_p, c_char_p, c_char_p]),
     "dr_srs_precompute": (c_int, [c_void_p, c_void_p, c_int]),
-    "dr_srs_table_info": (c_int, [c_void_p, POINTER(c_int)]),
+    "dr_srs_table_info": (c_int, [c_void_p, c_size_t, c_size_t, POINTER(c_int)]),
     "dr_srs_download": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "dr_srs_destroy": (None, [c_void_p]),
     "dr_srs_size": (c_size_t, [c_void_p]),
@@ -314,11 +314,12 @@ class Srs:
         _check(lib().dr_srs_precompute(self.ctx.handle, self.handle, window_bits))
         return self
 
-    def table_info(self) -> dict:
-        """Shape of the fixed-base table (dr_srs_table_info): window_bits, rows, windows per scalar and odd-multiple buckets in batched MSMs."""
+    def table_info(self, n: int = 0, batch: int = 0) -> dict:
+        """Shape of the fixed-base table and the tiling `batch` MSMs of n points over it take (dr_srs_table_info): window_bits, rows,
+        windows per scalar, and the window width of the odd-multiple tiling (0 = the window rows)."""
         info = (c_int * 4)()
-        _check(lib().dr_srs_table_info(self.handle, info))
-        return {"window_bits": info[0], "rows": info[1], "batched_windows": info[2], "odd_buckets": bool(info[3])}
+        _check(lib().dr_srs_table_info(self.handle, n, batch, info))
+        return {"window_bits": info[0], "rows": info[1], "batched_windows": info[2], "odd_window_bits": info[3], "odd_buckets": bool(info[3])}
 
     def precompute_comb(self) -> "Srs":
         """Comb table over the window table (see dr_srs_precompute_comb); MemoryError if it does not fit."""

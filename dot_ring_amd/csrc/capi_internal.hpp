@@ -120,8 +120,9 @@ struct dr_srs {
     uint32_t* d_table = nullptr;
     dr::WindowTable table_wt{};
     // small SRS: the table has one row per BIT (table[s][i] = 2^s * base[i]), table_wt.row[w] = start[w]; batched MSMs then tile the
-    // scalar by wider windows and keep buckets for odd digit multiples only (table_wt_odd, W == 0: not available)
-    dr::WindowTable table_wt_odd{};
+    // scalar by wider windows and keep buckets for odd digit multiples only (odd_window_for)
+    bool table_bit_rows = false;
+    int table_odd_delta = -2;            // windows of odd-multiple buckets: -2 = chosen per call (odd_window_for), -1 = never, >= 0: window_bits + this
     // optional comb table over the window table: comb[j][w][d-1] = d * table[w][j], every digit magnitude precomputed
     uint32_t* d_comb = nullptr;
     uint32_t comb_h = 0;
@@ -306,7 +307,8 @@ struct PhaseTrace {
 struct MsmTable {
     const uint32_t* table = nullptr;
     dr::WindowTable wt{};
-    dr::WindowTable wt_odd{};            // W != 0: the table has a row per bit; tiling for odd-multiple buckets (batched MSMs)
+    bool bit_rows = false;               // the table has a row per bit: a call may tile the scalars as it likes (odd-multiple buckets)
+    int odd_delta = -2;                  // see dr_srs::table_odd_delta
     uint32_t stride = 0, offset = 0;
     const uint32_t* comb = nullptr;      // comb[j][w][d-1], see k_g1_comb_msm
     uint32_t comb_h = 0;
@@ -315,6 +317,8 @@ struct MsmTable {
 int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch, std::vector<drh::G1>& results,
                const MsmTable* tbl = nullptr);
 MsmTable srs_table(const dr_srs* srs, size_t offset);
+// window width of the odd-multiple tiling msm_device takes for `batch` MSMs of n points over this table (0: the window rows)
+int odd_window_for(const MsmTable& t, size_t n, size_t batch);
 int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_rows);   // dr_srs_precompute with the table shape chosen
 void g1_result_to_bytes(const drh::G1& r, uint8_t* out96, int* is_inf);
 int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, int* is_inf);

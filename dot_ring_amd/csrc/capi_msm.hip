@@ -106,6 +106,29 @@ struct WideToken {
 };
 }  // namespace
 
+// Odd-multiple buckets (kernels_g1.hip.h: digit_bin) need a table with a row per bit, hundreds of MSMs (the per-set LDS sort and the
+// set-scan reduction; with fewer sets the L = 4 latency reduction of msm_device applies), at most 4096 buckets per set and lists that stay
+// below the 256-entry limit of the one-lane walk: the lowest buckets and their twins collect four digit magnitudes each, ~4.8 times the
+// average digit count with the narrower windows at the bottom.  Among the widths that qualify the cheapest wins: n W bucket additions +
+// ~5.2 addition-equivalents per bucket of the reduction (measured: level 1 + set scan per bucket against the walk's time per entry).
+// c = 13 for the 3N = 6144-point vectors of domain 2048, c = 14 for the 12288 of domain 4096.
+int odd_window_for(const MsmTable& t, size_t n, size_t batch) {
+    if (!t.table || !t.bit_rows || t.odd_delta == -1 || g_chunk_len != 16 || batch < 256 || n == 0) return 0;
+    const int cn = t.wt.cmax, lo = t.odd_delta >= 0 ? cn + t.odd_delta : cn, hi = t.odd_delta >= 0 ? cn + t.odd_delta : cn + 2;
+    int best = 0;
+    double best_cost = 0;
+    for (int c = lo; c <= hi; c++) {
+        if (c < 9 || c > 14) continue;
+        const size_t H = (size_t)1 << (c - 2), W = (256 + c - 1) / c;
+        if (batch * (H / 16) < ((size_t)1 << 17)) continue;
+        if ((n + 64) * W > ((size_t)1 << 20) || batch * (n + 64) * W >= (1ull << 32)) continue;
+        if (t.odd_delta < 0 && 4.8 * (double)n * (double)W / (double)(2 * H) > 230.0) continue;
+        const double cost = (double)n * (double)W + 5.2 * (double)H;
+        if (!best || cost < best_cost) { best = c; best_cost = cost; }
+    }
+    return best;
+}
+
 int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch,
                std::vector<drh::G1>& results, const MsmTable* tbl) {
     results.assign(batch, drh::G1::inf());
@@ -139,10 +162,14 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     if (single) {
         // A table with a row per bit and hundreds of MSMs (the batched prover): one more bit per window, buckets for odd multiples only
         // — as many buckets as before, a window less per scalar.  Needs the per-set LDS sort and the set-scan reduction (below).
-        const dr::WindowTable& wo = tbl->wt_odd;
-        const bool odd = wo.W != 0 && setscan_on && g_chunk_len == 16 && batch >= 256 && wo.cmax >= 9 && (1u << (wo.cmax - 2)) <= 4096 &&
-                         batch * (size_t)((1u << (wo.cmax - 2)) / 16) >= ((size_t)1 << 17) &&      // (fewer: the L = 4 chunk reduction below)
-                         (n + 64) * (size_t)wo.W <= (1u << 20) && batch * (n + 64) * (size_t)wo.W < (1ull << 32);
+        const int c_odd = setscan_on ? odd_window_for(*tbl, n, batch) : 0;
+        const bool odd = c_odd != 0;
+        dr::WindowTable wo{};
+        if (odd) {
+            wo = make_window_table(c_odd);
+            for (int w = 0; w < wo.W; w++) wo.row[w] = wo.start[w];
+            wo.odd = 1;
+        }
         pl.wt = odd ? wo : tbl->wt;
         pl.W = pl.wt.W;
         pl.H = odd ? 1u << (pl.wt.cmax - 2) : 1u << (pl.wt.cmax - 1);
@@ -490,7 +517,8 @@ MsmTable srs_table(const dr_srs* srs, size_t offset) {
     if (srs->d_table) {
         t.table = srs->d_table;
         t.wt = srs->table_wt;
-        t.wt_odd = srs->table_wt_odd;
+        t.bit_rows = srs->table_bit_rows;
+        t.odd_delta = srs->table_odd_delta;
         t.stride = (uint32_t)srs->count;
         t.offset = (uint32_t)offset;
         t.comb = srs->d_comb;
@@ -868,12 +896,12 @@ int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_row
     if ((uint64_t)wt.W * srs->count >= (1ull << 31)) return fail(DR_ERR_INVALID, "window table too large");
     if (srs->d_table) (void)hipFree(srs->d_table);
     srs->d_table = nullptr;
-    srs->table_wt_odd = dr::WindowTable{};
+    srs->table_bit_rows = false;
     // A small SRS gets a row for every bit (24 KB per base: 151 MB for the 6145 points of a 2048-point domain) — the window rows are a
     // subset of it, and batched MSMs may then tile the scalar differently (odd-multiple buckets, see msm_device).
     // DOTRING_SRS_BIT_ROWS_MB (default 512, 0 = never) bounds the table; DOTRING_SRS_ODD_BITS (default 1) is how much wider those windows are.
     static const size_t bit_rows_mb = std::getenv("DOTRING_SRS_BIT_ROWS_MB") ? (size_t)std::atol(std::getenv("DOTRING_SRS_BIT_ROWS_MB")) : 512;
-    static const int odd_bits = std::getenv("DOTRING_SRS_ODD_BITS") ? std::atoi(std::getenv("DOTRING_SRS_ODD_BITS")) : 1;
+    static const int odd_bits = std::getenv("DOTRING_SRS_ODD_BITS") ? std::atoi(std::getenv("DOTRING_SRS_ODD_BITS")) : -2;
     const bool bit_rows = allow_bit_rows && window_bits <= 16 && (size_t)256 * srs->count * 96 <= (bit_rows_mb << 20);
     const size_t rows = bit_rows ? 256 : (size_t)wt.W;
     HIP_TRY(hipMalloc((void**)&srs->d_table, rows * srs->count * 96));
@@ -881,11 +909,8 @@ int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_row
         for (int w = 0; w < wt.W; w++) wt.row[w] = wt.start[w];
         hipLaunchKernelGGL(dr::k_g1_bit_table, dim3(div_up(srs->count, 128)), dim3(128), 0, ctx->stream, srs->d_bases, (uint32_t)srs->count, 256u,
                            srs->d_table);
-        if (odd_bits >= 0 && table_window_ok(window_bits + odd_bits)) {
-            srs->table_wt_odd = make_window_table(window_bits + odd_bits);
-            for (int w = 0; w < srs->table_wt_odd.W; w++) srs->table_wt_odd.row[w] = srs->table_wt_odd.start[w];
-            srs->table_wt_odd.odd = 1;
-        }
+        srs->table_bit_rows = true;
+        srs->table_odd_delta = odd_bits < -1 ? -2 : odd_bits;
     } else {
         hipLaunchKernelGGL(dr::k_g1_window_table, dim3(div_up(srs->count, 128)), dim3(128), 0, ctx->stream, srs->d_bases, (uint32_t)srs->count, wt,
                            srs->d_table);
@@ -952,15 +977,17 @@ void dr_srs_destroy(dr_srs* srs) {
 
 size_t dr_srs_size(const dr_srs* srs) { return srs ? srs->count : 0; }
 
-int dr_srs_table_info(const dr_srs* srs, int info[4]) {
+int dr_srs_table_info(const dr_srs* srs, size_t n, size_t batch, int info[4]) {
     if (!srs || !info) return fail(DR_ERR_INVALID, "null argument");
     info[0] = info[1] = info[2] = info[3] = 0;
     if (!srs->d_table) return DR_OK;
-    const bool odd = srs->table_wt_odd.W != 0;
+    static const bool setscan_on = std::getenv("DOTRING_MSM_SETSCAN") == nullptr || std::atoi(std::getenv("DOTRING_MSM_SETSCAN")) != 0;
+    const MsmTable t = srs_table(srs, 0);
+    const int c_odd = setscan_on ? odd_window_for(t, n, batch) : 0;
     info[0] = srs->table_wt.cmax;
-    info[1] = odd || srs->table_wt.row[srs->table_wt.W - 1] != srs->table_wt.W - 1 ? 256 : srs->table_wt.W;
-    info[2] = odd ? srs->table_wt_odd.W : srs->table_wt.W;
-    info[3] = odd ? 1 : 0;
+    info[1] = srs->table_bit_rows ? 256 : srs->table_wt.W;
+    info[2] = c_odd ? (256 + c_odd - 1) / c_odd : srs->table_wt.W;
+    info[3] = c_odd;
     return DR_OK;
 }
 

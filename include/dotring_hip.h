@@ -146,13 +146,14 @@ DR_API int dr_g2_mul(const uint8_t g2_be[192], const uint8_t scalar_le[32], uint
  * 6145-point SRS at c = 12, 1.6 GB for 2^20 bases at c = 16) and makes every later MSM over this SRS use ONE bucket
  * set per MSM: a single bucket reduction instead of W and no window combination.  Results are unchanged. */
 DR_API int dr_srs_precompute(dr_ctx *ctx, dr_srs *srs, int window_bits);
-/* Shape of the table dr_srs_precompute built (all zero: none).  An SRS small enough (256 * count * 96 bytes within
- * DOTRING_SRS_BIT_ROWS_MB, default 512: 151 MB for 6145 points) gets a row for EVERY bit, table[s][i] = 2^s * base[i]; batches of
- * >= 256 MSMs then tile the scalars by windows one bit wider (DOTRING_SRS_ODD_BITS, default 1) and keep buckets for odd digit
- * multiples only — as many buckets, a window less per scalar.  Results are unchanged.
- *   info[0] window_bits, info[1] rows of the table (W or 256), info[2] windows per scalar in a batched MSM, info[3] 1 = odd-multiple
- *   buckets in batched MSMs */
-DR_API int dr_srs_table_info(const dr_srs *srs, int info[4]);
+/* Shape of the table dr_srs_precompute built (all zero: none) and the tiling `batch` MSMs of n points over it would take.  An SRS
+ * small enough (256 * count * 96 bytes within DOTRING_SRS_BIT_ROWS_MB, default 512: 151 MB for 6145 points) gets a row for EVERY bit,
+ * table[s][i] = 2^s * base[i]; batches of hundreds of MSMs then tile the scalars by wider windows (chosen per call from n and batch;
+ * DOTRING_SRS_ODD_BITS forces window_bits + that, -1 = never) and keep buckets for odd digit multiples only — a window or two less per
+ * scalar for the same number of buckets.  Results are unchanged.
+ *   info[0] window_bits, info[1] rows of the table (W or 256), info[2] windows per scalar for this (n, batch), info[3] window width of
+ *   the odd-multiple tiling for this (n, batch), 0 = the window rows */
+DR_API int dr_srs_table_info(const dr_srs *srs, size_t n, size_t batch, int info[4]);
 /* Comb table on top of the window table (window_bits <= 14): comb[i][w][d-1] = d * 2^(start_w) * base[i] for every
  * digit magnitude d <= 2^(window_bits-1) — count * W * 2^(window_bits-1) * 128 bytes (one cache line per entry: 35 GB for
  * the shipped SRS at 12 bits; MI355X has 288 GB).  Batched MSMs (>= 32 scalar vectors) over this SRS then skip bucket

@@ -418,9 +418,10 @@ def test_g1_msm_batched_odd_multiple_buckets(ctx, srs_bytes, bits, n, batch):
     two (every shift k up to the window width, i.e. every twin group), r - 1, all equal, all zero, 2^c - 1 patterns."""
     rng = random.Random(bits * 1000 + n)
     tabled = ctx.srs_load(srs_bytes[: 96 * n]).precompute(bits)
-    info = tabled.table_info()
-    assert info["window_bits"] == bits and info["rows"] == 256 and info["odd_buckets"]
+    info = tabled.table_info(n, batch)
+    assert info["window_bits"] == bits and info["rows"] == 256 and info["odd_window_bits"] == bits + 1
     assert info["batched_windows"] == -(-256 // (bits + 1))
+    assert not tabled.table_info(n, 64)["odd_buckets"]                         # few MSMs: the window rows
     r = coracle.FR_P
     vecs = []
     for b in range(batch):

@@ -144,7 +144,7 @@ for table, n, batch in ((9, 50, 8192), (10, 333, 4096), (12, 2047, 1024), (13, 7
     if scale < 1 and n > 400:
         continue
     srs = ctx.srs_load(srs_be[: 96 * n]).precompute(table)
-    assert srs.table_info()["odd_buckets"]
+    assert srs.table_info(n, batch)["odd_buckets"]
     kinds = [rng.choice(["dense", "sparse", "short", "repeated"]) for _ in range(batch)]
     rows = []
     for kind in kinds:
