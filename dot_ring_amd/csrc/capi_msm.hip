@@ -112,6 +112,13 @@ struct WideToken {
 // average digit count with the narrower windows at the bottom.  Among the widths that qualify the cheapest wins: n W bucket additions +
 // ~5.2 addition-equivalents per bucket of the reduction (measured: level 1 + set scan per bucket against the walk's time per entry).
 // c = 13 for the 3N = 6144-point vectors of domain 2048, c = 14 for the 12288 of domain 4096.
+// fewer first-level chunks than this over all sets of a table MSM: chunks of 4 buckets instead of 16 (shorter dependent chains for
+// launches that do not fill the chip; DOTRING_MSM_L4_BELOW)
+static size_t l4_below() {
+    static const size_t v = std::getenv("DOTRING_MSM_L4_BELOW") ? (size_t)std::atol(std::getenv("DOTRING_MSM_L4_BELOW")) : ((size_t)1 << 17);
+    return v;
+}
+
 int odd_window_for(const MsmTable& t, size_t n, size_t batch) {
     if (!t.table || !t.bit_rows || t.odd_delta == -1 || g_chunk_len != 16 || batch < 256 || n == 0) return 0;
     const int cn = t.wt.cmax, lo = t.odd_delta >= 0 ? cn + t.odd_delta : cn, hi = t.odd_delta >= 0 ? cn + t.odd_delta : cn + 2;
@@ -120,7 +127,7 @@ int odd_window_for(const MsmTable& t, size_t n, size_t batch) {
     for (int c = lo; c <= hi; c++) {
         if (c < 9 || c > 14) continue;
         const size_t H = (size_t)1 << (c - 2), W = (256 + c - 1) / c;
-        if (batch * (H / 16) < ((size_t)1 << 17)) continue;
+        if (batch * (H / 16) < l4_below()) continue;
         if ((n + 64) * W > ((size_t)1 << 20) || batch * (n + 64) * W >= (1ull << 32)) continue;
         if (t.odd_delta < 0 && 4.8 * (double)n * (double)W / (double)(2 * H) > 230.0) continue;
         const double cost = (double)n * (double)W + 5.2 * (double)H;
@@ -190,7 +197,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     const size_t bsets = single ? batch * groups : windows;        // bucket sets
     // few bucket sets of moderate size (a single MSM over a window table): the reduction is a latency chain of
     // 2L additions + a log2(H)-bit double-and-add + the fold of H/L partial sums; L = 4 makes it ~40 % shorter
-    if (single && pl.L == 16 && pl.H >= 256 && pl.H <= 4096 && bsets * (size_t)(pl.H / 16) < ((size_t)1 << 17)) {
+    if (single && pl.L == 16 && pl.H >= 256 && pl.H <= 4096 && bsets * (size_t)(pl.H / 16) < l4_below()) {
         pl.L = 4;
         pl.T = pl.H / 4;
     }
