@@ -398,25 +398,56 @@ inline void enc_te_point(const uint8_t xy[64], uint8_t out[32]) {
 }
 
 // affine twisted-Edwards addition: the verifier's seed + relation (ring/vrf.py:239-283)
-inline void te_add_affine(const TeCurveHost& cv, const uint8_t p1[64], const uint8_t p2[64], uint8_t out[64]) {
+// in two halves around the one inversion, so that a caller with many additions can invert all denominators together (batch_inv)
+struct TeAddPending { uint64_t e[4], t[4], dx[4], dy[4], den[4]; };
+inline void te_add_affine_prep(const TeCurveHost& cv, const uint8_t p1[64], const uint8_t p2[64], TeAddPending& pd) {
     const uint64_t* D = cv.d;
     const uint64_t* five = cv.neg_a;        // -a (5 on Bandersnatch)
     const Mod256& f = mod_p();
-    uint64_t x1[4], y1[4], x2[4], y2[4], a[4], b[4], c[4], e[4], t[4], one[4];
+    uint64_t x1[4], y1[4], x2[4], y2[4], a[4], b[4], c[4], t[4], one[4];
     load_le32(p1, x1); load_le32(p1 + 32, y1); load_le32(p2, x2); load_le32(p2 + 32, y2);
     f.set_u64(1, one);
     f.mul(x1, x2, a);                       // x1 x2
     f.mul(y1, y2, b);                       // y1 y2
     f.mul(a, b, c); f.mul(c, D, c);         // d x1 x2 y1 y2
-    f.mul(x1, y2, e); f.mul(y1, x2, t); f.add(e, t, e);          // x numerator
-    f.mul(a, five, t); f.add(b, t, t);                           // y numerator: y1 y2 - a x1 x2
-    uint64_t dx[4], dy[4], inv[4];
-    f.add(one, c, dx); f.sub(one, c, dy);
-    f.mul(dx, dy, inv); f.inv(inv, inv);                         // 1 / (dx dy)
+    f.mul(x1, y2, pd.e); f.mul(y1, x2, t); f.add(pd.e, t, pd.e);          // x numerator
+    f.mul(a, five, t); f.add(b, t, pd.t);                                 // y numerator: y1 y2 - a x1 x2
+    f.add(one, c, pd.dx); f.sub(one, c, pd.dy);
+    f.mul(pd.dx, pd.dy, pd.den);                                          // non-zero for points of the curve (complete law)
+}
+inline void te_add_affine_finish(const TeAddPending& pd, const uint64_t inv_den[4], uint8_t out[64]) {
+    const Mod256& f = mod_p();
     uint64_t ix[4], iy[4], x3[4], y3[4];
-    f.mul(inv, dy, ix); f.mul(inv, dx, iy);
-    f.mul(e, ix, x3); f.mul(t, iy, y3);
+    f.mul(inv_den, pd.dy, ix); f.mul(inv_den, pd.dx, iy);
+    f.mul(pd.e, ix, x3); f.mul(pd.t, iy, y3);
     store_le32(x3, out); store_le32(y3, out + 32);
+}
+inline void te_add_affine(const TeCurveHost& cv, const uint8_t p1[64], const uint8_t p2[64], uint8_t out[64]) {
+    TeAddPending pd;
+    te_add_affine_prep(cv, p1, p2, pd);
+    uint64_t inv[4];
+    mod_p().inv(pd.den, inv);                                             // 1 / (dx dy)
+    te_add_affine_finish(pd, inv, out);
+}
+// vals[k] <- vals[k]^-1 for n values with ONE inversion (Montgomery's trick); zeros stay zero
+inline void batch_inv(const Mod256& f, uint64_t (*vals)[4], size_t n) {
+    std::vector<uint64_t> pre(4 * (n + 1));
+    uint64_t one[4], acc[4];
+    f.set_u64(1, one);
+    std::memcpy(acc, one, 32);
+    for (size_t k = 0; k < n; k++) {
+        std::memcpy(&pre[4 * k], acc, 32);
+        if (!f.is_zero(vals[k])) f.mul(acc, vals[k], acc);
+    }
+    uint64_t inv[4];
+    f.inv(acc, inv);
+    for (size_t k = n; k-- > 0;) {
+        if (f.is_zero(vals[k])) continue;
+        uint64_t t[4];
+        f.mul(inv, &pre[4 * k], t);
+        f.mul(inv, vals[k], inv);
+        std::memcpy(vals[k], t, 32);
+    }
 }
 
 // ---------------------------------------------------------------- VRF transcript (primitives.py:26-55)
@@ -620,10 +651,28 @@ struct RingClaimScalars {      // what one proof contributes to the folded pairi
     uint64_t k_ip[4], k_x[4], k_y[4];
     uint64_t zeta[4], zeta_omega[4], agg_zeta[4], l_zw[4];
 };
-// alphas[7], nus[8], zeta, evals[7] (px py s b accip accx accy), l_zw: 32-byte LE canonical values; result_seed = seed + relation.
-// false when zeta lies in the domain (verify.py raises there).
-inline bool ring_verifier_terms(const TeCurveHost& cv, const RingVerifierDomain& dm, const uint8_t* alphas, const uint8_t* nus, const uint8_t* zeta_le,
-                                const uint8_t* evals, const uint8_t* l_zw_le, const uint8_t result_seed[64], RingClaimScalars& out) {
+// In two halves around the one inversion (batch verification inverts the denominators of many proofs together, batch_inv).
+struct RingTermsPending { uint64_t z1[4], d4[4], zn1[4], a[4], b[4], prod[4]; };
+inline bool ring_verifier_terms_prep(const RingVerifierDomain& dm, const uint8_t* zeta_le, RingTermsPending& pd) {
+    const Mod256& f = mod_p();
+    uint64_t zeta[4], one[4], t[4];
+    load_le32(zeta_le, zeta);
+    f.set_u64(1, one);
+    f.sub(zeta, one, pd.z1);
+    f.sub(zeta, dm.w_nm4, pd.d4);
+    std::memcpy(t, zeta, 32);
+    for (unsigned i = 0; i < dm.log2n; i++) f.mul(t, t, t);
+    f.sub(t, one, pd.zn1);
+    if (f.is_zero(pd.zn1)) return false;
+    // one inversion for the three denominators (zeros map to zero)
+    std::memcpy(pd.a, f.is_zero(pd.z1) ? one : pd.z1, 32);
+    std::memcpy(pd.b, f.is_zero(pd.d4) ? one : pd.d4, 32);
+    f.mul(pd.a, pd.b, pd.prod); f.mul(pd.prod, pd.zn1, pd.prod);
+    return true;
+}
+inline void ring_verifier_terms_finish(const TeCurveHost& cv, const RingVerifierDomain& dm, const uint8_t* alphas, const uint8_t* nus, const uint8_t* zeta_le,
+                                       const uint8_t* evals, const uint8_t* l_zw_le, const uint8_t result_seed[64], const RingTermsPending& pd,
+                                       const uint64_t inv[4] /* 1 / pd.prod */, RingClaimScalars& out) {
     const Mod256& f = mod_p();
     uint64_t al[7][4], ev[7][4], zeta[4], lzw[4], rsx[4], rsy[4], one[4];
     const uint64_t* five = cv.neg_a;        // -a of the curve
@@ -633,21 +682,10 @@ inline bool ring_verifier_terms(const TeCurveHost& cv, const RingVerifierDomain&
     load_le32(result_seed, rsx); load_le32(result_seed + 32, rsy);
     f.set_u64(1, one);
     const uint64_t *pxz = ev[0], *pyz = ev[1], *sz = ev[2], *bz = ev[3], *ipz = ev[4], *axz = ev[5], *ayz = ev[6];
-    uint64_t z1[4], d4[4], zn1[4], t[4], u[4];
-    f.sub(zeta, one, z1);
-    f.sub(zeta, dm.w_nm4, d4);
-    std::memcpy(t, zeta, 32);
-    for (unsigned i = 0; i < dm.log2n; i++) f.mul(t, t, t);
-    f.sub(t, one, zn1);
-    if (f.is_zero(zn1)) return false;
-    // one inversion for the three denominators (zeros map to zero)
+    const uint64_t *z1 = pd.z1, *d4 = pd.d4, *zn1 = pd.zn1, *a = pd.a, *b = pd.b;
+    uint64_t t[4], u[4];
     uint64_t iz1[4] = {0, 0, 0, 0}, id4[4] = {0, 0, 0, 0}, izn1[4];
     {
-        uint64_t a[4], b[4], prod[4], inv[4];
-        std::memcpy(a, f.is_zero(z1) ? one : z1, 32);
-        std::memcpy(b, f.is_zero(d4) ? one : d4, 32);
-        f.mul(a, b, prod); f.mul(prod, zn1, prod);
-        f.inv(prod, inv);
         f.mul(a, b, t); f.mul(inv, t, izn1);
         f.mul(inv, zn1, t);                  // 1/(a b)
         if (!f.is_zero(z1)) f.mul(t, b, iz1);
@@ -692,6 +730,16 @@ inline bool ring_verifier_terms(const TeCurveHost& cv, const RingVerifierDomain&
     f.mul(zeta, dm.omega, out.zeta_omega);
     std::memcpy(out.agg_zeta, agg, 32);
     std::memcpy(out.l_zw, lzw, 32);
+}
+// alphas[7], nus[8], zeta, evals[7] (px py s b accip accx accy), l_zw: 32-byte LE canonical values; result_seed = seed + relation.
+// false when zeta lies in the domain (verify.py raises there).
+inline bool ring_verifier_terms(const TeCurveHost& cv, const RingVerifierDomain& dm, const uint8_t* alphas, const uint8_t* nus, const uint8_t* zeta_le,
+                                const uint8_t* evals, const uint8_t* l_zw_le, const uint8_t result_seed[64], RingClaimScalars& out) {
+    RingTermsPending pd;
+    if (!ring_verifier_terms_prep(dm, zeta_le, pd)) return false;
+    uint64_t inv[4];
+    mod_p().inv(pd.prod, inv);
+    ring_verifier_terms_finish(cv, dm, alphas, nus, zeta_le, evals, l_zw_le, result_seed, pd, inv, out);
     return true;
 }
 
