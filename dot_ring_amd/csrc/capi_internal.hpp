@@ -122,6 +122,7 @@ struct dr_srs {
     // small SRS: the table has one row per BIT (table[s][i] = 2^s * base[i]), table_wt.row[w] = start[w]; batched MSMs then tile the
     // scalar by wider windows and keep buckets for odd digit multiples only (odd_window_for)
     bool table_bit_rows = false;
+    uint32_t table_pt_words = 24;        // words per table record: 24 (packed) or 32 (one point per 128-byte line)
     int table_odd_delta = -2;            // windows of odd-multiple buckets: -2 = chosen per call (odd_window_for), -1 = never, >= 0: window_bits + this
     // optional comb table over the window table: comb[j][w][d-1] = d * table[w][j], every digit magnitude precomputed
     uint32_t* d_comb = nullptr;
@@ -307,6 +308,7 @@ struct PhaseTrace {
 struct MsmTable {
     const uint32_t* table = nullptr;
     dr::WindowTable wt{};
+    uint32_t pt_words = 24;              // words per table record
     bool bit_rows = false;               // the table has a row per bit: a call may tile the scalars as it likes (odd-multiple buckets)
     int odd_delta = -2;                  // see dr_srs::table_odd_delta
     uint32_t stride = 0, offset = 0;

@@ -344,15 +344,16 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
                            ctx->cell_off.as<uint32_t>(), ctx->perm.as<uint32_t>());
     }));
     TRY(launch(ctx, "k_g1_accumulate", [&] {
-        hipLaunchKernelGGL(dr::k_g1_accumulate, dim3(div_up(nbuckets, 256)), dim3(256), 0, st, d_bases,
+        const uint32_t pt_words = single ? tbl->pt_words : 24u;
+        hipLaunchKernelGGL(dr::k_g1_accumulate, dim3(div_up(nbuckets, 256)), dim3(256), 0, st, d_bases, pt_words,
                            ctx->sorted.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(),
                            ctx->buckets.as<uint32_t>(), nbuckets);
         // lists of 256 entries or more (the lowest odd-multiple buckets of every set; skewed scalars): 16 lanes or a wave each; both
         // launches return at once when there are none
-        hipLaunchKernelGGL(dr::k_g1_accumulate_long<16>, dim3(2048), dim3(64), 0, st, d_bases, ctx->sorted.as<uint32_t>(),
+        hipLaunchKernelGGL(dr::k_g1_accumulate_long<16>, dim3(2048), dim3(64), 0, st, d_bases, pt_words, ctx->sorted.as<uint32_t>(),
                            ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(), ctx->cell_off.as<uint32_t>(),
                            szblocks, ctx->buckets.as<uint32_t>());
-        hipLaunchKernelGGL(dr::k_g1_accumulate_long<64>, dim3(2048), dim3(64), 0, st, d_bases, ctx->sorted.as<uint32_t>(),
+        hipLaunchKernelGGL(dr::k_g1_accumulate_long<64>, dim3(2048), dim3(64), 0, st, d_bases, pt_words, ctx->sorted.as<uint32_t>(),
                            ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(), ctx->cell_off.as<uint32_t>(),
                            szblocks, ctx->buckets.as<uint32_t>());
     }));
@@ -524,6 +525,7 @@ MsmTable srs_table(const dr_srs* srs, size_t offset) {
     if (srs->d_table) {
         t.table = srs->d_table;
         t.wt = srs->table_wt;
+        t.pt_words = srs->table_pt_words;
         t.bit_rows = srs->table_bit_rows;
         t.odd_delta = srs->table_odd_delta;
         t.stride = (uint32_t)srs->count;
@@ -904,23 +906,29 @@ int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_row
     if (srs->d_table) (void)hipFree(srs->d_table);
     srs->d_table = nullptr;
     srs->table_bit_rows = false;
-    // A small SRS gets a row for every bit (24 KB per base: 151 MB for the 6145 points of a 2048-point domain) — the window rows are a
+    // A small SRS gets a row for every bit (32 KB per base: 201 MB for the 6145 points of a 2048-point domain) — the window rows are a
     // subset of it, and batched MSMs may then tile the scalar differently (odd-multiple buckets, see msm_device).
     // DOTRING_SRS_BIT_ROWS_MB (default 512, 0 = never) bounds the table; DOTRING_SRS_ODD_BITS (default 1) is how much wider those windows are.
     static const size_t bit_rows_mb = std::getenv("DOTRING_SRS_BIT_ROWS_MB") ? (size_t)std::atol(std::getenv("DOTRING_SRS_BIT_ROWS_MB")) : 512;
     static const int odd_bits = std::getenv("DOTRING_SRS_ODD_BITS") ? std::atoi(std::getenv("DOTRING_SRS_ODD_BITS")) : -2;
-    const bool bit_rows = allow_bit_rows && window_bits <= 16 && (size_t)256 * srs->count * 96 <= (bit_rows_mb << 20);
+    // One table point per 128-byte line (24 of 32 words used): a packed 96-byte record straddles two lines five times out of eight, and
+    // the bucket walk — one random table point per addition — measured 1.1 % faster with a third fewer lines to fetch although the table is
+    // a third larger (A/B on one box, three alternations: 40.50 - 40.63 against 40.85 - 41.17 ms per 1024 proofs).  DOTRING_SRS_LINE=0: packed.
+    static const bool line = std::getenv("DOTRING_SRS_LINE") == nullptr || std::atoi(std::getenv("DOTRING_SRS_LINE")) != 0;
+    const uint32_t pt_words = line ? 32 : 24;
+    const bool bit_rows = allow_bit_rows && window_bits <= 16 && (size_t)256 * srs->count * 4 * pt_words <= (bit_rows_mb << 20);
     const size_t rows = bit_rows ? 256 : (size_t)wt.W;
-    HIP_TRY(hipMalloc((void**)&srs->d_table, rows * srs->count * 96));
+    HIP_TRY(hipMalloc((void**)&srs->d_table, rows * srs->count * 4 * pt_words));
+    srs->table_pt_words = pt_words;
     if (bit_rows) {
         for (int w = 0; w < wt.W; w++) wt.row[w] = wt.start[w];
         hipLaunchKernelGGL(dr::k_g1_bit_table, dim3(div_up(srs->count, 128)), dim3(128), 0, ctx->stream, srs->d_bases, (uint32_t)srs->count, 256u,
-                           srs->d_table);
+                           pt_words, srs->d_table);
         srs->table_bit_rows = true;
         srs->table_odd_delta = odd_bits < -1 ? -2 : odd_bits;
     } else {
         hipLaunchKernelGGL(dr::k_g1_window_table, dim3(div_up(srs->count, 128)), dim3(128), 0, ctx->stream, srs->d_bases, (uint32_t)srs->count, wt,
-                           srs->d_table);
+                           pt_words, srs->d_table);
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -956,7 +964,7 @@ int dr_srs_precompute_comb(dr_ctx* ctx, dr_srs* srs) {
     if (e == hipSuccess) e = hipMalloc((void**)&tp, chunk * Hc * 48);
     for (size_t lo = 0; e == hipSuccess && lo < rows; lo += chunk) {
         const uint32_t cnt = (uint32_t)std::min(chunk, rows - lo);
-        hipLaunchKernelGGL(dr::k_g1_comb_build, dim3(div_up(cnt, 128)), dim3(128), 0, ctx->stream, srs->d_table, (uint32_t)srs->count, wt, Hc, lo, cnt,
+        hipLaunchKernelGGL(dr::k_g1_comb_build, dim3(div_up(cnt, 128)), dim3(128), 0, ctx->stream, srs->d_table, srs->table_pt_words, (uint32_t)srs->count, wt, Hc, lo, cnt,
                            comb, tx, tp);
         e = hipStreamSynchronize(ctx->stream);
     }

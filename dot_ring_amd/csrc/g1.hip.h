@@ -54,6 +54,21 @@ DR_DEV G1Affine load_affine(const uint32_t* bases, size_t idx) {
     r.inf = any == 0 ? 1u : 0u;
     return r;
 }
+// (fixed-base tables may keep one point per 128-byte line: records of `words` 32-bit words, 24 of them used)
+DR_DEV G1Affine load_affine_at(const uint32_t* table, size_t idx, uint32_t words) {
+    const uint32_t* p = table + idx * words;
+    uint32_t wx[12], wy[12];
+    load_words12(p, wx);
+    load_words12(p + 12, wy);
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) any |= wx[i] | wy[i];
+    G1Affine r;
+    r.x = unpack28(wx);
+    r.y = unpack28(wy);
+    r.inf = any == 0 ? 1u : 0u;
+    return r;
+}
 DR_DEV void store_affine(uint32_t* bases, size_t idx, const G1Affine& a) {
     uint32_t* p = bases + idx * 24;
     if (a.inf) {

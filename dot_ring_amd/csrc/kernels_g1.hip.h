@@ -314,7 +314,7 @@ __global__ void k_g1_scatter(const int32_t* __restrict__ digits, uint32_t n, siz
 }
 
 // fixed-base window table: table[w][i] = 2^(start_w) * base[i]  (affine, Montgomery), one lane per base
-__global__ __launch_bounds__(256) void k_g1_window_table(const uint32_t* __restrict__ bases, uint32_t n, WindowTable wt, uint32_t* __restrict__ table) {
+__global__ __launch_bounds__(256) void k_g1_window_table(const uint32_t* __restrict__ bases, uint32_t n, WindowTable wt, uint32_t pt_words, uint32_t* __restrict__ table) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     G1Affine a = load_affine(bases, i);
@@ -326,19 +326,19 @@ __global__ __launch_bounds__(256) void k_g1_window_table(const uint32_t* __restr
             for (int j = 0; j < wt.width[w - 1]; j++) cur = g1_dbl(cur);
             a = g1_to_affine_dev(cur);
         }
-        store_affine(table, (size_t)w * n + i, a);
+        store_affine(table + ((size_t)w * n + i) * (pt_words - 24), (size_t)w * n + i, a);      // record of pt_words words
     }
 }
 
 // fixed-base table with one row per bit: table[s][i] = 2^s * base[i], s < rows (affine, Montgomery), one lane per base
-__global__ __launch_bounds__(128) void k_g1_bit_table(const uint32_t* __restrict__ bases, uint32_t n, uint32_t rows, uint32_t* __restrict__ table) {
+__global__ __launch_bounds__(128) void k_g1_bit_table(const uint32_t* __restrict__ bases, uint32_t n, uint32_t rows, uint32_t pt_words, uint32_t* __restrict__ table) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     G1Affine a = load_affine(bases, i);
 #pragma unroll 1
     for (uint32_t s = 0; s < rows; s++) {
         if (s > 0 && !a.inf) a = g1_to_affine_dev(g1_dbl_affine(a));
-        store_affine(table, (size_t)s * n + i, a);
+        store_affine(table + ((size_t)s * n + i) * (pt_words - 24), (size_t)s * n + i, a);      // record of pt_words words
     }
 }
 
@@ -864,20 +864,20 @@ __global__ __launch_bounds__(SZ_BLOCK) void k_size_place(const uint32_t* __restr
 constexpr uint32_t G1_LONG_BUCKET = 256, G1_LONG_CLASS_IDX = 192 + (G1_LONG_BUCKET - 192) / 8;    // size_class index 200: sizes 256 .. 263
 constexpr uint32_t G1_HEAVY_BUCKET = 4096;
 
-DR_DEV G1Xyzz g1_walk(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, uint32_t beg, uint32_t len, uint32_t first,
+DR_DEV G1Xyzz g1_walk(const uint32_t* __restrict__ bases, uint32_t pt_words, const uint32_t* __restrict__ sorted, uint32_t beg, uint32_t len, uint32_t first,
                       uint32_t stride) {
     G1Xyzz acc = g1_inf();
 #pragma unroll 1
     for (uint32_t p = first; p < len; p += stride) {
         uint32_t e = sorted[beg + p];
-        G1Affine q = load_affine(bases, e & 0x7fffffffu);
+        G1Affine q = load_affine_at(bases, e & 0x7fffffffu, pt_words);
         q = g1_neg_affine(q, (e >> 31) != 0);
         acc = g1_madd(acc, q);
     }
     return acc;
 }
 
-__global__ __launch_bounds__(256) void k_g1_accumulate(const uint32_t* __restrict__ bases,
+__global__ __launch_bounds__(256) void k_g1_accumulate(const uint32_t* __restrict__ bases, uint32_t pt_words /* 24, or 32: a table with one point per line */,
                                                        const uint32_t* __restrict__ sorted,
                                                        const uint32_t* __restrict__ offsets,
                                                        const uint32_t* __restrict__ counts,
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(256) void k_g1_accumulate(const uint32_t* __restric
     const size_t b = perm[t];
     const uint32_t len = counts[b];
     if (len >= G1_LONG_BUCKET) return;
-    store_xyzz(buckets, b, g1_walk(bases, sorted, offsets[b], len, 0, 1));
+    store_xyzz(buckets, b, g1_walk(bases, pt_words, sorted, offsets[b], len, 0, 1));
 }
 
 template <int WIDTH>
@@ -909,7 +909,7 @@ DR_DEV G1Xyzz xyzz_shfl_down(const G1Xyzz& p, unsigned delta) {
 // 16-lane instance takes lists of [G1_LONG_BUCKET, G1_HEAVY_BUCKET) entries, four per wave; the 64-lane instance the rest.
 // Grid-stride, so a fixed small grid serves any number of them; returns at once when there are none.
 template <int LANES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_accumulate_long(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_accumulate_long(const uint32_t* __restrict__ bases, uint32_t pt_words, const uint32_t* __restrict__ sorted,
                                                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_offsets,
                                                            uint32_t nblocks, uint32_t* __restrict__ buckets) {
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const uint32_t len = have ? counts[b] : 0;
         const bool mine = have && (LANES == 64 ? len >= G1_HEAVY_BUCKET : (len >= G1_LONG_BUCKET && len < G1_HEAVY_BUCKET));
         if (__ballot(mine) == 0) continue;
-        G1Xyzz acc = g1_walk(bases, sorted, have ? offsets[b] : 0u, mine ? len : 0u, lane, LANES);
+        G1Xyzz acc = g1_walk(bases, pt_words, sorted, have ? offsets[b] : 0u, mine ? len : 0u, lane, LANES);
 #pragma unroll 1
         for (unsigned d = LANES / 2; d >= 1; d >>= 1) acc = g1_add(acc, xyzz_shfl_down<LANES>(acc, d));
         if (mine && lane == 0) store_xyzz(buckets, b, acc);
@@ -1276,7 +1276,7 @@ constexpr int COMB_STRIDE = 32;      // words per comb entry: 96 bytes of data p
 
 // Build: one lane per (base j, window w) row: d*B for d = 1..hw by repeated mixed addition (XYZZ, staged in tmp), then
 // one inversion per row (Montgomery's trick over the row's ZZZ) turns them into affine Montgomery entries.
-__global__ __launch_bounds__(128) void k_g1_comb_build(const uint32_t* __restrict__ wtable /* [rows][count] affine, row of window w = wt.row[w] */, uint32_t count, WindowTable wt,
+__global__ __launch_bounds__(128) void k_g1_comb_build(const uint32_t* __restrict__ wtable /* [rows][count] affine, row of window w = wt.row[w] */, uint32_t pt_words, uint32_t count, WindowTable wt,
                                                        uint32_t Hc, size_t row_lo, uint32_t rows, uint32_t* __restrict__ comb,
                                                        uint32_t* __restrict__ tmp_xyzz /* [Hc][rows][48] */, uint32_t* __restrict__ tmp_pre /* [Hc][rows][12] */) {
     uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(128) void k_g1_comb_build(const uint32_t* __restric
     const uint32_t j = (uint32_t)(row / wt.W), w = (uint32_t)(row % wt.W);
     const uint32_t hw = 1u << (wt.width[w] - 1);
     uint32_t* out = comb + row * Hc * COMB_STRIDE;
-    const G1Affine B = load_affine(wtable, (size_t)wt.row[w] * count + j);
+    const G1Affine B = load_affine_at(wtable, (size_t)wt.row[w] * count + j, pt_words);
     if (B.inf) {
         uint32_t z[12] = {0};
         for (uint32_t d = 0; d < hw; d++) { store_words12(out + (size_t)d * COMB_STRIDE, z); store_words12(out + (size_t)d * COMB_STRIDE + 12, z); }

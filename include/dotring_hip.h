@@ -147,7 +147,7 @@ DR_API int dr_g2_mul(const uint8_t g2_be[192], const uint8_t scalar_le[32], uint
  * set per MSM: a single bucket reduction instead of W and no window combination.  Results are unchanged. */
 DR_API int dr_srs_precompute(dr_ctx *ctx, dr_srs *srs, int window_bits);
 /* Shape of the table dr_srs_precompute built (all zero: none) and the tiling `batch` MSMs of n points over it would take.  An SRS
- * small enough (256 * count * 96 bytes within DOTRING_SRS_BIT_ROWS_MB, default 512: 151 MB for 6145 points) gets a row for EVERY bit,
+ * small enough (256 * count * 128 bytes within DOTRING_SRS_BIT_ROWS_MB, default 512: 201 MB for 6145 points) gets a row for EVERY bit,
  * table[s][i] = 2^s * base[i]; batches of hundreds of MSMs then tile the scalars by wider windows (chosen per call from n and batch;
  * DOTRING_SRS_ODD_BITS forces window_bits + that, -1 = never) and keep buckets for odd digit multiples only — a window or two less per
  * scalar for the same number of buckets.  Results are unchanged.
