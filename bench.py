@@ -688,7 +688,7 @@ def main() -> int:
                             "parity_ok": bool(ok_d and ok_p), "parity_proofs": 2}
                 parity_ok = parity_ok and distinct["parity_ok"]
                 others = {}
-                for rs, st in ((256, 3), (3839, 5)):     # 3839 = the largest ring of domain 4096: BASELINE configs[4]'s per-GPU shape
+                for rs, st in ((256, 5), (3839, 5)):     # 3839 = the largest ring of domain 4096: BASELINE configs[4]'s per-GPU shape
                     leg = ring_size_leg(d, rs, batch, st, 2)
                     others[str(rs)] = leg
                     parity_ok = parity_ok and leg["parity_ok"]
