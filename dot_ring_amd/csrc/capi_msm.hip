@@ -908,7 +908,8 @@ int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_row
     srs->table_bit_rows = false;
     // A small SRS gets a row for every bit (32 KB per base: 201 MB for the 6145 points of a 2048-point domain) — the window rows are a
     // subset of it, and batched MSMs may then tile the scalar differently (odd-multiple buckets, see msm_device).
-    // DOTRING_SRS_BIT_ROWS_MB (default 512, 0 = never) bounds the table; DOTRING_SRS_ODD_BITS (default 1) is how much wider those windows are.
+    // DOTRING_SRS_BIT_ROWS_MB (default 512, 0 = never) bounds the table; DOTRING_SRS_ODD_BITS forces the width of those windows to
+    // window_bits + that (-1 = never odd-multiple buckets; default: chosen per call, odd_window_for).
     static const size_t bit_rows_mb = std::getenv("DOTRING_SRS_BIT_ROWS_MB") ? (size_t)std::atol(std::getenv("DOTRING_SRS_BIT_ROWS_MB")) : 512;
     static const int odd_bits = std::getenv("DOTRING_SRS_ODD_BITS") ? std::atoi(std::getenv("DOTRING_SRS_ODD_BITS")) : -2;
     // One table point per 128-byte line (24 of 32 words used): a packed 96-byte record straddles two lines five times out of eight, and
