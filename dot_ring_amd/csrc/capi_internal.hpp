@@ -315,6 +315,7 @@ struct MsmTable {
     const uint32_t* comb = nullptr;      // comb[j][w][d-1], see k_g1_comb_msm
     uint32_t comb_h = 0;
     uint32_t short_from = 0xffffffffu, n_short = 0;   // batched MSM: vectors from this index on are zero beyond n_short (sort hint)
+    bool fold_sign = false;              // scalars above r / 2 enter as their negatives (difference columns: r - 1 becomes -1, one digit)
 };
 int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch, std::vector<drh::G1>& results,
                const MsmTable* tbl = nullptr);

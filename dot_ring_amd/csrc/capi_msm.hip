@@ -221,7 +221,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     TRY(ctx->tiles.reserve((size_t)(div_up(std::max(ncells, nbuckets), dr::SCAN_TILE) + 1) * 4));
     TRY(ctx->perm.reserve(nbuckets * 4));
     TRY(ctx->cells.reserve(ncells * 4));
-    TRY(ctx->cell_off.reserve(ncells * 4));
+    TRY(ctx->cell_off.reserve((ncells + 2) * 4));
     TRY(ctx->buckets.reserve(nbuckets * 192));
     TRY(ctx->partial.reserve((bsets * pl.T + bsets * (pl.T / 256 + 1)) * 192));
     TRY(ctx->winsum.reserve(bsets * 192));
@@ -257,6 +257,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         sp.short_from = single ? tbl->short_from : 0xffffffffu;
         sp.n_short = single ? std::min<uint32_t>(tbl->n_short, (uint32_t)n) : 0;
         sp.aux = aux; sp.sets = (uint32_t)bsets;
+        sp.fold = single && tbl->fold_sign ? 1 : 0;
         TRY(ctx->sorted.reserve(bsets * per_set_digits * 4));
         // sets of more than a few thousand entries: the sorted segment is assembled in LDS and written in whole lines
         // (k_g1_sort_sets_staged; DOTRING_MSM_SORT_STAGED=0: scattered 4-byte stores as in round 1)
@@ -342,20 +343,23 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         exclusive_scan(ctx->cells.as<uint32_t>(), ctx->cell_off.as<uint32_t>(), ncells);
         hipLaunchKernelGGL(dr::k_size_place, dim3(szblocks), dim3(dr::SZ_BLOCK), 0, st, ctx->counts.as<uint32_t>(), nbuckets, szblocks,
                            ctx->cell_off.as<uint32_t>(), ctx->perm.as<uint32_t>());
+        // the launch's limit between the one-lane walk and the 16-lane walk, from the histogram (two words behind the cell offsets)
+        hipLaunchKernelGGL(dr::k_size_pick, dim3(1), dim3(256), 0, st, ctx->cell_off.as<uint32_t>(), szblocks, nbuckets, ctx->cell_off.as<uint32_t>() + ncells);
     }));
+    const uint32_t* d_pick = ctx->cell_off.as<uint32_t>() + ncells;
     TRY(launch(ctx, "k_g1_accumulate", [&] {
         const uint32_t pt_words = single ? tbl->pt_words : 24u;
         hipLaunchKernelGGL(dr::k_g1_accumulate, dim3(div_up(nbuckets, 256)), dim3(256), 0, st, d_bases, pt_words,
-                           ctx->sorted.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(),
+                           ctx->sorted.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(), d_pick,
                            ctx->buckets.as<uint32_t>(), nbuckets);
         // lists of 256 entries or more (the lowest odd-multiple buckets of every set; skewed scalars): 16 lanes or a wave each; both
         // launches return at once when there are none
         hipLaunchKernelGGL(dr::k_g1_accumulate_long<16>, dim3(2048), dim3(64), 0, st, d_bases, pt_words, ctx->sorted.as<uint32_t>(),
                            ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(), ctx->cell_off.as<uint32_t>(),
-                           szblocks, ctx->buckets.as<uint32_t>());
+                           szblocks, d_pick, ctx->buckets.as<uint32_t>());
         hipLaunchKernelGGL(dr::k_g1_accumulate_long<64>, dim3(2048), dim3(64), 0, st, d_bases, pt_words, ctx->sorted.as<uint32_t>(),
                            ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(), ctx->cell_off.as<uint32_t>(),
-                           szblocks, ctx->buckets.as<uint32_t>());
+                           szblocks, d_pick, ctx->buckets.as<uint32_t>());
     }));
     if (aux) {
         const size_t lanes = bsets * (size_t)std::max<uint32_t>(1, pl.H >> 4);

@@ -344,6 +344,7 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
         }));
         TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true, dr::NTT_FMT_STD8, dr::NTT_FMT_STD8, col_evals, 0));
         MsmTable t = srs_table(p->ps_srs, 0);
+        t.fold_sign = true;                 // first differences of bit columns: +-1
         TRY(msm_to_bytes(ctx, p->ps_srs->d_bases, p->diffs.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t));
     } else {
         TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true, dr::NTT_FMT_STD8, dr::NTT_FMT_STD8, col_evals, 0));

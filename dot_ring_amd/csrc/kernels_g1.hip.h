@@ -389,6 +389,7 @@ struct SortSetParams {
     uint32_t n_pad, digits_per_set;     // staged variant: row length (a multiple of 8) and u16 digits reserved per set
     uint32_t aux;                       // odd-multiple buckets: twin slots per set (0 otherwise); they live at [sets * H + set * aux, ...)
     uint32_t sets;
+    int fold;                           // table mode: scalars above r / 2 are replaced by their negatives (scalar_fold_sign)
 };
 
 DR_DEV void load_scalar_mod_r(const uint32_t* __restrict__ scalars, size_t idx, uint32_t (&k)[9]) {
@@ -405,6 +406,24 @@ DR_DEV void load_scalar_mod_r(const uint32_t* __restrict__ scalars, size_t idx, 
 #pragma unroll
         for (int j = 0; j < 8; j++) k[j] = borrow ? k[j] : d[j];
     }
+}
+
+// k (already < r) -> min(k, r - k); true when it was replaced: k P = -(r - k) P for a point of the order-r group.  A scalar just below r —
+// the "-1" of a difference column — then has ONE non-zero digit instead of one in almost every window (asked for by the caller of a fixed-base
+// table MSM whose scalars are differences — MsmTable::fold_sign, the summation-by-parts commitments; the bases are SRS-derived points of G1).
+DR_DEV bool scalar_fold_sign(uint32_t (&k)[9]) {
+    constexpr uint32_t R[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+    constexpr uint32_t HALF[8] = {0x80000000u, 0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u};   // (r - 1) / 2
+    uint32_t borrow = 0, d[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) (void)subb(HALF[j], k[j], borrow);       // borrow <=> k > (r - 1) / 2
+    const bool neg = borrow != 0;
+    borrow = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) d[j] = subb(R[j], k[j], borrow);
+#pragma unroll
+    for (int j = 0; j < 8; j++) k[j] = neg ? d[j] : k[j];
+    return neg;
 }
 
 // visit the signed digits of scalar k: f(window, digit) for windows [w_lo, w_hi) (the carry chain always starts at 0).
@@ -462,6 +481,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
     for (uint32_t i = i_lo + threadIdx.x; i < i_hi; i += SORT_BLOCK) {
         uint32_t k[9];
         load_scalar_mod_r(scalars, (size_t)b * sp.n + i, k);
+        if (sp.fold) (void)scalar_fold_sign(k);
         for_each_digit(k, wt, w_lo, w_hi, [&](int w, int32_t d) {
             uint32_t row;
             atomicAdd(&bins[digit_bin(wt, H, w, (uint32_t)(d < 0 ? -d : d), row)], 1u);
@@ -490,11 +510,12 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
     for (uint32_t i = i_lo + threadIdx.x; i < i_hi; i += SORT_BLOCK) {
         uint32_t k[9];
         load_scalar_mod_r(scalars, (size_t)b * sp.n + i, k);
+        const bool neg = sp.fold ? scalar_fold_sign(k) : false;
         for_each_digit(k, wt, w_lo, w_hi, [&](int w, int32_t d) {
             uint32_t row;
             uint32_t pos = atomicAdd(&bins[digit_bin(wt, H, w, (uint32_t)(d < 0 ? -d : d), row)], 1u);
             uint32_t entry = sp.single ? row * sp.tbl_stride + sp.tbl_offset + i : i;
-            sorted[base + pos] = entry | (d < 0 ? 0x80000000u : 0u);
+            sorted[base + pos] = entry | ((d < 0) != neg ? 0x80000000u : 0u);
         });
     }
 }
@@ -552,6 +573,7 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
         if (ii < n_set) {
             uint32_t k[9];
             load_scalar_mod_r(scalars, (size_t)b * sp.n + i_lo + ii, k);
+            const bool neg = sp.fold ? scalar_fold_sign(k) : false;
             for_each_digit<true>(k, wt, w_lo, w_hi, [&](int w, int32_t d) {
                 const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
                 uint32_t row, enc = mag;
@@ -561,7 +583,7 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
                     // odd multiples: pass 2 runs once per chunk, so the bin is worked out here, once: bin + 1 | (k & 3) << 13
                     if (wt.odd) enc = (bin + 1u) | (((uint32_t)__builtin_ctz(mag) & 3u) << 13);
                 }
-                dg[(size_t)(w - w_lo) * n_pad + ii] = (uint16_t)(enc | (d < 0 ? 0x8000u : 0u));
+                dg[(size_t)(w - w_lo) * n_pad + ii] = (uint16_t)(enc | ((d < 0) != neg && d != 0 ? 0x8000u : 0u));
             });
         } else {
             for (uint32_t r = 0; r < rows; r++) dg[(size_t)r * n_pad + ii] = 0;
@@ -861,7 +883,32 @@ __global__ __launch_bounds__(SZ_BLOCK) void k_size_place(const uint32_t* __restr
 // or more — the size ordering puts them first in `perm` — are left to k_g1_accumulate_long: 16 lanes per bucket (four buckets per
 // wave) up to G1_HEAVY_BUCKET entries, a whole wave beyond.  The prover's dense MSMs over window rows (~66 points per bucket,
 // Poisson) never get there.
-constexpr uint32_t G1_LONG_BUCKET = 256, G1_LONG_CLASS_IDX = 192 + (G1_LONG_BUCKET - 192) / 8;    // size_class index 200: sizes 256 .. 263
+constexpr uint32_t G1_LONG_BUCKET = 256;                  // (upper bound of the per-launch limit, k_size_pick)
+// The list length from which a launch hands its lists to k_g1_accumulate_long.  One lane adds an entry per ~17 us (two waves share a
+// SIMD); the whole launch needs total / 65536 lanes x 8.4 us when every lane is busy.  A list may take half of that: limit = total
+// entries / 265 k, within [32, G1_LONG_BUCKET], at a size-class boundary.  The dense launches (126 - 168 M entries) get 256 and, with
+// the twins, send nothing to the long-list kernel; the summation-by-parts launch (22 M entries, but ~130 "+-1" entries in one bucket of
+// every bit column) gets ~85 — it used to last as long as one lane needs for its longest list.  From the size-class histogram (cells
+// after their exclusive scan), one block.
+__global__ __launch_bounds__(256) void k_size_pick(const uint32_t* __restrict__ cell_offsets, uint32_t nblocks, size_t nbuckets, uint32_t* __restrict__ pick) {
+    __shared__ unsigned long long tot[256];
+    const uint32_t c = threadIdx.x, idx = 255u - c;
+    const uint32_t lo = cell_offsets[(size_t)c * nblocks], hi = c == 255u ? (uint32_t)nbuckets : cell_offsets[(size_t)(c + 1) * nblocks];
+    const uint32_t n_c = hi - lo, size = idx < 192u ? idx : 192u + 8u * (idx - 192u) + 4u;
+    tot[c] = (unsigned long long)n_c * size;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (c < s) tot[c] += tot[c + s];
+        __syncthreads();
+    }
+    if (c == 0) {
+        const unsigned long long want = tot[0] / 265000ull;
+        const uint32_t L = want < 32ull ? 32u : want > (unsigned long long)G1_LONG_BUCKET ? G1_LONG_BUCKET : (uint32_t)want;
+        const uint32_t idx_l = L < 192u ? L : 192u + (L - 192u) / 8u;
+        pick[0] = idx_l < 192u ? idx_l : 192u + 8u * (idx_l - 192u);       // first length of that class
+        pick[1] = idx_l;
+    }
+}
 constexpr uint32_t G1_HEAVY_BUCKET = 4096;
 
 DR_DEV G1Xyzz g1_walk(const uint32_t* __restrict__ bases, uint32_t pt_words, const uint32_t* __restrict__ sorted, uint32_t beg, uint32_t len, uint32_t first,
@@ -882,12 +929,13 @@ __global__ __launch_bounds__(256) void k_g1_accumulate(const uint32_t* __restric
                                                        const uint32_t* __restrict__ offsets,
                                                        const uint32_t* __restrict__ counts,
                                                        const uint32_t* __restrict__ perm /* size-ordered bucket ids */,
+                                                       const uint32_t* __restrict__ pick /* k_size_pick */,
                                                        uint32_t* __restrict__ buckets, size_t nbuckets) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nbuckets) return;
     const size_t b = perm[t];
     const uint32_t len = counts[b];
-    if (len >= G1_LONG_BUCKET) return;
+    if (len >= pick[0]) return;
     store_xyzz(buckets, b, g1_walk(bases, pt_words, sorted, offsets[b], len, 0, 1));
 }
 
@@ -912,10 +960,11 @@ template <int LANES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_accumulate_long(const uint32_t* __restrict__ bases, uint32_t pt_words, const uint32_t* __restrict__ sorted,
                                                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_offsets,
-                                                           uint32_t nblocks, uint32_t* __restrict__ buckets) {
+                                                           uint32_t nblocks, const uint32_t* __restrict__ pick /* k_size_pick */, uint32_t* __restrict__ buckets) {
     constexpr uint32_t PER_WAVE = 64 / LANES;
-    // class index >= G1_LONG_CLASS_IDX  <=>  class <= 255 - G1_LONG_CLASS_IDX; the next class starts at cell (256 - idx) * nblocks
-    const uint32_t n_long = cell_offsets[(size_t)(256u - G1_LONG_CLASS_IDX) * nblocks];
+    // class index >= pick[1]  <=>  class <= 255 - pick[1]; the next class starts at cell (256 - pick[1]) * nblocks
+    const uint32_t long_from = pick[0];
+    const uint32_t n_long = cell_offsets[(size_t)(256u - pick[1]) * nblocks];
     const uint32_t sub = threadIdx.x / LANES, lane = threadIdx.x % LANES;
 #pragma unroll 1
     for (uint32_t t0 = blockIdx.x * PER_WAVE; t0 < n_long; t0 += gridDim.x * PER_WAVE) {
@@ -923,7 +972,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const bool have = t < n_long;
         const size_t b = have ? perm[t] : 0;
         const uint32_t len = have ? counts[b] : 0;
-        const bool mine = have && (LANES == 64 ? len >= G1_HEAVY_BUCKET : (len >= G1_LONG_BUCKET && len < G1_HEAVY_BUCKET));
+        const bool mine = have && (LANES == 64 ? len >= G1_HEAVY_BUCKET : (len >= long_from && len < G1_HEAVY_BUCKET));
         if (__ballot(mine) == 0) continue;
         G1Xyzz acc = g1_walk(bases, pt_words, sorted, have ? offsets[b] : 0u, mine ? len : 0u, lane, LANES);
 #pragma unroll 1
