@@ -886,7 +886,7 @@ __global__ __launch_bounds__(SZ_BLOCK) void k_size_place(const uint32_t* __restr
 constexpr uint32_t G1_LONG_BUCKET = 256;                  // (upper bound of the per-launch limit, k_size_pick)
 // The list length from which a launch hands its lists to k_g1_accumulate_long.  One lane adds an entry per ~17 us (two waves share a
 // SIMD); the whole launch needs total / 65536 lanes x 8.4 us when every lane is busy.  A list may take half of that: limit = total
-// entries / 265 k, within [32, G1_LONG_BUCKET], at a size-class boundary.  The dense launches (126 - 168 M entries) get 256 and, with
+// entries / 265 k, within [64, G1_LONG_BUCKET], at a size-class boundary.  The dense launches (126 - 168 M entries) get 256 and, with
 // the twins, send nothing to the long-list kernel; the summation-by-parts launch (22 M entries, but ~130 "+-1" entries in one bucket of
 // every bit column) gets ~85 — it used to last as long as one lane needs for its longest list.  From the size-class histogram (cells
 // after their exclusive scan), one block.
@@ -903,7 +903,9 @@ __global__ __launch_bounds__(256) void k_size_pick(const uint32_t* __restrict__ 
     }
     if (c == 0) {
         const unsigned long long want = tot[0] / 265000ull;
-        const uint32_t L = want < 32ull ? 32u : want > (unsigned long long)G1_LONG_BUCKET ? G1_LONG_BUCKET : (uint32_t)want;
+        // (never below 64: the 16-lane kernel ends with four dependent full additions, ~0.1 ms — as long as one lane needs for ~6 entries more —
+        //  and a small launch, a single 2^16-point MSM, is a latency chain that would only get longer)
+        const uint32_t L = want < 64ull ? 64u : want > (unsigned long long)G1_LONG_BUCKET ? G1_LONG_BUCKET : (uint32_t)want;
         const uint32_t idx_l = L < 192u ? L : 192u + (L - 192u) / 8u;
         pick[0] = idx_l < 192u ? idx_l : 192u + 8u * (idx_l - 192u);       // first length of that class
         pick[1] = idx_l;
