@@ -921,9 +921,13 @@ int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_row
     // a third larger (A/B on one box, three alternations: 40.50 - 40.63 against 40.85 - 41.17 ms per 1024 proofs).  DOTRING_SRS_LINE=0: packed.
     static const bool line = std::getenv("DOTRING_SRS_LINE") == nullptr || std::atoi(std::getenv("DOTRING_SRS_LINE")) != 0;
     const uint32_t pt_words = line ? 32 : 24;
-    const bool bit_rows = allow_bit_rows && window_bits <= 16 && (size_t)256 * srs->count * 4 * pt_words <= (bit_rows_mb << 20);
-    const size_t rows = bit_rows ? 256 : (size_t)wt.W;
-    HIP_TRY(hipMalloc((void**)&srs->d_table, rows * srs->count * 4 * pt_words));
+    bool bit_rows = allow_bit_rows && window_bits <= 16 && (size_t)256 * srs->count * 4 * pt_words <= (bit_rows_mb << 20);
+    if (bit_rows && hipMalloc((void**)&srs->d_table, (size_t)256 * srs->count * 4 * pt_words) != hipSuccess) {
+        (void)hipGetLastError();                   // a device short of memory keeps the window rows (W rows instead of 256)
+        srs->d_table = nullptr;
+        bit_rows = false;
+    }
+    if (!bit_rows) HIP_TRY(hipMalloc((void**)&srs->d_table, (size_t)wt.W * srs->count * 4 * pt_words));
     srs->table_pt_words = pt_words;
     if (bit_rows) {
         for (int w = 0; w < wt.W; w++) wt.row[w] = wt.start[w];
