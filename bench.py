@@ -342,7 +342,11 @@ class RingWorkload:
         tv_params = d.RingProofParams.from_ring_size(self.ring_size, test_vectors=True, pcs=self.pcs)
         tv_ring = d.Ring(self.keys, tv_params)
         tv_root = d.RingRoot.from_ring(tv_ring, tv_params)
-        gpu_proofs = self.vrf.prove_batch(self.alphas[:m], self.ads[:m], self.sks[:m], self.pks[:m], tv_ring, tv_root)
+        # the WHOLE batch in deterministic mode, so that the m proofs compared below come through the same code path as the timed
+        # batches (from a few hundred MSMs on, the KZG commitments take the odd-multiple tiling of the bit-row SRS table)
+        nb = len(self.alphas)
+        gpu_all = self.vrf.prove_batch(self.alphas, self.ads, self.sks[:nb], self.pks[:nb], tv_ring, tv_root)
+        gpu_proofs = gpu_all[:m]
         o_srs = None
         if self.big:
             from oracle.pyref import kzg as okzg
