@@ -81,8 +81,23 @@ def test_device_prover_explicit_hidden_rows(ctx):
     rng = random.Random(9)
     rows = {name: [rng.randrange(obsn.P) for _ in range(3)] for name in ("b", "accip", "accx", "accy")}
     t = rng.randrange(obsn.N)
-    want = oring.prove_ring(o_ring, o_root, keys[4], t, rows)
     dp = device_prover.get_device_prover(ring)
+    # The witness commitments are sums over first differences d_j = e_j - e_(j+1) (e_N = 0), and the MSM over them replaces a scalar
+    # above r / 2 by its negative: hidden rows that put differences ON the threshold — (r - 1) / 2 stays, (r + 1) / 2 and r - 1 fold —
+    # next to 0, 1 and equal neighbours, commitments against the oracle's.
+    r = obsn.P
+    h = (r - 1) // 2
+    edge = {"b": [(2 * h + 1 + (r - 1)) % r, (2 * h + 1) % r, h],           # differences r - 1, (r + 1) / 2, (r - 1) / 2
+            "accip": [(h + 2) % r, h + 1, h + 1],                            # differences 1, 0, (r + 1) / 2
+            "accx": [0, 0, 0], "accy": [r - 1, 1, r - 1]}                    # differences 0, 0, 0 and r - 2, 2, r - 1
+    zk_e = b"".join(v.to_bytes(32, "little") for name in ("b", "accip", "accx", "accy") for v in edge[name])
+    nb = 32                                                                  # (from 16 proofs on the by-parts MSM sorts per set in LDS: the folding path)
+    _, wit_e = dp.witness([4] * nb, t.to_bytes(32, "little") * nb, zk_e * nb)
+    want_e = oring.prove_ring(o_ring, o_root, keys[4], t, edge)
+    assert len(wit_e) == 4 * nb
+    for i in (0, nb - 1):
+        assert b"".join(params.pcs.compress_g1(c) for c in wit_e[4 * i : 4 * i + 4]) == want_e[: 4 * 48], i
+    want = oring.prove_ring(o_ring, o_root, keys[4], t, rows)
     zk = b"".join(v.to_bytes(32, "little") for name in ("b", "accip", "accx", "accy") for v in rows[name])
     rel, wit = dp.witness([4], t.to_bytes(32, "little"), zk)
     pcs = params.pcs
