@@ -640,7 +640,7 @@ def main() -> int:
         # bucket additions of the dense MSMs in the profiled pass: pairs x windows of the SRS table (non-zero digit rate ~1)
         # (asked of the library: an SRS with a row per bit tiles the scalars of a batched MSM by windows one bit wider, dr_srs_table_info)
         tinfo = w.pcs._srs().device().table_info(3 * n_dom + 1, batch)
-        table_windows = tinfo["batched_windows"]
+        table_windows = tinfo["digits_per_scalar"]          # expected non-zero digits per scalar = bucket additions per pair
         dense_adds = float(batch) * pairs_per_proof * table_windows * args.steps
         total = batch * world * args.steps
         value = total / elapsed
@@ -728,7 +728,7 @@ def main() -> int:
                                   "isolated_chain_gadd_s": MEASURED_CHAIN_GADD_S,
                                   "isolated_chain_source": "profiles/r02_ubench_limbs_fused.txt (tools/ubench_limbs.hip on another box; not re-measured in this run)",
                                   "frac_of_isolated_chain": dense_adds / (acc_ms / 1e3) / 1e9 / MEASURED_CHAIN_GADD_S if acc_ms else None,
-                                  "table": tinfo, "windows_per_scalar": table_windows,
+                                  "table": tinfo, "additions_per_pair": table_windows,
                                   "note": "dense bucket additions only (7N pairs x windows per proof); by-parts and verify-side additions not counted"},
                          # per-proof unique traffic (11N scalars + 14 NTT passes' data + 784 B out), 3.17 KB per
                          # domain point = 6.5 MB per proof at N = 2048, over the whole job

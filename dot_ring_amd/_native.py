@@ -316,10 +316,13 @@ class Srs:
 
     def table_info(self, n: int = 0, batch: int = 0) -> dict:
         """Shape of the fixed-base table and the tiling `batch` MSMs of n points over it take (dr_srs_table_info): window_bits, rows,
-        windows per scalar, and the window width of the odd-multiple tiling (0 = the window rows)."""
-        info = (c_int * 4)()
+        digit rows per scalar, the per-call tiling (0 = window rows, 1 = odd-multiple windows, 2 = non-adjacent form) with its width, and
+        the expected non-zero digits per scalar (= bucket additions per pair)."""
+        info = (c_int * 6)()
         _check(lib().dr_srs_table_info(self.handle, n, batch, info))
-        return {"window_bits": info[0], "rows": info[1], "batched_windows": info[2], "odd_window_bits": info[3], "odd_buckets": bool(info[3])}
+        return {"window_bits": info[0], "rows": info[1], "batched_windows": info[2], "tiling_bits": info[3],
+                "tiling": ("window rows", "odd-multiple windows", "non-adjacent form")[info[4]], "digits_per_scalar": info[5] / 1000.0,
+                "odd_buckets": bool(info[4])}
 
     def precompute_comb(self) -> "Srs":
         """Comb table over the window table (see dr_srs_precompute_comb); MemoryError if it does not fit."""

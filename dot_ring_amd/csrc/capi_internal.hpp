@@ -320,8 +320,14 @@ struct MsmTable {
 int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch, std::vector<drh::G1>& results,
                const MsmTable* tbl = nullptr);
 MsmTable srs_table(const dr_srs* srs, size_t offset);
-// window width of the odd-multiple tiling msm_device takes for `batch` MSMs of n points over this table (0: the window rows)
-int odd_window_for(const MsmTable& t, size_t n, size_t batch);
+// the tiling msm_device takes for `batch` MSMs of n points over this table: mode 0 = the table's window rows, 1 = windows of c bits with
+// odd-multiple buckets and twins, 2 = width-c non-adjacent form (bit-row tables, hundreds of MSMs); slots = digit rows per scalar,
+// digits = expected non-zero digits per scalar
+struct Tiling {
+    int mode, c, slots;
+    double digits;
+};
+Tiling tiling_for(const MsmTable& t, size_t n, size_t batch);
 int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_rows);   // dr_srs_precompute with the table shape chosen
 void g1_result_to_bytes(const drh::G1& r, uint8_t* out96, int* is_inf);
 int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, int* is_inf);

@@ -119,7 +119,7 @@ static size_t l4_below() {
     return v;
 }
 
-int odd_window_for(const MsmTable& t, size_t n, size_t batch) {
+static int odd_window_for(const MsmTable& t, size_t n, size_t batch) {
     if (!t.table || !t.bit_rows || t.odd_delta == -1 || g_chunk_len != 16 || batch < 256 || n == 0) return 0;
     const int cn = t.wt.cmax, lo = t.odd_delta >= 0 ? cn + t.odd_delta : cn, hi = t.odd_delta >= 0 ? cn + t.odd_delta : cn + 2;
     int best = 0;
@@ -132,6 +132,45 @@ int odd_window_for(const MsmTable& t, size_t n, size_t batch) {
         if (t.odd_delta < 0 && 4.8 * (double)n * (double)W / (double)(2 * H) > 230.0) continue;
         const double cost = (double)n * (double)W + 5.2 * (double)H;
         if (!best || cost < best_cost) { best = c; best_cost = cost; }
+    }
+    return best;
+}
+
+// DOTRING_SRS_TILING=naf|odd|rows: the tiling batched MSMs take over a bit-row table (default naf)
+static int tiling_mode() {
+    static const int v = [] {
+        const char* e = std::getenv("DOTRING_SRS_TILING");
+        if (!e) return 2;
+        return std::strcmp(e, "rows") == 0 ? 0 : std::strcmp(e, "odd") == 0 ? 1 : 2;
+    }();
+    return v;
+}
+
+// Round 4: non-adjacent form.  With a row per bit a digit may sit at ANY bit position, so the scalar is recoded in width-w NAF
+// (kernels_g1.hip.h: for_each_wnaf_digit): 256 / (w + 1) odd digits on average — 18.3 for w = 13 where the 13-bit windows above have 20 —
+// spread evenly over the same 2^(w-2) odd-multiple buckets: no twins, no merge kernel, a flat list-length distribution.
+// w <= 13: the staged sort's u16 digit rows hold 11 bucket bits + 4 offset bits + sign.
+Tiling tiling_for(const MsmTable& t, size_t n, size_t batch) {
+    Tiling none{0, 0, 0, 0.0};
+    if (!t.table || !t.bit_rows || t.odd_delta == -1 || g_chunk_len != 16 || batch < 256 || n == 0 || tiling_mode() == 0) return none;
+    const int cn = t.wt.cmax;
+    if (tiling_mode() == 1) {
+        const int c = odd_window_for(t, n, batch);
+        if (!c) return none;
+        return Tiling{1, c, (256 + c - 1) / c, (double)((256 + c - 1) / c)};
+    }
+    const int lo = t.odd_delta >= 0 ? cn + t.odd_delta : cn - 1, hi = t.odd_delta >= 0 ? cn + t.odd_delta : cn + 2;
+    Tiling best = none;
+    double best_cost = 0;
+    for (int w = lo; w <= hi; w++) {
+        if (w < 9 || w > 13) continue;
+        const size_t H = (size_t)1 << (w - 2), slots = 255 / w + 1;
+        if (batch * (H / 16) < l4_below()) continue;
+        if ((n + 64) * slots > ((size_t)1 << 20) || batch * (n + 64) * slots >= (1ull << 32)) continue;
+        const double digits = 256.0 / (w + 1);
+        if (t.odd_delta < 0 && (double)n * digits / (double)H > 160.0) continue;      // lists stay well below the one-lane limit of 256
+        const double cost = (double)n * digits + 5.2 * (double)H;
+        if (!best.mode || cost < best_cost) { best = Tiling{2, w, (int)slots, digits}; best_cost = cost; }
     }
     return best;
 }
@@ -169,13 +208,18 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     if (single) {
         // A table with a row per bit and hundreds of MSMs (the batched prover): one more bit per window, buckets for odd multiples only
         // — as many buckets as before, a window less per scalar.  Needs the per-set LDS sort and the set-scan reduction (below).
-        const int c_odd = setscan_on ? odd_window_for(*tbl, n, batch) : 0;
-        const bool odd = c_odd != 0;
+        const Tiling tl = setscan_on ? tiling_for(*tbl, n, batch) : Tiling{0, 0, 0, 0.0};
+        const bool odd = tl.mode != 0;
         dr::WindowTable wo{};
-        if (odd) {
-            wo = make_window_table(c_odd);
+        if (tl.mode == 1) {
+            wo = make_window_table(tl.c);
             for (int w = 0; w < wo.W; w++) wo.row[w] = wo.start[w];
             wo.odd = 1;
+        } else if (tl.mode == 2) {                       // slots of the non-adjacent form: positions [c j, c j + c)
+            wo.W = tl.slots;
+            wo.cmax = tl.c;
+            for (int j = 0; j < wo.W; j++) { wo.start[j] = wo.row[j] = (uint8_t)(tl.c * j); wo.width[j] = (uint8_t)tl.c; }
+            wo.odd = 2;
         }
         pl.wt = odd ? wo : tbl->wt;
         pl.W = pl.wt.W;
@@ -209,7 +253,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         pl.T = pl.H / 4;
     }
     // odd-multiple buckets: every set has a few twin buckets besides its H (kernels_g1.hip.h: digit_bin), kept after all sets' buckets
-    const uint32_t aux = pl.wt.odd ? (dr::odd_twin_count(pl.H) + 15u) & ~15u : 0u;
+    const uint32_t aux = pl.wt.odd == 1 ? (dr::odd_twin_count(pl.H) + 15u) & ~15u : 0u;
     const size_t nbuckets = bsets * (size_t)(pl.H + aux);
     const size_t ndigits = windows * n;
     if (nbuckets >= (1ull << 32) || ndigits >= (1ull << 32))
@@ -1001,17 +1045,19 @@ void dr_srs_destroy(dr_srs* srs) {
 
 size_t dr_srs_size(const dr_srs* srs) { return srs ? srs->count : 0; }
 
-int dr_srs_table_info(const dr_srs* srs, size_t n, size_t batch, int info[4]) {
+int dr_srs_table_info(const dr_srs* srs, size_t n, size_t batch, int info[6]) {
     if (!srs || !info) return fail(DR_ERR_INVALID, "null argument");
-    info[0] = info[1] = info[2] = info[3] = 0;
+    for (int i = 0; i < 6; i++) info[i] = 0;
     if (!srs->d_table) return DR_OK;
     static const bool setscan_on = std::getenv("DOTRING_MSM_SETSCAN") == nullptr || std::atoi(std::getenv("DOTRING_MSM_SETSCAN")) != 0;
     const MsmTable t = srs_table(srs, 0);
-    const int c_odd = setscan_on ? odd_window_for(t, n, batch) : 0;
+    const Tiling tl = setscan_on ? tiling_for(t, n, batch) : Tiling{0, 0, 0, 0.0};
     info[0] = srs->table_wt.cmax;
     info[1] = srs->table_bit_rows ? 256 : srs->table_wt.W;
-    info[2] = c_odd ? (256 + c_odd - 1) / c_odd : srs->table_wt.W;
-    info[3] = c_odd;
+    info[2] = tl.mode ? tl.slots : srs->table_wt.W;
+    info[3] = tl.c;
+    info[4] = tl.mode;
+    info[5] = (int)std::lround(1000.0 * (tl.mode ? tl.digits : (double)srs->table_wt.W));
     return DR_OK;
 }
 

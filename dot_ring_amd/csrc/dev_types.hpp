@@ -14,6 +14,10 @@ namespace dr {
 // (row[w] = start[w]: table[s][i] = 2^s * base[i] for every s < 256; any tiling of the 256 bits can then be used per call).
 // `odd` (bit rows only): a digit of magnitude m = 2^k * u, u odd, takes the point of row start_w + k and goes to bucket (u - 1) / 2 —
 // only odd multiples have buckets, 2^(cmax-2) per set instead of 2^(cmax-1); a set's value is sum_j (2j + 1) B_j.
+// `odd` == 2 (bit rows only, round 4): the scalar is recoded in width-cmax non-adjacent form — odd digits |d| < 2^(cmax-1), at least cmax
+// positions apart, so there are 256 / (cmax + 1) of them on average instead of 256 / cmax window digits — into the same 2^(cmax-2)
+// odd-multiple buckets; a digit at bit position p takes its point from row p.  The W "windows" are then slots: slot j = positions
+// [cmax j, cmax j + cmax) holds at most one digit (start[j] = row[j] = cmax j, width[j] = cmax).
 struct WindowTable {
     int W, cmax;
     uint8_t start[40];   // first bit of window w   (W <= 40: widths >= 7 ... see make_plan)

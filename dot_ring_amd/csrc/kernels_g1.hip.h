@@ -19,6 +19,7 @@
 #pragma once
 #include "dev_types.hpp"
 #include "g1.hip.h"
+#include "msm_recode.hip.h"
 
 namespace dr {
 
@@ -426,28 +427,7 @@ DR_DEV bool scalar_fold_sign(uint32_t (&k)[9]) {
     return neg;
 }
 
-// visit the signed digits of scalar k: f(window, digit) for windows [w_lo, w_hi) (the carry chain always starts at 0).
-// The scalar words are indexed only by the unrolled outer loop: a run-time index (k[start >> 5]) would put the array in
-// scratch memory and cost one memory round trip per digit (measured: 5.4 -> 1.x ms for the prover's sort kernel).
-template <bool WITH_ZEROS = false, class F>
-DR_DEV void for_each_digit(const uint32_t (&k)[9], const WindowTable& wt, int w_lo, int w_hi, F&& f) {
-    uint32_t carry = 0;
-    int w = 0;
-#pragma unroll
-    for (int li = 0; li < 8; li++) {
-        const uint64_t two = (uint64_t)k[li] | ((uint64_t)k[li + 1] << 32);
-        while (w < w_hi && (wt.start[w] >> 5) == li) {
-            const int c = wt.width[w], sh = wt.start[w] & 31;
-            const uint32_t half = 1u << (c - 1);
-            uint32_t raw = ((uint32_t)(two >> sh) & ((1u << c) - 1)) + carry;
-            int32_t d;
-            if (raw > half) { d = (int32_t)raw - (int32_t)(1u << c); carry = 1; }
-            else { d = (int32_t)raw; carry = 0; }
-            if (w >= w_lo && (WITH_ZEROS || d != 0)) f(w, d);
-            w++;
-        }
-    }
-}
+// (for_each_digit / for_each_wnaf_digit — how a scalar becomes bucket entries — live in msm_recode.hip.h: the host tests run them too)
 
 __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __restrict__ scalars, WindowTable wt, SortSetParams sp,
                                                              uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
@@ -482,6 +462,10 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
         uint32_t k[9];
         load_scalar_mod_r(scalars, (size_t)b * sp.n + i, k);
         if (sp.fold) (void)scalar_fold_sign(k);
+        if (wt.odd == 2) {
+            for_each_wnaf_digit(k, wt, [&](int, uint32_t, int32_t d) { atomicAdd(&bins[((uint32_t)(d < 0 ? -d : d) - 1u) >> 1], 1u); });
+            continue;
+        }
         for_each_digit(k, wt, w_lo, w_hi, [&](int w, int32_t d) {
             uint32_t row;
             atomicAdd(&bins[digit_bin(wt, H, w, (uint32_t)(d < 0 ? -d : d), row)], 1u);
@@ -511,6 +495,14 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
         uint32_t k[9];
         load_scalar_mod_r(scalars, (size_t)b * sp.n + i, k);
         const bool neg = sp.fold ? scalar_fold_sign(k) : false;
+        if (wt.odd == 2) {
+            for_each_wnaf_digit(k, wt, [&](int j, uint32_t o, int32_t d) {
+                const uint32_t pos = atomicAdd(&bins[((uint32_t)(d < 0 ? -d : d) - 1u) >> 1], 1u);
+                const uint32_t entry = ((uint32_t)wt.row[j] + o) * sp.tbl_stride + sp.tbl_offset + i;
+                sorted[base + pos] = entry | ((d < 0) != neg ? 0x80000000u : 0u);
+            });
+            continue;
+        }
         for_each_digit(k, wt, w_lo, w_hi, [&](int w, int32_t d) {
             uint32_t row;
             uint32_t pos = atomicAdd(&bins[digit_bin(wt, H, w, (uint32_t)(d < 0 ? -d : d), row)], 1u);
@@ -574,6 +566,17 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
             uint32_t k[9];
             load_scalar_mod_r(scalars, (size_t)b * sp.n + i_lo + ii, k);
             const bool neg = sp.fold ? scalar_fold_sign(k) : false;
+            if (wt.odd == 2) {
+                for_each_wnaf_digit<true>(k, wt, [&](int j, uint32_t o, int32_t d) {
+                    uint32_t enc = WNAF_EMPTY16;
+                    if (d != 0) {
+                        const uint32_t bin = ((uint32_t)(d < 0 ? -d : d) - 1u) >> 1;
+                        atomicAdd(&bins[bin], 1u);
+                        enc = bin | (o << 11) | ((d < 0) != neg ? 0x8000u : 0u);
+                    }
+                    dg[(size_t)j * n_pad + ii] = (uint16_t)enc;
+                });
+            } else
             for_each_digit<true>(k, wt, w_lo, w_hi, [&](int w, int32_t d) {
                 const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
                 uint32_t row, enc = mag;
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
                 dg[(size_t)(w - w_lo) * n_pad + ii] = (uint16_t)(enc | ((d < 0) != neg && d != 0 ? 0x8000u : 0u));
             });
         } else {
-            for (uint32_t r = 0; r < rows; r++) dg[(size_t)r * n_pad + ii] = 0;
+            for (uint32_t r = 0; r < rows; r++) dg[(size_t)r * n_pad + ii] = wt.odd == 2 ? (uint16_t)WNAF_EMPTY16 : (uint16_t)0;
         }
     }
     __syncthreads();
@@ -639,10 +642,13 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
 #pragma unroll
                     for (int t = 0; t < 8; t++) {
                         const uint32_t dd = (words[t >> 1] >> (16 * (t & 1))) & 0xffffu;
-                        const uint32_t j = (dd & (wt.odd ? 0x1fffu : 0x7fffu)) - 1u;   // dd == 0 -> 0xffffffff: outside every range
+                        // dd == 0 (windows) / offset field 15 (non-adjacent form) -> 0xffffffff: outside every range
+                        const uint32_t j = wt.odd == 2 ? (((dd >> 11) & 15u) == 15u ? 0xffffffffu : (dd & 0x7ffu)) : (dd & (wt.odd ? 0x1fffu : 0x7fffu)) - 1u;
                         if (j >= j_lo && j < j_hi) {
                             uint32_t up = 0;
-                            if (wt.odd) {                                     // row + k: k = 4 g + (k & 3), g from the bin's range (digit_bin)
+                            if (wt.odd == 2) {
+                                up = ((dd >> 11) & 15u) * sp.tbl_stride;      // the digit's offset in its slot: row[slot] + offset
+                            } else if (wt.odd) {                              // row + k: k = 4 g + (k & 3), g from the bin's range (digit_bin)
                                 const uint32_t d1 = HR + ((HR >> 4) ? (HR >> 4) : 1u), d2 = d1 + ((HR >> 8) ? (HR >> 8) : 1u);
                                 const uint32_t g = j < HR ? 0u : j < d1 ? 1u : j < d2 ? 2u : 3u;
                                 up = (4u * g + ((dd >> 13) & 3u)) * sp.tbl_stride;

@@ -410,17 +410,19 @@ def test_g1_msm_fixed_base_table_matches_plain(ctx, srs_bytes, bits):
     tabled.close()
 
 
-@pytest.mark.parametrize("bits,n,batch", [(9, 96, 8192), (12, 1500, 1024)])
-def test_g1_msm_batched_odd_multiple_buckets(ctx, srs_bytes, bits, n, batch):
-    """A small SRS gets a table with a row per bit, and a batch of hundreds of MSMs over it takes the odd-multiple tiling
-    (one bit wider windows, buckets for odd digit multiples and their twins, dr_srs_table_info): the very same scalar vectors in
-    batches of 64 take the window rows — the results must agree, and a sample of them with the oracle.  Edge vectors: powers of
-    two (every shift k up to the window width, i.e. every twin group), r - 1, all equal, all zero, 2^c - 1 patterns."""
+@pytest.mark.parametrize("bits,n,batch,width", [(9, 96, 8192, 10), (12, 1500, 1024, 13)])
+def test_g1_msm_batched_odd_multiple_buckets(ctx, srs_bytes, bits, n, batch, width):
+    """A small SRS gets a table with a row per bit, and a batch of hundreds of MSMs over it recodes its scalars in width-w
+    non-adjacent form (odd digits at arbitrary bit positions into odd-multiple buckets, dr_srs_table_info): the very same scalar
+    vectors in batches of 64 take the window rows — the results must agree, and a sample of them with the oracle.  Edge vectors:
+    powers of two (every row), r - 1, all equal, all zero, 2^c - 1 patterns, runs of ones that carry across every slot, alternating
+    bits, values whose top digit lands on the last rows.  (96 points: the plain LDS sort; 1500: the staged one.)"""
     rng = random.Random(bits * 1000 + n)
     tabled = ctx.srs_load(srs_bytes[: 96 * n]).precompute(bits)
     info = tabled.table_info(n, batch)
-    assert info["window_bits"] == bits and info["rows"] == 256 and info["odd_window_bits"] == bits + 1
-    assert info["batched_windows"] == -(-256 // (bits + 1))
+    assert info["window_bits"] == bits and info["rows"] == 256
+    assert info["tiling"] == "non-adjacent form" and info["tiling_bits"] == width
+    assert info["batched_windows"] == 255 // width + 1 and abs(info["digits_per_scalar"] - 256 / (width + 1)) < 0.01
     assert not tabled.table_info(n, 64)["odd_buckets"]                         # few MSMs: the window rows
     r = coracle.FR_P
     vecs = []
@@ -430,25 +432,37 @@ def test_g1_msm_batched_odd_multiple_buckets(ctx, srs_bytes, bits, n, batch):
         elif b == 1:
             v = [r - 1] * n
         elif b == 2:
-            v = [(1 << (i % 255)) % r for i in range(n)]                       # single bits: every row, every shift
+            v = [(1 << (i % 255)) % r for i in range(n)]                       # single bits: every row
         elif b == 3:
             v = [((1 << (bits + 1)) - 1) << ((bits + 1) * (i % 16)) for i in range(n)]
         elif b == 4:
             v = [5] * n                                                        # one long list
         elif b == 5:
             v = [(1 << 255) % r if i % 2 else ((1 << (bits)) << (7 * (i % 30))) % r for i in range(n)]
+        elif b == 6:
+            v = [((1 << (200 + i % 55)) - 1 - (i % 7)) % r for i in range(n)]  # long runs of ones: the carry crosses every slot
+        elif b == 7:
+            v = [(int("5" * 64, 16) >> (i % 9)) % r for i in range(n)]         # alternating bits
+        elif b == 8:
+            v = [(int("a" * 64, 16) >> (i % 5)) % r for i in range(n)]
+        elif b == 9:
+            v = [r - 1 - i if i % 2 else (r >> 1) + i for i in range(n)]       # top digits on the last rows, (r - 1) / 2 and neighbours
+        elif b == 10:
+            v = [((1 << width) - 1) * (1 << (i % 240)) % r for i in range(n)]  # 2^w - 1 at every offset of every slot
+        elif b == 11:
+            v = [(((1 << (width - 1)) + (i % 3) - 1) << (i % 241)) % r for i in range(n)]   # around the sign threshold of a digit
         else:
             v = [rng.randrange(r) for _ in range(n)]
         vecs.append(b"".join(x.to_bytes(32, "little") for x in v))
     ctx.prof_reset()
     ctx.prof_enable(True)
     got = ctx.g1_msm_batch(tabled, b"".join(vecs), n)
-    assert ctx.prof_get("k_g1_merge_twins")[1] == 1                            # the odd-multiple path did run
+    assert ctx.prof_get("k_g1_merge_twins")[1] == 0                            # no twins in this tiling
     ctx.prof_enable(False)
     assert len(got) == batch
     for lo in range(0, batch, 64 * 16):                                        # window rows: 64 vectors per call, every 16th chunk
         assert ctx.g1_msm_batch(tabled, b"".join(vecs[lo : lo + 64]), n) == got[lo : lo + 64], lo
-    for b in (0, 1, 2, 3, 4, 5, 6, batch - 1):
+    for b in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, batch - 1):
         assert got[b] == _oracle_msm_be(srs_bytes, vecs[b], n), b
     tabled.close()
 

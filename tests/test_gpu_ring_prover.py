@@ -140,9 +140,10 @@ def test_ring_1024_domain_2048_matches_oracle(ctx):
     assert proofs[1].encode() == oring.ring_vrf_prove(o_ring, o_root, b"b", b"ad", sk)
     assert proofs[1].verify(b"b", b"ad", ring, root)
     assert d.RingVRF[d.Bandersnatch].batch_verify(proofs, [b"a", b"b"], [b"", b"ad"], ring, root)
-    # BASELINE config 4's batch: 1024 deterministic proofs in ONE call.  At that size the KZG MSMs take the odd-multiple buckets over the
-    # bit-row SRS table (dr_srs_table_info) where the two proofs above took its window rows: same inputs, same bytes.
-    assert params.pcs._srs().device().table_info(3 * 2048, 1024)["odd_window_bits"] == 13
+    # BASELINE config 4's batch: 1024 deterministic proofs in ONE call.  At that size the KZG MSMs recode their scalars in width-13 non-adjacent form
+    # over the bit-row SRS table (dr_srs_table_info) where the two proofs above took its window rows: same inputs, same bytes.
+    tinfo = params.pcs._srs().device().table_info(3 * 2048, 1024)
+    assert tinfo["tiling"] == "non-adjacent form" and tinfo["tiling_bits"] == 13
     n = 1024
     als = [b"a", b"b"] + [b"in-%d" % i for i in range(n - 2)]
     ads = [b"", b"ad"] + [b"ad-%d" % (i % 3) for i in range(n - 2)]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of environment knobs inside ONE GPU-box call: bash tools/ab_knobs.sh "X=1" "DOTRING_PROVE_PARTS=2" ...
 for cfg in "$@"; do
-  env $cfg python bench.py --extras 0 --msm-log2n 0 --cpu-proofs 2 --cpu-workers 0 --steps 4 > gpurun_out/ab.json 2> gpurun_out/ab.err
+  env $cfg python bench.py --extras 0 --msm-log2n 0 --cpu-proofs 2 --cpu-workers 0 --steps ${AB_STEPS:-4} > gpurun_out/ab.json 2> gpurun_out/ab.err
   python - "$cfg" <<PY
 import json,sys
 l=json.loads(open("gpurun_out/ab.json").read().strip().splitlines()[-1])
