@@ -487,6 +487,30 @@ def test_ntt_matches_oracle(ctx, log2n):
     assert back == data
 
 
+def test_ntt_matches_the_reference_kernel_fixtures(ctx, golden_dir):
+    """dr_ntt against outputs of the REFERENCE'S OWN NTT kernel (tests/golden/ntt/ntt_cases.json, written by oracle/gen_ntt_fixtures.py
+    from ntt.pyx + scalar.pyx over bls12_381_scalar.c): n = 2 ... 16384, forward, inverse with scale 1/n, an arbitrary scale; three
+    transforms per call so the batched path runs too."""
+    import hashlib
+    import json
+
+    import os
+
+    from oracle.gen_ntt_fixtures import seeded_inputs as _ntt_fixture_inputs
+
+    with open(os.path.join(golden_dir, "ntt", "ntt_cases.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) == 42
+    for case in cases:
+        n = 1 << case["log2n"]
+        raw = b"".join(v.to_bytes(32, "little") for v in _ntt_fixture_inputs(n, case["input_tag"]))
+        assert hashlib.sha256(raw).hexdigest() == case["input_sha256"]
+        scale = None if case["scale"] is None else int(case["scale"], 16)
+        out = ctx.ntt(raw * 3, case["log2n"], int(case["omega"], 16), scale)
+        for b in range(3):
+            assert hashlib.sha256(out[32 * n * b : 32 * n * (b + 1)]).hexdigest() == case["output_sha256"], (case["log2n"], case["kind"], b)
+
+
 def test_bsn_decode_points_matches_oracle(ctx):
     """dr_bsn_decode_points (decompression + subgroup check on the GPU) against the oracle's dec_point on valid keys,
     random strings (about half are not x-coordinates of anything, most of the rest have a torsion component),

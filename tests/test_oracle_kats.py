@@ -1,5 +1,6 @@
 """CPU: the oracle against every golden vector the reference's own tests hold for the hot path."""
 import ctypes
+import hashlib
 import json
 import os
 import random
@@ -210,3 +211,62 @@ def test_params_capacity_table():
         ring.Params.from_ring_size(3840)
     with pytest.raises(ValueError):
         ring.Params.from_ring_size(0)
+
+
+from oracle.gen_ntt_fixtures import seeded_inputs as _ntt_fixture_inputs      # the input rule of tests/golden/ntt/ntt_cases.json
+
+
+def test_ntt_matches_the_reference_kernel_fixtures(golden_dir):
+    """tests/golden/ntt/ntt_cases.json holds outputs of the REFERENCE'S OWN NTT kernel (ntt.pyx + scalar.pyx over bls12_381_scalar.c,
+    built into oracle/_ref by oracle/build_ref_ntt.sh, vectors written by oracle/gen_ntt_fixtures.py): n = 2 ... 16384, forward,
+    inverse with scale 1/n, and an arbitrary scale.  The oracle's NTT must reproduce every one of them."""
+    with open(os.path.join(golden_dir, "ntt", "ntt_cases.json")) as f:
+        fx = json.load(f)
+    assert int(fx["modulus"], 16) == bsn.P and len(fx["cases"]) == 42
+    for case in fx["cases"]:
+        n = 1 << case["log2n"]
+        vals = _ntt_fixture_inputs(n, case["input_tag"])
+        raw = b"".join(v.to_bytes(32, "little") for v in vals)
+        assert hashlib.sha256(raw).hexdigest() == case["input_sha256"]
+        if "input" in case:
+            assert [int(v, 16) for v in case["input"]] == vals
+        scale = None if case["scale"] is None else int(case["scale"], 16)
+        out = bytes(coracle.ntt_raw(raw, n, int(case["omega"], 16), scale))
+        assert hashlib.sha256(out).hexdigest() == case["output_sha256"], (case["log2n"], case["kind"])
+        got = [int.from_bytes(out[32 * i : 32 * i + 32], "little") for i in range(n)]
+        assert [hex(v) for v in got[:4]] == case["output_head"] and [hex(v) for v in got[-4:]] == case["output_tail"]
+        if "output" in case:
+            assert [hex(v) for v in got] == case["output"]
+
+
+def test_reference_ntt_build_matches_fixtures_when_present(golden_dir):
+    """Where oracle/_ref/pyx exists (this container: built from /root/reference by oracle/build_ref_ntt.sh), the reference kernel
+    itself is run again on three cases and must equal both the committed fixtures and the oracle."""
+    root = os.path.abspath(os.path.join(golden_dir, "..", ".."))
+    pyx = os.path.join(root, "oracle", "_ref", "pyx")
+    if not os.path.isdir(os.path.join(pyx, "dot_ring")):
+        pytest.skip("oracle/_ref/pyx not built (the reference sources are absent here)")
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, json, hashlib; sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])\n"
+        "from oracle import gen_ntt_fixtures as g\n"
+        "from dot_ring.ring_proof.polynomial.ntt import BlsScalarNTTPlan\n"
+        "out = {}\n"
+        "for log2n, kind in ((3, 'forward'), (11, 'inverse'), (13, 'scaled')):\n"
+        "    n = 1 << log2n; w = g.root_of_unity(n)\n"
+        "    omega = w if kind != 'inverse' else pow(w, -1, g.P)\n"
+        "    scale = None if kind == 'forward' else pow(n, -1, g.P) if kind == 'inverse' else (0x1234567 + 977 * log2n) * pow(3, 200 + log2n, g.P) % g.P\n"
+        "    v = g.seeded_inputs(n, f'{log2n}-{kind}')\n"
+        "    plan = BlsScalarNTTPlan(g.stage_twiddles(n, omega), g.bit_reverse(n))\n"
+        "    plan.transform(v) if scale is None else plan.transform_scaled(v, scale)\n"
+        "    out[f'{log2n}-{kind}'] = g.digest(v)\n"
+        "print(json.dumps(out))\n"
+    )
+    proc = subprocess.run([sys.executable, "-c", code, os.path.abspath(pyx), root], capture_output=True, text=True, check=True)
+    got = json.loads(proc.stdout)
+    with open(os.path.join(golden_dir, "ntt", "ntt_cases.json")) as f:
+        fx = {c["input_tag"]: c["output_sha256"] for c in json.load(f)["cases"]}
+    for tag, dg in got.items():
+        assert fx[tag] == dg, tag
