@@ -242,7 +242,7 @@ void dr_ctx_destroy(dr_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (Scratch* s : {&ctx->scalars, &ctx->digits, &ctx->counts, &ctx->offsets, &ctx->cursor, &ctx->tiles, &ctx->sorted,
                        &ctx->buckets, &ctx->partial, &ctx->winsum, &ctx->result, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->perm, &ctx->cells,
-                       &ctx->cell_off, &ctx->vfy_bases, &ctx->vfy_in, &ctx->vfy_std})
+                       &ctx->cell_off, &ctx->part_base, &ctx->heavy, &ctx->vfy_bases, &ctx->vfy_in, &ctx->vfy_std})
         s->release();
     for (auto& it : ctx->prof_pending) {
         (void)hipEventDestroy(it.second.first);

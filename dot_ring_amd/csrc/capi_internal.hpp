@@ -97,7 +97,7 @@ struct dr_ctx {
     std::map<std::string, ProfEntry> prof_data;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
     // MSM workspaces
-    Scratch scalars, digits, counts, offsets, cursor, tiles, sorted, buckets, partial, winsum, result, io_a, io_b, io_c, perm, cells, cell_off;
+    Scratch scalars, digits, counts, offsets, cursor, tiles, sorted, buckets, partial, winsum, result, io_a, io_b, io_c, perm, cells, cell_off, part_base, heavy;
     Scratch vfy_bases, vfy_in, vfy_std;      // dr_ringvrf_verify_batch: decompressed G1 points stay resident between its steps
     dr_ctx* aux = nullptr;                   // second stream for the latency-bound Bandersnatch side of the batch verifier
     dr_ctx* aux2 = nullptr;                  // third stream: the verifier's two G1 MSMs run side by side
@@ -317,8 +317,9 @@ struct MsmTable {
     uint32_t short_from = 0xffffffffu, n_short = 0;   // batched MSM: vectors from this index on are zero beyond n_short (sort hint)
     bool fold_sign = false;              // scalars above r / 2 enter as their negatives (difference columns: r - 1 becomes -1, one digit)
 };
+// exact_streams: internal — the second run of a call whose partition sort overfilled a stream (see msm_device)
 int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch, std::vector<drh::G1>& results,
-               const MsmTable* tbl = nullptr);
+               const MsmTable* tbl = nullptr, bool exact_streams = false);
 MsmTable srs_table(const dr_srs* srs, size_t offset);
 // the tiling msm_device takes for `batch` MSMs of n points over this table: mode 0 = the table's window rows, 1 = windows of c bits with
 // odd-multiple buckets and twins, 2 = width-c non-adjacent form (bit-row tables, hundreds of MSMs); slots = digit rows per scalar,

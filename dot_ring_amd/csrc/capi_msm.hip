@@ -176,12 +176,14 @@ Tiling tiling_for(const MsmTable& t, size_t n, size_t batch) {
 }
 
 int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch,
-               std::vector<drh::G1>& results, const MsmTable* tbl) {
+               std::vector<drh::G1>& results, const MsmTable* tbl, bool exact_streams) {
     results.assign(batch, drh::G1::inf());
+    const uint32_t* const d_bases_in = d_bases;          // (d_bases is redirected to the table below; a second run starts from the caller's)
     if (n == 0 || batch == 0) return DR_OK;
     if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "MSM size must be below 2^31");
     WideToken token_(ctx, batch >= 64);
     const bool single = tbl != nullptr && tbl->table != nullptr;
+    PhaseTrace tr_("msm_device");                 // DOTRING_TRACE=1: where the wall time of a call goes
     // comb table + many MSMs: a plain sum of looked-up points per MSM, nothing to sort or reduce
     if (single && tbl->comb && batch >= 32 && g_use_comb) {
         TRY(ctx->result.reserve(batch * 192));
@@ -232,7 +234,10 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     // table mode: split the points of each MSM into index groups when one bucket set per MSM would leave lanes idle
     uint32_t groups = 1;
     if (single) {
-        const size_t target_lanes = 524288;       // 8 waves per SIMD: finer slices balance better than 4 (2^20 bases: accumulate 3.98 -> 3.6 ms)
+        // 8 waves per SIMD: finer slices balance better than 4 (2^20 bases: accumulate 3.98 -> 3.6 ms); below 2^19 points half of that —
+        // every bucket is another lane-step of the reduction's chain, and the walk is short anyway (2^16 pairs over 16-bit windows:
+        // 8 groups 0.875 ms, 16 groups 1.03, 2 groups 0.96)
+        const size_t target_lanes = n >= ((size_t)1 << 19) ? 524288 : 262144;
         while (groups < 64 && batch * groups * (size_t)pl.H < target_lanes && (size_t)n / (groups * 2) >= 64) groups *= 2;
         static const int force_groups = std::getenv("DOTRING_MSM_GROUPS") ? std::atoi(std::getenv("DOTRING_MSM_GROUPS")) : 0;
         if (force_groups > 0 && batch == 1 && (size_t)n / (size_t)force_groups >= 64) groups = (uint32_t)force_groups;
@@ -269,6 +274,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     TRY(ctx->buckets.reserve(nbuckets * 192));
     TRY(ctx->partial.reserve((bsets * pl.T + bsets * (pl.T / 256 + 1)) * 192));
     TRY(ctx->winsum.reserve(bsets * 192));
+    TRY(ctx->heavy.reserve((ndigits / 1024 + ndigits / 4096 + 64) * 192));          // segment sums of lists >= 1024 entries (segments >= 1024)
     hipStream_t st = ctx->stream;
     auto exclusive_scan = [&](const uint32_t* in, uint32_t* out, size_t count) {
         const unsigned nt = div_up(count, dr::SCAN_TILE);
@@ -290,7 +296,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         while (part_p < dr::PART_MAX_P && (pl.H / part_p > dr::PART_MAX_HP || per_set_digits / part_p > chunk - chunk / 16)) part_p *= 2;
         while ((pl.H >> part_shift) > part_p) part_shift++;
     }
-    const bool part_sort = part_on && !lds_sort && single && batch == 1 && pl.W <= 32 && per_set_scalars <= 65536 && pl.H >= part_p &&
+    const bool part_sort = part_on && !lds_sort && single && batch == 1 && pl.W <= 32 && pl.H >= part_p &&
                            pl.H / part_p <= dr::PART_MAX_HP && per_set_digits / part_p <= 48 * (size_t)(dr::PART_STAGE - dr::PART_SLACK) &&
                            bsets * per_set_digits < (1ull << 32) && per_set_digits >= 65536;
     if (lds_sort) {
@@ -328,10 +334,13 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
                                    ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
         }));
     }
-    // partition sort: every partition stream gets room for 4x its share of the set's entries (at least 64 k): 0.27 GB of streams
-    // at 2^20 pairs where room for ALL entries of the set in each of the 32 streams took 2.1 GB.  A distribution that overfills a
-    // stream (few distinct scalars) shows in the fill counters after pass A and takes the global-atomic path below instead.
+    // partition sort: every partition stream gets room for 4x its share of the set's entries (at least 64 k records of 8 bytes: 0.44 GB
+    // of streams at 2^20 pairs and 512 partitions).  Pass A counts every entry whether or not it fitted; a distribution that overfills a
+    // stream (few distinct scalars) shows in the fill counters, and pass A then runs again with the streams packed at their exact
+    // offsets.  Only a partition of more than 64 stage chunks (2.2 M entries) takes the global-atomic path below.
     bool sorted_done = lds_sort;
+    const uint32_t* part_flag = nullptr;
+    uint32_t part_overflow = 0;
     if (!sorted_done && part_sort) {
         dr::PartParams pp{};
         pp.n = (uint32_t)n; pp.H = pl.H; pp.groups = groups; pp.P = part_p; pp.pshift = part_shift;
@@ -341,23 +350,43 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         pp.capacity = (uint32_t)per_set_digits;
         pp.tbl_stride = tbl->stride; pp.tbl_offset = tbl->offset;
         for (int w = 0; w < pl.W; w++) pp.row[w] = pl.wt.row[w];
-        TRY(ctx->digits.reserve(bsets * (size_t)part_p * pp.cap_part * 4));
-        TRY(ctx->cursor.reserve(bsets * (size_t)part_p * 4));
+        const size_t nparts = bsets * (size_t)part_p;
+        TRY(ctx->digits.reserve(nparts * pp.cap_part * 8));
+        TRY(ctx->cursor.reserve((nparts + 1) * 4));               // fill counters + the overflow flag
+        TRY(ctx->part_base.reserve(nparts * 4));
         TRY(ctx->sorted.reserve(bsets * per_set_digits * 4));
-        HIP_TRY(hipMemsetAsync(ctx->cursor.p, 0, bsets * (size_t)part_p * 4, st));
-        TRY(launch(ctx, "k_g1_part_scatter", [&] {
-            hipLaunchKernelGGL(dr::k_g1_part_scatter, dim3((unsigned)(bsets * pp.tiles_per_set)), dim3(dr::PART_BLOCK), 0, st, d_scalars, pl.wt, pp,
-                               ctx->cursor.as<uint32_t>(), ctx->digits.as<uint32_t>());
-        }));
-        std::vector<uint32_t> fill(bsets * (size_t)part_p);
-        HIP_TRY(hipMemcpyAsync(fill.data(), ctx->cursor.p, fill.size() * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        uint32_t* d_flag = ctx->cursor.as<uint32_t>() + nparts;
+        const uint32_t* d_exact = nullptr;
         bool fits = true;
-        for (uint32_t f : fill) fits = fits && f <= pp.cap_part;
+        if (exact_streams) {
+            // second run of this call: the first try overfilled a stream.  Its fill counters — still in place — are exact whether or not
+            // a record fitted: pack the streams at their exact offsets (they take at most the first try's room) and scatter again.
+            std::vector<uint32_t> fill(nparts), exact(nparts);
+            HIP_TRY(hipMemcpyAsync(fill.data(), ctx->cursor.p, nparts * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            uint64_t run = 0;
+            uint32_t most = 0;
+            for (size_t q = 0; q < nparts; q++) { exact[q] = (uint32_t)run; run += fill[q]; most = std::max(most, fill[q]); }
+            fits = most <= dr::PART_MAX_CHUNKS * (dr::PART_STAGE - dr::PART_SLACK) && run <= nparts * (uint64_t)pp.cap_part;
+            if (fits) {
+                HIP_TRY(hipMemcpyAsync(ctx->part_base.p, exact.data(), nparts * 4, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipStreamSynchronize(st));               // `exact` leaves scope
+                d_exact = ctx->part_base.as<uint32_t>();
+            }
+        }
+        if (fits) {
+            HIP_TRY(hipMemsetAsync(ctx->cursor.p, 0, (nparts + 1) * 4, st));
+            TRY(launch(ctx, "k_g1_part_scatter", [&] {
+                hipLaunchKernelGGL(dr::k_g1_part_scatter, dim3((unsigned)(bsets * pp.tiles_per_set)), dim3(dr::PART_BLOCK), 0, st, d_scalars, pl.wt, pp,
+                                   ctx->cursor.as<uint32_t>(), d_exact, ctx->digits.as<uint2>());
+            }));
+        }
+        if (!exact_streams) part_flag = d_flag;                   // read back with the results: set => this call runs again, exact
         if (fits) {
             TRY(launch(ctx, "k_g1_part_sort", [&] {
-                hipLaunchKernelGGL(dr::k_g1_part_sort, dim3((unsigned)(bsets * part_p)), dim3(dr::PART_BLOCK), 0, st, ctx->digits.as<uint32_t>(),
-                                   ctx->cursor.as<uint32_t>(), pp, ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(), ctx->sorted.as<uint32_t>());
+                hipLaunchKernelGGL(dr::k_g1_part_sort, dim3((unsigned)nparts), dim3(dr::PART_BLOCK), 0, st, ctx->digits.as<uint2>(),
+                                   ctx->cursor.as<uint32_t>(), d_exact, pp, d_flag, ctx->counts.as<uint32_t>(), ctx->offsets.as<uint32_t>(),
+                                   ctx->sorted.as<uint32_t>());
             }));
             sorted_done = true;
         }
@@ -380,6 +409,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
                                ctx->sorted.as<uint32_t>());
         }));
     }
+    tr_.mark("sort");
     // size-ordered bucket permutation for the accumulate kernel
     TRY(launch(ctx, "k_size_sort", [&] {
         hipLaunchKernelGGL(dr::k_size_hist, dim3(szblocks), dim3(dr::SZ_BLOCK), 0, st, ctx->counts.as<uint32_t>(), nbuckets, szblocks,
@@ -401,9 +431,13 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         hipLaunchKernelGGL(dr::k_g1_accumulate_long<16>, dim3(2048), dim3(64), 0, st, d_bases, pt_words, ctx->sorted.as<uint32_t>(),
                            ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(), ctx->cell_off.as<uint32_t>(),
                            szblocks, d_pick, ctx->buckets.as<uint32_t>());
-        hipLaunchKernelGGL(dr::k_g1_accumulate_long<64>, dim3(2048), dim3(64), 0, st, d_bases, pt_words, ctx->sorted.as<uint32_t>(),
+        // lists of 1024 entries or more (equal scalars, 0 / 1 columns): segments spread over 2048 waves, then one wave per bucket folds
+        // its segment sums
+        hipLaunchKernelGGL(dr::k_g1_accumulate_heavy, dim3(dr::G1_HEAVY_SLOTS), dim3(64), 0, st, d_bases, pt_words, ctx->sorted.as<uint32_t>(),
                            ctx->offsets.as<uint32_t>(), ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(), ctx->cell_off.as<uint32_t>(),
-                           szblocks, d_pick, ctx->buckets.as<uint32_t>());
+                           szblocks, ctx->buckets.as<uint32_t>(), ctx->heavy.as<uint32_t>());
+        hipLaunchKernelGGL(dr::k_g1_heavy_fold, dim3(256), dim3(64), 0, st, ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(),
+                           ctx->cell_off.as<uint32_t>(), szblocks, ctx->heavy.as<uint32_t>(), ctx->buckets.as<uint32_t>());
     }));
     if (aux) {
         const size_t lanes = bsets * (size_t)std::max<uint32_t>(1, pl.H >> 4);
@@ -421,8 +455,12 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     // a single MSM over a wide window table (H >= 8192 buckets per index group): workgroup scan, (V, S) pairs to the host
     // (DOTRING_MSM_WGSCAN=0: chunk sums + double-and-add + fold, as in round 2)
     static const bool wgscan_on = std::getenv("DOTRING_MSM_WGSCAN") == nullptr || std::atoi(std::getenv("DOTRING_MSM_WGSCAN")) != 0;
-    const bool wgscan = wgscan_on && !setscan && !leveled && single && batch == 1 && pl.H >= 8192 && pl.H % dr::WS_SPAN == 0;
-    const size_t wg_per_set = pl.H / dr::WS_SPAN, wg_count = bsets * wg_per_set;
+    // buckets per lane of that scan: as few as keep the launch within one wave per SIMD (65536 lanes), at most 8
+    uint32_t ws_per_lane = 1;
+    while (ws_per_lane < 8 && bsets * (size_t)pl.H > (size_t)65536 * ws_per_lane) ws_per_lane *= 2;
+    const uint32_t ws_span = dr::WS_BLOCK * ws_per_lane;
+    const bool wgscan = wgscan_on && !setscan && !leveled && single && batch == 1 && pl.H >= 8192 && pl.H % ws_span == 0;
+    const size_t wg_per_set = pl.H / ws_span, wg_count = bsets * wg_per_set;
     if (setscan) {
         const size_t cnt = bsets * pl.T;
         TRY(ctx->partial.reserve(2 * cnt * 192));
@@ -471,8 +509,13 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         // (V, S) pairs are combined on the host below
         TRY(ctx->partial.reserve(2 * wg_count * 192));
         TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
-            hipLaunchKernelGGL(dr::k_g1_reduce_wg_scan, dim3((unsigned)wg_count), dim3(dr::WS_BLOCK), 0, st, ctx->buckets.as<uint32_t>(),
-                               ctx->partial.as<uint32_t>());
+            uint32_t* in = ctx->buckets.as<uint32_t>();
+            uint32_t* out = ctx->partial.as<uint32_t>();
+            const dim3 grid((unsigned)wg_count), block(dr::WS_BLOCK);
+            if (ws_per_lane == 8) hipLaunchKernelGGL(dr::k_g1_reduce_wg_scan<8>, grid, block, 0, st, in, out);
+            else if (ws_per_lane == 4) hipLaunchKernelGGL(dr::k_g1_reduce_wg_scan<4>, grid, block, 0, st, in, out);
+            else if (ws_per_lane == 2) hipLaunchKernelGGL(dr::k_g1_reduce_wg_scan<2>, grid, block, 0, st, in, out);
+            else hipLaunchKernelGGL(dr::k_g1_reduce_wg_scan<1>, grid, block, 0, st, in, out);
         }));
     } else {
         TRY(launch(ctx, "k_g1_reduce_chunks", [&] {
@@ -495,37 +538,64 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     }
 
     static_assert(sizeof(drh::G1) == 192, "XYZZ layout");
+    tr_.mark("enqueue");
     if (single && wgscan) {
-        // set value = sum_g (V_g + 2048 g S_g) over the set's workgroups: a running sum (descending g) on the worker threads, one
-        // bucket set per task; then the index groups are added up
+        // set value = sum_g (V_g + span g S_g) over the set's workgroups (span = 256 x buckets per lane).  Segments of 16 workgroups are folded side by side on the
+        // worker threads — (v, r, w) = (sum V_g, sum S_g, sum (g - g0) S_g) by a running sum —, then sum_g g S_g = sum_s w_s + 16 sum_s s r_s
+        // is a second running sum over the segments (one 2^19-bucket set: 16 segments of ~50 group operations, then ~40).
         std::vector<drh::G1> vs(2 * wg_count);
         HIP_TRY(hipMemcpyAsync(vs.data(), ctx->partial.p, vs.size() * 192, hipMemcpyDeviceToHost, st));
+        if (part_flag) HIP_TRY(hipMemcpyAsync(&part_overflow, part_flag, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        std::vector<drh::G1> per_set(bsets);
-        const std::function<void(size_t)> one_set = [&](size_t set) {
-            drh::G1* p = vs.data() + 2 * set * wg_per_set;
-            g1_dev_to_host(p, 2 * wg_per_set);
+        tr_.mark("gpu");
+        if (part_overflow) return msm_device(ctx, d_bases_in, d_scalars, n, batch, results, tbl, true);
+        constexpr size_t SEG = 16;
+        const size_t segs_per_set = (wg_per_set + SEG - 1) / SEG, nseg = bsets * segs_per_set;
+        std::vector<drh::G1> seg_v(nseg), seg_r(nseg), seg_w(nseg);
+        const std::function<void(size_t)> one_seg = [&](size_t t) {
+            const size_t set = t / segs_per_set, g0 = (t % segs_per_set) * SEG, g1 = std::min(wg_per_set, g0 + SEG);
+            drh::G1* p = vs.data() + 2 * (set * wg_per_set + g0);
+            g1_dev_to_host(p, 2 * (g1 - g0));
             drh::G1 run = drh::G1::inf(), w = drh::G1::inf(), v = drh::G1::inf();
-            for (size_t g = wg_per_set; g-- > 0;) {
+            for (size_t g = g1 - g0; g-- > 0;) {
                 v = drh::g1_add(v, p[2 * g]);
-                if (g >= 1) { run = drh::g1_add(run, p[2 * g + 1]); w = drh::g1_add(w, run); }    // w = sum_g g S_g
+                run = drh::g1_add(run, p[2 * g + 1]);
+                if (g >= 1) w = drh::g1_add(w, run);                                               // w = sum_g (g - g0) S_g
             }
-            for (int k = 0; k < 11; k++) w = drh::g1_dbl(w);                                        // x 2048
-            per_set[set] = drh::g1_add(v, w);
+            seg_v[t] = v; seg_r[t] = run; seg_w[t] = w;
         };
-        // a task is ~60 group operations (~50 us): one per worker thread (parallel_for would keep so few items on one thread)
-        if (drh::WorkerPool* pool = drh::worker_pool()) pool->run(bsets, (unsigned)std::min<size_t>(bsets, drh::host_threads()), one_set);
+        // a task is ~50 group operations (~40 us): one per worker thread (parallel_for would keep so few items on one thread)
+        if (drh::WorkerPool* pool = drh::worker_pool()) pool->run(nseg, (unsigned)std::min<size_t>(nseg, drh::host_threads()), one_seg);
+        else for (size_t t = 0; t < nseg; t++) one_seg(t);
+        std::vector<drh::G1> set_sum(bsets);
+        const std::function<void(size_t)> one_set = [&](size_t set) {
+            drh::G1 v = drh::G1::inf(), w = drh::G1::inf(), run = drh::G1::inf(), sr = drh::G1::inf();
+            for (size_t sg = segs_per_set; sg-- > 0;) {
+                const size_t t = set * segs_per_set + sg;
+                v = drh::g1_add(v, seg_v[t]);
+                w = drh::g1_add(w, seg_w[t]);
+                if (sg >= 1) { run = drh::g1_add(run, seg_r[t]); sr = drh::g1_add(sr, run); }       // sr = sum_s s r_s
+            }
+            for (int k = 0; k < 4; k++) sr = drh::g1_dbl(sr);                                       // x 16
+            w = drh::g1_add(w, sr);
+            for (uint32_t k = 1; k < ws_span; k <<= 1) w = drh::g1_dbl(w);                          // x span
+            set_sum[set] = drh::g1_add(v, w);
+        };
+        if (drh::WorkerPool* pool = bsets > 1 ? drh::worker_pool() : nullptr) pool->run(bsets, (unsigned)std::min<size_t>(bsets, drh::host_threads()), one_set);
         else for (size_t set = 0; set < bsets; set++) one_set(set);
         drh::G1 acc = drh::G1::inf();
-        for (size_t set = 0; set < bsets; set++) acc = drh::g1_add(acc, per_set[set]);
+        for (size_t set = 0; set < bsets; set++) acc = drh::g1_add(acc, set_sum[set]);
         results[0] = acc;
+        tr_.mark("host_fold");
     } else if (single) {
         // the bucket-set sum IS the MSM value: no window combination
         if (groups > 1 || batch == 1) {
             // few MSMs: fetch the per-group sums and add them on the host (<= 64 additions per MSM)
             std::vector<drh::G1> parts(bsets);
             HIP_TRY(hipMemcpyAsync(parts.data(), ctx->winsum.p, bsets * 192, hipMemcpyDeviceToHost, st));
+            if (part_flag) HIP_TRY(hipMemcpyAsync(&part_overflow, part_flag, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            if (part_overflow) return msm_device(ctx, d_bases_in, d_scalars, n, batch, results, tbl, true);
             g1_dev_to_host(parts.data(), parts.size());
             for (size_t b = 0; b < batch; b++) {
                 drh::G1 acc = drh::G1::inf();

@@ -670,26 +670,28 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
     }
 }
 
-// ---- 3a''. two-pass sort for a FEW HUGE bucket sets (one 2^20-point MSM over a window table: 16 index groups x 32768
-// buckets, a million entries per set — too many for one workgroup's LDS, and the digits -> global-atomic histogram -> scan ->
-// global-atomic scatter chain above costs 1.5 ms of the 5.3 ms MSM).
-//   pass A (k_g1_part_scatter): a workgroup takes a tile of scalars of one set (2048 at 16 windows), computes their digits and splits the
-//     entries by the top bits of the bucket index into P partitions: per-wave counters in LDS, the tile's entries grouped by
-//     partition in an LDS stage, ONE global atomic per (tile, partition) to reserve room in that partition's stream, then the
-//     stage is copied out in runs of ~1000 entries.  A stream entry packs sign | bucket-in-partition (10 bits) | window (5) |
-//     scalar index within the set (16).
-//   pass B (k_g1_part_sort): one workgroup per (set, partition) sorts its ~32 k entries by bucket entirely in LDS (histogram,
+// ---- 3a''. two-pass sort for a FEW HUGE bucket sets (one 2^16 .. 2^22-point MSM over a window table: at 2^20 one set of 2^19
+// buckets and 13.6 M entries with 20-bit windows — too many for one workgroup's LDS, and the digits -> global-atomic histogram ->
+// scan -> global-atomic scatter chain costs 1.5 ms of such an MSM).
+//   pass A (k_g1_part_scatter): a workgroup takes a tile of scalars of one set (2048 at <= 16 windows), computes their digits and
+//     splits the entries by the top bits of the bucket index into P <= 1024 partitions: counters in LDS (per wave while P <= 64: a
+//     handful of partitions would be 1024 lanes on a few addresses), the tile's entries grouped by partition in an LDS stage, ONE
+//     global atomic per (tile, partition) to reserve room in that partition's stream, then the stage is copied out in runs.
+//     A stream record is 64 bits: the finished `sorted` entry (table index | sign << 31) and the bucket within the partition.
+//   pass B (k_g1_part_sort): one workgroup per (set, partition) sorts its ~30 k records by bucket entirely in LDS (histogram,
 //     scan, placement into a stage, coalesced copy-out — k_g1_sort_sets_staged's second half on a stream instead of digit
 //     rows), and writes counts / offsets / sorted in the layout the accumulate kernel reads.
-// A partition stream has room for cap_part entries (4x an even share): pass A never writes past it, the host compares the fill
-// counters with cap_part after pass A and sorts with the global-atomic kernels when a stream was overfilled (few distinct scalars).
+// Room per stream: first try, cap_part records each (4x an even share) at p * cap_part; pass A counts every entry in part_fill
+// whether or not it fitted, so when a stream was overfilled (few distinct scalars) the host knows the exact sizes and runs pass A
+// again with exact stream offsets (exact_base) — no scalar distribution falls back to global atomics unless one partition holds
+// more than 64 stage chunks (2.2 M entries).  Wave-uniform bins (all-equal scalars) cost one LDS atomic per wave, not 64.
 constexpr int PART_BLOCK = 1024;
-constexpr uint32_t PART_TILE_ENTRIES = 32768, PART_MAX_P = 32, PART_MAX_HP = 1024, PART_STAGE = 36864, PART_SLACK = 2048;
+constexpr uint32_t PART_TILE_ENTRIES = 32768, PART_MAX_P = 1024, PART_MAX_HP = 1024, PART_STAGE = 36864, PART_SLACK = 2048, PART_MAX_CHUNKS = 64;
 
 struct PartParams {
     uint32_t n, H, groups, tiles_per_set, P, pshift;      // pshift = log2(H / P): bucket >> pshift = partition
-    uint32_t tile;                                        // scalars per pass-A workgroup: tile * W <= PART_TILE_ENTRIES
-    uint32_t cap_part;                                    // entries reserved per partition stream
+    uint32_t tile;                                        // scalars per pass-A workgroup: tile * W <= PART_TILE_ENTRIES, tile <= 2048
+    uint32_t cap_part;                                    // records reserved per partition stream (first try)
     uint32_t capacity;                                    // entries reserved per set in `sorted`
     uint32_t tbl_stride, tbl_offset;
     uint8_t row[32];                                      // table row of window w (WindowTable::row; W <= 32 here)
@@ -702,92 +704,140 @@ DR_DEV void part_set_range(const PartParams& pp, uint32_t set, uint32_t& b, uint
     i_hi = (uint32_t)(((uint64_t)(g + 1) * pp.n + pp.groups - 1) / pp.groups);
 }
 
+// one more entry in bins[j] for every active lane; returns the lane's position.  Lanes of a wave that name the same bin are peeled off
+// together, up to four bins per call (few distinct scalars: a million entries in a handful of buckets): one lane adds the group's
+// count and the others take their rank — 64 serialised LDS atomics on one address become one.  Whatever is left (random scalars: the
+// first peel finds its lane alone and the loop stops) takes a plain atomic.
+DR_DEV uint32_t lds_count_aggregated(uint32_t* bins, uint32_t j) {
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long todo = __ballot(1);
+    uint32_t pos = 0;
+    bool done = false;
+#pragma unroll 1
+    for (int round = 0; round < 4 && todo; round++) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t j0 = (uint32_t)__shfl((int)j, leader, 64);
+        const unsigned long long same = __ballot(!done && j == j0);
+        if (__popcll(same) < 2 && round == 0) break;              // spread-out bins: no point in peeling
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&bins[j0], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (!done && j == j0) { pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull)); done = true; }
+        todo &= ~same;
+    }
+    if (!done) pos = atomicAdd(&bins[j], 1u);
+    return pos;
+}
+
 __global__ __launch_bounds__(PART_BLOCK) void k_g1_part_scatter(const uint32_t* __restrict__ scalars, WindowTable wt, PartParams pp,
-                                                                uint32_t* __restrict__ part_fill, uint32_t* __restrict__ streams) {
+                                                                uint32_t* __restrict__ part_fill, const uint32_t* __restrict__ exact_base,
+                                                                uint2* __restrict__ streams) {
     constexpr int WAVES = PART_BLOCK / 64;
     __shared__ uint32_t stage[PART_TILE_ENTRIES];
-    __shared__ uint32_t cnt[WAVES][PART_MAX_P];                   // per-wave counts, then per-wave cursors into the stage
+    __shared__ uint32_t cnt[PART_MAX_P];                          // P <= 64: [wave][P]; else one counter per partition
     __shared__ uint32_t pbase[PART_MAX_P + 1], gbase[PART_MAX_P];
+    __shared__ uint32_t smem[PART_BLOCK / 64];
     const uint32_t set = blockIdx.x / pp.tiles_per_set, tile = blockIdx.x % pp.tiles_per_set, tid = threadIdx.x, wave = tid >> 6;
+    const bool per_wave = pp.P * WAVES <= PART_MAX_P;
     uint32_t b, i_lo, i_hi;
     part_set_range(pp, set, b, i_lo, i_hi);
     const uint32_t t_lo = i_lo + tile * pp.tile < i_hi ? i_lo + tile * pp.tile : i_hi, t_hi = t_lo + pp.tile < i_hi ? t_lo + pp.tile : i_hi;
-    for (uint32_t k = tid; k < WAVES * PART_MAX_P; k += PART_BLOCK) (&cnt[0][0])[k] = 0;
+    for (uint32_t k = tid; k < PART_MAX_P; k += PART_BLOCK) cnt[k] = 0;
     __syncthreads();
-    const uint32_t lowmask = (1u << pp.pshift) - 1u;
-    // count per (wave, partition)
+    const uint32_t lowmask = (1u << pp.pshift) - 1u, woff = per_wave ? wave * pp.P : 0u;
+    // count per partition
     for (uint32_t i = t_lo + tid; i < t_hi; i += PART_BLOCK) {
         uint32_t k[9];
         load_scalar_mod_r(scalars, (size_t)b * pp.n + i, k);
         for_each_digit(k, wt, 0, wt.W, [&](int, int32_t d) {
             const uint32_t j = (uint32_t)(d < 0 ? -d : d) - 1u;
-            atomicAdd(&cnt[wave][j >> pp.pshift], 1u);
+            atomicAdd(&cnt[woff + (j >> pp.pshift)], 1u);
         });
     }
     __syncthreads();
-    // stage layout: partition-major, wave-minor; cnt becomes the cursor of each (wave, partition) run
-    if (tid < 64) {
+    // stage layout: partition-major (wave-minor); cnt becomes the cursor of each run
+    {
         uint32_t total = 0;
-        if (tid < pp.P) for (int w = 0; w < WAVES; w++) total += cnt[w][tid];
-        uint32_t x = total;
-#pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            uint32_t y = __shfl_up(x, s, 64);
-            if ((int)tid >= s) x += y;
-        }
         if (tid < pp.P) {
-            uint32_t run = x - total;
-            pbase[tid] = run;
-            gbase[tid] = total ? atomicAdd(&part_fill[(size_t)set * pp.P + tid], total) : 0u;
-            for (int w = 0; w < WAVES; w++) { uint32_t c = cnt[w][tid]; cnt[w][tid] = run; run += c; }
+            if (per_wave) for (int w = 0; w < WAVES; w++) total += cnt[w * pp.P + tid];
+            else total = cnt[tid];
         }
-        if (tid == pp.P - 1) pbase[pp.P] = x;
+        uint32_t grand;
+        const uint32_t run0 = block_exclusive_scan<PART_BLOCK>(total, smem, grand);
+        if (tid < pp.P) {
+            pbase[tid] = run0;
+            gbase[tid] = total ? atomicAdd(&part_fill[(size_t)set * pp.P + tid], total) : 0u;
+            if (per_wave) {
+                uint32_t run = run0;
+                for (int w = 0; w < WAVES; w++) { const uint32_t c = cnt[w * pp.P + tid]; cnt[w * pp.P + tid] = run; run += c; }
+            } else {
+                cnt[tid] = run0;
+            }
+        }
+        if (tid == 0) pbase[pp.P] = grand;
     }
     __syncthreads();
     for (uint32_t i = t_lo + tid; i < t_hi; i += PART_BLOCK) {
         uint32_t k[9];
         load_scalar_mod_r(scalars, (size_t)b * pp.n + i, k);
-        const uint32_t local = i - i_lo;
+        const uint32_t local = i - t_lo;                                        // < 2048
         for_each_digit(k, wt, 0, wt.W, [&](int w, int32_t d) {
             const uint32_t j = (uint32_t)(d < 0 ? -d : d) - 1u;
-            const uint32_t pos = atomicAdd(&cnt[wave][j >> pp.pshift], 1u);
-            stage[pos] = (d < 0 ? 0x80000000u : 0u) | ((j & lowmask) << 21) | ((uint32_t)w << 16) | local;
+            const uint32_t pos = atomicAdd(&cnt[woff + (j >> pp.pshift)], 1u);
+            stage[pos] = (d < 0 ? 0x80000000u : 0u) | ((j & lowmask) << 16) | ((uint32_t)w << 11) | local;
         });
     }
     __syncthreads();
-    // copy out: entry idx of the stage belongs to the partition whose [pbase[p], pbase[p+1]) holds it
-    const uint32_t total = pbase[pp.P];
+    // copy out: record idx of the stage belongs to the partition whose [pbase[p], pbase[p+1]) holds it
+    const uint32_t total = pbase[pp.P], entry0 = pp.tbl_offset + t_lo;
     for (uint32_t idx = tid; idx < total; idx += PART_BLOCK) {
-        uint32_t lo = 0, hi = pp.P;                                 // largest p with pbase[p] <= idx
+        uint32_t lo = 0, hi = pp.P;                                             // largest p with pbase[p] <= idx
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pbase[mid] <= idx) lo = mid; else hi = mid; }
-        const uint32_t at = gbase[lo] + (idx - pbase[lo]);
-        if (at < pp.cap_part) streams[((size_t)set * pp.P + lo) * pp.cap_part + at] = stage[idx];   // an overfull stream: the host sees its fill count
+        const uint32_t at = gbase[lo] + (idx - pbase[lo]), e = stage[idx];
+        const size_t blk = (size_t)set * pp.P + lo;
+        const uint32_t entry = ((uint32_t)pp.row[(e >> 11) & 31u] * pp.tbl_stride + entry0 + (e & 0x7ffu)) | (e & 0x80000000u);
+        if (exact_base) streams[(size_t)exact_base[blk] + at] = make_uint2(entry, (e >> 16) & 0x3ffu);
+        else if (at < pp.cap_part) streams[blk * pp.cap_part + at] = make_uint2(entry, (e >> 16) & 0x3ffu);   // an overfull stream: the host sees its fill count
     }
 }
 
-__global__ __launch_bounds__(PART_BLOCK) void k_g1_part_sort(const uint32_t* __restrict__ streams, const uint32_t* __restrict__ part_fill,
-                                                             PartParams pp, uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                             uint32_t* __restrict__ sorted) {
-    constexpr uint32_t CHUNK = PART_STAGE - PART_SLACK, MAX_CHUNKS = 64;
+__global__ __launch_bounds__(PART_BLOCK) void k_g1_part_sort(const uint2* __restrict__ streams, const uint32_t* __restrict__ part_fill,
+                                                             const uint32_t* __restrict__ exact_base, PartParams pp, uint32_t* __restrict__ overflow,
+                                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
+    constexpr uint32_t CHUNK = PART_STAGE - PART_SLACK, MAX_CHUNKS = PART_MAX_CHUNKS;
     __shared__ uint32_t bins[PART_MAX_HP];
     __shared__ uint32_t stage[PART_STAGE];
     __shared__ uint32_t cs[MAX_CHUNKS + 1], jb[MAX_CHUNKS + 1];
     __shared__ uint32_t smem[PART_BLOCK / 64];
-    __shared__ uint32_t part_base_s;
     const uint32_t blk = blockIdx.x, set = blk / pp.P, part = blk % pp.P, tid = threadIdx.x, HP = 1u << pp.pshift;
-    uint32_t b, i_lo, i_hi;
-    part_set_range(pp, set, b, i_lo, i_hi);
     const uint32_t n_ent = part_fill[blk];
-    const uint32_t* src = streams + (size_t)blk * pp.cap_part;
+    const uint2* src = streams + (exact_base ? (size_t)exact_base[blk] : (size_t)blk * pp.cap_part);
+    if ((!exact_base && n_ent > pp.cap_part) || n_ent > MAX_CHUNKS * CHUNK) {
+        // the first try's stream was overfilled (or no stage plan covers this partition): its buckets read as empty, the flag tells the
+        // host to run the sort again with exact stream offsets — the host does not wait for the fill counters before launching this kernel
+        const size_t bucket0 = (size_t)set * pp.H + (size_t)part * HP;
+        for (uint32_t j = tid; j < HP; j += PART_BLOCK) { counts[bucket0 + j] = 0; offsets[bucket0 + j] = 0; }
+        if (tid == 0) atomicOr(overflow, 1u);
+        return;
+    }
     for (uint32_t j = tid; j < HP; j += PART_BLOCK) bins[j] = 0;
     for (uint32_t k = tid; k <= MAX_CHUNKS; k += PART_BLOCK) { cs[k] = 0xffffffffu; jb[k] = HP; }
-    if (tid == 0) {
-        uint32_t pb = 0;
-        for (uint32_t q = 0; q < part; q++) pb += part_fill[(size_t)set * pp.P + q];
-        part_base_s = pb;
+    // entries of the set's earlier partitions: where this partition's segment of `sorted` begins
+    uint32_t part_base;
+    {
+        uint32_t v = 0;
+        for (uint32_t q = tid; q < part; q += PART_BLOCK) v += part_fill[(size_t)set * pp.P + q];
+        (void)block_exclusive_scan<PART_BLOCK>(v, smem, part_base);          // (ends with a barrier: bins / cs / jb are initialised)
     }
-    __syncthreads();
-    for (uint32_t idx = tid; idx < n_ent; idx += PART_BLOCK) atomicAdd(&bins[(src[idx] >> 21) & 0x3ffu], 1u);
+    // (four records in flight per lane: a partition of a million records — equal scalars — is one workgroup's work)
+    for (uint32_t i0 = tid; i0 < n_ent; i0 += 4 * PART_BLOCK) {
+        uint32_t jj[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) jj[u] = i0 + u * PART_BLOCK < n_ent ? src[i0 + u * PART_BLOCK].y : 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (jj[u] != 0xffffffffu) (void)lds_count_aggregated(bins, jj[u]);
+    }
     __syncthreads();
     const uint32_t per = (HP + PART_BLOCK - 1) / PART_BLOCK, lo = tid * per < HP ? tid * per : HP, hi = lo + per < HP ? lo + per : HP;
     uint32_t local = 0;
@@ -799,7 +849,7 @@ __global__ __launch_bounds__(PART_BLOCK) void k_g1_part_sort(const uint32_t* __r
     }
     uint32_t total;
     uint32_t run = block_exclusive_scan<PART_BLOCK>(local, smem, total);
-    const uint32_t base = set * pp.capacity + part_base_s;
+    const uint32_t base = set * pp.capacity + part_base;
     const uint32_t K = (total + CHUNK - 1) / CHUNK;                 // 1 for evenly spread scalars; <= MAX_CHUNKS (host)
     for (uint32_t j = lo; j < hi; j++) {
         const uint32_t c = bins[j];
@@ -819,18 +869,21 @@ __global__ __launch_bounds__(PART_BLOCK) void k_g1_part_sort(const uint32_t* __r
         }
     }
     __syncthreads();
-    const uint32_t entry0 = pp.tbl_offset + i_lo;
     for (uint32_t k = 0; k < K; k++) {
         const uint32_t j_lo = jb[k], j_hi = jb[k + 1], p_lo = cs[k], p_hi = cs[k + 1], c0 = k * CHUNK;
         if (j_lo < j_hi) {
-            for (uint32_t idx = tid; idx < n_ent; idx += PART_BLOCK) {
-                const uint32_t e = src[idx], j = (e >> 21) & 0x3ffu;
-                if (j >= j_lo && j < j_hi) {
-                    const uint32_t pos = atomicAdd(&bins[j], 1u);
-                    const uint32_t entry = ((uint32_t)pp.row[(e >> 16) & 31u] * pp.tbl_stride + entry0 + (e & 0xffffu)) | (e & 0x80000000u);
-                    const uint32_t rel = pos - c0;
-                    if (rel < PART_STAGE) stage[rel] = entry;
-                    else sorted[base + pos] = entry;
+            for (uint32_t i0 = tid; i0 < n_ent; i0 += 4 * PART_BLOCK) {
+                uint2 e[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) e[u] = i0 + u * PART_BLOCK < n_ent ? src[i0 + u * PART_BLOCK] : make_uint2(0u, 0xffffffffu);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (e[u].y >= j_lo && e[u].y < j_hi) {
+                        const uint32_t pos = lds_count_aggregated(bins, e[u].y);
+                        const uint32_t rel = pos - c0;
+                        if (rel < PART_STAGE) stage[rel] = e[u].x;
+                        else sorted[base + pos] = e[u].x;
+                    }
                 }
             }
         }
@@ -887,7 +940,7 @@ __global__ __launch_bounds__(SZ_BLOCK) void k_size_place(const uint32_t* __restr
 // and one lane adding them one after the other would be the kernel's whole run time (6145 equal scalars: 28 ms in one lane, 0.5 ms
 // in a wave); odd-multiple buckets put a few hundred into the lowest buckets of EVERY set.  Lists of G1_LONG_BUCKET (256) entries
 // or more — the size ordering puts them first in `perm` — are left to k_g1_accumulate_long: 16 lanes per bucket (four buckets per
-// wave) up to G1_HEAVY_BUCKET entries, a whole wave beyond.  The prover's dense MSMs over window rows (~66 points per bucket,
+// wave) up to G1_HEAVY_BUCKET entries; longer ones are cut into segments, a wave each (k_g1_accumulate_heavy).  The prover's dense MSMs over window rows (~66 points per bucket,
 // Poisson) never get there.
 constexpr uint32_t G1_LONG_BUCKET = 256;                  // (upper bound of the per-launch limit, k_size_pick)
 // The list length from which a launch hands its lists to k_g1_accumulate_long.  One lane adds an entry per ~17 us (two waves share a
@@ -917,7 +970,7 @@ __global__ __launch_bounds__(256) void k_size_pick(const uint32_t* __restrict__ 
         pick[1] = idx_l;
     }
 }
-constexpr uint32_t G1_HEAVY_BUCKET = 4096;
+constexpr uint32_t G1_HEAVY_BUCKET = 1024;
 
 DR_DEV G1Xyzz g1_walk(const uint32_t* __restrict__ bases, uint32_t pt_words, const uint32_t* __restrict__ sorted, uint32_t beg, uint32_t len, uint32_t first,
                       uint32_t stride) {
@@ -962,7 +1015,7 @@ DR_DEV G1Xyzz xyzz_shfl_down(const G1Xyzz& p, unsigned delta) {
 }
 // LANES (16 or 64) lanes per long bucket: perm[0 .. n_long), n_long = where the size classes below G1_LONG_BUCKET begin in the
 // exclusive scan of the [class][block] cells.  The lanes stride over the list, a shuffle tree folds their partial sums.  The
-// 16-lane instance takes lists of [G1_LONG_BUCKET, G1_HEAVY_BUCKET) entries, four per wave; the 64-lane instance the rest.
+// Lists of [the launch's limit, G1_HEAVY_BUCKET) entries, four per wave; longer ones: k_g1_accumulate_heavy.
 // Grid-stride, so a fixed small grid serves any number of them; returns at once when there are none.
 template <int LANES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_accumulate_long(const uint32_t* __restrict__ bases, uint32_t pt_words, const uint32_t* __restrict__ sorted,
@@ -980,13 +1033,111 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const bool have = t < n_long;
         const size_t b = have ? perm[t] : 0;
         const uint32_t len = have ? counts[b] : 0;
-        const bool mine = have && (LANES == 64 ? len >= G1_HEAVY_BUCKET : (len >= long_from && len < G1_HEAVY_BUCKET));
+        const bool mine = have && len >= long_from && len < G1_HEAVY_BUCKET;
         if (__ballot(mine) == 0) continue;
         G1Xyzz acc = g1_walk(bases, pt_words, sorted, have ? offsets[b] : 0u, mine ? len : 0u, lane, LANES);
 #pragma unroll 1
         for (unsigned d = LANES / 2; d >= 1; d >>= 1) acc = g1_add(acc, xyzz_shfl_down<LANES>(acc, d));
         if (mine && lane == 0) store_xyzz(buckets, b, acc);
     }
+}
+
+// Lists of G1_HEAVY_BUCKET entries or more — equal scalars, 0/1 columns, r - 1 everywhere: a window's whole digit row in one bucket,
+// a million entries at 2^20 — are cut into segments (heavy_segment_size), one wave per segment
+// (k_g1_accumulate_heavy), and the segment sums of a bucket are folded by one wave (k_g1_heavy_fold): no wave serialises more than
+// 64 additions per lane, whatever the scalars.  Both kernels find their work by the same scan: the buckets of the largest size class
+// (>= 696 entries) lead `perm`; 64 of them at a time, a wave prefix sum over their segment counts numbers the segments, and segment s
+// belongs to block s mod gridDim.  Fixed small grids; both return at once when the class is empty.
+constexpr uint32_t G1_HEAVY_SLOTS = 2048;                 // grid of k_g1_accumulate_heavy: two waves per SIMD
+// Segment length of a launch: the heavy lists' entries spread over the walk's 2048 waves — total / (2048 - heavy buckets), every
+// bucket's last segment being partial —, a multiple of 64, at least 1024 (a segment ends with a six-addition shuffle tree); 4096 when
+// there are too many heavy buckets for that.  Both kernels compute it the same way (one pass over the leading size class).
+DR_DEV uint32_t heavy_segment_size(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ perm, uint32_t n_class0) {
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long total = 0;
+    uint32_t n_heavy = 0;
+#pragma unroll 1
+    for (uint32_t t0 = 0; t0 < n_class0; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        const uint32_t len = t < n_class0 ? counts[perm[t]] : 0u;
+        const bool heavy = len >= G1_HEAVY_BUCKET;
+        unsigned long long v = heavy ? len : 0u;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) v += (unsigned long long)__shfl_xor((long long)v, sft, 64);
+        total += v;
+        n_heavy += (uint32_t)__popcll(__ballot(heavy));
+    }
+    if (n_heavy == 0 || n_heavy > G1_HEAVY_SLOTS / 2) return 4096u;
+    const unsigned long long per = (total + (G1_HEAVY_SLOTS - n_heavy) - 1) / (G1_HEAVY_SLOTS - n_heavy);
+    const unsigned long long seg = (per + 63ull) & ~63ull;
+    return seg < 1024ull ? 1024u : seg > 0x40000000ull ? 0x40000000u : (uint32_t)seg;
+}
+template <class F>
+DR_DEV void for_each_heavy_bucket(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ perm, uint32_t n_class0, uint32_t seg, F&& f) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t seg_base = 0;
+#pragma unroll 1
+    for (uint32_t t0 = 0; t0 < n_class0; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        const uint32_t b = t < n_class0 ? perm[t] : 0u;
+        const uint32_t len = t < n_class0 ? counts[b] : 0u;
+        const uint32_t nseg = len >= G1_HEAVY_BUCKET ? (len + seg - 1) / seg : 0u;
+        uint32_t incl = nseg;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)incl, sft, 64);
+            if ((int)lane >= sft) incl += y;
+        }
+        unsigned long long heavy = __ballot(nseg != 0);
+        while (heavy) {
+            const int src = __builtin_ctzll(heavy);
+            heavy &= heavy - 1;
+            f((uint32_t)__shfl((int)b, src, 64), (uint32_t)__shfl((int)len, src, 64), (uint32_t)__shfl((int)nseg, src, 64),
+              seg_base + (uint32_t)__shfl((int)(incl - nseg), src, 64));
+        }
+        seg_base += (uint32_t)__shfl((int)incl, 63, 64);
+    }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_accumulate_heavy(
+    const uint32_t* __restrict__ bases, uint32_t pt_words, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
+    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_offsets, uint32_t nblocks,
+    uint32_t* __restrict__ buckets, uint32_t* __restrict__ seg_sums) {
+    const uint32_t n_class0 = cell_offsets[nblocks], lane = threadIdx.x;
+    if (n_class0 == 0) return;
+    const uint32_t seg = heavy_segment_size(counts, perm, n_class0);
+    for_each_heavy_bucket(counts, perm, n_class0, seg, [&](uint32_t b, uint32_t len, uint32_t nseg, uint32_t first_seg) {
+        // segments first_seg .. first_seg + nseg - 1; this block takes those congruent to its index
+        uint32_t s = (blockIdx.x + gridDim.x - first_seg % gridDim.x) % gridDim.x;
+#pragma unroll 1
+        for (; s < nseg; s += gridDim.x) {
+            const uint32_t lo = s * seg, cnt = len - lo < seg ? len - lo : seg;
+            G1Xyzz acc = g1_walk(bases, pt_words, sorted, offsets[b] + lo, cnt, lane, 64);
+#pragma unroll 1
+            for (unsigned d = 32; d >= 1; d >>= 1) acc = g1_add(acc, xyzz_shfl_down<64>(acc, d));
+            if (lane == 0) {
+                if (nseg == 1) store_xyzz(buckets, b, acc);
+                else store_xyzz(seg_sums, first_seg + s, acc);
+            }
+        }
+    });
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_heavy_fold(
+    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_offsets, uint32_t nblocks,
+    const uint32_t* __restrict__ seg_sums, uint32_t* __restrict__ buckets) {
+    const uint32_t n_class0 = cell_offsets[nblocks], lane = threadIdx.x;
+    if (n_class0 == 0) return;
+    const uint32_t seg = heavy_segment_size(counts, perm, n_class0);
+    for_each_heavy_bucket(counts, perm, n_class0, seg, [&](uint32_t b, uint32_t, uint32_t nseg, uint32_t first_seg) {
+        if (nseg < 2 || first_seg % gridDim.x != blockIdx.x) return;
+        G1Xyzz acc = g1_inf();
+#pragma unroll 1
+        for (uint32_t s = lane; s < nseg; s += 64) acc = g1_add(acc, load_xyzz(seg_sums, first_seg + s));
+#pragma unroll 1
+        for (unsigned d = 32; d >= 1; d >>= 1) acc = g1_add(acc, xyzz_shfl_down<64>(acc, d));
+        if (lane == 0) store_xyzz(buckets, b, acc);
+    });
 }
 
 // twins of odd-multiple buckets (digit_bin) back into their buckets: one lane per bucket that has a twin (j < H / 16)
@@ -1221,18 +1372,22 @@ __global__ __launch_bounds__(RS_BLOCK) void k_g1_reduce_set_scan(const uint32_t*
 // buckets).  The chunk kernel's per-lane chain there is 32 running-sum additions + a 15-bit double-and-add (~22 operations), then
 // a fold of 2048 chunk results per set: 0.80 + 0.22 ms at 2^20, pure latency on half a wave per SIMD.  Here a workgroup of 256 lanes
 // takes 2048 consecutive buckets of one set, 8 per lane:
-//     lane l:   R_l = sum_i B_i,  w_l = sum_i (i + 1) B_i          (16 additions, buckets descending)
+//     lane l:   R_l = sum_i B_i,  w_l = sum_i (i + 1) B_i          (16 additions, buckets descending; 8 buckets per lane here)
 //     bucket j = 2048 g + 8 l + i of the set has weight j + 1:  sum = sum_l w_l + 8 sum_l l R_l + 2048 g sum_l R_l
 //     sum_l l R_l = sum_{k >= 1} X_k,  X_k = sum_{l >= k} R_l:  a suffix scan of R over the 256 lanes (8 log steps through LDS),
 //     Y_l = w_l + 8 X_l [l >= 1] (three doublings, one addition), a tree sum of Y (8 steps).
 // Per workgroup out: V = sum_l Y_l and S = X_0 = sum_l R_l; the host adds V + 2048 g S over the H / 2048 workgroups of a set (a
 // running sum of a few dozen points on the worker threads) — 33 additions + 3 doublings deep where the chunk kernel and its fold
 // are ~66.  One inlined addition, operands muxed per step, like k_g1_reduce_set_scan.
-constexpr int WS_BLOCK = 256, WS_PER_LANE = 8, WS_SPAN = WS_BLOCK * WS_PER_LANE;
+// Buckets per lane: 8 fills one wave per SIMD at 2^19 buckets (the kernel's three accumulators take ~390 registers: one resident wave);
+// a smaller MSM has fewer buckets than the chip has such lanes and takes 4, 2 or 1 per lane — the chain is 2 PER_LANE + 17 additions
+// deep (33 at 8, 19 at 1), and the chain is all this launch costs (2^16 pairs: 0.54 -> ~0.3 ms).
+constexpr int WS_BLOCK = 256;
+template <int WS_PER_LANE>
 __global__ __launch_bounds__(WS_BLOCK) void k_g1_reduce_wg_scan(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ out /* [workgroup][2]: V, S */) {
     __shared__ uint32_t sm[WS_BLOCK * XYZZ_RAW_WORDS];
     const uint32_t l = threadIdx.x;
-    const size_t b0 = ((size_t)blockIdx.x * WS_BLOCK + l) * WS_PER_LANE;      // first bucket of this lane (sets are multiples of 2048 buckets)
+    const size_t b0 = ((size_t)blockIdx.x * WS_BLOCK + l) * WS_PER_LANE;      // first bucket of this lane (sets are multiples of the span)
     G1Xyzz run = g1_inf(), w = g1_inf(), v = g1_inf();
     constexpr int n_local = 2 * WS_PER_LANE, lg = 8, s_scan = n_local, s_comb = s_scan + lg, s_tree = s_comb + 1, s_end = s_tree + lg;
 #pragma unroll 1
@@ -1249,8 +1404,12 @@ __global__ __launch_bounds__(WS_BLOCK) void k_g1_reduce_wg_scan(const uint32_t* 
             if (l + dist < WS_BLOCK) b = get_raw(sm + l + dist, WS_BLOCK);
             __syncthreads();
             a = run; dst = 0;
-        } else if (step == s_comb) {                        // v = 8 X_l (lanes >= 1) + w_l
-            if (l >= 1) { v = g1_dbl(run); v = g1_dbl(v); v = g1_dbl(v); }
+        } else if (step == s_comb) {                        // v = PER_LANE X_l (lanes >= 1) + w_l
+            if (l >= 1) {
+                v = run;
+#pragma unroll 1
+                for (int k = 1; k < WS_PER_LANE; k <<= 1) v = g1_dbl(v);
+            }
             a = v; b = w; dst = 2;
         } else {                                            // tree over the workgroup
             const uint32_t dist = WS_BLOCK >> (step - s_tree + 1);

@@ -320,32 +320,73 @@ def test_fr29_field_arithmetic_against_big_integers(ctx):
         assert rec[9:] == [(x * y + x) * r261 % p, (x + 27 * y) * r261 % p, (x - 28 * y) * r261 % p], (hex(x), hex(y))
 
 
-def test_g1_msm_partition_sort_skewed_and_ragged(ctx):
-    """the two-pass partition sort of one huge table MSM (k_g1_part_scatter / k_g1_part_sort) away from uniformly random
-    scalars: a ragged size (index groups of unequal length, a last tile of a few scalars), every scalar equal (one bucket per
-    window gets everything: a partition of many stage chunks, entries past the LDS stage), a 0/1 column, three distinct values,
-    zero scalars mixed in — closed form [sum k_i (1 + i)] G each time"""
+def _skewed_columns(n, rng):
     import bench
 
-    n = (1 << 18) + 37
-    srs = ctx.srs_synthetic(bench.G1_BE, n, first=1)
-    srs.precompute(16)
-    rng = random.Random(4242)
     vals, _ = bench.seeded_scalars(n, b"part")
-    cols = {
+    return {
         "random": vals,
         "same": [0x1234567 << 180 | 0xABCDEF] * n,
         "bits": [rng.randrange(2) for _ in range(n)],
         "three values, zeros": [rng.choice([0, 5, 1 << 200, coracle.FR_P - 7]) for _ in range(n)],
         "minus one": [coracle.FR_P - 1] * n,
     }
-    for name, col in cols.items():
+
+
+def _closed_form_be(col):
+    import bench
+
+    expect = sum(k * (1 + i) for i, k in enumerate(col)) % coracle.FR_P
+    want = coracle.g1_msm_raw(bench.be_to_le_points(bench.G1_BE), expect.to_bytes(32, "little"), 1)
+    return bytes(want)[:48][::-1] + bytes(want)[48:][::-1]
+
+
+def test_g1_msm_partition_sort_skewed_and_ragged(ctx):
+    """the two-pass partition sort of one huge table MSM (k_g1_part_scatter / k_g1_part_sort) away from uniformly random
+    scalars: a ragged size (index groups of unequal length, a last tile of a few scalars), every scalar equal (one bucket per
+    window gets everything: a stream overfilled on the first try, the second run with exact stream offsets, a partition of many
+    stage chunks, entries past the LDS stage), a 0/1 column, three distinct values, zero scalars mixed in — closed form
+    [sum k_i (1 + i)] G each time; 16- and 18-bit windows (32 and 256 partitions: per-wave and per-workgroup counters)"""
+    import bench
+
+    n = (1 << 18) + 37
+    for bits in (16, 18):
+        srs = ctx.srs_synthetic(bench.G1_BE, n, first=1)
+        srs.precompute(bits)
+        for name, col in _skewed_columns(n, random.Random(4242)).items():
+            raw = b"".join(k.to_bytes(32, "little") for k in col)
+            assert ctx.g1_msm(srs, raw) == _closed_form_be(col), (bits, name)
+        srs.close()
+
+
+def test_g1_msm_degenerate_scalars_at_full_size_within_twice_the_random_time(ctx):
+    """BASELINE configs[2] at 2^20 pairs over 20-bit windows (one set of 2^19 buckets, 512 partitions): all-equal scalars, a 0/1
+    column, r - 1 everywhere and three distinct values put a million entries into a handful of buckets.  Their lists are cut into
+    segments over 2048 waves (k_g1_accumulate_heavy / k_g1_heavy_fold) and the sort runs a second time with exact stream offsets:
+    the results still equal the closed form, and no such vector takes more than twice the time of a random one."""
+    import time
+
+    import bench
+
+    n = 1 << 20
+    srs = ctx.srs_synthetic(bench.G1_BE, n, first=1)
+    srs.precompute(20)
+    times = {}
+    for name, col in _skewed_columns(n, random.Random(77)).items():
         raw = b"".join(k.to_bytes(32, "little") for k in col)
-        got = ctx.g1_msm(srs, raw)
-        expect = sum(k * (1 + i) for i, k in enumerate(col)) % coracle.FR_P
-        want = coracle.g1_msm_raw(bench.be_to_le_points(bench.G1_BE), expect.to_bytes(32, "little"), 1)
-        assert got == bytes(want)[:48][::-1] + bytes(want)[48:][::-1], name
+        d = ctx.alloc(32 * n).upload(raw)
+        got = ctx.g1_msm_dev(srs, d, n)
+        assert got == _closed_form_be(col), name
+        for _ in range(2):
+            ctx.g1_msm_dev(srs, d, n)
+        t0 = time.perf_counter()
+        for _ in range(4):
+            ctx.g1_msm_dev(srs, d, n)
+        times[name] = (time.perf_counter() - t0) / 4
+        d.free()
     srs.close()
+    for name, t in times.items():
+        assert t <= 2.0 * times["random"], (name, times)
 
 
 @pytest.mark.parametrize("bits,batch", [(12, 2100), (9, 16500)])
