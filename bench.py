@@ -77,7 +77,7 @@ VALU_PEAK_GADD_S = 1024 * 2.4e9 / 4.2 * 64 / MADD_INSTRUCTIONS / 1e9
 MEASURED_CHAIN_GADD_S = 7.56
 ALG_BYTES_PER_PAIR = 128       # 96 B affine base + 32 B scalar per (base, scalar) pair
 ALG_BYTES_PER_SCALAR_MUL = 160  # 64 B point + 32 B scalar + 64 B result
-MSM_KERNELS = ("k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_part_scatter", "k_g1_part_sort", "k_g1_sort_sets", "k_size_sort", "k_g1_accumulate", "k_g1_merge_twins", "k_g1_reduce_chunks",
+MSM_KERNELS = ("k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_part_scatter", "k_g1_part_sort", "k_g1_sort_sets", "k_size_sort", "k_g1_accumulate", "k_g1_reduce_chunks",
                "k_g1_reduce_windows", "k_g1_horner", "k_g1_results_affine")
 RING_KERNELS = ("k_bsn_scalar_mul", "k_bsn_encode_to_curve", "k_bsn_msm_groups", "k_bsn_fixed_base", "k_te_msm_prepare", "k_te_msm_accumulate",
                 "k_te_msm_reduce", "k_ring_chain", "k_ring_columns", "k_ntt_local",
@@ -224,6 +224,57 @@ def g1_msm_measurement(ctx, log2n: int, steps: int, cpu_sample_log2: int, do_cpu
     return out
 
 
+def g1_msm_batched_leg(ctx, pcs, domain: int, batch: int, steps: int, valu_peak_gadd_s: float):
+    """The second half of BASELINE's metric at the ring sizes it names: the batched G1 MSMs a batch of ring proofs runs —
+    `KZG.commit` of `batch` polynomials of 3N coefficients (/root/reference/dot_ring/ring_proof/pcs/kzg.py:152-175) over the SRS of
+    that domain (the shipped file up to N = 2048, the known-tau SRS at N = 4096) as ONE dr_g1_msm_batch_dev call on device-resident
+    scalar vectors: base-scalar pairs per second, the bucket walk's share of the HBM and VALU ceilings, 2 vectors against the oracle.
+    Scalars: uniform 255-bit values from a seeded generator (reduced mod r on the device)."""
+    import numpy as np
+
+    from oracle import coracle
+
+    n = 3 * domain
+    srs = pcs._srs().device()
+    rng = np.random.default_rng(20261005 + domain)
+    raw = bytearray(rng.bytes(32 * n * batch))
+    raw[31::32] = bytes(b & 0x7F for b in raw[31::32])                 # < 2^255
+    raw = bytes(raw)
+    d_scalars = ctx.alloc(32 * n * batch).upload(raw)
+    out = ctx.g1_msm_batch_dev(srs, d_scalars, n, batch)               # warm-up + the checked results
+    bases_le = be_to_le_points(srs.download(0, n))
+    ok = True
+    for b in (0, batch - 1):
+        want = bytes(coracle.g1_msm_raw(bases_le, raw[32 * n * b : 32 * n * (b + 1)], n))
+        ok = ok and out[b] == want[:48][::-1] + want[48:][::-1]
+    ctx.g1_msm_batch_dev(srs, d_scalars, n, batch)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.g1_msm_batch_dev(srs, d_scalars, n, batch)
+    elapsed = time.perf_counter() - t0
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(steps):
+        ctx.g1_msm_batch_dev(srs, d_scalars, n, batch)
+    ctx.prof_enable(False)
+    kern = {k: round(ctx.prof_get(k)[0] / steps, 3) for k in MSM_KERNELS if ctx.prof_get(k)[1]}
+    acc_ms = ctx.prof_get("k_g1_accumulate")[0] / steps
+    tinfo = srs.table_info(n, batch)
+    pairs = n * batch
+    adds = pairs * tinfo["digits_per_scalar"]
+    d_scalars.free()
+    return {"domain_size": domain, "pairs_per_msm": n, "msms_per_call": batch, "pairs_per_call": pairs, "steps": steps,
+            "scalar_muls_per_s": pairs * steps / elapsed, "ms_per_call": elapsed / steps * 1e3, "kernel_ms_per_call": kern,
+            "parity_ok": bool(ok), "parity_vectors": 2, "table": tinfo,
+            "roofline": {"bound": "hbm", "kernel": "k_g1_accumulate", "avg_kernel_ms": acc_ms,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_PAIR * pairs,
+                         "achieved": ALG_BYTES_PER_PAIR * pairs / (acc_ms / 1e3) / 1e9 if acc_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ALG_BYTES_PER_PAIR * pairs / (acc_ms / 1e3) / 1e9 / HBM_PEAK_GBS if acc_ms else None,
+                         "valu": {"achieved_gadd_s": adds / (acc_ms / 1e3) / 1e9 if acc_ms else None, "peak_gadd_s": valu_peak_gadd_s,
+                                  "frac": adds / (acc_ms / 1e3) / 1e9 / valu_peak_gadd_s if acc_ms else None,
+                                  "additions_per_pair": tinfo["digits_per_scalar"]}}}
+
+
 def bsn_scalar_mul_measurement(ctx, cv, n: int, steps: int):
     """BASELINE configs[1] / SURVEY 8(d) config 2: n variable-base scalar multiplications, P_i = public key of
     secret_from_seed(sha256("bsn-pt" || LE64(i))), k_i = sha256("bsn-k" || LE64(i)) mod n, all n compared with the oracle."""
@@ -351,7 +402,7 @@ class RingWorkload:
         tv_ring = d.Ring(self.keys, tv_params)
         tv_root = d.RingRoot.from_ring(tv_ring, tv_params)
         # the WHOLE batch in deterministic mode, so that the m proofs compared below come through the same code path as the timed
-        # batches (from a few hundred MSMs on, the KZG commitments take the odd-multiple tiling of the bit-row SRS table)
+        # batches (from a few hundred MSMs on, the KZG commitments recode their scalars in non-adjacent form over the bit-row SRS table)
         nb = len(self.alphas)
         gpu_all = self.vrf.prove_batch(self.alphas, self.ads, self.sks[:nb], self.pks[:nb], tv_ring, tv_root)
         gpu_proofs = gpu_all[:m]

@@ -316,12 +316,12 @@ class Srs:
 
     def table_info(self, n: int = 0, batch: int = 0) -> dict:
         """Shape of the fixed-base table and the tiling `batch` MSMs of n points over it take (dr_srs_table_info): window_bits, rows,
-        digit rows per scalar, the per-call tiling (0 = window rows, 1 = odd-multiple windows, 2 = non-adjacent form) with its width, and
+        digit rows per scalar, the per-call tiling (window rows or the non-adjacent form over a bit-row table) with its width, and
         the expected non-zero digits per scalar (= bucket additions per pair)."""
         info = (c_int * 6)()
         _check(lib().dr_srs_table_info(self.handle, n, batch, info))
         return {"window_bits": info[0], "rows": info[1], "batched_windows": info[2], "tiling_bits": info[3],
-                "tiling": ("window rows", "odd-multiple windows", "non-adjacent form")[info[4]], "digits_per_scalar": info[5] / 1000.0,
+                "tiling": ("window rows", "-", "non-adjacent form")[info[4]], "digits_per_scalar": info[5] / 1000.0,
                 "odd_buckets": bool(info[4])}
 
     def precompute_comb(self) -> "Srs":

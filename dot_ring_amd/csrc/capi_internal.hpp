@@ -120,10 +120,10 @@ struct dr_srs {
     uint32_t* d_table = nullptr;
     dr::WindowTable table_wt{};
     // small SRS: the table has one row per BIT (table[s][i] = 2^s * base[i]), table_wt.row[w] = start[w]; batched MSMs then tile the
-    // scalar by wider windows and keep buckets for odd digit multiples only (odd_window_for)
+    // scalar in non-adjacent form with buckets for odd digit multiples only (tiling_for)
     bool table_bit_rows = false;
     uint32_t table_pt_words = 24;        // words per table record: 24 (packed) or 32 (one point per 128-byte line)
-    int table_odd_delta = -2;            // windows of odd-multiple buckets: -2 = chosen per call (odd_window_for), -1 = never, >= 0: window_bits + this
+    int table_naf_delta = -2;            // width of the non-adjacent form of batched MSMs: -2 = chosen per call (tiling_for), -1 = never, >= 0: window_bits + this
     // optional comb table over the window table: comb[j][w][d-1] = d * table[w][j], every digit magnitude precomputed
     uint32_t* d_comb = nullptr;
     uint32_t comb_h = 0;
@@ -309,8 +309,8 @@ struct MsmTable {
     const uint32_t* table = nullptr;
     dr::WindowTable wt{};
     uint32_t pt_words = 24;              // words per table record
-    bool bit_rows = false;               // the table has a row per bit: a call may tile the scalars as it likes (odd-multiple buckets)
-    int odd_delta = -2;                  // see dr_srs::table_odd_delta
+    bool bit_rows = false;               // the table has a row per bit: a call may recode the scalars as it likes (non-adjacent form)
+    int naf_delta = -2;                  // see dr_srs::table_naf_delta
     uint32_t stride = 0, offset = 0;
     const uint32_t* comb = nullptr;      // comb[j][w][d-1], see k_g1_comb_msm
     uint32_t comb_h = 0;
@@ -321,9 +321,8 @@ struct MsmTable {
 int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, size_t batch, std::vector<drh::G1>& results,
                const MsmTable* tbl = nullptr, bool exact_streams = false);
 MsmTable srs_table(const dr_srs* srs, size_t offset);
-// the tiling msm_device takes for `batch` MSMs of n points over this table: mode 0 = the table's window rows, 1 = windows of c bits with
-// odd-multiple buckets and twins, 2 = width-c non-adjacent form (bit-row tables, hundreds of MSMs); slots = digit rows per scalar,
-// digits = expected non-zero digits per scalar
+// the tiling msm_device takes for `batch` MSMs of n points over this table: mode 0 = the table's window rows, 2 = width-c non-adjacent
+// form (bit-row tables, hundreds of MSMs); slots = digit rows per scalar, digits = expected non-zero digits per scalar
 struct Tiling {
     int mode, c, slots;
     double digits;

@@ -106,12 +106,6 @@ struct WideToken {
 };
 }  // namespace
 
-// Odd-multiple buckets (kernels_g1.hip.h: digit_bin) need a table with a row per bit, hundreds of MSMs (the per-set LDS sort and the
-// set-scan reduction; with fewer sets the L = 4 latency reduction of msm_device applies), at most 4096 buckets per set and lists that stay
-// below the 256-entry limit of the one-lane walk: the lowest buckets and their twins collect four digit magnitudes each, ~4.8 times the
-// average digit count with the narrower windows at the bottom.  Among the widths that qualify the cheapest wins: n W bucket additions +
-// ~5.2 addition-equivalents per bucket of the reduction (measured: level 1 + set scan per bucket against the walk's time per entry).
-// c = 13 for the 3N = 6144-point vectors of domain 2048, c = 14 for the 12288 of domain 4096.
 // fewer first-level chunks than this over all sets of a table MSM: chunks of 4 buckets instead of 16 (shorter dependent chains for
 // launches that do not fill the chip; DOTRING_MSM_L4_BELOW)
 static size_t l4_below() {
@@ -119,56 +113,39 @@ static size_t l4_below() {
     return v;
 }
 
-static int odd_window_for(const MsmTable& t, size_t n, size_t batch) {
-    if (!t.table || !t.bit_rows || t.odd_delta == -1 || g_chunk_len != 16 || batch < 256 || n == 0) return 0;
-    const int cn = t.wt.cmax, lo = t.odd_delta >= 0 ? cn + t.odd_delta : cn, hi = t.odd_delta >= 0 ? cn + t.odd_delta : cn + 2;
-    int best = 0;
-    double best_cost = 0;
-    for (int c = lo; c <= hi; c++) {
-        if (c < 9 || c > 14) continue;
-        const size_t H = (size_t)1 << (c - 2), W = (256 + c - 1) / c;
-        if (batch * (H / 16) < l4_below()) continue;
-        if ((n + 64) * W > ((size_t)1 << 20) || batch * (n + 64) * W >= (1ull << 32)) continue;
-        if (t.odd_delta < 0 && 4.8 * (double)n * (double)W / (double)(2 * H) > 230.0) continue;
-        const double cost = (double)n * (double)W + 5.2 * (double)H;
-        if (!best || cost < best_cost) { best = c; best_cost = cost; }
-    }
-    return best;
-}
-
-// DOTRING_SRS_TILING=naf|odd|rows: the tiling batched MSMs take over a bit-row table (default naf)
-static int tiling_mode() {
-    static const int v = [] {
+// DOTRING_SRS_TILING=rows: batched MSMs keep the window rows of a bit-row table (default: the non-adjacent form below)
+static bool naf_tiling_on() {
+    static const bool v = [] {
         const char* e = std::getenv("DOTRING_SRS_TILING");
-        if (!e) return 2;
-        return std::strcmp(e, "rows") == 0 ? 0 : std::strcmp(e, "odd") == 0 ? 1 : 2;
+        return !(e && std::strcmp(e, "rows") == 0);
     }();
     return v;
 }
 
-// Round 4: non-adjacent form.  With a row per bit a digit may sit at ANY bit position, so the scalar is recoded in width-w NAF
-// (kernels_g1.hip.h: for_each_wnaf_digit): 256 / (w + 1) odd digits on average — 18.3 for w = 13 where the 13-bit windows above have 20 —
-// spread evenly over the same 2^(w-2) odd-multiple buckets: no twins, no merge kernel, a flat list-length distribution.
-// w <= 13: the staged sort's u16 digit rows hold 11 bucket bits + 4 offset bits + sign.
+// A table with a row per bit and hundreds of MSMs (the batched prover): a digit may sit at ANY bit position, so every scalar is recoded
+// in width-w non-adjacent form (msm_recode.hip.h: for_each_wnaf_digit): 256 / (w + 1) + ~0.55 odd digits on average — 18.8 for w = 13
+// where 13-bit windows have 20 — into 2^(w-2) odd-multiple buckets per set (value of a set: sum_j (2j + 1) B_j).  Round 3 reached the
+// same bucket count with 13-bit windows whose digits 2^k u went to bucket (u - 1) / 2 with the point of row start + k, which put every
+// power of two of a window into bucket 0 and needed twin buckets and a merge kernel; the non-adjacent form has odd digits only and
+// shares the bits at the top evenly, so the fullest bucket holds ~4x the average list and stays in the one-lane walk.
+// Needs the per-set LDS sort and the set-scan reduction (hundreds of sets; with fewer the L = 4 latency reduction of msm_device
+// applies); w <= 13: the staged sort's u16 digit rows hold 11 bucket bits + 4 offset bits + sign.  Among the widths that qualify the
+// cheapest wins: n x digits bucket additions + ~5.2 addition-equivalents per bucket of the reduction (measured: level 1 + set scan
+// per bucket against the walk's time per entry): w = 13 for the 3N = 6144-point vectors of domain 2048 and the 12288 of domain 4096.
 Tiling tiling_for(const MsmTable& t, size_t n, size_t batch) {
     Tiling none{0, 0, 0, 0.0};
-    if (!t.table || !t.bit_rows || t.odd_delta == -1 || g_chunk_len != 16 || batch < 256 || n == 0 || tiling_mode() == 0) return none;
+    if (!t.table || !t.bit_rows || t.naf_delta == -1 || g_chunk_len != 16 || batch < 256 || n == 0 || !naf_tiling_on()) return none;
     const int cn = t.wt.cmax;
-    if (tiling_mode() == 1) {
-        const int c = odd_window_for(t, n, batch);
-        if (!c) return none;
-        return Tiling{1, c, (256 + c - 1) / c, (double)((256 + c - 1) / c)};
-    }
-    const int lo = t.odd_delta >= 0 ? cn + t.odd_delta : cn - 1, hi = t.odd_delta >= 0 ? cn + t.odd_delta : cn + 2;
+    const int lo = t.naf_delta >= 0 ? cn + t.naf_delta : cn - 1, hi = t.naf_delta >= 0 ? cn + t.naf_delta : cn + 2;
     Tiling best = none;
     double best_cost = 0;
     for (int w = lo; w <= hi; w++) {
         if (w < 9 || w > 13) continue;
-        const size_t H = (size_t)1 << (w - 2), slots = 255 / w + 1;
+        const size_t H = (size_t)1 << (w - 2), slots = (256 + w - 1) / w;
         if (batch * (H / 16) < l4_below()) continue;
         if ((n + 64) * slots > ((size_t)1 << 20) || batch * (n + 64) * slots >= (1ull << 32)) continue;
-        const double digits = 256.0 / (w + 1);
-        if (t.odd_delta < 0 && (double)n * digits / (double)H > 160.0) continue;      // lists stay well below the one-lane limit of 256
+        const double digits = 256.0 / (w + 1) + 0.55;        // (+ the evenly shared digits at the top and the end effects: 18.8 measured at w = 13)
+        if (t.naf_delta < 0 && (double)n * digits / (double)H > 160.0) continue;      // the fullest lists (~4x) stay near the one-lane limit
         const double cost = (double)n * digits + 5.2 * (double)H;
         if (!best.mode || cost < best_cost) { best = Tiling{2, w, (int)slots, digits}; best_cost = cost; }
     }
@@ -213,14 +190,15 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         const Tiling tl = setscan_on ? tiling_for(*tbl, n, batch) : Tiling{0, 0, 0, 0.0};
         const bool odd = tl.mode != 0;
         dr::WindowTable wo{};
-        if (tl.mode == 1) {
-            wo = make_window_table(tl.c);
-            for (int w = 0; w < wo.W; w++) wo.row[w] = wo.start[w];
-            wo.odd = 1;
-        } else if (tl.mode == 2) {                       // slots of the non-adjacent form: positions [c j, c j + c)
+        if (odd) {                                       // slots of the non-adjacent form: positions [c j, c j + c) of k << shift
             wo.W = tl.slots;
             wo.cmax = tl.c;
-            for (int j = 0; j < wo.W; j++) { wo.start[j] = wo.row[j] = (uint8_t)(tl.c * j); wo.width[j] = (uint8_t)tl.c; }
+            const int shift = wo.W * tl.c - 256;          // (msm_recode.hip.h: for_each_wnaf_digit)
+            for (int j = 0; j < wo.W; j++) {
+                wo.start[j] = (uint8_t)(tl.c * j);
+                wo.row[j] = (uint8_t)(j ? tl.c * j - shift : 0);
+                wo.width[j] = (uint8_t)tl.c;
+            }
             wo.odd = 2;
         }
         pl.wt = odd ? wo : tbl->wt;
@@ -257,9 +235,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         pl.L = 4;
         pl.T = pl.H / 4;
     }
-    // odd-multiple buckets: every set has a few twin buckets besides its H (kernels_g1.hip.h: digit_bin), kept after all sets' buckets
-    const uint32_t aux = pl.wt.odd == 1 ? (dr::odd_twin_count(pl.H) + 15u) & ~15u : 0u;
-    const size_t nbuckets = bsets * (size_t)(pl.H + aux);
+    const size_t nbuckets = bsets * (size_t)pl.H;
     const size_t ndigits = windows * n;
     if (nbuckets >= (1ull << 32) || ndigits >= (1ull << 32))
         return fail(DR_ERR_INVALID, "MSM batch too large for one launch (split the batch)");
@@ -306,7 +282,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         sp.capacity = (uint32_t)per_set_digits;
         sp.short_from = single ? tbl->short_from : 0xffffffffu;
         sp.n_short = single ? std::min<uint32_t>(tbl->n_short, (uint32_t)n) : 0;
-        sp.aux = aux; sp.sets = (uint32_t)bsets;
+        sp.sets = (uint32_t)bsets;
         sp.fold = single && tbl->fold_sign ? 1 : 0;
         TRY(ctx->sorted.reserve(bsets * per_set_digits * 4));
         // sets of more than a few thousand entries: the sorted segment is assembled in LDS and written in whole lines
@@ -439,19 +415,13 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         hipLaunchKernelGGL(dr::k_g1_heavy_fold, dim3(256), dim3(64), 0, st, ctx->counts.as<uint32_t>(), ctx->perm.as<uint32_t>(),
                            ctx->cell_off.as<uint32_t>(), szblocks, ctx->heavy.as<uint32_t>(), ctx->buckets.as<uint32_t>());
     }));
-    if (aux) {
-        const size_t lanes = bsets * (size_t)std::max<uint32_t>(1, pl.H >> 4);
-        TRY(launch(ctx, "k_g1_merge_twins", [&] {
-            hipLaunchKernelGGL(dr::k_g1_merge_twins, dim3(div_up(lanes, 128)), dim3(128), 0, st, ctx->buckets.as<uint32_t>(), (uint32_t)bsets, pl.H, aux);
-        }));
-    }
     // many bucket sets (batched prover): level-wise reduction, 2 additions per entry and no scalar multiplications;
     // few sets (single MSMs): chunk sums + double-and-add, whose latency is one short chain
     const bool leveled = g_reduce_levels && pl.L == 16 && pl.H >= 256 && bsets * (size_t)(pl.H / 16) >= g_level_threshold;
     // many sets of <= 2048 buckets (every batched MSM of the prover): first level with 2 additions per bucket, then one workgroup
     // per set scans and folds its <= 128 chunk results (DOTRING_MSM_SETSCAN=0: the chunk + double-and-add kernels below)
     const bool setscan = setscan_on && pl.L == 16 && pl.T >= 8 && pl.T <= 256 && bsets >= 256;
-    if (pl.wt.odd && !(setscan && lds_sort)) return fail(DR_ERR_DEVICE, "internal: odd-multiple buckets planned for a path that does not support them");
+    if (pl.wt.odd && !(setscan && lds_sort)) return fail(DR_ERR_DEVICE, "internal: non-adjacent form planned for a path that does not support it");
     // a single MSM over a wide window table (H >= 8192 buckets per index group): workgroup scan, (V, S) pairs to the host
     // (DOTRING_MSM_WGSCAN=0: chunk sums + double-and-add + fold, as in round 2)
     static const bool wgscan_on = std::getenv("DOTRING_MSM_WGSCAN") == nullptr || std::atoi(std::getenv("DOTRING_MSM_WGSCAN")) != 0;
@@ -645,7 +615,7 @@ MsmTable srs_table(const dr_srs* srs, size_t offset) {
         t.wt = srs->table_wt;
         t.pt_words = srs->table_pt_words;
         t.bit_rows = srs->table_bit_rows;
-        t.odd_delta = srs->table_odd_delta;
+        t.naf_delta = srs->table_naf_delta;
         t.stride = (uint32_t)srs->count;
         t.offset = (uint32_t)offset;
         t.comb = srs->d_comb;
@@ -1025,11 +995,11 @@ int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_row
     srs->d_table = nullptr;
     srs->table_bit_rows = false;
     // A small SRS gets a row for every bit (32 KB per base: 201 MB for the 6145 points of a 2048-point domain) — the window rows are a
-    // subset of it, and batched MSMs may then tile the scalar differently (odd-multiple buckets, see msm_device).
-    // DOTRING_SRS_BIT_ROWS_MB (default 512, 0 = never) bounds the table; DOTRING_SRS_ODD_BITS forces the width of those windows to
-    // window_bits + that (-1 = never odd-multiple buckets; default: chosen per call, odd_window_for).
+    // subset of it, and batched MSMs may then recode the scalars in non-adjacent form (tiling_for).
+    // DOTRING_SRS_BIT_ROWS_MB (default 512, 0 = never) bounds the table; DOTRING_SRS_NAF_BITS forces the width of that form to
+    // window_bits + that (-1 = never; default: chosen per call, tiling_for).
     static const size_t bit_rows_mb = std::getenv("DOTRING_SRS_BIT_ROWS_MB") ? (size_t)std::atol(std::getenv("DOTRING_SRS_BIT_ROWS_MB")) : 512;
-    static const int odd_bits = std::getenv("DOTRING_SRS_ODD_BITS") ? std::atoi(std::getenv("DOTRING_SRS_ODD_BITS")) : -2;
+    static const int naf_bits = std::getenv("DOTRING_SRS_NAF_BITS") ? std::atoi(std::getenv("DOTRING_SRS_NAF_BITS")) : -2;
     // One table point per 128-byte line (24 of 32 words used): a packed 96-byte record straddles two lines five times out of eight, and
     // the bucket walk — one random table point per addition — measured 1.1 % faster with a third fewer lines to fetch although the table is
     // a third larger (A/B on one box, three alternations: 40.50 - 40.63 against 40.85 - 41.17 ms per 1024 proofs).  DOTRING_SRS_LINE=0: packed.
@@ -1048,7 +1018,7 @@ int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_row
         hipLaunchKernelGGL(dr::k_g1_bit_table, dim3(div_up(srs->count, 128)), dim3(128), 0, ctx->stream, srs->d_bases, (uint32_t)srs->count, 256u,
                            pt_words, srs->d_table);
         srs->table_bit_rows = true;
-        srs->table_odd_delta = odd_bits < -1 ? -2 : odd_bits;
+        srs->table_naf_delta = naf_bits < -1 ? -2 : naf_bits;
     } else {
         hipLaunchKernelGGL(dr::k_g1_window_table, dim3(div_up(srs->count, 128)), dim3(128), 0, ctx->stream, srs->d_bases, (uint32_t)srs->count, wt,
                            pt_words, srs->d_table);

@@ -12,12 +12,11 @@ namespace dr {
 // and funnel n/2^t points into each of its few buckets — one lane then walks a chain thousands of points long.
 // Fixed-base tables come in two shapes: one row per window (row[w] = w: table[w][i] = 2^(start_w) * base[i]) or one row per BIT
 // (row[w] = start[w]: table[s][i] = 2^s * base[i] for every s < 256; any tiling of the 256 bits can then be used per call).
-// `odd` (bit rows only): a digit of magnitude m = 2^k * u, u odd, takes the point of row start_w + k and goes to bucket (u - 1) / 2 —
-// only odd multiples have buckets, 2^(cmax-2) per set instead of 2^(cmax-1); a set's value is sum_j (2j + 1) B_j.
-// `odd` == 2 (bit rows only, round 4): the scalar is recoded in width-cmax non-adjacent form — odd digits |d| < 2^(cmax-1), at least cmax
-// positions apart, so there are 256 / (cmax + 1) of them on average instead of 256 / cmax window digits — into the same 2^(cmax-2)
-// odd-multiple buckets; a digit at bit position p takes its point from row p.  The W "windows" are then slots: slot j = positions
-// [cmax j, cmax j + cmax) holds at most one digit (start[j] = row[j] = cmax j, width[j] = cmax).
+// `odd` == 2 (bit rows only): only odd multiples have buckets — 2^(cmax-2) per set, a set's value is sum_j (2j + 1) B_j — and the scalar
+// is recoded in width-cmax non-adjacent form (msm_recode.hip.h: for_each_wnaf_digit): odd digits |d| < 2^(cmax-1), about
+// 256 / (cmax + 1) of them instead of 256 / cmax window digits; a digit at bit position p takes its point from row p.  The W
+// "windows" are then slots of k << (W cmax - 256): slot j = positions [cmax j, cmax j + cmax) starts at most one digit
+// (start[j] = cmax j, row[j] = the table row of the slot's first position, width[j] = cmax).
 struct WindowTable {
     int W, cmax;
     uint8_t start[40];   // first bit of window w   (W <= 40: widths >= 7 ... see make_plan)

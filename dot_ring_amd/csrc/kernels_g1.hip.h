@@ -343,34 +343,11 @@ __global__ __launch_bounds__(128) void k_g1_bit_table(const uint32_t* __restrict
     }
 }
 
-// Odd-multiple buckets and their twins.  m = 2^k u (u odd) goes to bucket (u - 1) / 2 with the point of row start_w + k; left at
-// that, bucket 0 would collect m = 1, 2, 4, ... — cmax lists in one, hundreds of entries in the lowest buckets of every set.  So the
-// shifts are taken in groups of four: k < 4 feeds the bucket itself, k in [4g, 4g + 4), g >= 1, feeds a TWIN of it (same weight,
-// its own list; only buckets below H / 16^g have one), and k_g1_merge_twins adds the twins back before the reduction.  No list is
-// then longer than four times the average digit count.  Bins of a set: [0, H) the buckets, then the twins of g = 1, 2, 3.
-DR_DEV uint32_t odd_twin_offset(uint32_t H, uint32_t g) {          // first bin of group g >= 1
-    uint32_t off = H;
-    for (uint32_t q = 1; q < g; q++) off += (H >> (4 * q)) ? (H >> (4 * q)) : 1u;
-    return off;
-}
-inline uint32_t odd_twin_count(uint32_t H) {                       // host: bins beyond H (groups 1 .. 3)
-    uint32_t n = 0;
-    for (uint32_t q = 1; q <= 3; q++) n += (H >> (4 * q)) ? (H >> (4 * q)) : 1u;
-    return n;
-}
-// a digit of magnitude mag in window w -> its bin within the set (bucket or twin); `row` = the table row its point comes from
-DR_DEV uint32_t digit_bin(const WindowTable& wt, uint32_t H, int w, uint32_t mag, uint32_t& row) {
-    if (wt.odd) {
-        const uint32_t k = (uint32_t)__builtin_ctz(mag), g = k >> 2, j = mag >> (k + 1);
-        row = (uint32_t)wt.row[w] + k;
-        return g == 0 ? j : odd_twin_offset(H, g) + j;
-    }
+// a digit of magnitude mag in window w -> its bin within the set; `row` = the table row its point comes from (windows: one bucket per
+// magnitude; the non-adjacent form of bit-row tables has its own visitor, msm_recode.hip.h: for_each_wnaf_digit)
+DR_DEV uint32_t digit_bin(const WindowTable& wt, int w, uint32_t mag, uint32_t& row) {
     row = wt.row[w];
     return mag - 1u;
-}
-// where the bin of a set lives in counts / offsets / buckets: the sets' H buckets first, then `aux` twin slots per set
-DR_DEV size_t bin_slot(uint32_t set, uint32_t H, uint32_t bin, uint32_t aux, size_t aux_base) {
-    return bin < H ? (size_t)set * H + bin : aux_base + (size_t)set * aux + (bin - H);
 }
 
 // ---- 1'-3'. LDS counting sort: ONE workgroup owns one bucket set.  When a bucket set is small (H <= 8192 counters =
@@ -379,7 +356,7 @@ DR_DEV size_t bin_slot(uint32_t set, uint32_t H, uint32_t bin, uint32_t aux, siz
 // Each set gets a fixed-capacity segment of `sorted` (capacity = the most digits it can receive), so segment bases
 // need no cross-set scan.  Pass 1 counts, pass 2 recomputes the digits and places them.
 constexpr int SORT_BLOCK = 256;
-constexpr uint32_t SORT_MAX_H = 8192, SORT_MAX_AUX = 320;      // (twins of odd-multiple buckets: H <= 4096 there)
+constexpr uint32_t SORT_MAX_H = 8192;
 
 struct SortSetParams {
     uint32_t n, batch, H, groups;      // groups: table-mode index groups per MSM (1 otherwise)
@@ -388,7 +365,6 @@ struct SortSetParams {
     uint32_t capacity;                  // entries reserved per set in `sorted`
     uint32_t short_from, n_short;       // scalar vectors b >= short_from are zero beyond n_short entries: not even read
     uint32_t n_pad, digits_per_set;     // staged variant: row length (a multiple of 8) and u16 digits reserved per set
-    uint32_t aux;                       // odd-multiple buckets: twin slots per set (0 otherwise); they live at [sets * H + set * aux, ...)
     uint32_t sets;
     int fold;                           // table mode: scalars above r / 2 are replaced by their negatives (scalar_fold_sign)
 };
@@ -432,10 +408,9 @@ DR_DEV bool scalar_fold_sign(uint32_t (&k)[9]) {
 __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __restrict__ scalars, WindowTable wt, SortSetParams sp,
                                                              uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
                                                              uint32_t* __restrict__ sorted) {
-    __shared__ uint32_t bins[SORT_MAX_H + SORT_MAX_AUX];
+    __shared__ uint32_t bins[SORT_MAX_H];
     __shared__ uint32_t smem[SORT_BLOCK / 64];
-    const uint32_t H = sp.H, HB = sp.H + sp.aux, set = blockIdx.x;      // HB bins: the buckets and their twins
-    const size_t aux_base = (size_t)sp.sets * H;
+    const uint32_t H = sp.H, HB = sp.H, set = blockIdx.x;
     // which scalars and windows feed this set
     uint32_t b, i_lo, i_hi;
     int w_lo, w_hi;
@@ -468,7 +443,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
         }
         for_each_digit(k, wt, w_lo, w_hi, [&](int w, int32_t d) {
             uint32_t row;
-            atomicAdd(&bins[digit_bin(wt, H, w, (uint32_t)(d < 0 ? -d : d), row)], 1u);
+            atomicAdd(&bins[digit_bin(wt, w, (uint32_t)(d < 0 ? -d : d), row)], 1u);
         });
     }
     __syncthreads();
@@ -477,7 +452,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
     uint32_t local = 0;
     for (uint32_t j = lo; j < hi; j++) {
         uint32_t c = bins[j];
-        counts[bin_slot(set, H, j, sp.aux, aux_base)] = c;
+        counts[(size_t)set * H + j] = c;
         local += c;
     }
     uint32_t total;
@@ -486,7 +461,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
     for (uint32_t j = lo; j < hi; j++) {
         uint32_t c = bins[j];
         bins[j] = run;                                  // becomes the placement cursor
-        offsets[bin_slot(set, H, j, sp.aux, aux_base)] = base + run;
+        offsets[(size_t)set * H + j] = base + run;
         run += c;
     }
     __syncthreads();
@@ -505,7 +480,7 @@ __global__ __launch_bounds__(SORT_BLOCK) void k_g1_sort_sets(const uint32_t* __r
         }
         for_each_digit(k, wt, w_lo, w_hi, [&](int w, int32_t d) {
             uint32_t row;
-            uint32_t pos = atomicAdd(&bins[digit_bin(wt, H, w, (uint32_t)(d < 0 ? -d : d), row)], 1u);
+            uint32_t pos = atomicAdd(&bins[digit_bin(wt, w, (uint32_t)(d < 0 ? -d : d), row)], 1u);
             uint32_t entry = sp.single ? row * sp.tbl_stride + sp.tbl_offset + i : i;
             sorted[base + pos] = entry | ((d < 0) != neg ? 0x80000000u : 0u);
         });
@@ -533,12 +508,11 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
                                                                     uint16_t* __restrict__ digits16, uint32_t* __restrict__ counts,
                                                                     uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
     constexpr uint32_t SORT2_CHUNK = SORT2_CAP - SORT2_SLACK;
-    __shared__ uint32_t bins[MAX_H + SORT_MAX_AUX];
+    __shared__ uint32_t bins[MAX_H];
     __shared__ uint32_t stage[SORT2_CAP];
     __shared__ uint32_t cs[SORT2_MAX_CHUNKS + 1], jb[SORT2_MAX_CHUNKS + 1];
     __shared__ uint32_t smem[SORT2_BLOCK / 64];
-    const uint32_t HR = sp.H, H = sp.H + sp.aux, set = blockIdx.x, tid = threadIdx.x;      // H bins: HR buckets and their twins
-    const size_t aux_base = (size_t)sp.sets * HR;
+    const uint32_t H = sp.H, set = blockIdx.x, tid = threadIdx.x;
     uint32_t b, i_lo, i_hi;
     int w_lo, w_hi;
     if (sp.single) {
@@ -581,10 +555,7 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
                 const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
                 uint32_t row, enc = mag;
                 if (d != 0) {
-                    const uint32_t bin = digit_bin(wt, HR, w, mag, row);
-                    atomicAdd(&bins[bin], 1u);
-                    // odd multiples: pass 2 runs once per chunk, so the bin is worked out here, once: bin + 1 | (k & 3) << 13
-                    if (wt.odd) enc = (bin + 1u) | (((uint32_t)__builtin_ctz(mag) & 3u) << 13);
+                    atomicAdd(&bins[digit_bin(wt, w, mag, row)], 1u);
                 }
                 dg[(size_t)(w - w_lo) * n_pad + ii] = (uint16_t)(enc | ((d < 0) != neg && d != 0 ? 0x8000u : 0u));
             });
@@ -598,7 +569,7 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
     uint32_t local = 0;
     for (uint32_t j = lo; j < hi; j++) {
         uint32_t c = bins[j];
-        counts[bin_slot(set, HR, j, sp.aux, aux_base)] = c;
+        counts[(size_t)set * H + j] = c;
         local += c;
     }
     uint32_t total;
@@ -608,7 +579,7 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
     for (uint32_t j = lo; j < hi; j++) {
         uint32_t c = bins[j];
         bins[j] = run;                                  // becomes the placement cursor
-        offsets[bin_slot(set, HR, j, sp.aux, aux_base)] = base + run;
+        offsets[(size_t)set * H + j] = base + run;
         const uint32_t k = run / SORT2_CHUNK;           // chunk in which this bucket's segment starts (k <= K; k == K only for
         atomicMin(&jb[k], j);                           //  empty buckets at the very end)
         atomicMin(&cs[k], run);
@@ -643,15 +614,11 @@ __global__ __launch_bounds__(SORT2_BLOCK) void k_g1_sort_sets_staged(const uint3
                     for (int t = 0; t < 8; t++) {
                         const uint32_t dd = (words[t >> 1] >> (16 * (t & 1))) & 0xffffu;
                         // dd == 0 (windows) / offset field 15 (non-adjacent form) -> 0xffffffff: outside every range
-                        const uint32_t j = wt.odd == 2 ? (((dd >> 11) & 15u) == 15u ? 0xffffffffu : (dd & 0x7ffu)) : (dd & (wt.odd ? 0x1fffu : 0x7fffu)) - 1u;
+                        const uint32_t j = wt.odd == 2 ? (((dd >> 11) & 15u) == 15u ? 0xffffffffu : (dd & 0x7ffu)) : (dd & 0x7fffu) - 1u;
                         if (j >= j_lo && j < j_hi) {
                             uint32_t up = 0;
                             if (wt.odd == 2) {
                                 up = ((dd >> 11) & 15u) * sp.tbl_stride;      // the digit's offset in its slot: row[slot] + offset
-                            } else if (wt.odd) {                              // row + k: k = 4 g + (k & 3), g from the bin's range (digit_bin)
-                                const uint32_t d1 = HR + ((HR >> 4) ? (HR >> 4) : 1u), d2 = d1 + ((HR >> 8) ? (HR >> 8) : 1u);
-                                const uint32_t g = j < HR ? 0u : j < d1 ? 1u : j < d2 ? 2u : 3u;
-                                up = (4u * g + ((dd >> 13) & 3u)) * sp.tbl_stride;
                             }
                             const uint32_t pos = atomicAdd(&bins[j], 1u);
                             const uint32_t entry = (row_entry + up + v * 8 + (uint32_t)t) | ((dd & 0x8000u) << 16);
@@ -942,7 +909,7 @@ __global__ __launch_bounds__(SZ_BLOCK) void k_size_place(const uint32_t* __restr
 // or more — the size ordering puts them first in `perm` — are left to k_g1_accumulate_long: 16 lanes per bucket (four buckets per
 // wave) up to G1_HEAVY_BUCKET entries; longer ones are cut into segments, a wave each (k_g1_accumulate_heavy).  The prover's dense MSMs over window rows (~66 points per bucket,
 // Poisson) never get there.
-constexpr uint32_t G1_LONG_BUCKET = 256;                  // (upper bound of the per-launch limit, k_size_pick)
+constexpr uint32_t G1_LONG_BUCKET = 512;                  // (upper bound of the per-launch limit, k_size_pick)
 // The list length from which a launch hands its lists to k_g1_accumulate_long.  One lane adds an entry per ~17 us (two waves share a
 // SIMD); the whole launch needs total / 65536 lanes x 8.4 us when every lane is busy.  A list may take half of that: limit = total
 // entries / 265 k, within [64, G1_LONG_BUCKET], at a size-class boundary.  The dense launches (126 - 168 M entries) get 256 and, with
@@ -1018,7 +985,7 @@ DR_DEV G1Xyzz xyzz_shfl_down(const G1Xyzz& p, unsigned delta) {
 // Lists of [the launch's limit, G1_HEAVY_BUCKET) entries, four per wave; longer ones: k_g1_accumulate_heavy.
 // Grid-stride, so a fixed small grid serves any number of them; returns at once when there are none.
 template <int LANES>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_accumulate_long(const uint32_t* __restrict__ bases, uint32_t pt_words, const uint32_t* __restrict__ sorted,
+__global__ __launch_bounds__(64) void k_g1_accumulate_long(const uint32_t* __restrict__ bases, uint32_t pt_words, const uint32_t* __restrict__ sorted,
                                                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_offsets,
                                                            uint32_t nblocks, const uint32_t* __restrict__ pick /* k_size_pick */, uint32_t* __restrict__ buckets) {
@@ -1099,7 +1066,7 @@ DR_DEV void for_each_heavy_bucket(const uint32_t* __restrict__ counts, const uin
     }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_accumulate_heavy(
+__global__ __launch_bounds__(64) void k_g1_accumulate_heavy(
     const uint32_t* __restrict__ bases, uint32_t pt_words, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
     const uint32_t* __restrict__ counts, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_offsets, uint32_t nblocks,
     uint32_t* __restrict__ buckets, uint32_t* __restrict__ seg_sums) {
@@ -1123,7 +1090,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     });
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_g1_heavy_fold(
+__global__ __launch_bounds__(64) void k_g1_heavy_fold(
     const uint32_t* __restrict__ counts, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ cell_offsets, uint32_t nblocks,
     const uint32_t* __restrict__ seg_sums, uint32_t* __restrict__ buckets) {
     const uint32_t n_class0 = cell_offsets[nblocks], lane = threadIdx.x;
@@ -1138,22 +1105,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (unsigned d = 32; d >= 1; d >>= 1) acc = g1_add(acc, xyzz_shfl_down<64>(acc, d));
         if (lane == 0) store_xyzz(buckets, b, acc);
     });
-}
-
-// twins of odd-multiple buckets (digit_bin) back into their buckets: one lane per bucket that has a twin (j < H / 16)
-__global__ __launch_bounds__(128) void k_g1_merge_twins(uint32_t* __restrict__ buckets, uint32_t sets, uint32_t H, uint32_t aux) {
-    const uint32_t D1 = (H >> 4) ? (H >> 4) : 1u;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (size_t)sets * D1) return;
-    const uint32_t set = (uint32_t)(gid / D1), j = (uint32_t)(gid % D1);
-    const size_t twin0 = (size_t)sets * H + (size_t)set * aux;
-    G1Xyzz acc = load_xyzz(buckets, (size_t)set * H + j);
-#pragma unroll 1
-    for (uint32_t g = 1; g <= 3; g++) {
-        const uint32_t Dg = (H >> (4 * g)) ? (H >> (4 * g)) : 1u;
-        if (j < Dg) acc = g1_add(acc, load_xyzz(buckets, twin0 + (odd_twin_offset(H, g) - H) + j));
-    }
-    store_xyzz(buckets, (size_t)set * H + j, acc);
 }
 
 // ---- 5. bucket reduction.  Window value = sum_j (j+1) * B_j.  Chunk [s, s+L): running sums give

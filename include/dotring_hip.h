@@ -149,12 +149,12 @@ DR_API int dr_srs_precompute(dr_ctx *ctx, dr_srs *srs, int window_bits);
 /* Shape of the table dr_srs_precompute built (all zero: none) and the tiling `batch` MSMs of n points over it would take.  An SRS
  * small enough (256 * count * 128 bytes within DOTRING_SRS_BIT_ROWS_MB, default 512: 201 MB for 6145 points) gets a row for EVERY bit,
  * table[s][i] = 2^s * base[i]; batches of hundreds of MSMs then recode every scalar in width-w non-adjacent form (w chosen per call from
- * n and batch; DOTRING_SRS_ODD_BITS forces window_bits + that, -1 = never): 256 / (w + 1) odd digits per scalar on average, each one a
+ * n and batch; DOTRING_SRS_NAF_BITS forces window_bits + that, -1 = never; DOTRING_SRS_TILING=rows keeps the window rows): 256 / (w + 1) odd digits per scalar on average, each one a
  * point of the row of its bit position added to one of 2^(w-2) odd-multiple buckets — against 256 / window_bits additions over the
  * window rows.  Results are unchanged.
  *   info[0] window_bits, info[1] rows of the table (W or 256), info[2] digit rows (windows / slots) per scalar for this (n, batch),
- *   info[3] width w of the per-call tiling (0 = the window rows), info[4] tiling: 0 = window rows, 1 = w-bit windows with odd-multiple
- *   buckets (DOTRING_SRS_TILING=odd), 2 = width-w non-adjacent form, info[5] expected non-zero digits per scalar x 1000 */
+ *   info[3] width w of the per-call tiling (0 = the window rows), info[4] tiling: 0 = window rows, 2 = width-w non-adjacent
+ *   form, info[5] expected non-zero digits per scalar x 1000 */
 DR_API int dr_srs_table_info(const dr_srs *srs, size_t n, size_t batch, int info[6]);
 /* Comb table on top of the window table (window_bits <= 14): comb[i][w][d-1] = d * 2^(start_w) * base[i] for every
  * digit magnitude d <= 2^(window_bits-1) — count * W * 2^(window_bits-1) * 128 bytes (one cache line per entry: 35 GB for

@@ -1,6 +1,7 @@
 // Host check of dot_ring_amd/csrc/msm_recode.hip.h — the very functions the sort kernels of the G1 Pippenger run.
-// for_each_wnaf_digit(k, w): digits odd, |d| < 2^(w-1), at most one per slot, at least w positions apart, rows < 256,
-// sum d 2^position = k, at most 255 / w + 1 slots; for_each_digit: sum d 2^start = k with |d| <= 2^(c-1).
+// for_each_wnaf_digit(k, w): digits odd, |d| < 2^(w-1), at most one per slot, non-overlapping (a digit of a bits ends before the next
+// one starts), rows < 256, sum d 2^row = k, ceil(256 / w) slots, and — over uniformly random scalars — no bucket of a set collects more
+// than five times the average list (the top digits share the remaining bits evenly); for_each_digit: sum d 2^start = k, |d| <= 2^(c-1).
 // Scalars: edges of the field, runs of ones, alternating bits, single bits, 2^w - 1 at every offset, and random values.
 #include <cstdio>
 #include <cstdlib>
@@ -54,11 +55,12 @@ static void fail(const char* what, int w, const uint32_t (&k)[9]) {
     }
 }
 
-static dr::WindowTable naf_table(int w) {
+static dr::WindowTable naf_table(int w) {         // capi_msm.hip: msm_device, tiling mode 2
     dr::WindowTable wt{};
-    wt.W = 255 / w + 1;
+    wt.W = (256 + w - 1) / w;
     wt.cmax = w;
-    for (int j = 0; j < wt.W; j++) { wt.start[j] = wt.row[j] = (uint8_t)(w * j); wt.width[j] = (uint8_t)w; }
+    const int shift = wt.W * w - 256;
+    for (int j = 0; j < wt.W; j++) { wt.start[j] = (uint8_t)(w * j); wt.row[j] = (uint8_t)(j ? w * j - shift : 0); wt.width[j] = (uint8_t)w; }
     wt.odd = 2;
     return wt;
 }
@@ -76,34 +78,37 @@ static dr::WindowTable window_table(int c) {     // capi_msm.hip: make_window_ta
 }
 
 static unsigned long long total_digits[16], total_scalars[16];
+static bool stats = false;                        // set for the uniformly random scalars: bucket loads are meaningful only there
+static std::vector<unsigned long long> bin_load[16];
 
 static void check(const uint32_t (&k)[9]) {
     if (!below_r(k)) return;
     for (int w = 9; w <= 13; w++) {
         const dr::WindowTable wt = naf_table(w);
         Big sum;
-        int last_pos = -1000, last_slot = -1, count = 0, slots_seen = 0;
+        int last_end = -1, last_slot = -1, count = 0, slots_seen = 0;
         bool ok = true;
         dr::for_each_wnaf_digit<true>(k, wt, [&](int j, uint32_t o, int32_t d) {
             slots_seen++;
             if (j != last_slot + 1) ok = false;                        // WITH_ZEROS visits every slot once, in order
             last_slot = j;
             if (d == 0) return;
-            const int pos = w * j + (int)o;
+            const int pos = (int)wt.row[j] + (int)o;                   // table row = bit position of the digit
             if (!(d & 1) || d >= (1 << (w - 1)) || d <= -(1 << (w - 1))) ok = false;
-            if ((int)o >= w || pos > 255 || pos - last_pos < w) ok = false;
-            if (((uint32_t)(d < 0 ? -d : d) - 1u) >> 1 >= (1u << (w - 2))) ok = false;
-            last_pos = pos;
+            if (o > 14u || pos > 255 || pos <= last_end) ok = false;   // offset fits its 4-bit field; digits do not overlap
+            const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            if ((mag - 1u) >> 1 >= (1u << (w - 2))) ok = false;
+            last_end = pos + (32 - __builtin_clz(mag)) - 1;            // top bit of |d| 2^pos
             count++;
             sum.add_shifted(d, (unsigned)pos);
+            if (stats) bin_load[w][(mag - 1u) >> 1]++;
         });
         if (!ok || slots_seen != wt.W || !sum.equals(k)) fail("non-adjacent form", w, k);
         // the same digits without the empty slots
         int count2 = 0;
         dr::for_each_wnaf_digit(k, wt, [&](int, uint32_t, int32_t d) { count2 += d != 0; });
         if (count2 != count) fail("non-adjacent form, WITH_ZEROS = false", w, k);
-        total_digits[w] += (unsigned long long)count;
-        total_scalars[w]++;
+        if (stats) { total_digits[w] += (unsigned long long)count; total_scalars[w]++; }
     }
     for (int c = 7; c <= 16; c++) {
         const dr::WindowTable wt = window_table(c);
@@ -163,19 +168,37 @@ int main() {
                 for (int i = 0; i < 3 && pos / 32 + i < 8; i++) k[pos / 32 + i] = (uint32_t)(sv >> (32 * i));
                 check(k);
             }
-    // random values: dense, sparse, and random with the top cleared
-    for (int it = 0; it < 200000; it++) {
+    // random values: sparse, dense, and random with the top cleared
+    for (int it = 0; it < 60000; it++) {
         clear();
-        const int mode = it % 4;
+        const int mode = it % 3;
         for (int i = 0; i < 8; i++) {
             uint32_t v = (uint32_t)rng();
-            if (mode == 1) v &= (uint32_t)rng();
-            if (mode == 2) v |= (uint32_t)rng();
-            if (mode == 3) v &= (uint32_t)rng() & (uint32_t)rng();
+            if (mode == 0) v &= (uint32_t)rng();
+            if (mode == 1) v |= (uint32_t)rng();
+            if (mode == 2) v &= (uint32_t)rng() & (uint32_t)rng();
             k[i] = v;
         }
         k[7] &= 0x7fffffffu;
         check(k);
+    }
+    // uniformly random scalars below r: digit count and bucket loads
+    for (int w = 9; w <= 13; w++) bin_load[w].assign((size_t)1 << (w - 2), 0);
+    stats = true;
+    for (int it = 0; it < 200000; it++) {
+        clear();
+        for (int i = 0; i < 8; i++) k[i] = (uint32_t)rng();
+        k[7] &= 0x7fffffffu;
+        check(k);                                                      // (values >= r are skipped)
+    }
+    stats = false;
+    for (int w = 9; w <= 13; w++) {
+        const double avg = (double)total_digits[w] / (double)bin_load[w].size();
+        unsigned long long most = 0;
+        for (unsigned long long v : bin_load[w]) most = v > most ? v : most;
+        std::printf("w = %d: fullest bucket holds %.2f x the average list\n", w, (double)most / avg);
+        if ((double)most > 5.0 * avg) { std::fprintf(stderr, "FAIL: skewed buckets at w = %d\n", w); failures++; }
+        if ((double)total_digits[w] / (double)total_scalars[w] > 256.0 / (w + 1) + 0.8) { std::fprintf(stderr, "FAIL: too many digits at w = %d\n", w); failures++; }
     }
     if (failures) {
         std::fprintf(stderr, "%d failures\n", failures);

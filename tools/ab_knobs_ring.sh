@@ -7,6 +7,6 @@ for cfg in "$@"; do
 import json,sys
 l=json.loads(open("gpurun_out/ab.json").read().strip().splitlines()[-1])
 k=l["gpu_kernel_ms_per_step"]
-print(sys.argv[1], "value=%.0f prove_only=%.0f parity=%s" % (l["value"], l["prove_only_proofs_per_s"], l["parity_ok"]), {n:k.get(n) for n in ("k_g1_accumulate","k_g1_reduce_chunks","k_g1_reduce_windows","k_g1_sort_sets","k_g1_merge_twins")}, l["roofline"]["valu"].get("table"))
+print(sys.argv[1], "value=%.0f prove_only=%.0f parity=%s" % (l["value"], l["prove_only_proofs_per_s"], l["parity_ok"]), {n:k.get(n) for n in ("k_g1_accumulate","k_g1_reduce_chunks","k_g1_reduce_windows","k_g1_sort_sets")}, l["roofline"]["valu"].get("table"))
 PY
 done

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "dot_ring_amd", "csrc", "build")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 # kernel (substring of the mangled name) -> minimal number of v_mad_i64_i32 that makes a loop "the" loop
-KERNELS = {"k_g1_accumulateEPKj": 2000, "k_te_msm_accumulateILi1E": 600}
+KERNELS = {"k_g1_accumulateILb0EE": 2000, "k_te_msm_accumulateILi1E": 600}
 OUT = os.path.join(ROOT, "dot_ring_amd", "kernel_counts.json")
 
 _HEAD = re.compile(r"^([0-9a-f]+) <(\S+)>:")
@@ -85,7 +85,7 @@ def main() -> int:
                 if mads >= want[0][1] and (best is None or hi - lo < best[0]):
                     best = (hi - lo, total, valu, mads)
             if best:
-                short = re.sub(r"^_ZN2dr\d+", "", name).split("EPK")[0].split("ILi")[0]
+                short = re.sub(r"^_ZN2dr\d+", "", name).split("EPK")[0].split("ILi")[0].split("ILb")[0]
                 result[short] = {"loop_instructions": best[1], "loop_valu_instructions": best[2], "loop_v_mad_i64_i32": best[3],
                                  "symbol": name, "source": "llvm-objdump -d of " + os.path.basename(co) + " at build time"}
     with open(OUT, "w") as f:

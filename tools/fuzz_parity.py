@@ -136,7 +136,7 @@ for table in (0, 9, 12, 14):
     srs.close()
 report("g1 msm shapes", total, wrong, t0)
 
-# 6b. round 3: large batches over a bit-row table (odd-multiple buckets and their twins) against the same vectors in batches of 32
+# 6b. large batches over a bit-row table (non-adjacent form, odd-multiple buckets) against the same vectors in batches of 32
 # (window rows) and a sample against the oracle; scalars dense, sparse, short, repeated
 t0 = time.perf_counter()
 wrong = total = 0
@@ -167,7 +167,7 @@ for table, n, batch in ((9, 50, 8192), (10, 333, 4096), (12, 2047, 1024), (13, 7
         wrong += got[b] != (None if w == bytes(96) else w[:48][::-1] + w[48:][::-1])
         total += 1
     srs.close()
-report("g1 msm odd-multiple buckets", total, wrong, t0)
+report("g1 msm non-adjacent form over bit rows", total, wrong, t0)
 
 # 7. Bandersnatch bucket Pippenger (K4, from 256 terms): random sizes, uniform / short / repeated scalars (heavy buckets)
 t0 = time.perf_counter()

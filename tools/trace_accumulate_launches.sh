@@ -1,10 +1,10 @@
 #!/bin/bash
 # Every launch of the bucket walk in one bench step, under different knob sets, inside ONE GPU-box call:
-#   bash tools/trace_accumulate_launches.sh "DOTRING_SRS_TILING=odd" "DOTRING_SRS_TILING=naf"
+#   bash tools/trace_accumulate_launches.sh "DOTRING_SRS_TILING=rows" "X=1"
 # pass 1: kernel trace (duration and grid of each k_g1_accumulate launch of the last step); passes 2-3: --pmc groups, per launch.
 root=$(pwd)
 export TMPDIR=/tmp
-groups=("SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE")
+groups=("SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_HIT_sum TCC_MISS_sum")
 for cfg in "$@"; do
   tag=$(echo "$cfg" | tr ' =' '__')
   out=$root/gpurun_out/tral/$tag
@@ -22,7 +22,7 @@ print("==", cfg)
 rows = []
 for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_g1_accumulate" in r["Kernel_Name"] and "accumulate_long" not in r["Kernel_Name"]:
+        if "k_g1_accumulate<" in r["Kernel_Name"]:
             rows.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)))
 rows.sort()
 big = [r for r in rows if r[2] >= 500000]
@@ -30,7 +30,7 @@ print("  launches (grid lanes, ms), last 12 with >= 500 k lanes:", [(r[2], round
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_g1_accumulate" in r["Kernel_Name"] and "accumulate_long" not in r["Kernel_Name"]:
+        if "k_g1_accumulate<" in r["Kernel_Name"]:
             g = int(r.get("Grid_Size", 0) or 0)
             if g >= 500000:
                 per[r["Counter_Name"]][g].append(float(r["Counter_Value"]))
