@@ -198,7 +198,10 @@ def g1_msm_measurement(ctx, log2n: int, steps: int, cpu_sample_log2: int, do_cpu
     acc_ms, acc_n = ctx.prof_get("k_g1_accumulate")
     kern = {k: round(ctx.prof_get(k)[0] / max(1, min(steps, 5)), 3) for k in MSM_KERNELS if ctx.prof_get(k)[1]}
     total_kernel_ms = sum(kern.values())
-    out = {"pairs": n, "table_window_bits": table_bits, "scalar_muls_per_s": n * steps / elapsed, "ms_per_msm": elapsed / steps * 1e3,
+    out = {"pairs": n, "table_window_bits": table_bits,
+           "inputs": "bases (1 + i) G1 (dr_srs_synthetic: the closed form [sum k_i (1 + i)] G1 checks all 2^log2n terms) instead of SURVEY 8(d)'s "
+                     "SRS prefix + [t^i] G1; scalars uniform in [0, r) from SHAKE256('g1msm' || tag) as 8(d) fixes them",
+           "scalar_muls_per_s": n * steps / elapsed, "ms_per_msm": elapsed / steps * 1e3,
            "k_g1_accumulate_avg_ms": acc_ms / max(1, acc_n), "kernel_ms_per_msm": kern,
            "non_accumulate_share": 1.0 - kern.get("k_g1_accumulate", 0.0) / (elapsed / steps * 1e3) if elapsed else None,
            "kernel_ms_sum": round(total_kernel_ms, 3),
@@ -424,6 +427,50 @@ class RingWorkload:
         return ok, cpu_proofs, cpu_s
 
 
+def ring_roofline(w: "RingWorkload", steps: int, barrier=lambda: None):
+    """`steps` more steps of the workload with the per-kernel timers on (HIP events on the streams the kernels are launched on):
+    the bucket walk's average launch time against its algorithmic bytes (128 B per dense pair, 32 B per by-parts scalar) and against
+    the VALU issue ceiling.  Returns (roofline dict, per-kernel ms per step)."""
+    from dot_ring_amd import runtime
+
+    all_ctx = runtime.contexts()
+    for c in all_ctx:
+        c.prof_reset()
+        c.prof_enable(True)
+    elapsed_prof, _ = w.run(steps, 0, barrier)
+    for c in all_ctx:
+        c.prof_enable(False)
+
+    def prof_sum(name):
+        ms = cnt = 0
+        for c in all_ctx:
+            m_, n_ = c.prof_get(name)
+            ms, cnt = ms + m_, cnt + n_
+        return ms, cnt
+
+    kernel_ms = {name: prof_sum(name)[0] / max(1, steps) for name in MSM_KERNELS + RING_KERNELS}
+    acc_ms, acc_launches = prof_sum("k_g1_accumulate")
+    n_dom, batch = w.ring.params.domain_size, w.batch
+    # dense (base, scalar) pairs per proof: quotient 3N+1, two opening quotients 3N + (N-1)  (SURVEY 3.3); the four witness columns
+    # (4N) are committed by summation by parts: 4N scalars are read, only ~1.1k bases gathered, so they are priced at the 32 B scalar
+    pairs_per_proof, scalar_only_per_proof = 7 * n_dom, 4 * n_dom
+    tinfo = w.pcs._srs().device().table_info(3 * n_dom + 1, batch)
+    dense_adds = float(batch) * pairs_per_proof * tinfo["digits_per_scalar"] * steps
+    avg_acc_s = (acc_ms / max(1, acc_launches)) / 1e3
+    alg_bytes_launch = (ALG_BYTES_PER_PAIR * batch * pairs_per_proof + 32.0 * batch * scalar_only_per_proof) * steps / max(1, acc_launches)
+    achieved = alg_bytes_launch / avg_acc_s / 1e9 if avg_acc_s > 0 else 0.0
+    gadd = dense_adds / (acc_ms / 1e3) / 1e9 if acc_ms else None
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "kernel": "k_g1_accumulate", "avg_kernel_ms": avg_acc_s * 1e3, "launches_per_step": acc_launches / max(1, steps),
+            "algorithmic_bytes_per_launch": alg_bytes_launch,
+            "timers": "HIP events per launch, in a second pass of the same steps (the timed region runs without them); "
+                      f"that pass took {elapsed_prof / steps * 1e3:.2f} ms per step",
+            "valu": {"achieved_gadd_s": gadd, "peak_gadd_s": VALU_PEAK_GADD_S, "frac": gadd / VALU_PEAK_GADD_S if gadd else None,
+                     "instructions_per_addition": MADD_INSTRUCTIONS, "table": tinfo, "additions_per_pair": tinfo["digits_per_scalar"],
+                     "note": "dense bucket additions only (7N pairs x non-zero digits per proof); by-parts and verify-side additions not counted"}}
+    return roof, kernel_ms
+
+
 def single_call_leg(w: "RingWorkload", reps: int = 10):
     """Latency of ONE RingVRF.prove and ONE RingVRF.verify on the headline ring (the reference publishes 534.57 ms / 3.99 ms for
     them, docs/BENCHMARK.md:72-73); fresh inputs per call so nothing is memoised, minimum and median over `reps`."""
@@ -473,7 +520,7 @@ def pipelined_leg(w: "RingWorkload", steps: int):
             "note": "batch_verify of batch k on a helper thread while prove_batch of batch k + 1 runs; same work as the headline"}
 
 
-def ring_size_leg(d, ring_size: int, batch: int, steps: int, parity_proofs: int, rank: int = 0, ctl=None, barrier=lambda: None):
+def ring_size_leg(d, ring_size: int, batch: int, steps: int, parity_proofs: int, rank: int = 0, ctl=None, barrier=lambda: None, with_roofline: bool = False):
     """prove_batch + batch_verify at another ring size.  With a control communicator every rank runs its own `batch` proofs
     between two barriers, the time is the max over ranks and proofs_per_s the whole job's; parity (rank 0) against the oracle."""
     world = 1 if ctl is None else ctl.world
@@ -483,12 +530,24 @@ def ring_size_leg(d, ring_size: int, batch: int, steps: int, parity_proofs: int,
         stats = [struct.unpack("<dB", b) for b in ctl.all_gather(struct.pack("<dB", elapsed, 1 if all_ok else 0))]
         elapsed, all_ok = max(s_[0] for s_ in stats), all(s_[1] for s_ in stats)
     ok, _, _ = w.parity(parity_proofs) if parity_proofs and rank == 0 else (True, None, 0.0)
+    roof = msm_batched = None
+    if rank == 0 and with_roofline:
+        roof, _ = ring_roofline(w, min(steps, 2))
+        from dot_ring_amd import runtime
+
+        msm_batched = g1_msm_batched_leg(runtime.context(), w.pcs, w.ring.params.domain_size, batch, 3, VALU_PEAK_GADD_S)
+        ok = ok and msm_batched["parity_ok"]
     out = {"ring_size": ring_size, "domain_size": w.ring.params.domain_size, "max_ring_size": w.ring.params.max_ring_size,
            "batch": batch, "steps": steps, "ranks": world,
            "proofs_per_s": batch * world * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
            "prove_only_proofs_per_s": batch * steps / w.prove_s, "verify_only_proofs_per_s": batch * steps / w.verify_s,
            "parity_ok": bool(ok and all_ok), "parity_proofs": parity_proofs if rank == 0 else 0,
            "ring_root_s": w.ring_root_s, "srs": "known-tau, 12289 points" if w.big else "shipped 2^11 file"}
+    if ctl is not None:
+        out["ms_per_step_by_rank"] = [s_[0] / steps * 1e3 for s_ in stats]
+    if roof is not None:
+        out["roofline"] = roof
+        out["g1_msm_batched"] = msm_batched
     del w
     return out
 
@@ -524,7 +583,9 @@ def sharded_msm_leg(ctx, comm, log2_total: int, steps: int, scaling: str):
     d_scalars.free()
     srs.close()
     return {"sharding": "bases", "scaling": scaling, "pairs_total": n, "pairs_per_rank": cnt, "ranks": comm.world,
-            "rccl_ranks": comm.rccl_ranks() if hasattr(comm, "rccl_ranks") else None, "collective": type(comm).__name__, "scalar_muls_per_s": n * steps / elapsed, "ms_per_msm": elapsed / steps * 1e3,
+            "rccl_ranks": comm.rccl_ranks() if hasattr(comm, "rccl_ranks") else None, "collective": type(comm).__name__,
+            "rehearsal": None if hasattr(comm, "rccl_ranks") else "TCP star with every rank on ONE GPU (DOTRING_BENCH_SHARE_GPU=1): not an RCCL / multi-GPU figure",
+            "scalar_muls_per_s": n * steps / elapsed, "ms_per_msm": elapsed / steps * 1e3,
             "parity_closed_form_all_ranks": all(s[1] for s in stats)}
 
 
@@ -536,19 +597,22 @@ def launch_ranks(n: int, argv, script: str | None = None) -> int:
     import subprocess
 
     port = None
-    for _ in range(64):                                 # MASTER_PORT and MASTER_PORT + 1 (the control star) both free
+    for _ in range(64):                                 # MASTER_PORT, + 1 (the control star) and + 2 (the status star) all free
         with socket.socket() as a:
             a.bind(("127.0.0.1", 0))
             cand = a.getsockname()[1]
-            with socket.socket() as b:
-                try:
+            if cand >= 65533:
+                continue
+            try:
+                with socket.socket() as b, socket.socket() as c:
                     b.bind(("127.0.0.1", cand + 1))
-                except OSError:
-                    continue
+                    c.bind(("127.0.0.1", cand + 2))
+            except (OSError, OverflowError):
+                continue
         port = cand
         break
     if port is None:
-        print("bench.py: no free port pair for the rank processes", file=sys.stderr)
+        print("bench.py: no three free ports in a row for the rank processes", file=sys.stderr)
         return 2
     procs = []
     for r in range(n):
@@ -632,6 +696,9 @@ def main() -> int:
     # star on MASTER_ADDR:MASTER_PORT+1.  RCCL serves the leg that has a real exchange step (the base-sharded MSM below) and
     # is brought up there, after the headline is measured, so that nothing about the collective library can cost the headline.
     ctl = parallel.SocketComm(rank, world, timeout=900.0) if world > 1 else None
+    # the outcome of the guarded collective leg travels on a star of its own: a thread abandoned inside that leg may still hold `ctl`
+    # (the RCCL bootstrap and the TCP rehearsal use it), and a stale frame of its would desynchronise the status records
+    status_star = parallel.SocketComm(rank, world, port=parallel._comm_endpoint()[1] + 1, timeout=900.0) if world > 1 else None
     batch = args.batch
 
     # ---- setup (untimed): ring, ring root, per-ring prover tables in HBM
@@ -653,24 +720,12 @@ def main() -> int:
         stats = [struct.unpack("<dB", b) for b in ctl.all_gather(struct.pack("<dB", elapsed, 1 if all_ok else 0))]
         elapsed, all_ok = max(s[0] for s in stats), all(s[1] for s in stats)
 
+    rank_ms = None
+    if ctl is not None:
+        rank_ms = [s_[0] / args.steps * 1e3 for s_ in stats]           # every rank's own timed region (straggling shows here)
+
     # ---- the same steps again with the per-kernel timers on (every context of this process: prove_batch's helper threads too)
-    all_ctx = runtime.contexts()
-    for c in all_ctx:
-        c.prof_reset()
-        c.prof_enable(True)
-    elapsed_prof, _ = w.run(args.steps, 0, barrier)
-    for c in all_ctx:
-        c.prof_enable(False)
-
-    def prof_sum(name):
-        ms = cnt = 0
-        for c in all_ctx:
-            m_, n_ = c.prof_get(name)
-            ms, cnt = ms + m_, cnt + n_
-        return ms, cnt
-
-    kernel_ms = {name: prof_sum(name)[0] / max(1, args.steps) for name in MSM_KERNELS + RING_KERNELS}
-    acc_ms, acc_launches = prof_sum("k_g1_accumulate")
+    roof, kernel_ms = ring_roofline(w, args.steps, barrier)
 
     rc = 0
     line = None
@@ -679,8 +734,6 @@ def main() -> int:
         # dense (base, scalar) pairs per proof: quotient 3N+1, two opening quotients 3N + (N-1)  (SURVEY 3.3); the four
         # witness columns (4N) are committed by summation by parts: 4N scalars are read, only ~1.1k bases gathered,
         # so they are priced at the 32 B scalar alone
-        pairs_per_proof = 7 * n_dom
-        scalar_only_per_proof = 4 * n_dom
         parity_ok = all_ok
         cpu = cpu_all = None
         if args.cpu_proofs > 0:
@@ -696,17 +749,8 @@ def main() -> int:
             if world == 1 and not w.big and args.cpu_workers != 0:
                 cpu_all = cpu_baseline_all_cores(w.keys, args.ring_size, w.signer_sk, max(2, m // 4), args.cpu_workers, cpu_proofs)
 
-        # bucket additions of the dense MSMs in the profiled pass: pairs x windows of the SRS table (non-zero digit rate ~1)
-        # (asked of the library: an SRS with a row per bit tiles the scalars of a batched MSM by windows one bit wider, dr_srs_table_info)
-        tinfo = w.pcs._srs().device().table_info(3 * n_dom + 1, batch)
-        table_windows = tinfo["digits_per_scalar"]          # expected non-zero digits per scalar = bucket additions per pair
-        dense_adds = float(batch) * pairs_per_proof * table_windows * args.steps
         total = batch * world * args.steps
         value = total / elapsed
-        avg_acc_s = (acc_ms / max(1, acc_launches)) / 1e3
-        pairs_per_launch = (batch * pairs_per_proof * args.steps + 0.0) / max(1, acc_launches)      # prove-side MSM pairs / launches
-        alg_bytes_launch = ALG_BYTES_PER_PAIR * pairs_per_launch + 32.0 * batch * scalar_only_per_proof * args.steps / max(1, acc_launches)
-        achieved = alg_bytes_launch / avg_acc_s / 1e9 if avg_acc_s > 0 else 0.0
         traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
@@ -717,7 +761,31 @@ def main() -> int:
                                                     "NOT measured in this run)") if traffic else None
             except Exception:
                 traffic = None
-        g1 = bsn = others = distinct = single = pipelined = sweep = None
+        roof["traffic"], roof["traffic_source"] = traffic, traffic_source
+        # the clock the chip holds under this kernel, from GRBM_GUI_ACTIVE / duration of its launches in the rocprofv3 --pmc pass
+        # (profiles/hbm_traffic.json: "_clock_ghz"); the nominal 2.4 GHz prices the ceiling too high
+        clock_ghz, clock_source = 2.0, "default (no _clock_ghz in profiles/hbm_traffic.json)"
+        try:
+            rec = json.load(open(tpath))
+            if rec.get("_clock_ghz"):
+                clock_ghz, clock_source = float(rec["_clock_ghz"]), rec.get("_clock_source", "profiles/hbm_traffic.json")
+        except Exception:
+            pass
+        v = roof["valu"]
+        v.update({"peak_gadd_s_nominal_clock": VALU_PEAK_GADD_S, "nominal_clock_ghz": 2.4,
+                  "peak_gadd_s_at_measured_clock": VALU_PEAK_GADD_S * clock_ghz / 2.4, "measured_clock_ghz": clock_ghz, "measured_clock_source": clock_source,
+                  "frac_at_measured_clock": v["achieved_gadd_s"] / (VALU_PEAK_GADD_S * clock_ghz / 2.4) if v["achieved_gadd_s"] else None,
+                  "instructions_source": MADD_SOURCE, "isolated_chain_gadd_s": MEASURED_CHAIN_GADD_S,
+                  "isolated_chain_source": "profiles/r02_ubench_limbs_fused.txt (tools/ubench_limbs.hip on another box; not re-measured in this run)"})
+        # per-proof unique traffic (11N scalars + 14 NTT passes' data + 784 B out), 3.17 KB per
+        # domain point = 6.5 MB per proof at N = 2048, over the whole job
+        roof["whole_proof"] = {"algorithmic_bytes_per_proof": 3174 * n_dom, "achieved": 3174 * n_dom * value / 1e9, "unit": "GB/s",
+                               "frac": 3174 * n_dom * value / 1e9 / (HBM_PEAK_GBS * world)}
+        g1 = bsn = others = distinct = single = pipelined = sweep = msm_batched = None
+        if world == 1 and args.extras:
+            # the second half of BASELINE's metric at this ring size: the batched G1 MSM of `batch` 3N-term commitments
+            msm_batched = g1_msm_batched_leg(ctx, w.pcs, n_dom, batch, 3, VALU_PEAK_GADD_S)
+            parity_ok = parity_ok and msm_batched["parity_ok"]
         if world == 1 and args.msm_log2n > 0:
             g1 = g1_msm_measurement(ctx, args.msm_log2n, 10, 17, True)
             parity_ok = parity_ok and g1.get("parity_closed_form", True) and g1.get("parity_sample", True)
@@ -752,7 +820,7 @@ def main() -> int:
                 parity_ok = parity_ok and distinct["parity_ok"]
                 others = {}
                 for rs, st in ((256, 5), (3839, 5)):     # 3839 = the largest ring of domain 4096: BASELINE configs[4]'s per-GPU shape
-                    leg = ring_size_leg(d, rs, batch, st, 2)
+                    leg = ring_size_leg(d, rs, batch, st, 2, with_roofline=True)
                     others[str(rs)] = leg
                     parity_ok = parity_ok and leg["parity_ok"]
         line = {
@@ -763,6 +831,7 @@ def main() -> int:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_by_rank": rank_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -773,26 +842,7 @@ def main() -> int:
                                    + (", known-tau SRS of 12289 points" if w.big else ""),
                        "ring_size": args.ring_size, "domain_size": n_dom, "batch_per_gpu": batch,
                        "sharding": "proofs sharded per rank, no collective" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "k_g1_accumulate", "avg_kernel_ms": avg_acc_s * 1e3,
-                         "launches_per_step": acc_launches / max(1, args.steps), "algorithmic_bytes_per_launch": alg_bytes_launch,
-                         "timers": "HIP events per launch, in a second pass of the same K steps (the timed region runs without them); "
-                                   f"that pass took {elapsed_prof / args.steps * 1e3:.2f} ms per step",
-                         # the kernel is integer-VALU bound, so the informative ceiling is the VALU issue rate: mixed additions/s
-                         # against 1024 SIMDs x 2.4 GHz / 4.2 cycles x 64 lanes / MADD_INSTRUCTIONS (a derived ceiling: the issue
-                         # cost per instruction is measured, profiles/r02_ubench_valu.txt, the instruction count is the generated code's)
-                         "valu": {"achieved_gadd_s": dense_adds / (acc_ms / 1e3) / 1e9 if acc_ms else None, "peak_gadd_s": VALU_PEAK_GADD_S,
-                                  "frac": dense_adds / (acc_ms / 1e3) / 1e9 / VALU_PEAK_GADD_S if acc_ms else None,
-                                  "instructions_per_addition": MADD_INSTRUCTIONS, "instructions_source": MADD_SOURCE,
-                                  "isolated_chain_gadd_s": MEASURED_CHAIN_GADD_S,
-                                  "isolated_chain_source": "profiles/r02_ubench_limbs_fused.txt (tools/ubench_limbs.hip on another box; not re-measured in this run)",
-                                  "frac_of_isolated_chain": dense_adds / (acc_ms / 1e3) / 1e9 / MEASURED_CHAIN_GADD_S if acc_ms else None,
-                                  "table": tinfo, "additions_per_pair": table_windows,
-                                  "note": "dense bucket additions only (7N pairs x windows per proof); by-parts and verify-side additions not counted"},
-                         # per-proof unique traffic (11N scalars + 14 NTT passes' data + 784 B out), 3.17 KB per
-                         # domain point = 6.5 MB per proof at N = 2048, over the whole job
-                         "whole_proof": {"algorithmic_bytes_per_proof": 3174 * n_dom, "achieved": 3174 * n_dom * value / 1e9, "unit": "GB/s",
-                                         "frac": 3174 * n_dom * value / 1e9 / (HBM_PEAK_GBS * world)}},
+            "roofline": roof,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
             "parity_ok": parity_ok,
@@ -801,6 +851,7 @@ def main() -> int:
             "gpu_kernel_ms_per_step": {k: round(v, 3) for k, v in kernel_ms.items() if v > 0.0005},
             "bsn_scalar_mul": bsn,
             "g1_msm": g1,
+            "g1_msm_batched": msm_batched,
             "g1_msm_sharded": None,
             "other_ring_sizes": others,
             "distinct_signers": distinct,
@@ -823,6 +874,9 @@ def main() -> int:
     if ctl is not None and args.extras:
         leg5 = ring_size_leg(d, 3839, batch, max(1, min(args.steps, 5)), 2 if args.cpu_proofs > 0 else 0, rank, ctl, barrier)
         if line is not None:
+            leg5["rccl_ranks"] = None
+            leg5["collective"] = "none: proofs are sharded per rank (its one exchange step is the base-sharded MSM, g1_msm_sharded)" + (
+                "; every rank on ONE GPU (DOTRING_BENCH_SHARE_GPU rehearsal)" if share_mode in ("1", "rccl") else "")
             leg5["config"] = (f"BASELINE configs[4]: RingVRF[Bandersnatch] prove_batch + batch_verify, ring 3839 (domain 4096), {batch} proofs per "
                               f"rank = {batch * world} proofs per step on {world} GPUs; its sharded MSM: g1_msm_sharded")
             line["config5"] = leg5
@@ -866,7 +920,7 @@ def main() -> int:
         # rank whose peers failed in a SocketComm rehearsal would otherwise be the only witness
         mine = json.dumps({"rank": rank, "state": state, "stage": box["stage"], "error": box.get("error")}).encode()[:480].ljust(480)
         try:
-            reports = [json.loads(b.decode().strip()) for b in ctl.all_gather(mine)]
+            reports = [json.loads(b.decode().strip()) for b in status_star.all_gather(mine)]
         except Exception as exc:              # noqa: BLE001 — a peer that is gone: still print, still fail
             reports = [{"rank": rank, "state": state, "stage": box["stage"], "error": box.get("error")},
                        {"rank": None, "state": "error", "stage": "status exchange", "error": f"{type(exc).__name__}: {exc}"}]
@@ -894,6 +948,7 @@ def main() -> int:
         if rc == 0:
             ctl.barrier()
         ctl.close()
+        status_star.close()
     return rc
 
 
