@@ -77,7 +77,7 @@ VALU_PEAK_GADD_S = 1024 * 2.4e9 / 4.2 * 64 / MADD_INSTRUCTIONS / 1e9
 MEASURED_CHAIN_GADD_S = 7.56
 ALG_BYTES_PER_PAIR = 128       # 96 B affine base + 32 B scalar per (base, scalar) pair
 ALG_BYTES_PER_SCALAR_MUL = 160  # 64 B point + 32 B scalar + 64 B result
-MSM_KERNELS = ("k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_part_scatter", "k_g1_part_sort", "k_g1_sort_sets", "k_size_sort", "k_g1_accumulate", "k_g1_reduce_chunks",
+MSM_KERNELS = ("wipe", "k_g1_digits", "k_scan", "k_g1_scatter", "k_g1_part_scatter", "k_g1_part_sort", "k_g1_sort_sets", "k_size_sort", "k_g1_accumulate", "k_g1_reduce_chunks",
                "k_g1_reduce_windows", "k_g1_horner", "k_g1_results_affine")
 RING_KERNELS = ("k_bsn_scalar_mul", "k_bsn_encode_to_curve", "k_bsn_msm_groups", "k_bsn_fixed_base", "k_te_msm_prepare", "k_te_msm_accumulate",
                 "k_te_msm_reduce", "k_ring_chain", "k_ring_columns", "k_ntt_local",

@@ -74,6 +74,9 @@ _PROTOTYPES = {
     "dr_ring_prove_quotient": (c_int, [c_void_p, c_size_t, c_char_p, c_void_p, POINTER(c_int)]),
     "dr_ring_prove_evals": (c_int, [c_void_p, c_size_t, c_char_p, c_void_p]),
     "dr_ring_prove_openings": (c_int, [c_void_p, c_size_t, c_char_p, c_void_p, POINTER(c_int)]),
+    "dr_ctx_scratch_residue": (c_int, [c_void_p, POINTER(ctypes.c_uint64)]),
+    "dr_ring_prover_wipe": (c_int, [c_void_p]),
+    "dr_ring_prover_residue": (c_int, [c_void_p, POINTER(ctypes.c_uint64)]),
     "dr_ntt": (c_int, [c_void_p, c_void_p, c_uint, c_size_t, c_char_p, c_char_p]),
     "dr_ntt_dev": (c_int, [c_void_p, c_void_p, c_uint, c_size_t, c_char_p, c_char_p]),
 }
@@ -406,6 +409,16 @@ class RingProver:
         _check(lib().dr_ring_prove_openings(self.handle, batch, nus, out, inf))
         return self._points(out.raw, inf, 2 * batch)
 
+    def wipe(self) -> None:
+        """Zero the per-batch state and the MSM scratch on the device now (every batch already ends with it)."""
+        _check(lib().dr_ring_prover_wipe(self.handle))
+
+    def residue(self) -> int:
+        """Non-zero 32-bit words left in the prover's per-batch device state and its contexts' scratch (0 after a wipe)."""
+        words = ctypes.c_uint64(0)
+        _check(lib().dr_ring_prover_residue(self.handle, byref(words)))
+        return words.value
+
     def ringvrf_prove_batch(self, suite: "VrfSuiteStruct", alphas, ads, salts, secret_scalars: bytes, producer_index: list,
                             fs_prefix: bytes, zk_random48: bytes | None):
         """dr_ringvrf_prove_batch: the whole batch (hashing on the library's worker threads, GPU phases in between).
@@ -447,6 +460,12 @@ class Context:
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
+
+    def scratch_residue(self) -> int:
+        """Non-zero 32-bit words in this context's scratch buffers (0 after a batch prover has wiped them)."""
+        words = ctypes.c_uint64(0)
+        _check(lib().dr_ctx_scratch_residue(self.handle, byref(words)))
+        return words.value
 
     # ---- profiling
     def prof_enable(self, on: bool = True) -> None:

@@ -136,7 +136,8 @@ struct PedersenBatch {
                 std::memcpy(a + 256, blind.data() + 32 * i, 32);
             }
         });
-        return DR_OK;
+        // device copies of x, b, k, k_b (scalar uploads of the fixed-base and variable-base launches) do not outlive the call either
+        return ctx_wipe_scratch(actx);
     }
 };
 
@@ -187,6 +188,11 @@ int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_
     } else {
         TRY(ped.tail(ctx, out_proofs, 784, out_aux, DR_RINGVRF_AUX_BYTES));
     }
+    struct WipeGuard {       // an exit before the last ring phase (which wipes on its own) still leaves no witness state in HBM
+        dr_ring_prover* p;
+        bool armed = true;
+        ~WipeGuard() { if (armed) (void)dr_ring_prover_wipe(p); }
+    } wipe_guard{p};
     struct Joiner {          // every exit path below must wait for the helper before the buffers it uses go away
         std::thread& t;
         ~Joiner() { if (t.joinable()) t.join(); }
@@ -255,6 +261,7 @@ int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_
     });
     tr_.mark("fs3");
     TRY(dr_ring_prove_openings(p, B, nus.data(), opens.data(), open_inf.data()));
+    wipe_guard.armed = false;        // (the openings phase ended with the wipe)
     tr_.mark("openings");
     // 8. payload: 4 compressed commitments, 7 evaluations, C_q, l(zeta*omega), 2 opening proofs  (proof_payload.py:68-117)
     std::vector<int> rc(B, DR_OK);
@@ -504,6 +511,13 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         // units, where another context's bucket walk cannot hold them up; `st` below is then the side stream
         SideSection side_(ctx);
         hipStream_t st = ctx->stream;
+        // the third stream (G1 decompression, below) writes its verdicts into this context's io_c: it starts behind whatever this stream
+        // still has to do with its scratch — a prover that ran on this context leaves the wipe of its buffers in the stream
+        // (capi_core.hip: ctx_wipe_scratch) — but not behind the decoding kernel launched next
+        hipEvent_t scratch_ready;
+        HIP_TRY(hipEventCreateWithFlags(&scratch_ready, hipEventDisableTiming));
+        struct EventGuard { hipEvent_t e; ~EventGuard() { (void)hipEventDestroy(e); } } scratch_ready_guard{scratch_ready};
+        HIP_TRY(hipEventRecord(scratch_ready, st));
         HIP_TRY(hipMemcpyAsync(ctx->io_a.p, te_enc.data(), n_te * 32, hipMemcpyHostToDevice, st));
         uint32_t* d_ok = ctx->io_c.as<uint32_t>();
         TRY(launch(ctx, "k_bsn_decode_points", [&] {
@@ -520,6 +534,7 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         dr_ctx* dctx = side_.active ? ctx : ctx->aux2;
         hipStream_t st2 = dctx->stream;
         ctx->aux2->prof = ctx->prof;
+        if (st2 != st) HIP_TRY(hipStreamWaitEvent(st2, scratch_ready, 0));
         HIP_TRY(hipMemcpyAsync(g1_in.p, g1_enc.data(), 7 * B * 48, hipMemcpyHostToDevice, st2));
         TRY(launch(dctx, "k_g1_decompress", [&] {
             g1_launch_decompress(st2, g1_in.as<uint8_t>(), g1_bases.as<uint32_t>(), d_ok + n_te, 7 * B);
@@ -848,7 +863,16 @@ int dr_ietf_prove_batch(dr_ctx* ctx, const dr_vrf_suite* suite, int thin, size_t
         for (size_t i = 0; i < B; i++)
             if (alpha_off[i + 1] < alpha_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
                 return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
-        std::vector<uint8_t> xs(B * 32), inputs(B * 64);
+        std::vector<uint8_t> xs(B * 32), inputs(B * 64), pts(2 * B * 64), sc(2 * B * 32), firsts(2 * B * 64), ks(B * 32);
+        struct SecretGuard {         // secret scalars and nonces, on the host and in the context's scratch, do not outlive the call
+            std::vector<uint8_t>*a, *b, *c;
+            dr_ctx* ctx;
+            ~SecretGuard() {
+                for (std::vector<uint8_t>* v : {a, b, c})
+                    if (!v->empty()) explicit_bzero(v->data(), v->size());
+                (void)ctx_wipe_scratch(ctx);
+            }
+        } secret_guard{&xs, &sc, &ks, ctx};
         for (size_t i = 0; i < B; i++) {
             uint64_t x[4];
             mn.reduce_bytes(secret_scalars + 32 * i, 32, false, x);
@@ -856,7 +880,6 @@ int dr_ietf_prove_batch(dr_ctx* ctx, const dr_vrf_suite* suite, int thin, size_t
         }
         TRY(encode_to_curve_msgs(ctx, su, B, alphas, alpha_off, salts, salt_off, inputs.data()));
         // pk_i = x_i G and O_i = x_i I_i in one launch
-        std::vector<uint8_t> pts(2 * B * 64), sc(2 * B * 32), firsts(2 * B * 64);
         for (size_t i = 0; i < B; i++) {
             std::memcpy(pts.data() + 64 * i, su.generator, 64);
             std::memcpy(pts.data() + 64 * (B + i), inputs.data() + 64 * i, 64);
@@ -874,7 +897,7 @@ int dr_ietf_prove_batch(dr_ctx* ctx, const dr_vrf_suite* suite, int thin, size_t
         const uint8_t* outs = firsts.data() + 64 * B;
         // transcripts, delinearisation scalar z, nonces
         std::vector<drh::Bytes> tr(B);
-        std::vector<uint8_t> gpts(B * 128), gsc(B * 64), ks(B * 32);
+        std::vector<uint8_t> gpts(B * 128), gsc(B * 64);
         std::vector<int> bad(B, 0);
         uint8_t enc_g[32];
         drh::enc_te_point(su.generator, enc_g);

@@ -174,6 +174,62 @@ hipError_t create_masked_stream(hipStream_t* st, int device, bool side) {
 }
 }  // namespace
 
+// ---- wiping (capi_internal.hpp)
+namespace {
+__global__ void k_count_nonzero(const uint32_t* __restrict__ buf, size_t words, unsigned long long* __restrict__ out) {
+    unsigned long long local = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) local += buf[i] != 0;
+    for (int s = 32; s >= 1; s >>= 1) local += __shfl_xor(local, s, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+}
+std::vector<Scratch*> ctx_scratch_list(dr_ctx* ctx) {
+    return {&ctx->scalars, &ctx->digits, &ctx->counts, &ctx->offsets, &ctx->cursor, &ctx->tiles, &ctx->sorted, &ctx->buckets, &ctx->partial,
+            &ctx->winsum, &ctx->result, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->perm, &ctx->cells, &ctx->cell_off, &ctx->part_base, &ctx->heavy};
+}
+}  // namespace
+
+bool dri::wipe_enabled() {
+    static const bool on = std::getenv("DOTRING_WIPE") == nullptr || std::atoi(std::getenv("DOTRING_WIPE")) != 0;
+    return on;
+}
+int dri::ctx_wipe_scratch(dr_ctx* ctx) {
+    if (!wipe_enabled()) return DR_OK;
+    TRY(use_ctx(ctx));
+    hipError_t e = hipSuccess;
+    TRY(launch(ctx, "wipe", [&] {
+        for (Scratch* s : ctx_scratch_list(ctx))
+            if (s->p && s->cap && e == hipSuccess) e = hipMemsetAsync(s->p, 0, s->cap, ctx->stream);
+    }));
+    HIP_TRY(e);
+    return DR_OK;
+}
+int dri::count_nonzero_words(dr_ctx* ctx, const void* d_buf, size_t bytes, uint64_t* total) {
+    if (!d_buf || bytes < 4) return DR_OK;
+    unsigned long long* d_cnt = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_cnt, 8));
+    hipError_t e = hipMemsetAsync(d_cnt, 0, 8, ctx->stream);
+    unsigned long long host = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_count_nonzero, dim3(1024), dim3(256), 0, ctx->stream, (const uint32_t*)d_buf, bytes / 4, d_cnt);
+        e = hipMemcpyAsync(&host, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_cnt);
+    if (e != hipSuccess) return fail(DR_ERR_DEVICE, std::string("residue count: ") + hipGetErrorString(e));
+    *total += host;
+    return DR_OK;
+}
+int dr_ctx_scratch_residue(dr_ctx* ctx, uint64_t* words) {
+    if (!ctx || !words) return fail(DR_ERR_INVALID, "null argument");
+    *words = 0;
+    return ctx_scratch_residue(ctx, words);
+}
+int dri::ctx_scratch_residue(dr_ctx* ctx, uint64_t* words) {
+    TRY(use_ctx(ctx));
+    for (Scratch* s : ctx_scratch_list(ctx)) TRY(count_nonzero_words(ctx, s->p, s->cap, words));
+    return DR_OK;
+}
+
 int dr_ctx_create(int device_id, dr_ctx** out) { return ctx_create_role(device_id, 0, out); }
 
 int dri::ctx_create_role(int device_id, int role, dr_ctx** out) {

@@ -136,6 +136,14 @@ namespace dri {
 
 int use_ctx(dr_ctx* ctx);
 int prof_collect(dr_ctx* ctx);
+// Secrets do not stay in HBM past the call that used them: zero every scratch buffer of the context (scalar uploads, MSM digit rows,
+// sorted entries, buckets and partial sums — all of them functions of the scalars), stream-ordered behind the work already enqueued;
+// the caller does not wait.  DOTRING_WIPE=0 turns every wipe of the library off (the A/B of its cost).
+bool wipe_enabled();
+int ctx_wipe_scratch(dr_ctx* ctx);
+// non-zero 32-bit words in the context's scratch buffers (the test of the wipe)
+int ctx_scratch_residue(dr_ctx* ctx, uint64_t* words);
+int count_nonzero_words(dr_ctx* ctx, const void* d_buf, size_t bytes, uint64_t* total);   // adds to *total
 // dr_ctx_create with a role: 0 = a caller's context (wide stream + its own side stream when the chip is partitioned),
 // 1 = a helper context whose whole stream is latency-bound work (lives on the side compute units), 2 = a helper that runs
 // chip-filling kernels (wide stream only)

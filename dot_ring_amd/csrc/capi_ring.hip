@@ -532,6 +532,48 @@ int dr_ring_prove_openings(dr_ring_prover* p, size_t batch, const uint8_t* nus, 
         std::memcpy(out_openings + 192 * b + 96, o.data() + 96 * (batch + b), 96);
         if (is_inf) { is_inf[2 * b] = inf[b]; is_inf[2 * b + 1] = inf[batch + b]; }
     }
+    // the last phase of a batch: its results are on the host, nothing of the witness has to outlive it
+    return dr_ring_prover_wipe(p);
+}
+
+namespace {
+std::vector<Scratch*> prover_batch_state(dr_ring_prover* p) {
+    return {&p->idx, &p->blind, &p->zk, &p->chain_ext, &p->prefix, &p->chain_aff, &p->cnt, &p->relation, &p->rps, &p->cols, &p->wit4, &p->alphas,
+            &p->alphas9, &p->alpha_aux, &p->agg, &p->q, &p->zetas, &p->evals, &p->ks, &p->lin, &p->nus, &p->nus9, &p->aggo, &p->chunkv, &p->quot1,
+            &p->quot2, &p->diffs, &p->special, &p->hid};
+}
+}  // namespace
+
+// Blinding factors, hidden rows, the bit column and every polynomial derived from them (witness columns and their evaluations, the
+// by-parts differences, quotient, linearisation and opening quotients — 2.6 GB for 1024 proofs at N = 2048) are zeroed when the last
+// phase of a batch has delivered its results, and so is the MSM scratch of the prover's context (digit rows, sorted entries, buckets of
+// the witness MSMs).  Stream-ordered memsets, not waited for: they run while the host builds the proof bytes, and the next call on this
+// stream is ordered behind them.  Per-ring tables (public) stay.  Also callable on request (a Ring about to be parked).
+int dr_ring_prover_wipe(dr_ring_prover* p) {
+    if (!p) return fail(DR_ERR_INVALID, "null argument");
+    if (!wipe_enabled()) return DR_OK;
+    TRY(use_ctx(p->ctx));
+    hipError_t e = hipSuccess;
+    TRY(launch(p->ctx, "wipe", [&] {
+        for (Scratch* s : prover_batch_state(p))
+            if (s->p && s->cap && e == hipSuccess) e = hipMemsetAsync(s->p, 0, s->cap, p->ctx->stream);
+    }));
+    HIP_TRY(e);
+    p->fwd_pending = p->quot2_pending = false;
+    return ctx_wipe_scratch(p->ctx);
+}
+
+// test hook: non-zero 32-bit words left in the prover's per-batch state, its context's scratch and its helper context's scratch
+int dr_ring_prover_residue(dr_ring_prover* p, uint64_t* words) {
+    if (!p || !words) return fail(DR_ERR_INVALID, "null argument");
+    *words = 0;
+    TRY(use_ctx(p->ctx));
+    for (Scratch* s : prover_batch_state(p)) TRY(count_nonzero_words(p->ctx, s->p, s->cap, words));
+    TRY(ctx_scratch_residue(p->ctx, words));
+    if (p->aux_ctx) {
+        TRY(ctx_scratch_residue(p->aux_ctx, words));
+        TRY(use_ctx(p->ctx));
+    }
     return DR_OK;
 }
 

@@ -267,6 +267,15 @@ DR_API int dr_ring_prove_witness(dr_ring_prover *p, size_t batch, const uint32_t
 DR_API int dr_ring_prove_quotient(dr_ring_prover *p, size_t batch, const uint8_t *alphas, uint8_t *out_cq, int *is_inf);
 DR_API int dr_ring_prove_evals(dr_ring_prover *p, size_t batch, const uint8_t *zetas, uint8_t *out_evals);
 DR_API int dr_ring_prove_openings(dr_ring_prover *p, size_t batch, const uint8_t *nus, uint8_t *out_openings, int *is_inf);
+/* Secrets do not stay in HBM.  dr_ring_prove_openings — the last phase of a batch — ends by zeroing the prover's per-batch state
+ * (blinding factors, hidden rows, the witness columns with their bit column, every polynomial derived from them) and the MSM scratch
+ * of its context; the batch entry points (dr_ringvrf_prove_batch, dr_pedersen_prove_batch, dr_ietf_prove_batch) also zero the device
+ * copies of secret scalars and nonces.  Stream-ordered memsets that the call does not wait for.  dr_ring_prover_wipe does the same on
+ * request; dr_ring_prover_residue counts the non-zero 32-bit words left in those buffers (0 after a wipe; a test hook).
+ * DOTRING_WIPE=0 disables the wipes (to measure their cost). */
+DR_API int dr_ring_prover_wipe(dr_ring_prover *p);
+DR_API int dr_ctx_scratch_residue(dr_ctx *ctx, uint64_t *words);    /* the same count for one context's scratch buffers */
+DR_API int dr_ring_prover_residue(dr_ring_prover *p, uint64_t *words);
 
 
 /* ---- native batch orchestration ------------------------------------------------------------------

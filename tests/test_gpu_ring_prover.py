@@ -373,3 +373,39 @@ def test_jubjub_device_prover_domain_1024_matches_oracle(ctx):
         assert proofs[2].encode() == oring.ring_vrf_prove(o_ring, o_root, als[2], als[2], sks[299].to_bytes(32, "little"))
         assert vrf.batch_verify(proofs, als, als, ring, root)
         assert not vrf.batch_verify(proofs, als[::-1], als, ring, root)
+
+
+def test_prove_batch_leaves_no_secret_state_in_hbm():
+    """After RingVRF.prove_batch has returned, the device holds nothing of the batch's secrets: the prover's per-batch state (blinding
+    factors, hidden rows, the witness columns with their bit column, every polynomial derived from them), the MSM scratch of its
+    context (digit rows, sorted entries, buckets) and the scratch of the Pedersen helper context (device copies of x, b, k, k_b) read
+    as zeros (dr_ring_prover_residue counts non-zero words in all of them).  Proofs still verify, a second batch on the wiped state
+    gives the same bytes, and the Pedersen / IETF batch provers leave their contexts clean too."""
+    import dot_ring_amd as d
+    from dot_ring_amd import runtime
+    from dot_ring_amd.ring_proof import device_prover
+
+    cv = d.Bandersnatch
+    sks = [(900 + i).to_bytes(32, "little") for i in range(40)]
+    keys = [cv.public_key_from_secret(sk) for sk in sks]
+    params = d.RingProofParams.from_ring_size(40, test_vectors=True)
+    ring = d.Ring(keys, params)
+    root = d.RingRoot.from_ring(ring, params)
+    vrf = d.RingVRF[cv]
+    n = 24
+    als, ads = [b"wipe-%d" % i for i in range(n)], [b"ad"] * n
+    first = vrf.prove_batch(als, ads, sks[:n], keys[:n], ring, root)
+    prover = device_prover.get_device_prover(ring, 0)
+    assert prover.residue() == 0
+    assert vrf.batch_verify(first, als, ads, ring, root)
+    again = vrf.prove_batch(als, ads, sks[:n], keys[:n], ring, root)
+    assert [p.encode() for p in again] == [p.encode() for p in first]
+    assert prover.residue() == 0
+    one = vrf.prove(b"single", b"", sks[3], keys[3], ring, root)               # the single-proof API goes the same way
+    assert one.verify(b"single", b"", ring, root) and prover.residue() == 0
+    # Pedersen and IETF batch provers: the calling thread's context is clean afterwards
+    ctx = runtime.context()
+    d.PedersenVRF[cv].prove_batch(als, sks[:n], ads)
+    assert ctx.scratch_residue() == 0
+    d.TinyVRF[cv].prove_batch(als, sks[:n], ads)
+    assert ctx.scratch_residue() == 0
