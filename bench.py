@@ -347,11 +347,6 @@ class RingWorkload:
         self.ads = [b"bench-batch-ad" + (first_index + i).to_bytes(8, "little") for i in range(batch)]
         self.sks, self.pks = [self.signer_sk] * batch, [self.signer_pk] * batch
         self.prove_s = self.verify_s = 0.0
-        self.lanes = max(1, int(os.environ.get("DOTRING_BENCH_LANES", "1")))
-        if self.lanes > 1:
-            from concurrent.futures import ThreadPoolExecutor
-
-            self._pool = ThreadPoolExecutor(max_workers=self.lanes - 1)
 
     def distinct_signers(self):
         """every proof signed by another ring member (ring_size >= batch)"""
@@ -366,21 +361,11 @@ class RingWorkload:
         return proofs, ok, t1 - t, time.perf_counter() - t1
 
     def step(self):
-        """One step = the whole batch proved and verified.  lanes == 1: one prove_batch call, then one batch_verify call.
-        lanes == 2 (DOTRING_BENCH_LANES): the application pipelines the batch as two half-batches from two threads, each
-        proving then verifying its half on its own context, so that one half's latency-bound kernels and host phases run under
-        the other half's bucket walk."""
-        if self.lanes <= 1 or self.batch < 2 * self.lanes:
-            proofs, ok, tp, tv = self._span(0, self.batch)
-            self.prove_s += tp
-            self.verify_s += tv
-            return proofs, ok
-        cuts = [self.batch * i // self.lanes for i in range(self.lanes + 1)]
-        futures = [self._pool.submit(self._span, lo, hi) for lo, hi in zip(cuts[1:], cuts[2:])]
-        parts = [self._span(cuts[0], cuts[1])] + [f.result() for f in futures]
-        self.prove_s += max(p[2] for p in parts)
-        self.verify_s += max(p[3] for p in parts)
-        return [pr for p in parts for pr in p[0]], all(p[1] for p in parts)
+        """One step = the whole batch proved and verified: one prove_batch call, then one batch_verify call."""
+        proofs, ok, tp, tv = self._span(0, self.batch)
+        self.prove_s += tp
+        self.verify_s += tv
+        return proofs, ok
 
     def run(self, steps: int, warmup: int, barrier=lambda: None):
         for _ in range(warmup):

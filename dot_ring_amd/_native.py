@@ -48,7 +48,6 @@ _PROTOTYPES = {
     "dr_fr_ops_selftest": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, c_void_p, c_void_p]),
     "dr_srs_load": (c_int, [c_void_p, c_char_p, c_size_t, POINTER(c_void_p)]),
     "dr_srs_synthetic": (c_int, [c_void_p, c_char_p, c_uint, c_size_t, POINTER(c_void_p)]),
-    "dr_srs_precompute_comb": (c_int, [c_void_p, c_void_p]),
     "dr_srs_powers": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, POINTER(c_void_p)]),
     "dr_g2_mul": (c_int, [c_char_p, c_char_p, c_char_p]),
     "dr_srs_precompute": (c_int, [c_void_p, c_void_p, c_int]),
@@ -326,11 +325,6 @@ class Srs:
         return {"window_bits": info[0], "rows": info[1], "batched_windows": info[2], "tiling_bits": info[3],
                 "tiling": ("window rows", "-", "non-adjacent form")[info[4]], "digits_per_scalar": info[5] / 1000.0,
                 "odd_buckets": bool(info[4])}
-
-    def precompute_comb(self) -> "Srs":
-        """Comb table over the window table (see dr_srs_precompute_comb); MemoryError if it does not fit."""
-        _check(lib().dr_srs_precompute_comb(self.ctx.handle, self.handle))
-        return self
 
     def download(self, offset: int, count: int) -> bytes:
         out = ctypes.create_string_buffer(max(96 * count, 1))

@@ -74,7 +74,7 @@ struct PedersenBatch {
         const int cv = su.cv->id;
         ybar.resize(B * 64); ks.resize(B * 32); kbs.resize(B * 32); pts3.resize(2 * B * 128); sc3.resize(2 * B * 64); third.resize(2 * B * 64);
         // 4. blinded public keys  Y_bar_i = x_i*G + b_i*B: both bases are constants of the suite -> fixed-base window tables
-        static const bool fixed = std::getenv("DOTRING_BSN_FIXED_BASE") == nullptr || std::atoi(std::getenv("DOTRING_BSN_FIXED_BASE")) != 0;
+        constexpr bool fixed = true;            // (te_msm_groups, the variable-base launches, stays for callers with other bases)
         uint8_t gb[128];
         std::memcpy(gb, su.generator, 64);
         std::memcpy(gb + 64, su.blinding_base, 64);
@@ -181,13 +181,7 @@ int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_
     actx->prof = ctx->prof;
     int ped_rc = DR_OK;
     std::string ped_err;
-    const bool overlap = std::getenv("DOTRING_PROVE_OVERLAP") == nullptr || std::atoi(std::getenv("DOTRING_PROVE_OVERLAP")) != 0;
-    std::thread ped_thread;
-    if (overlap) {
-        ped_thread = std::thread([&] { run_guarded(ped_rc, ped_err, [&] { return ped.tail(actx, out_proofs, 784, out_aux, DR_RINGVRF_AUX_BYTES); }); });
-    } else {
-        TRY(ped.tail(ctx, out_proofs, 784, out_aux, DR_RINGVRF_AUX_BYTES));
-    }
+    std::thread ped_thread([&] { run_guarded(ped_rc, ped_err, [&] { return ped.tail(actx, out_proofs, 784, out_aux, DR_RINGVRF_AUX_BYTES); }); });
     struct WipeGuard {       // an exit before the last ring phase (which wipes on its own) still leaves no witness state in HBM
         dr_ring_prover* p;
         bool armed = true;
@@ -507,9 +501,6 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         TRY(ctx->io_a.reserve(n_te * 32));
         TRY(ctx->io_b.reserve(n_te * 64));
         TRY(ctx->io_c.reserve(n_te * 4 + n_g1 * 4));
-        // partitioned chip (DOTRING_SIDE_CUS): both decoders are latency chains and run one after the other on the side compute
-        // units, where another context's bucket walk cannot hold them up; `st` below is then the side stream
-        SideSection side_(ctx);
         hipStream_t st = ctx->stream;
         // the third stream (G1 decompression, below) writes its verdicts into this context's io_c: it starts behind whatever this stream
         // still has to do with its scratch — a prover that ran on this context leaves the wipe of its buffers in the stream
@@ -531,7 +522,7 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         // the G1 decompression (a 380-squaring chain on ~100 waves) runs next to the Bandersnatch decoding (~1 ms on 128 waves) on
         // the third stream; an event brings it back into this stream before anything reads the bases
         if (!ctx->aux2) TRY(ctx_create_role(ctx->device, 2, &ctx->aux2));
-        dr_ctx* dctx = side_.active ? ctx : ctx->aux2;
+        dr_ctx* dctx = ctx->aux2;
         hipStream_t st2 = dctx->stream;
         ctx->aux2->prof = ctx->prof;
         if (st2 != st) HIP_TRY(hipStreamWaitEvent(st2, scratch_ready, 0));
@@ -886,7 +877,7 @@ int dr_ietf_prove_batch(dr_ctx* ctx, const dr_vrf_suite* suite, int thin, size_t
             std::memcpy(sc.data() + 32 * i, xs.data() + 32 * i, 32);
             std::memcpy(sc.data() + 32 * (B + i), xs.data() + 32 * i, 32);
         }
-        static const bool fixed = std::getenv("DOTRING_BSN_FIXED_BASE") == nullptr || std::atoi(std::getenv("DOTRING_BSN_FIXED_BASE")) != 0;
+        constexpr bool fixed = true;            // (te_msm_groups, the variable-base launches, stays for callers with other bases)
         if (fixed) {                    // pk = x G from the generator's window table; O = x I is variable-base
             TRY(te_fixed_base_groups(ctx, cv, su.generator, xs.data(), B, 1, firsts.data()));
             TRY(te_scalar_mul_batch(ctx, cv, inputs.data(), xs.data(), B, firsts.data() + 64 * B));

@@ -28,12 +28,6 @@ int prof_collect(dr_ctx* ctx) {
     return DR_OK;
 }
 
-uint32_t g_chunk_len = 16;
-bool g_bsn_glv = true;
-bool g_use_comb = true;
-bool g_chain_wave = true;
-size_t g_level_threshold = (size_t)1 << 18;
-bool g_reduce_levels = true;
 int g_force_c = 0;
 bool window_ok(int c) { return c >= 7 && c <= 16; }
 
@@ -148,32 +142,6 @@ int bsn_consts_init(hipStream_t st) {
 }
 }  // namespace
 
-namespace {
-// DOTRING_SIDE_CUS=k (0 = off): compute units taken from the chip-filling kernels and given to the latency-bound ones.
-// Mask bits are interleaved over the XCDs by the driver (bit i -> XCD i mod 8), so the top k bits are k/8 units per XCD.
-int side_cus() {
-    static const int k = [] {
-        const char* e = std::getenv("DOTRING_SIDE_CUS");
-        int v = e ? std::atoi(e) : 0;
-        return v < 0 ? 0 : v;
-    }();
-    return k;
-}
-// role 0 / 2: all but the top k units; role 1: the top k units
-hipError_t create_masked_stream(hipStream_t* st, int device, bool side) {
-    const int k = side_cus();
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDeviceProperties(&prop, device);
-    if (e != hipSuccess) return e;
-    const int total = prop.multiProcessorCount;
-    if (k <= 0 || k >= total) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
-    for (int i = 0; i < total; i++)
-        if ((i >= total - k) == side) mask[(size_t)i / 32] |= 1u << (i % 32);
-    return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
-}
-}  // namespace
-
 // ---- wiping (capi_internal.hpp)
 namespace {
 __global__ void k_count_nonzero(const uint32_t* __restrict__ buf, size_t words, unsigned long long* __restrict__ out) {
@@ -242,16 +210,8 @@ int dri::ctx_create_role(int device_id, int role, dr_ctx** out) {
     dr_ctx* ctx = new (std::nothrow) dr_ctx();
     if (!ctx) return fail(DR_ERR_NOMEM, "out of host memory");
     ctx->device = device_id;
-    hipError_t e = create_masked_stream(&ctx->stream, device_id, role == 1);
-    if (e == hipSuccess && role == 0 && side_cus() > 0) {
-        e = create_masked_stream(&ctx->side, device_id, true);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_in, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->side_out, hipEventDisableTiming);
-    }
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
-        if (ctx->side_in) (void)hipEventDestroy(ctx->side_in);
-        if (ctx->side_out) (void)hipEventDestroy(ctx->side_out);
-        if (ctx->side) (void)hipStreamDestroy(ctx->side);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return fail(DR_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -259,21 +219,8 @@ int dri::ctx_create_role(int device_id, int role, dr_ctx** out) {
     const char* fc = std::getenv("DOTRING_MSM_WINDOW");
     g_force_c = fc ? std::atoi(fc) : 0;
     if (!window_ok(g_force_c)) g_force_c = 0;
-    const char* cl = std::getenv("DOTRING_MSM_CHUNK");
-    if (cl) {
-        int v = std::atoi(cl);
-        if (v == 8 || v == 16 || v == 32 || v == 64 || v == 128) g_chunk_len = (uint32_t)v;
-    }
-    if (const char* lv = std::getenv("DOTRING_MSM_LEVELS")) g_reduce_levels = std::atoi(lv) != 0;
-    if (const char* ll = std::getenv("DOTRING_MSM_LEVEL_LANES")) g_level_threshold = (size_t)std::max(1L, std::atol(ll));
-    if (const char* cw = std::getenv("DOTRING_CHAIN_WAVE")) g_chain_wave = std::atoi(cw) != 0;
-    if (const char* cb = std::getenv("DOTRING_MSM_COMB")) g_use_comb = std::atoi(cb) != 0;
-    if (const char* gl = std::getenv("DOTRING_BSN_GLV")) g_bsn_glv = std::atoi(gl) != 0;
     int rc = bsn_consts_init(ctx->stream);
     if (rc != DR_OK) {
-        if (ctx->side_in) (void)hipEventDestroy(ctx->side_in);
-        if (ctx->side_out) (void)hipEventDestroy(ctx->side_out);
-        if (ctx->side) (void)hipStreamDestroy(ctx->side);
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return rc;
@@ -306,12 +253,6 @@ void dr_ctx_destroy(dr_ctx* ctx) {
     }
     for (auto& e : ctx->twiddles.entries) (void)hipFree(e.d_tw);
     for (auto& fb : ctx->fixed_bases) (void)hipFree(fb.d_table);
-    if (ctx->side) {
-        (void)hipStreamSynchronize(ctx->side);
-        (void)hipStreamDestroy(ctx->side);
-        (void)hipEventDestroy(ctx->side_in);
-        (void)hipEventDestroy(ctx->side_out);
-    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -384,8 +325,8 @@ int te_scalar_mul_batch_dev(dr_ctx* ctx, int cv, const void* d_pts, const void* 
     if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "batch too large");
     // 4-bit windows (64 KiB of LDS per wave, 2 waves per CU) while the launch is latency-bound; 2-bit windows
     // (16 KiB, 10 waves per CU) once there are more waves than the 4-bit kernel can keep resident
-    static const long w2_from = std::getenv("DOTRING_BSN_W2_FROM") ? std::atol(std::getenv("DOTRING_BSN_W2_FROM")) : 32768;
-    if (g_bsn_glv && drh::te_curve(cv) && drh::te_curve(cv)->glv && n < 16384) {
+    constexpr long w2_from = 32768;
+    if (drh::te_curve(cv) && drh::te_curve(cv)->glv && n < 16384) {
         // latency-bound launch: GLV on lane pairs, the scalars reduced and decomposed by the lanes themselves (k_bsn_scalar_mul_glv<true>)
         TRY(ctx->io_b.reserve(4));
         HIP_TRY(hipMemsetAsync(ctx->io_b.p, 0, 4, ctx->stream));
@@ -457,13 +398,12 @@ int te_scalar_mul_batch(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_
     if (n == 0) return DR_OK;
     if (!pts_xy || !scalars || !out_xy) return fail(DR_ERR_INVALID, "null buffer");
     TRY(check_fr_elems(pts_xy, 2 * n, "point"));
-    if (g_bsn_glv && drh::te_curve(cv)->glv && n < 16384) {       // latency-bound launch: halve the chain with GLV on lane pairs
+    if (drh::te_curve(cv)->glv && n < 16384) {       // latency-bound launch: halve the chain with GLV on lane pairs
         std::vector<uint32_t> split;
         TRY(glv_split_scalars(scalars, n, split));
         TRY(ctx->io_a.reserve(n * 64));
         TRY(ctx->io_b.reserve(n * 48));
         TRY(ctx->io_c.reserve(n * 64));
-        SideSection side_(ctx);
         HIP_TRY(hipMemcpyAsync(ctx->io_a.p, pts_xy, n * 64, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(ctx->io_b.p, split.data(), n * 48, hipMemcpyHostToDevice, ctx->stream));
         TRY(launch(ctx, "k_bsn_scalar_mul", [&] {
@@ -501,7 +441,7 @@ int te_msm_groups(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_t* sca
     size_t n = groups * m;
     if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "batch too large");
     TRY(check_fr_elems(pts_xy, 2 * n, "point"));
-    if (g_bsn_glv && drh::te_curve(cv)->glv && m <= 32 && n < 16384) {
+    if (drh::te_curve(cv)->glv && m <= 32 && n < 16384) {
         std::vector<uint32_t> split;
         TRY(glv_split_scalars(scalars, n, split));
         uint32_t mpad2 = 2;
@@ -580,7 +520,6 @@ int te_fixed_base_groups(dr_ctx* ctx, int cv, const uint8_t* bases_xy, const uin
     const uint32_t per_block = 64 / (mpad * dr::TE_FIXED_LANES);
     TRY(ctx->io_b.reserve(groups * m * 32));
     TRY(ctx->io_c.reserve(groups * 64));
-    SideSection side_(groups * m < 65536 ? ctx : nullptr);
     HIP_TRY(hipMemcpyAsync(ctx->io_b.p, scalars, groups * m * 32, hipMemcpyHostToDevice, ctx->stream));
     TRY(launch(ctx, "k_bsn_fixed_base", [&] {
         LAUNCH_CV(cv, dr::k_te_fixed_base_groups, dim3(div_up(groups, per_block)), dim3(64), 0, ctx->stream, tabs, ctx->io_b.as<uint32_t>(),
@@ -615,7 +554,7 @@ int te_msm(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_t* scalars, s
     }
     // from a few hundred terms: the bucket method (K4, capi_msm.hip) — ~W additions per term instead of a full scalar
     // multiplication (~250 doublings + 64 additions) per term
-    static const size_t pip_from = std::getenv("DOTRING_BSN_PIPPENGER_FROM") ? (size_t)std::atol(std::getenv("DOTRING_BSN_PIPPENGER_FROM")) : 256;
+    constexpr size_t pip_from = 256;
     if (pip_from > 0 && n >= pip_from) {
         if (!pts_xy || !scalars) return fail(DR_ERR_INVALID, "null buffer");
         TRY(check_fr_elems(pts_xy, 2 * n, "point"));
@@ -685,7 +624,6 @@ int te_decode_points(dr_ctx* ctx, int cv, bool tai, const uint8_t* enc, size_t n
     TRY(ctx->io_a.reserve(n * 32));
     TRY(ctx->io_b.reserve(n * 64));
     TRY(ctx->io_c.reserve(n * 4));
-    SideSection side_(n <= 8192 ? ctx : nullptr);
     HIP_TRY(hipMemcpyAsync(ctx->io_a.p, enc, n * 32, hipMemcpyHostToDevice, ctx->stream));
     TRY(launch(ctx, "k_bsn_decode_points", [&] {
         launch_decode_points(ctx, ctx->stream, cv, tai, ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), ctx->io_c.as<uint32_t>(), n);
@@ -904,7 +842,7 @@ int dr_encode_to_curve_batch(dr_ctx* ctx, const dr_vrf_suite* suite, const uint8
 // suites, batches beyond the GLV kernel's range) take the two separate calls.
 int encode_and_mul(dr_ctx* ctx, const drh::VrfSuite& su, size_t B, const uint8_t* data, const uint64_t* off, const uint8_t* salts,
                    const uint64_t* salt_off, const uint8_t* xs, uint8_t* inputs_xy, uint8_t* outs_xy, const std::function<void()>* while_waiting) {
-    if (su.cv->tai || !su.cv->glv || !g_bsn_glv || B == 0 || B >= 16384) {
+    if (su.cv->tai || !su.cv->glv || B == 0 || B >= 16384) {
         if (while_waiting) (*while_waiting)();
         TRY(encode_to_curve_msgs(ctx, su, B, data, off, salts, salt_off, inputs_xy));
         return te_scalar_mul_batch(ctx, su.cv->id, inputs_xy, xs, B, outs_xy);
@@ -920,7 +858,6 @@ int encode_and_mul(dr_ctx* ctx, const drh::VrfSuite& su, size_t B, const uint8_t
     TRY(ctx->io_a.reserve(B * 64));
     TRY(ctx->io_b.reserve(B * 48));
     TRY(ctx->io_c.reserve(2 * B * 64));
-    SideSection side_(ctx);                                // two latency chains of 16..32 waves: the side compute units
     uint32_t* d_in = ctx->io_c.as<uint32_t>();
     uint32_t* d_out = d_in + B * 16;
     HIP_TRY(hipMemcpyAsync(ctx->io_a.p, us.data(), B * 64, hipMemcpyHostToDevice, ctx->stream));

@@ -87,11 +87,6 @@ using dri::Scratch;
 struct dr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    // DOTRING_SIDE_CUS=k: `stream` is confined to all but k compute units and `side` owns those k (hipExtStreamCreateWithCUMask):
-    // latency-bound kernels (a few dozen waves on a long dependent chain) go to `side` through SideSection, where another
-    // context's chip-filling bucket walk cannot starve them of workgroup slots.  nullptr = no partition (one plain stream).
-    hipStream_t side = nullptr;
-    hipEvent_t side_in = nullptr, side_out = nullptr;
     bool prof = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<std::string, ProfEntry> prof_data;
@@ -124,9 +119,6 @@ struct dr_srs {
     bool table_bit_rows = false;
     uint32_t table_pt_words = 24;        // words per table record: 24 (packed) or 32 (one point per 128-byte line)
     int table_naf_delta = -2;            // width of the non-adjacent form of batched MSMs: -2 = chosen per call (tiling_for), -1 = never, >= 0: window_bits + this
-    // optional comb table over the window table: comb[j][w][d-1] = d * table[w][j], every digit magnitude precomputed
-    uint32_t* d_comb = nullptr;
-    uint32_t comb_h = 0;
     // derived bases for summation-by-parts commitments, keyed by log2(domain size): PS_j = sum_{i<=j} L_i(tau) G
     std::map<unsigned, dr_srs*> lagrange_prefix;
     std::mutex derive_mutex;             // provers for the same SRS may be created from different threads
@@ -144,31 +136,8 @@ int ctx_wipe_scratch(dr_ctx* ctx);
 // non-zero 32-bit words in the context's scratch buffers (the test of the wipe)
 int ctx_scratch_residue(dr_ctx* ctx, uint64_t* words);
 int count_nonzero_words(dr_ctx* ctx, const void* d_buf, size_t bytes, uint64_t* total);   // adds to *total
-// dr_ctx_create with a role: 0 = a caller's context (wide stream + its own side stream when the chip is partitioned),
-// 1 = a helper context whose whole stream is latency-bound work (lives on the side compute units), 2 = a helper that runs
-// chip-filling kernels (wide stream only)
+// dr_ctx_create for a helper context of another one (second / third stream of the same GPU); `role` is kept for the call sites' sake
 int ctx_create_role(int device_id, int role, dr_ctx** out);
-
-// Everything enqueued on ctx->stream while a SideSection is alive goes to the context's side stream instead, ordered after
-// the work already enqueued on the main stream; on destruction the main stream waits for it.  A no-op without a partition.
-struct SideSection {
-    dr_ctx* ctx;
-    bool active;
-    explicit SideSection(dr_ctx* c) : ctx(c), active(c && c->side) {
-        if (!active) return;
-        (void)hipEventRecord(ctx->side_in, ctx->stream);
-        (void)hipStreamWaitEvent(ctx->side, ctx->side_in, 0);
-        std::swap(ctx->stream, ctx->side);
-    }
-    ~SideSection() {
-        if (!active) return;
-        std::swap(ctx->stream, ctx->side);
-        (void)hipEventRecord(ctx->side_out, ctx->side);
-        (void)hipStreamWaitEvent(ctx->stream, ctx->side_out, 0);
-    }
-    SideSection(const SideSection&) = delete;
-    SideSection& operator=(const SideSection&) = delete;
-};
 
 // kernel launch wrapper with optional hipEvent timing on the ctx stream
 template <class F>
@@ -240,12 +209,6 @@ inline void g1_host_to_dev(drh::G1* pts, size_t n) {
     } while (0)
 
 // ---- knobs (environment, read in dr_ctx_create; defined in capi_core.hip)
-extern uint32_t g_chunk_len;       // buckets per lane in k_g1_reduce_chunks (DOTRING_MSM_CHUNK)
-extern bool g_bsn_glv;             // GLV lane-pair kernels for latency-bound Bandersnatch launches (DOTRING_BSN_GLV=0: plain 64-window kernels)
-extern bool g_use_comb;            // use comb tables when an SRS has one (DOTRING_MSM_COMB=0: bucket method)
-extern bool g_chain_wave;          // one wave per proof for the witness accumulator chain (DOTRING_CHAIN_WAVE=0: one lane per proof)
-extern size_t g_level_threshold;   // chunk lanes from which the level-wise reduction is used (DOTRING_MSM_LEVEL_LANES)
-extern bool g_reduce_levels;       // level-wise bucket reduction for many bucket sets (DOTRING_MSM_LEVELS=0 disables)
 extern int g_force_c;              // test hook: DOTRING_MSM_WINDOW
 bool window_ok(int c);
 
@@ -320,8 +283,6 @@ struct MsmTable {
     bool bit_rows = false;               // the table has a row per bit: a call may recode the scalars as it likes (non-adjacent form)
     int naf_delta = -2;                  // see dr_srs::table_naf_delta
     uint32_t stride = 0, offset = 0;
-    const uint32_t* comb = nullptr;      // comb[j][w][d-1], see k_g1_comb_msm
-    uint32_t comb_h = 0;
     uint32_t short_from = 0xffffffffu, n_short = 0;   // batched MSM: vectors from this index on are zero beyond n_short (sort hint)
     bool fold_sign = false;              // scalars above r / 2 enter as their negatives (difference columns: r - 1 becomes -1, one digit)
 };

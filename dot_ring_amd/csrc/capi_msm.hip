@@ -80,38 +80,16 @@ MsmPlan make_plan(size_t n, int force_c, bool latency_bound = false) {
     }
     p.wt.odd = 0;
     p.H = 1u << (p.wt.cmax - 1);
-    p.L = std::min<uint32_t>(p.H, g_chunk_len);
+    p.L = std::min<uint32_t>(p.H, 16u);
     p.T = p.H / p.L;
     return p;
 }
 }  // namespace
 
-namespace {
-// DOTRING_WIDE_TOKEN=1 (experiment): contexts of one process take turns with their chip-filling MSM pipelines — a
-// batched MSM holds the token from its sort to the end of its bucket reduction, so that another lane's wide kernels never queue
-// up behind this one's bucket walk (where they would wait for workgroup slots with their stream blocked).
-std::mutex g_wide_mutex;
-struct WideToken {
-    dr_ctx* ctx;
-    bool held;
-    WideToken(dr_ctx* c, bool want) : ctx(c), held(false) {
-        static const bool on = std::getenv("DOTRING_WIDE_TOKEN") && std::atoi(std::getenv("DOTRING_WIDE_TOKEN")) != 0;
-        if (on && want) { g_wide_mutex.lock(); held = true; }
-    }
-    ~WideToken() {
-        if (!held) return;
-        (void)hipStreamSynchronize(ctx->stream);
-        g_wide_mutex.unlock();
-    }
-};
-}  // namespace
 
 // fewer first-level chunks than this over all sets of a table MSM: chunks of 4 buckets instead of 16 (shorter dependent chains for
-// launches that do not fill the chip; DOTRING_MSM_L4_BELOW)
-static size_t l4_below() {
-    static const size_t v = std::getenv("DOTRING_MSM_L4_BELOW") ? (size_t)std::atol(std::getenv("DOTRING_MSM_L4_BELOW")) : ((size_t)1 << 17);
-    return v;
-}
+// launches that do not fill the chip)
+static constexpr size_t l4_below() { return (size_t)1 << 17; }
 
 // DOTRING_SRS_TILING=rows: batched MSMs keep the window rows of a bit-row table (default: the non-adjacent form below)
 static bool naf_tiling_on() {
@@ -134,7 +112,7 @@ static bool naf_tiling_on() {
 // per bucket against the walk's time per entry): w = 13 for the 3N = 6144-point vectors of domain 2048 and the 12288 of domain 4096.
 Tiling tiling_for(const MsmTable& t, size_t n, size_t batch) {
     Tiling none{0, 0, 0, 0.0};
-    if (!t.table || !t.bit_rows || t.naf_delta == -1 || g_chunk_len != 16 || batch < 256 || n == 0 || !naf_tiling_on()) return none;
+    if (!t.table || !t.bit_rows || t.naf_delta == -1 || batch < 256 || n == 0 || !naf_tiling_on()) return none;
     const int cn = t.wt.cmax;
     const int lo = t.naf_delta >= 0 ? cn + t.naf_delta : cn - 1, hi = t.naf_delta >= 0 ? cn + t.naf_delta : cn + 2;
     Tiling best = none;
@@ -158,36 +136,13 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     const uint32_t* const d_bases_in = d_bases;          // (d_bases is redirected to the table below; a second run starts from the caller's)
     if (n == 0 || batch == 0) return DR_OK;
     if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "MSM size must be below 2^31");
-    WideToken token_(ctx, batch >= 64);
     const bool single = tbl != nullptr && tbl->table != nullptr;
     PhaseTrace tr_("msm_device");                 // DOTRING_TRACE=1: where the wall time of a call goes
-    // comb table + many MSMs: a plain sum of looked-up points per MSM, nothing to sort or reduce
-    if (single && tbl->comb && batch >= 32 && g_use_comb) {
-        TRY(ctx->result.reserve(batch * 192));
-        // threads per MSM: enough waves to fill 1024 SIMDs x 3 resident waves, at most 4 waves (one block)
-        unsigned waves = (unsigned)std::max<size_t>(1, std::min<size_t>(4, (3072 + batch / 2) / batch));
-        while (waves > 1 && (size_t)waves * 64 > n) waves--;
-        const unsigned threads = waves * 64;
-        const size_t lds = (size_t)tbl->wt.W * threads * 2;
-        TRY(ctx->partial.reserve(batch * threads * 192));
-        TRY(launch(ctx, "k_g1_comb_msm", [&] {
-            hipLaunchKernelGGL(dr::k_g1_comb_msm, dim3((unsigned)batch), dim3(threads), lds, ctx->stream, d_scalars, (uint32_t)n, tbl->wt, tbl->comb,
-                               tbl->comb_h, tbl->offset, ctx->partial.as<uint32_t>());
-        }));
-        TRY(launch(ctx, "k_g1_reduce_windows", [&] {
-            hipLaunchKernelGGL(dr::k_g1_reduce_windows, dim3((unsigned)batch), dim3(dr::RW_BLOCK), 0, ctx->stream, ctx->partial.as<uint32_t>(), threads,
-                               ctx->result.as<uint32_t>());
-        }));
-        return DR_OK;
-    }
-    // (DOTRING_MSM_LATENCY_WINDOW=0: the throughput model for every size)
-    static const bool latency_on = std::getenv("DOTRING_MSM_LATENCY_WINDOW") == nullptr || std::atoi(std::getenv("DOTRING_MSM_LATENCY_WINDOW")) != 0;
-    MsmPlan pl = make_plan(n, g_force_c, latency_on && !single && batch == 1 && n <= 32768);
-    static const bool setscan_on = std::getenv("DOTRING_MSM_SETSCAN") == nullptr || std::atoi(std::getenv("DOTRING_MSM_SETSCAN")) != 0;
+    MsmPlan pl = make_plan(n, g_force_c, !single && batch == 1 && n <= 32768);
     if (single) {
         // A table with a row per bit and hundreds of MSMs (the batched prover): one more bit per window, buckets for odd multiples only
         // — as many buckets as before, a window less per scalar.  Needs the per-set LDS sort and the set-scan reduction (below).
-        const Tiling tl = setscan_on ? tiling_for(*tbl, n, batch) : Tiling{0, 0, 0, 0.0};
+        const Tiling tl = tiling_for(*tbl, n, batch);
         const bool odd = tl.mode != 0;
         dr::WindowTable wo{};
         if (odd) {                                       // slots of the non-adjacent form: positions [c j, c j + c) of k << shift
@@ -204,7 +159,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         pl.wt = odd ? wo : tbl->wt;
         pl.W = pl.wt.W;
         pl.H = odd ? 1u << (pl.wt.cmax - 2) : 1u << (pl.wt.cmax - 1);
-        pl.L = std::min<uint32_t>(pl.H, g_chunk_len);
+        pl.L = std::min<uint32_t>(pl.H, 16u);
         pl.T = pl.H / pl.L;
         d_bases = tbl->table;
         if (((uint64_t)pl.wt.row[pl.W - 1] + pl.wt.cmax + 1) * tbl->stride >= (1ull << 31)) return fail(DR_ERR_INVALID, "window table too large");
@@ -263,16 +218,14 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     const size_t per_set_scalars = single ? (n + groups - 1) / groups : n;
     const size_t per_set_digits = single ? per_set_scalars * (size_t)pl.W : n;
     const bool lds_sort = pl.H <= dr::SORT_MAX_H && bsets >= 64 && per_set_digits <= (1u << 20) && bsets * per_set_digits < (1ull << 32);
-    // a few huge sets over a window table (one 2^20-point MSM): two-pass partition sort (k_g1_part_scatter / k_g1_part_sort;
-    // DOTRING_MSM_PART_SORT=0: digits -> global histogram -> scan -> global scatter)
-    static const bool part_on = std::getenv("DOTRING_MSM_PART_SORT") == nullptr || std::atoi(std::getenv("DOTRING_MSM_PART_SORT")) != 0;
+    // a few huge sets over a window table (one 2^20-point MSM): two-pass partition sort (k_g1_part_scatter / k_g1_part_sort)
     uint32_t part_p = 1, part_shift = 0;
     {
         const size_t chunk = dr::PART_STAGE - dr::PART_SLACK;
         while (part_p < dr::PART_MAX_P && (pl.H / part_p > dr::PART_MAX_HP || per_set_digits / part_p > chunk - chunk / 16)) part_p *= 2;
         while ((pl.H >> part_shift) > part_p) part_shift++;
     }
-    const bool part_sort = part_on && !lds_sort && single && batch == 1 && pl.W <= 32 && pl.H >= part_p &&
+    const bool part_sort = !lds_sort && single && batch == 1 && pl.W <= 32 && pl.H >= part_p &&
                            pl.H / part_p <= dr::PART_MAX_HP && per_set_digits / part_p <= 48 * (size_t)(dr::PART_STAGE - dr::PART_SLACK) &&
                            bsets * per_set_digits < (1ull << 32) && per_set_digits >= 65536;
     if (lds_sort) {
@@ -286,11 +239,10 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         sp.fold = single && tbl->fold_sign ? 1 : 0;
         TRY(ctx->sorted.reserve(bsets * per_set_digits * 4));
         // sets of more than a few thousand entries: the sorted segment is assembled in LDS and written in whole lines
-        // (k_g1_sort_sets_staged; DOTRING_MSM_SORT_STAGED=0: scattered 4-byte stores as in round 1)
-        static const bool staged_on = std::getenv("DOTRING_MSM_SORT_STAGED") == nullptr || std::atoi(std::getenv("DOTRING_MSM_SORT_STAGED")) != 0;
+        // (k_g1_sort_sets_staged)
         const bool small_h = pl.H <= dr::SORT2_SMALL_H;
         const uint32_t stage_chunk = (small_h ? dr::SORT2_CAP_SMALL_H : dr::SORT2_CAP_LARGE_H) - dr::SORT2_SLACK;
-        const bool staged = staged_on && per_set_digits >= 4096 && per_set_digits / stage_chunk + 1 <= dr::SORT2_MAX_CHUNKS;
+        const bool staged = per_set_digits >= 4096 && per_set_digits / stage_chunk + 1 <= dr::SORT2_MAX_CHUNKS;
         if (staged) {
             sp.n_pad = (uint32_t)((per_set_scalars + 7) & ~(size_t)7);
             sp.digits_per_set = sp.n_pad * (uint32_t)(single ? pl.W : 1);
@@ -417,19 +369,17 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     }));
     // many bucket sets (batched prover): level-wise reduction, 2 additions per entry and no scalar multiplications;
     // few sets (single MSMs): chunk sums + double-and-add, whose latency is one short chain
-    const bool leveled = g_reduce_levels && pl.L == 16 && pl.H >= 256 && bsets * (size_t)(pl.H / 16) >= g_level_threshold;
+    const bool leveled = pl.L == 16 && pl.H >= 256 && bsets * (size_t)(pl.H / 16) >= ((size_t)1 << 18);
     // many sets of <= 2048 buckets (every batched MSM of the prover): first level with 2 additions per bucket, then one workgroup
-    // per set scans and folds its <= 128 chunk results (DOTRING_MSM_SETSCAN=0: the chunk + double-and-add kernels below)
-    const bool setscan = setscan_on && pl.L == 16 && pl.T >= 8 && pl.T <= 256 && bsets >= 256;
+    // per set scans and folds its <= 128 chunk results
+    const bool setscan = pl.L == 16 && pl.T >= 8 && pl.T <= 256 && bsets >= 256;
     if (pl.wt.odd && !(setscan && lds_sort)) return fail(DR_ERR_DEVICE, "internal: non-adjacent form planned for a path that does not support it");
     // a single MSM over a wide window table (H >= 8192 buckets per index group): workgroup scan, (V, S) pairs to the host
-    // (DOTRING_MSM_WGSCAN=0: chunk sums + double-and-add + fold, as in round 2)
-    static const bool wgscan_on = std::getenv("DOTRING_MSM_WGSCAN") == nullptr || std::atoi(std::getenv("DOTRING_MSM_WGSCAN")) != 0;
     // buckets per lane of that scan: as few as keep the launch within one wave per SIMD (65536 lanes), at most 8
     uint32_t ws_per_lane = 1;
     while (ws_per_lane < 8 && bsets * (size_t)pl.H > (size_t)65536 * ws_per_lane) ws_per_lane *= 2;
     const uint32_t ws_span = dr::WS_BLOCK * ws_per_lane;
-    const bool wgscan = wgscan_on && !setscan && !leveled && single && batch == 1 && pl.H >= 8192 && pl.H % ws_span == 0;
+    const bool wgscan = !setscan && !leveled && single && batch == 1 && pl.H >= 8192 && pl.H % ws_span == 0;
     const size_t wg_per_set = pl.H / ws_span, wg_count = bsets * wg_per_set;
     if (setscan) {
         const size_t cnt = bsets * pl.T;
@@ -597,7 +547,6 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         results[0] = acc;
     } else {
         TRY(ctx->result.reserve(batch * 192));
-        SideSection side_(ctx);                            // a 255-doubling chain per MSM on batch / 64 waves
         TRY(launch(ctx, "k_g1_horner", [&] {
             hipLaunchKernelGGL(dr::k_g1_horner, dim3(div_up(batch, 64)), dim3(64), 0, ctx->stream, ctx->winsum.as<uint32_t>(),
                                (uint32_t)batch, pl.wt, ctx->result.as<uint32_t>());
@@ -618,8 +567,6 @@ MsmTable srs_table(const dr_srs* srs, size_t offset) {
         t.naf_delta = srs->table_naf_delta;
         t.stride = (uint32_t)srs->count;
         t.offset = (uint32_t)offset;
-        t.comb = srs->d_comb;
-        t.comb_h = srs->comb_h;
     }
     return t;
 }
@@ -638,13 +585,12 @@ int msm_to_bytes(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars
 
 // batch > 1: results were left in ctx->result (XYZZ).  The affine conversion is one 381-bit field inversion per
 // result: on the GPU a division-step chain (divstep28.hip.h: ≈ 0.08 ms of pure latency per call, whatever the batch; 0.5 ms with
-// the binary Euclid, 0.85 ms with the Fermat power before that).  Measured alternative for whole batches (DOTRING_AFFINE_ON_HOST=1): download XYZZ and invert
-// on the worker threads — less GPU time but more wall time per 1024 proofs, so the kernel stays the default there.
+// the binary Euclid, 0.85 ms with the Fermat power before that).  (Downloading XYZZ and inverting on the worker threads was measured for whole
+// batches: less GPU time but more wall time per 1024 proofs.)
 int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, int* is_inf) {
-    static const bool on_host = std::getenv("DOTRING_AFFINE_ON_HOST") && std::atoi(std::getenv("DOTRING_AFFINE_ON_HOST")) != 0;
     // a handful of results (a single proof's 4 witness commitments, 2 openings): the kernel's one inversion chain is 0.6 ms of
     // latency whatever the count, the host inverts in ~15 us each
-    if (on_host || batch <= 16) {
+    if (batch <= 16) {
         static_assert(sizeof(drh::G1) == 192, "XYZZ layout");
         std::vector<drh::G1> res(batch);
         HIP_TRY(hipMemcpyAsync(res.data(), ctx->result.p, batch * 192, hipMemcpyDeviceToHost, ctx->stream));
@@ -655,7 +601,6 @@ int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, in
         return DR_OK;
     }
     TRY(ctx->io_c.reserve(batch * 96));
-    SideSection side_(ctx);                                // one inversion chain on batch / 64 waves
     TRY(launch(ctx, "k_g1_results_affine", [&] {
         hipLaunchKernelGGL(dr::k_g1_results_affine, dim3(div_up(batch, 64)), dim3(64), 0, ctx->stream, ctx->result.as<uint32_t>(),
                            (uint32_t)batch, ctx->io_c.as<uint32_t>());
@@ -982,7 +927,6 @@ int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_row
     TRY(use_ctx(ctx));
     if (!srs) return fail(DR_ERR_INVALID, "null argument");
     if (srs->device != ctx->device) return fail(DR_ERR_INVALID, "SRS lives on another device");
-    if (srs->d_comb) { (void)hipFree(srs->d_comb); srs->d_comb = nullptr; srs->comb_h = 0; }     // derived from the window table
     if (window_bits == 0) {
         if (srs->d_table) (void)hipFree(srs->d_table);
         srs->d_table = nullptr;
@@ -996,15 +940,12 @@ int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_row
     srs->table_bit_rows = false;
     // A small SRS gets a row for every bit (32 KB per base: 201 MB for the 6145 points of a 2048-point domain) — the window rows are a
     // subset of it, and batched MSMs may then recode the scalars in non-adjacent form (tiling_for).
-    // DOTRING_SRS_BIT_ROWS_MB (default 512, 0 = never) bounds the table; DOTRING_SRS_NAF_BITS forces the width of that form to
-    // window_bits + that (-1 = never; default: chosen per call, tiling_for).
+    // DOTRING_SRS_BIT_ROWS_MB (default 512, 0 = never) bounds the table; the width of that form is chosen per call (tiling_for).
     static const size_t bit_rows_mb = std::getenv("DOTRING_SRS_BIT_ROWS_MB") ? (size_t)std::atol(std::getenv("DOTRING_SRS_BIT_ROWS_MB")) : 512;
-    static const int naf_bits = std::getenv("DOTRING_SRS_NAF_BITS") ? std::atoi(std::getenv("DOTRING_SRS_NAF_BITS")) : -2;
     // One table point per 128-byte line (24 of 32 words used): a packed 96-byte record straddles two lines five times out of eight, and
     // the bucket walk — one random table point per addition — measured 1.1 % faster with a third fewer lines to fetch although the table is
-    // a third larger (A/B on one box, three alternations: 40.50 - 40.63 against 40.85 - 41.17 ms per 1024 proofs).  DOTRING_SRS_LINE=0: packed.
-    static const bool line = std::getenv("DOTRING_SRS_LINE") == nullptr || std::atoi(std::getenv("DOTRING_SRS_LINE")) != 0;
-    const uint32_t pt_words = line ? 32 : 24;
+    // a third larger (A/B on one box, three alternations: 40.50 - 40.63 against 40.85 - 41.17 ms per 1024 proofs).
+    const uint32_t pt_words = 32;
     bool bit_rows = allow_bit_rows && window_bits <= 16 && (size_t)256 * srs->count * 4 * pt_words <= (bit_rows_mb << 20);
     if (bit_rows && hipMalloc((void**)&srs->d_table, (size_t)256 * srs->count * 4 * pt_words) != hipSuccess) {
         (void)hipGetLastError();                   // a device short of memory keeps the window rows (W rows instead of 256)
@@ -1018,7 +959,6 @@ int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_row
         hipLaunchKernelGGL(dr::k_g1_bit_table, dim3(div_up(srs->count, 128)), dim3(128), 0, ctx->stream, srs->d_bases, (uint32_t)srs->count, 256u,
                            pt_words, srs->d_table);
         srs->table_bit_rows = true;
-        srs->table_naf_delta = naf_bits < -1 ? -2 : naf_bits;
     } else {
         hipLaunchKernelGGL(dr::k_g1_window_table, dim3(div_up(srs->count, 128)), dim3(128), 0, ctx->stream, srs->d_bases, (uint32_t)srs->count, wt,
                            pt_words, srs->d_table);
@@ -1033,49 +973,9 @@ int srs_precompute(dr_ctx* ctx, dr_srs* srs, int window_bits, bool allow_bit_row
     return DR_OK;
 }
 
-int dr_srs_precompute_comb(dr_ctx* ctx, dr_srs* srs) {
-    TRY(use_ctx(ctx));
-    if (!srs) return fail(DR_ERR_INVALID, "null argument");
-    if (srs->device != ctx->device) return fail(DR_ERR_INVALID, "SRS lives on another device");
-    if (!srs->d_table) return fail(DR_ERR_INVALID, "dr_srs_precompute must come first");
-    if (srs->d_comb) return DR_OK;
-    const dr::WindowTable& wt = srs->table_wt;
-    if (wt.cmax > 14) return fail(DR_ERR_INVALID, "comb tables need window_bits <= 14");
-    const uint32_t Hc = 1u << (wt.cmax - 1);
-    const size_t rows = (size_t)srs->count * wt.W;
-    const size_t bytes = rows * Hc * (size_t)dr::COMB_STRIDE * 4;
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    if (bytes + ((size_t)8 << 30) > free_b) return fail(DR_ERR_NOMEM, "comb table of " + std::to_string(bytes >> 20) + " MiB does not fit");
-    uint32_t* comb = nullptr;
-    if (hipMalloc((void**)&comb, bytes) != hipSuccess) return fail(DR_ERR_NOMEM, "comb table allocation failed");
-    // rows per launch bounded by 4 GiB of staging (XYZZ + prefix product per entry)
-    const size_t per_row = (size_t)Hc * (192 + 48);
-    const size_t chunk = std::max<size_t>(128, std::min<size_t>(rows, ((size_t)4 << 30) / per_row) / 128 * 128);
-    uint32_t *tx = nullptr, *tp = nullptr;
-    hipError_t e = hipMalloc((void**)&tx, chunk * Hc * 192);
-    if (e == hipSuccess) e = hipMalloc((void**)&tp, chunk * Hc * 48);
-    for (size_t lo = 0; e == hipSuccess && lo < rows; lo += chunk) {
-        const uint32_t cnt = (uint32_t)std::min(chunk, rows - lo);
-        hipLaunchKernelGGL(dr::k_g1_comb_build, dim3(div_up(cnt, 128)), dim3(128), 0, ctx->stream, srs->d_table, srs->table_pt_words, (uint32_t)srs->count, wt, Hc, lo, cnt,
-                           comb, tx, tp);
-        e = hipStreamSynchronize(ctx->stream);
-    }
-    if (tx) (void)hipFree(tx);
-    if (tp) (void)hipFree(tp);
-    if (e != hipSuccess) {
-        (void)hipFree(comb);
-        return fail(e == hipErrorOutOfMemory ? DR_ERR_NOMEM : DR_ERR_DEVICE, std::string("comb table: ") + hipGetErrorString(e));
-    }
-    srs->d_comb = comb;
-    srs->comb_h = Hc;
-    return DR_OK;
-}
-
 void dr_srs_destroy(dr_srs* srs) {
     if (!srs) return;
     (void)hipSetDevice(srs->device);
-    if (srs->d_comb) (void)hipFree(srs->d_comb);
     for (auto& it : srs->lagrange_prefix) dr_srs_destroy(it.second);
     srs->lagrange_prefix.clear();
     if (srs->d_table) (void)hipFree(srs->d_table);
@@ -1089,9 +989,8 @@ int dr_srs_table_info(const dr_srs* srs, size_t n, size_t batch, int info[6]) {
     if (!srs || !info) return fail(DR_ERR_INVALID, "null argument");
     for (int i = 0; i < 6; i++) info[i] = 0;
     if (!srs->d_table) return DR_OK;
-    static const bool setscan_on = std::getenv("DOTRING_MSM_SETSCAN") == nullptr || std::atoi(std::getenv("DOTRING_MSM_SETSCAN")) != 0;
     const MsmTable t = srs_table(srs, 0);
-    const Tiling tl = setscan_on ? tiling_for(t, n, batch) : Tiling{0, 0, 0, 0.0};
+    const Tiling tl = tiling_for(t, n, batch);
     info[0] = srs->table_wt.cmax;
     info[1] = srs->table_bit_rows ? 256 : srs->table_wt.W;
     info[2] = tl.mode ? tl.slots : srs->table_wt.W;

@@ -48,9 +48,8 @@ struct dr_ring_prover {
     // per-ring tables
     Scratch ring_pts_mont;              // [N][16]
     Scratch fixed_coef;                 // [3][N][8] std (px, py, s coefficients)
-    Scratch fixed4, lag4, not_last;     // tables on the 4N domain, FS9 records (raw 9-limb Montgomery 2^261); with `cosets`: on the three
-                                        // non-trivial cosets only, coset-major ([poly][c - 1][j])
-    bool cosets = true;                 // DOTRING_NTT_COSETS=0: the full 4N-point transforms and constraint evaluation of round 2
+    Scratch fixed4, lag4, not_last;     // tables on the 4N domain, FS9 records (raw 9-limb Montgomery 2^261): on the three
+                                        // non-trivial cosets, coset-major ([poly][c - 1][j])
     Scratch coset_scale;                // [3][N] FS9: zeta^(c m) R^2, the multipliers of the scaled N-point NTT input
     Scratch special;                    // [B][3] FS9: the aggregated constraint polynomial at the three hidden rows of coset 0
     Scratch hid;                        // [B][4][4][8] std: rows N-3, N-2, N-1, 0 of the witness columns' evaluations (saved by the witness phase)
@@ -128,12 +127,9 @@ int lagrange_prefix_srs(dr_ctx* ctx, const dr_srs* srs_c, unsigned log2n, const 
     // them the bucket reduction, small (DOTRING_PS_WINDOW, default 10)
     int ps_bits = 10;
     if (const char* e = std::getenv("DOTRING_PS_WINDOW")) { int v = std::atoi(e); if (v >= 7 && v <= 16) ps_bits = v; }
-    rc = srs_precompute(ctx, ps, ps_bits, std::getenv("DOTRING_PS_BIT_ROWS") && std::atoi(std::getenv("DOTRING_PS_BIT_ROWS")) != 0);
+    // window rows only: vectors of a few hundred scalars, most of them +-1, gain nothing from the non-adjacent form of a bit-row table
+    rc = srs_precompute(ctx, ps, ps_bits, false);
     if (rc != DR_OK) { dr_srs_destroy(ps); return rc; }
-    // the by-parts scalars are sparse: in the comb kernel a wave skips a slot only when all 64 lanes have a zero digit,
-    // while the bucket method never sees zero digits at all — DOTRING_PS_COMB=1 builds the comb table anyway
-    if (srs->d_comb && ps_bits <= 14 && std::getenv("DOTRING_PS_COMB") && std::atoi(std::getenv("DOTRING_PS_COMB")) != 0)
-        (void)dr_srs_precompute_comb(ctx, ps);
     srs->lagrange_prefix[log2n] = ps;
     *out = ps;
     return DR_OK;
@@ -153,7 +149,7 @@ int dr_ring_prover_create_te(dr_ctx* ctx, int curve, const dr_srs* srs, unsigned
     *out = nullptr;
     TRY(check_curve(curve));
     if (log2n < 9 || log2n > 12) return fail(DR_ERR_INVALID, "domain_size must be between 512 and 4096");
-    const uint32_t n = 1u << log2n, m = 4 * n;
+    const uint32_t n = 1u << log2n;
     if (max_ring + drh::te_curve(curve)->scalar_bits + 4 > n) return fail(DR_ERR_INVALID, "max_ring_size exceeds supported size");
     if (srs->count < 3 * (size_t)n + 1) return fail(DR_ERR_INVALID, "polynomial degree exceeds SRS size");
     TRY(check_fr_elems(nm_points_xy, 2 * (size_t)n, "ring point"));
@@ -167,8 +163,7 @@ int dr_ring_prover_create_te(dr_ctx* ctx, int curve, const dr_srs* srs, unsigned
     p->curve = curve;
     if (!drh::Fr::load_le(p->omega_n, omega_n) || !drh::Fr::load_le(p->omega_4n, omega_4n))
         return fail(DR_ERR_INVALID, "omega is not a canonical field element");
-    if (std::getenv("DOTRING_WITNESS_BY_PARTS") == nullptr || std::atoi(std::getenv("DOTRING_WITNESS_BY_PARTS")) != 0)
-        TRY(lagrange_prefix_srs(ctx, srs, log2n, p->omega_n, &p->ps_srs));
+    TRY(lagrange_prefix_srs(ctx, srs, log2n, p->omega_n, &p->ps_srs));       // the witness commitments go by summation by parts
     dr::RingConsts& rc = p->rc;
     rc.log2n = log2n; rc.n = n; rc.max_ring = max_ring; rc.rows = n - 4;
     drh::Fr sx, sy;
@@ -187,7 +182,6 @@ int dr_ring_prover_create_te(dr_ctx* ctx, int curve, const dr_srs* srs, unsigned
     rc.tail9[3] = dr::fs_arg_mont(drh::Fr::one());
     rc.omega9 = dr::fs_arg_mont(p->omega_n);
     rc.nl_hidden[0] = dr::fs_arg_mont(w3 - w4); rc.nl_hidden[1] = dr::fs_arg_mont(w2 - w4); rc.nl_hidden[2] = dr::fs_arg_mont(w1 - w4);
-    p->cosets = std::getenv("DOTRING_NTT_COSETS") == nullptr || std::atoi(std::getenv("DOTRING_NTT_COSETS")) != 0;
     hipStream_t st = ctx->stream;
     // ring points -> Montgomery table ; fixed evaluation columns
     TRY(p->ring_pts_mont.reserve((size_t)n * 64));
@@ -201,42 +195,25 @@ int dr_ring_prover_create_te(dr_ctx* ctx, int curve, const dr_srs* srs, unsigned
         MsmTable t = srs_table(srs, 0);
         TRY(msm_to_bytes(ctx, srs->d_bases, p->fixed_coef.as<uint32_t>(), n, 3, p->root, p->root_inf, &t));
     }
-    Scratch pad4, lagc;
+    Scratch lagc;
     TRY(lagc.reserve((size_t)2 * n * 32));
     hipLaunchKernelGGL(dr::k_ring_lagrange, dim3(div_up(n, 256)), dim3(256), 0, st, lagc.as<uint32_t>(), n,
                        arg_of(drh::Fr::from_u64(n).inv()), arg_of(w4.inv()));
-    if (p->cosets) {
-        // tables on the three non-trivial cosets, coset-major: per polynomial three N-point NTTs of its coefficients scaled by zeta^(c m)
-        TRY(p->coset_scale.reserve((size_t)3 * n * dr::L29 * 4));
-        hipLaunchKernelGGL(dr::k_ring_coset_scale, dim3(div_up((size_t)3 * n, 256)), dim3(256), 0, st, p->coset_scale.as<uint32_t>(), n,
-                           dr::fs_arg_mont(p->omega_4n));
-        TRY(p->fixed4.reserve((size_t)3 * 3 * n * dr::L29 * 4));
-        TRY(ring_ntt(p, p->fixed4.as<uint32_t>(), log2n, 9, false, dr::NTT_FMT_STD8_SCALED, dr::NTT_FMT_FS9, p->fixed_coef.as<uint32_t>(), 0, 3,
-                     p->coset_scale.as<uint32_t>()));
-        TRY(p->lag4.reserve((size_t)2 * 3 * n * dr::L29 * 4));
-        TRY(ring_ntt(p, p->lag4.as<uint32_t>(), log2n, 6, false, dr::NTT_FMT_STD8_SCALED, dr::NTT_FMT_FS9, lagc.as<uint32_t>(), 0, 3,
-                     p->coset_scale.as<uint32_t>()));
-        TRY(p->not_last.reserve((size_t)3 * n * dr::L29 * 4));
-        hipLaunchKernelGGL(dr::k_ring_not_last3, dim3(div_up((size_t)3 * n, 256)), dim3(256), 0, st, p->not_last.as<uint32_t>(), n, arg_of(p->omega_4n),
-                           arg_of(w4));
-    } else {
-        // 4N-domain tables: zero-padded coefficients -> forward NTT with FS9 output (raw 9-limb Montgomery records)
-        TRY(pad4.reserve((size_t)3 * m * 32));
-        TRY(p->fixed4.reserve((size_t)3 * m * dr::L29 * 4));
-        hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up((size_t)3 * m, 256)), dim3(256), 0, st, p->fixed_coef.as<uint32_t>(), n,
-                           pad4.as<uint32_t>(), m, (size_t)3);
-        TRY(ring_ntt(p, p->fixed4.as<uint32_t>(), log2n + 2, 3, false, dr::NTT_FMT_STD8, dr::NTT_FMT_FS9, pad4.as<uint32_t>(), 0));
-        TRY(p->lag4.reserve((size_t)2 * m * dr::L29 * 4));
-        hipLaunchKernelGGL(dr::k_ring_pad, dim3(div_up((size_t)2 * m, 256)), dim3(256), 0, st, lagc.as<uint32_t>(), n, pad4.as<uint32_t>(), m, (size_t)2);
-        TRY(ring_ntt(p, p->lag4.as<uint32_t>(), log2n + 2, 2, false, dr::NTT_FMT_STD8, dr::NTT_FMT_FS9, pad4.as<uint32_t>(), 0));
-        TRY(p->not_last.reserve((size_t)m * dr::L29 * 4));
-        // x - w^(N-4) on the 4N domain: built in the 8-word Montgomery form (pad4 is free again), then converted
-        hipLaunchKernelGGL(dr::k_ring_not_last, dim3(div_up(m, 256)), dim3(256), 0, st, pad4.as<uint32_t>(), m, arg_of(p->omega_4n), arg_of(w4));
-        hipLaunchKernelGGL(dr::k_fr_mont_to_fs9, dim3(div_up(m, 256)), dim3(256), 0, st, pad4.as<uint32_t>(), p->not_last.as<uint32_t>(), (size_t)m);
-    }
+    // tables on the three non-trivial cosets, coset-major: per polynomial three N-point NTTs of its coefficients scaled by zeta^(c m)
+    TRY(p->coset_scale.reserve((size_t)3 * n * dr::L29 * 4));
+    hipLaunchKernelGGL(dr::k_ring_coset_scale, dim3(div_up((size_t)3 * n, 256)), dim3(256), 0, st, p->coset_scale.as<uint32_t>(), n,
+                       dr::fs_arg_mont(p->omega_4n));
+    TRY(p->fixed4.reserve((size_t)3 * 3 * n * dr::L29 * 4));
+    TRY(ring_ntt(p, p->fixed4.as<uint32_t>(), log2n, 9, false, dr::NTT_FMT_STD8_SCALED, dr::NTT_FMT_FS9, p->fixed_coef.as<uint32_t>(), 0, 3,
+                 p->coset_scale.as<uint32_t>()));
+    TRY(p->lag4.reserve((size_t)2 * 3 * n * dr::L29 * 4));
+    TRY(ring_ntt(p, p->lag4.as<uint32_t>(), log2n, 6, false, dr::NTT_FMT_STD8_SCALED, dr::NTT_FMT_FS9, lagc.as<uint32_t>(), 0, 3,
+                 p->coset_scale.as<uint32_t>()));
+    TRY(p->not_last.reserve((size_t)3 * n * dr::L29 * 4));
+    hipLaunchKernelGGL(dr::k_ring_not_last3, dim3(div_up((size_t)3 * n, 256)), dim3(256), 0, st, p->not_last.as<uint32_t>(), n, arg_of(p->omega_4n),
+                       arg_of(w4));
     HIP_TRY(hipStreamSynchronize(st));
     lagc.release();
-    pad4.release();
     HIP_TRY(hipGetLastError());
     guard.release();
     *out = p;
@@ -319,14 +296,9 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
         HIP_TRY(hipMemcpyAsync(p->zk.p, zk_rows, batch * 12 * 32, hipMemcpyHostToDevice, st));
     }
     TRY(launch(ctx, "k_ring_chain", [&] {
-        if (g_chain_wave)
-            LAUNCH_CV(p->curve, dr::k_ring_chain_wave, dim3((unsigned)batch), dim3(64), 0, st, p->ring_pts_mont.as<uint32_t>(), p->idx.as<uint32_t>(),
+        LAUNCH_CV(p->curve, dr::k_ring_chain_wave, dim3((unsigned)batch), dim3(64), 0, st, p->ring_pts_mont.as<uint32_t>(), p->idx.as<uint32_t>(),
                                p->blind.as<uint32_t>(), rc, (uint32_t)batch, p->chain_ext.as<uint32_t>(), p->chain_aff.as<uint32_t>(),
                                p->cnt.as<uint32_t>());
-        else
-            LAUNCH_CV(p->curve, dr::k_ring_chain, dim3(div_up(batch, 64)), dim3(64), 0, st, p->ring_pts_mont.as<uint32_t>(), p->idx.as<uint32_t>(),
-                               p->blind.as<uint32_t>(), rc, (uint32_t)batch, p->chain_ext.as<uint32_t>(), p->prefix.as<uint32_t>(),
-                               p->chain_aff.as<uint32_t>(), p->cnt.as<uint32_t>());
     }));
     TRY(launch(ctx, "k_ring_columns", [&] {
         hipLaunchKernelGGL(dr::k_ring_relations, dim3(div_up(batch, 64)), dim3(64), 0, st, p->chain_aff.as<uint32_t>(), p->cnt.as<uint32_t>(),
@@ -335,7 +307,7 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
                            p->chain_aff.as<uint32_t>(), zk_rows ? p->zk.as<uint32_t>() : nullptr, rc, (uint32_t)batch, col_evals);
     }));
     HIP_TRY(hipMemcpyAsync(out_relation_xy, p->relation.p, batch * 64, hipMemcpyDeviceToHost, st));
-    if (p->ps_srs) {
+    {
         // commit in evaluation form by summation by parts (sparse scalars), then interpolate for the later phases
         TRY(p->diffs.reserve(batch * 4 * (size_t)n * 32));
         TRY(launch(ctx, "k_ring_diff", [&] {
@@ -346,23 +318,17 @@ int dr_ring_prove_witness(dr_ring_prover* p, size_t batch, const uint32_t* produ
         MsmTable t = srs_table(p->ps_srs, 0);
         t.fold_sign = true;                 // first differences of bit columns: +-1
         TRY(msm_to_bytes(ctx, p->ps_srs->d_bases, p->diffs.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t));
-    } else {
-        TRY(ring_ntt(p, p->cols.as<uint32_t>(), rc.log2n, batch * 4, true, dr::NTT_FMT_STD8, dr::NTT_FMT_STD8, col_evals, 0));
-        MsmTable t = srs_table(p->srs, 0);
-        TRY(msm_to_bytes(ctx, p->srs->d_bases, p->cols.as<uint32_t>(), n, batch * 4, out_commitments, is_inf, &t));
     }
     p->fwd_pending = false;
-    if (p->cosets) {
-        // The commitments are on the host; the caller now hashes them into the transcript (0.3 - 0.45 ms for 1024 proofs).  What the
-        // quotient phase does first needs no challenge: the four columns on the three cosets.  Launched here and NOT waited for, the
-        // transforms run beside that hashing; the hidden rows of coset 0 are saved first, the transforms overwrite the evaluation columns.
-        TRY(p->hid.reserve(batch * 16 * 32));
-        hipLaunchKernelGGL(dr::k_ring_save_rows, dim3(div_up(batch * 16, 256)), dim3(256), 0, st, col_evals, n, (uint32_t)batch, p->hid.as<uint32_t>());
-        TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n, batch * 12, false, dr::NTT_FMT_STD8_SCALED, dr::NTT_FMT_FS9, p->cols.as<uint32_t>(), 0, 3,
-                     p->coset_scale.as<uint32_t>()));
-        HIP_TRY(hipGetLastError());
-        p->fwd_pending = true;
-    }
+    // The commitments are on the host; the caller now hashes them into the transcript (0.3 - 0.45 ms for 1024 proofs).  What the
+    // quotient phase does first needs no challenge: the four columns on the three cosets.  Launched here and NOT waited for, the
+    // transforms run beside that hashing; the hidden rows of coset 0 are saved first, the transforms overwrite the evaluation columns.
+    TRY(p->hid.reserve(batch * 16 * 32));
+    hipLaunchKernelGGL(dr::k_ring_save_rows, dim3(div_up(batch * 16, 256)), dim3(256), 0, st, col_evals, n, (uint32_t)batch, p->hid.as<uint32_t>());
+    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n, batch * 12, false, dr::NTT_FMT_STD8_SCALED, dr::NTT_FMT_FS9, p->cols.as<uint32_t>(), 0, 3,
+                 p->coset_scale.as<uint32_t>()));
+    HIP_TRY(hipGetLastError());
+    p->fwd_pending = true;
     return DR_OK;
 }
 
@@ -389,37 +355,24 @@ int dr_ring_prove_quotient(dr_ring_prover* p, size_t batch, const uint8_t* alpha
     TRY(p->alpha_aux.reserve(batch * 2 * dr::L29 * 4));
     hipLaunchKernelGGL(dr::k_ring_alpha_aux, dim3(div_up(batch, 64)), dim3(64), 0, st, p->alphas.as<uint32_t>(), p->rps.as<uint32_t>(), rc,
                        (uint32_t)batch, p->alpha_aux.as<uint32_t>());
-    if (p->cosets) {
-        // coset 0: the three hidden rows from the N-domain evaluations the witness phase saved
-        TRY(p->special.reserve(batch * 3 * dr::L29 * 4));
-        if (!p->fwd_pending) return fail(DR_ERR_INVALID, "quotient phase without a witness phase for this batch");
-        p->fwd_pending = false;
-        // (the forward transforms — N coefficients per column -> evaluations on the cosets zeta^c H, c = 1..3: three N-point NTTs of the
-        //  coefficients scaled by zeta^(c m), raw 9-limb records, coset-major — were launched by the witness phase and are in this stream)
-        TRY(launch(ctx, "k_ring_constraints", [&] {
-            LAUNCH_CV(p->curve, dr::k_ring_hidden_rows, dim3(div_up(batch * 3, 64)), dim3(64), 0, st, p->hid.as<uint32_t>(), p->ring_pts_mont.as<uint32_t>(),
-                      p->alphas9.as<uint32_t>(), rc, (uint32_t)batch, p->special.as<uint32_t>());
-        }));
-        TRY(launch(ctx, "k_ring_constraints", [&] {
-            LAUNCH_CV(p->curve, dr::k_ring_constraints3, dim3(div_up(batch * 3 * (size_t)n, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(),
-                      p->fixed4.as<uint32_t>(), p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas9.as<uint32_t>(),
-                      p->alpha_aux.as<uint32_t>(), rc, (uint32_t)batch, p->agg.as<uint32_t>());
-        }));
-        // inverse 4N-point transform of (zeros and the hidden rows on coset 0, the three evaluated cosets): standard-form coefficients
-        TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch, true, dr::NTT_FMT_FS9_COSETS, dr::NTT_FMT_STD8, p->agg.as<uint32_t>(), 0, 1, nullptr,
-                     p->special.as<uint32_t>()));
-    } else {
-    // N coefficients per column -> evaluations on the 4N domain: the NTT reads the columns directly (zero padding implied) and
-    // leaves the evaluations as raw 9-limb records
-    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch * 4, false, dr::NTT_FMT_STD8, dr::NTT_FMT_FS9, p->cols.as<uint32_t>(), 2));
+    // coset 0: the three hidden rows from the N-domain evaluations the witness phase saved
+    TRY(p->special.reserve(batch * 3 * dr::L29 * 4));
+    if (!p->fwd_pending) return fail(DR_ERR_INVALID, "quotient phase without a witness phase for this batch");
+    p->fwd_pending = false;
+    // (the forward transforms — N coefficients per column -> evaluations on the cosets zeta^c H, c = 1..3: three N-point NTTs of the
+    //  coefficients scaled by zeta^(c m), raw 9-limb records, coset-major — were launched by the witness phase and are in this stream)
     TRY(launch(ctx, "k_ring_constraints", [&] {
-        LAUNCH_CV(p->curve, dr::k_ring_constraints, dim3(div_up(batch * m, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(), p->fixed4.as<uint32_t>(),
-                           p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas9.as<uint32_t>(), p->alpha_aux.as<uint32_t>(), rc,
-                           (uint32_t)batch, p->agg.as<uint32_t>());
+        LAUNCH_CV(p->curve, dr::k_ring_hidden_rows, dim3(div_up(batch * 3, 64)), dim3(64), 0, st, p->hid.as<uint32_t>(), p->ring_pts_mont.as<uint32_t>(),
+                  p->alphas9.as<uint32_t>(), rc, (uint32_t)batch, p->special.as<uint32_t>());
     }));
-    // the constraint kernel wrote raw sums; the coefficients (standard form) land in the (now free) wit4 buffer
-    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch, true, dr::NTT_FMT_FS9, dr::NTT_FMT_STD8, p->agg.as<uint32_t>(), 0));
-    }
+    TRY(launch(ctx, "k_ring_constraints", [&] {
+        LAUNCH_CV(p->curve, dr::k_ring_constraints3, dim3(div_up(batch * 3 * (size_t)n, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(),
+                  p->fixed4.as<uint32_t>(), p->lag4.as<uint32_t>(), p->not_last.as<uint32_t>(), p->alphas9.as<uint32_t>(),
+                  p->alpha_aux.as<uint32_t>(), rc, (uint32_t)batch, p->agg.as<uint32_t>());
+    }));
+    // inverse 4N-point transform of (zeros and the hidden rows on coset 0, the three evaluated cosets): standard-form coefficients
+    TRY(ring_ntt(p, p->wit4.as<uint32_t>(), rc.log2n + 2, batch, true, dr::NTT_FMT_FS9_COSETS, dr::NTT_FMT_STD8, p->agg.as<uint32_t>(), 0, 1, nullptr,
+                 p->special.as<uint32_t>()));
     TRY(launch(ctx, "k_ring_quotient", [&] {
         hipLaunchKernelGGL(dr::k_ring_quotient, dim3(div_up(batch * qn, 256)), dim3(256), 0, st, p->wit4.as<uint32_t>(), rc, (uint32_t)batch,
                            p->q.as<uint32_t>());

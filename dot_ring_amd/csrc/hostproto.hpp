@@ -43,8 +43,7 @@ inline unsigned host_threads() {
 // A persistent pool of host_threads() - 1 workers: starting 16 threads costs ~0.35 ms, and one batch goes through a dozen
 // short parallel loops (0.1-0.5 ms of hashing each).  Several threads may run parallel loops at once (the prover's main
 // thread and its Pedersen helper): jobs queue up, every worker drains the oldest one, and the CALLER works on its own job too,
-// so a loop finishes even when no worker is free (or after a fork, when none exists).  DOTRING_HOST_POOL=0 goes back to
-// one std::thread per slice.
+// so a loop finishes even when no worker is free (or after a fork, when none exists).
 class WorkerPool {
     struct Job {
         const std::function<void(size_t)>* f;
@@ -127,8 +126,7 @@ public:
     }
 };
 inline WorkerPool* worker_pool() {
-    static const bool enabled = [] { const char* e = std::getenv("DOTRING_HOST_POOL"); return !e || std::atoi(e) != 0; }();
-    if (!enabled || host_threads() <= 1) return nullptr;
+    if (host_threads() <= 1) return nullptr;
     static WorkerPool pool(host_threads() - 1);
     return &pool;
 }

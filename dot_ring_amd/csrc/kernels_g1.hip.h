@@ -1432,99 +1432,4 @@ __global__ __launch_bounds__(256) void k_g1_results_affine(const uint32_t* __res
     store_words12(out + (size_t)i * 24 + 12, w);
 }
 
-// ---- 7. comb tables: every multiple a digit can select, precomputed --------------------------------------------------
-// For a FIXED base set used by thousands of MSMs (the SRS under a batch of proofs) and 288 GB of HBM, go one step beyond
-// the window table: comb[j][w][d-1] = d * 2^(start_w) * P_j for every digit magnitude d <= 2^(c-1)
-// (26.6 GB for the 6145-point SRS at c = 12).  An MSM is then a plain sum of n*W looked-up points: no bucket sort, no
-// size ordering, no bucket reduction — per MSM one block walks the scalars, recodes them and adds the selected entries.
-// Same number of mixed additions as the bucket method's accumulation, nothing else.
-
-constexpr int COMB_STRIDE = 32;      // words per comb entry: 96 bytes of data padded to one 128-byte line
-
-// Build: one lane per (base j, window w) row: d*B for d = 1..hw by repeated mixed addition (XYZZ, staged in tmp), then
-// one inversion per row (Montgomery's trick over the row's ZZZ) turns them into affine Montgomery entries.
-__global__ __launch_bounds__(128) void k_g1_comb_build(const uint32_t* __restrict__ wtable /* [rows][count] affine, row of window w = wt.row[w] */, uint32_t pt_words, uint32_t count, WindowTable wt,
-                                                       uint32_t Hc, size_t row_lo, uint32_t rows, uint32_t* __restrict__ comb,
-                                                       uint32_t* __restrict__ tmp_xyzz /* [Hc][rows][48] */, uint32_t* __restrict__ tmp_pre /* [Hc][rows][12] */) {
-    uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= rows) return;
-    const size_t row = row_lo + lane;
-    const uint32_t j = (uint32_t)(row / wt.W), w = (uint32_t)(row % wt.W);
-    const uint32_t hw = 1u << (wt.width[w] - 1);
-    uint32_t* out = comb + row * Hc * COMB_STRIDE;
-    const G1Affine B = load_affine_at(wtable, (size_t)wt.row[w] * count + j, pt_words);
-    if (B.inf) {
-        uint32_t z[12] = {0};
-        for (uint32_t d = 0; d < hw; d++) { store_words12(out + (size_t)d * COMB_STRIDE, z); store_words12(out + (size_t)d * COMB_STRIDE + 12, z); }
-        return;
-    }
-    G1Xyzz acc = g1_from_affine(B);
-    Fq28 run = Fq28::one();
-#pragma unroll 1
-    for (uint32_t d = 0; d < hw; d++) {
-        store_xyzz(tmp_xyzz, (size_t)d * rows + lane, acc);
-        store_fq28(tmp_pre + ((size_t)d * rows + lane) * 12, run);
-        run = mul(run, acc.zzz);
-        acc = g1_madd(acc, B);
-    }
-    Fq28 inv_run = inv(run);
-#pragma unroll 1
-    for (int d = (int)hw - 1; d >= 0; d--) {
-        G1Xyzz p = load_xyzz(tmp_xyzz, (size_t)d * rows + lane);
-        Fq28 izzz = mul(inv_run, load_fq28(tmp_pre + ((size_t)d * rows + lane) * 12));
-        inv_run = mul(inv_run, p.zzz);
-        Fq28 izz = sqr(mul(p.zz, izzz));
-        store_fq28(out + (size_t)d * COMB_STRIDE, mul(p.x, izz));
-        store_fq28(out + (size_t)d * COMB_STRIDE + 12, mul(p.y, izzz));
-    }
-}
-
-// MSM over a comb table: one block of `blockDim.x` (a multiple of 64) threads per MSM; thread t takes scalars t, t + T, ...
-// Digits of one scalar go through LDS so that the 6800-instruction addition appears ONCE in the loop nest.
-#ifndef COMB_TOUCH_AHEAD
-#define COMB_TOUCH_AHEAD 1
-#endif
-__global__ __launch_bounds__(256) void k_g1_comb_msm(const uint32_t* __restrict__ scalars /* [batch][n][8] */, uint32_t n, WindowTable wt,
-                                                      const uint32_t* __restrict__ comb, uint32_t Hc, uint32_t tbl_offset,
-                                                      uint32_t* __restrict__ results /* [batch][T] XYZZ partial sums */) {
-    extern __shared__ uint32_t comb_smem[];                 // [W][T] packed digits
-    const uint32_t T = blockDim.x, tid = threadIdx.x, b = blockIdx.x;
-    int16_t* dig = reinterpret_cast<int16_t*>(comb_smem);
-    G1Xyzz acc = g1_inf();
-#pragma unroll 1
-    for (uint32_t i = tid; i < n; i += T) {
-        uint32_t k[9];
-        load_scalar_mod_r(scalars, (size_t)b * n + i, k);
-        for (int w = 0; w < wt.W; w++) dig[w * T + tid] = 0;
-        for_each_digit(k, wt, 0, wt.W, [&](int w, int32_t d) { dig[w * T + tid] = (int16_t)d; });
-        const size_t row0 = ((size_t)tbl_offset + i) * wt.W;
-        // touch-ahead: the entries live in a multi-GB table, i.e. every gather is an HBM access.  Holding the next entry
-        // in registers across the 6800-instruction addition would cost 24 VGPRs (and the third resident wave); one
-        // dword from each of its two cache lines, requested an addition ahead, pulls it into L2 for 2 VGPRs.
-        auto entry = [&](int w, int32_t d) { return (size_t)((row0 + w) * Hc + (uint32_t)((d < 0 ? -d : d) - 1)) * COMB_STRIDE; };
-        int32_t dn = dig[tid];
-#pragma unroll 1
-        for (int w = 0; w < wt.W; w++) {
-            const int32_t d = dn;
-            uint32_t t0 = 0, t1 = 0;
-            if (w + 1 < wt.W) {
-                dn = dig[(w + 1) * T + tid];
-                if (dn != 0 && COMB_TOUCH_AHEAD) {
-                    const uint32_t* nx = comb + entry(w + 1, dn);
-                    t0 = __builtin_nontemporal_load(nx);
-                    t1 = __builtin_nontemporal_load(nx + 23);
-                }
-            }
-            if (d != 0) {
-                const uint32_t* e = comb + entry(w, d);
-                acc = g1_madd(acc, g1_neg_affine(load_affine(e, 0), d < 0));
-            }
-            asm volatile("" ::"v"(t0), "v"(t1));          // keep the touch loads alive until after the addition
-        }
-    }
-    // per-thread partial sums; k_g1_reduce_windows folds the T partials of each MSM (keeping the out-of-line full
-    // addition, and with it any scratch use, out of this kernel)
-    store_xyzz(results, (size_t)b * T + tid, acc);
-}
-
 }  // namespace dr

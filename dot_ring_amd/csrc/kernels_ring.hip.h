@@ -91,17 +91,6 @@ __global__ void k_fr_std_to_fs9(const uint32_t* __restrict__ src, uint32_t* __re
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) fs_store9(dst + i * L29, fs_from_std(gload_fr(src + i * 8)));
 }
-// 8-word Montgomery (2^256) elements -> FS9 records
-__global__ void k_fr_mont_to_fs9(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t count) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) fs_store9(dst + i * L29, from_mont256(gload_fr(src + i * 8)));
-}
-// not_last[i] = w4^i - w_N^(N-4)   (Montgomery), i < m
-__global__ void k_ring_not_last(uint32_t* __restrict__ out, uint32_t m, FrArg w4_mont, FrArg last_root_mont) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    gstore_fr(out + (size_t)i * 8, sub(fr_pow_u32(from_arg(w4_mont), i), from_arg(last_root_mont)));
-}
 
 // ---- the three non-trivial cosets of H in the 4N domain (round 3) ---------------------------------------------------
 // The 4N-domain point i = 4 j + c is w^j zeta^c (zeta = w_4N).  Everything the constraint kernel touches is kept coset-major,
@@ -167,75 +156,6 @@ struct RingConsts {
     FsArg nl_hidden[3];                  // w^(N-3+r) - w^(N-4), r = 0..2: the factor (x - w^(N-4)) at the three hidden rows
 };
 
-// One lane per proof: the conditional-sum accumulator visits at most 255 distinct values (seed, then one addition
-// for the producer key and one per set bit of the blinding factor).  They are produced in extended coordinates,
-// normalised together with ONE inversion (Montgomery's trick) and written as affine Montgomery pairs;
-// entry [cnt] is the relation point (last value minus the seed).  cnt_out[proof] = number of accumulator values.
-template <int CV>
-__global__ void k_ring_chain(const uint32_t* __restrict__ ring_pts_mont /* N*16: x,y Montgomery */,
-                             const uint32_t* __restrict__ producer_idx, const uint32_t* __restrict__ blinding /* B*8 */,
-                             RingConsts rc, uint32_t batch,
-                             uint32_t* __restrict__ chain_ext /* B*256*32 scratch */, uint32_t* __restrict__ prefix /* B*256*8 scratch */,
-                             uint32_t* __restrict__ chain_aff /* B*256*16 */, uint32_t* __restrict__ cnt_out) {
-    uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pid >= batch) return;
-    uint32_t* ext = chain_ext + (size_t)pid * RING_CHAIN * 32;
-    uint32_t* pre = prefix + (size_t)pid * RING_CHAIN * 8;
-    uint32_t* aff = chain_aff + (size_t)pid * RING_CHAIN * 16;
-    // (the curve arithmetic runs on Fs values, fr29.hip.h; the ring table, the seed and the affine results are in the 2^256
-    //  Montgomery form the column kernels read: one product per coordinate at the boundary.  The scratch keeps packed words.)
-    auto put = [&](uint32_t idx, const TePoint& p) {
-        gstore_fr(ext + idx * 32, pack(p.x)); gstore_fr(ext + idx * 32 + 8, pack(p.y));
-        gstore_fr(ext + idx * 32 + 16, pack(p.z)); gstore_fr(ext + idx * 32 + 24, pack(p.t));
-    };
-    auto ring_point = [&](uint32_t row) {
-        TePoint p;
-        p.x = from_mont256(gload_fr(ring_pts_mont + (size_t)row * 16));
-        p.y = from_mont256(gload_fr(ring_pts_mont + (size_t)row * 16 + 8));
-        p.z = Fs::one();
-        p.t = mul(p.x, p.y);
-        return p;
-    };
-    TePoint acc;
-    acc.x = from_mont256(from_arg(rc.seed_x)); acc.y = from_mont256(from_arg(rc.seed_y)); acc.z = Fs::one(); acc.t = mul(acc.x, acc.y);
-    TePoint seed = acc;
-    uint32_t cnt = 0;
-    put(cnt++, acc);
-    acc = te_add<CV>(acc, ring_point(producer_idx[pid]));
-    put(cnt++, acc);
-    uint32_t t[8];
-    {
-        Fr tt = gload_fr(blinding + (size_t)pid * 8);
-#pragma unroll
-        for (int j = 0; j < 8; j++) t[j] = tt.l[j];
-    }
-#pragma unroll 1
-    for (uint32_t j = 0; j < 253; j++) {
-        if ((t[j >> 5] >> (j & 31)) & 1) {
-            acc = te_add<CV>(acc, ring_point(rc.max_ring + j));
-            put(cnt++, acc);
-        }
-    }
-    cnt_out[pid] = cnt;
-    put(cnt, te_add<CV>(acc, te_cneg(seed, true)));           // relation = result - seed
-    const uint32_t total = cnt + 1;
-    // batch inversion of the Z coordinates
-    Fs run = Fs::one();
-#pragma unroll 1
-    for (uint32_t i = 0; i < total; i++) {
-        gstore_fr(pre + i * 8, pack(run));
-        run = mul(run, unpack(gload_fr(ext + i * 32 + 16)));
-    }
-    Fs inv_run = inv(run);
-#pragma unroll 1
-    for (int i = (int)total - 1; i >= 0; i--) {
-        const Fs z = unpack(gload_fr(ext + i * 32 + 16));
-        const Fs zi = mul(inv_run, unpack(gload_fr(pre + i * 8)));
-        inv_run = mul(inv_run, z);
-        gstore_fr(aff + i * 16, to_mont256(mul(unpack(gload_fr(ext + i * 32)), zi)));
-        gstore_fr(aff + i * 16 + 8, to_mont256(mul(unpack(gload_fr(ext + i * 32 + 8)), zi)));
-    }
-}
 
 // The same chain with one WAVE per proof: lane l owns blinding bits 4l..4l+3.  Local sums of the selected bit points,
 // an inclusive scan across the wave (6 shuffle steps), then every lane walks its own <= 4 additions from
@@ -418,41 +338,6 @@ __global__ void k_ring_relations(const uint32_t* __restrict__ chain_aff, const u
     gstore_fr(rps_mont + (size_t)pid * 16 + 8, gload_fr(last + 8));
 }
 
-// ---- K7: the seven constraints, fused with the alpha aggregation ------------------------------------------------
-// One lane per (proof, point of the 4N domain).  Reads the four witness columns at i and at i + 4 (the w_N shift),
-// the per-ring tables at i, and writes sum_k alpha_k * c_k(i)   (constraints.py:83-151, proof_builder.py:175-180).
-// Arithmetic: ring_body.hip.h body_constraints on the unsaturated field — 23 products of 206 instructions (two of them fused),
-// additions and subtractions of 9, five carry passes: ~5.2 k instructions per point where the saturated field took ~7.7 k.
-template <int CV>
-__global__ __launch_bounds__(256) void k_ring_constraints(const uint32_t* __restrict__ wit4 /* [B][4][m] FS9 (forward NTT output): b, accip, accx, accy */,
-                                                          const uint32_t* __restrict__ fixed4 /* [3][m] FS9: px, py, s */,
-                                                          const uint32_t* __restrict__ lag4 /* [2][m] FS9: L0, Llast */,
-                                                          const uint32_t* __restrict__ not_last /* [m] FS9 */,
-                                                          const uint32_t* __restrict__ alphas /* [B][7] FS9 (converted once per batch) */,
-                                                          const uint32_t* __restrict__ alpha_aux /* [B][2] FS9: k_ring_alpha_aux */,
-                                                          RingConsts rc, uint32_t batch, uint32_t* __restrict__ agg /* [B][m] FS9, raw sums */) {
-    const uint32_t m = rc.n * 4;
-    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (size_t)batch * m) return;
-    uint32_t pid = (uint32_t)(gid / m), i = (uint32_t)(gid % m);
-    uint32_t k = i + 4;
-    if (k >= m) k -= m;
-    const uint32_t* w = wit4 + (size_t)pid * 4 * m * L29;
-    const Fs b = fs_load9(w + ((size_t)0 * m + i) * L29);
-    const Fs ip = fs_load9(w + ((size_t)1 * m + i) * L29), ip_n = fs_load9(w + ((size_t)1 * m + k) * L29);
-    const Fs x1 = fs_load9(w + ((size_t)2 * m + i) * L29), x3 = fs_load9(w + ((size_t)2 * m + k) * L29);
-    const Fs y1 = fs_load9(w + ((size_t)3 * m + i) * L29), y3 = fs_load9(w + ((size_t)3 * m + k) * L29);
-    const Fs x2 = fs_load9(fixed4 + ((size_t)0 * m + i) * L29), y2 = fs_load9(fixed4 + ((size_t)1 * m + i) * L29);
-    const Fs s = fs_load9(fixed4 + ((size_t)2 * m + i) * L29);
-    const Fs l0 = fs_load9(lag4 + (size_t)i * L29), ln = fs_load9(lag4 + ((size_t)m + i) * L29);
-    const Fs nl = fs_load9(not_last + (size_t)i * L29);
-    const uint32_t* al = alphas + (size_t)pid * 7 * L29;
-    const uint32_t* ax = alpha_aux + (size_t)pid * 2 * L29;
-    const Fs acc = body_constraints<CV>(b, ip, ip_n, x1, x3, y1, y3, x2, y2, s, l0, ln, nl, fs_load9(al), fs_load9(al + L29), fs_load9(al + 2 * L29),
-                                        fs_load9(al + 3 * L29), fs_load9(al + 4 * L29), fs_load9(al + 5 * L29), fs_load9(al + 6 * L29), fs_load9(ax),
-                                        fs_load9(ax + L29));
-    fs_store9(agg + gid * L29, acc);
-}
 
 // per proof: A = a5 seed_x + a6 seed_y, B = a5 r_x + a6 r_y + a7 for k_ring_constraints (computed on the 8-word field from the
 // Montgomery-256 alphas, written as FS9 records)

@@ -69,26 +69,13 @@ def _candidate_srs_files(min_g1_count: int):
 
 
 def _precompute_tables(dev) -> None:
-    """Fixed-base tables of an SRS in HBM.  Default: 12-bit windows feeding the bucket pipeline.  DOTRING_SRS_COMB=1
-    switches to 14-bit windows plus the comb table of every digit multiple (count * 19 * 8192 entries of 128 B: 122 GB
-    for the shipped 6145 points), which turns the batched MSMs into plain sums of looked-up points.  Measured A/B on one
-    box it is NOT faster (69 ms vs 61 ms of MSM kernels per 1024 proofs; the random 128 B gathers miss L2) and costs
-    10-13 s to build, hence opt-in; it falls back to the default when the table does not fit.  DOTRING_SRS_WINDOW
-    overrides the width (0 = no table at all)."""
-    want_comb = os.environ.get("DOTRING_SRS_COMB", "0") != "0"
+    """Fixed-base tables of an SRS in HBM: 12-bit windows feeding the bucket pipeline — for an SRS of up to ~16 k points a row per bit,
+    over which batches of hundreds of MSMs recode their scalars in non-adjacent form (dr_srs_table_info).  DOTRING_SRS_WINDOW overrides
+    the width (0 = no table at all)."""
     explicit = os.environ.get("DOTRING_SRS_WINDOW")
-    bits = int(explicit) if explicit is not None else (14 if want_comb else 12)
-    if not bits:
-        return
-    dev.precompute(bits)
-    if want_comb and bits <= 14:
-        try:
-            dev.precompute_comb()
-            return
-        except MemoryError:
-            pass
-        if explicit is None:
-            dev.precompute(12)
+    bits = int(explicit) if explicit is not None else 12
+    if bits:
+        dev.precompute(bits)
 
 
 class SRS:

@@ -204,21 +204,6 @@ def _public_keys_column_data(nm_points, domain_size, omega, prime, pcs):
     return tuple(px_e), tuple(px_c), px_cm, tuple(py_e), tuple(py_c), py_cm
 
 
-_POOL = None
-_POOL_LOCK = threading.Lock()
-
-
-def _helper_pool():
-    """Persistent helper threads of prove_batch (each keeps its own GPU context for the life of the process)."""
-    global _POOL
-    with _POOL_LOCK:
-        if _POOL is None:
-            from concurrent.futures import ThreadPoolExecutor
-
-            _POOL = ThreadPoolExecutor(max_workers=3, thread_name_prefix="dotring-prove")
-        return _POOL
-
-
 # ------------------------------------------------------------------ RingVRF (vrf.py:30-305, proof_payload.py)
 @dataclass
 class RingVRF(VRF):
@@ -424,13 +409,9 @@ class RingVRF(VRF):
 
     @classmethod
     def prove_batch(cls, alphas, additional_data, secret_keys, producer_keys, ring: Ring, ring_root: RingRoot | None = None,
-                    salts=None, pipeline: int | None = None) -> list:
+                    salts=None) -> list:
         """Additive API: a batch of proofs over ONE ring; element i equals
-        prove(alphas[i], additional_data[i], secret_keys[i], producer_keys[i], ring, ring_root).
-        pipeline = number of slices the batch is cut into; the slices' GPU phases run back to back on one stream while
-        the calling thread hashes the transcripts of the other slices (dot_ring_amd/pipeline.py).  Measured on MI355X the
-        fixed-latency kernels of the extra slices cost what the overlap saves (+0..4 %), so the default is 1 slice
-        (env DOTRING_PROVE_PIPELINE)."""
+        prove(alphas[i], additional_data[i], secret_keys[i], producer_keys[i], ring, ring_root)."""
         count = len(alphas)
         if not (len(additional_data) == len(secret_keys) == len(producer_keys) == count):
             raise ValueError("batch arguments must have equal lengths")
@@ -438,7 +419,7 @@ class RingVRF(VRF):
             return []
         cv = cls.cv
         from ..curve import scalar_mul_batch
-        from ..pipeline import run_pipelined
+        from ..pipeline import drive
 
         gen = cv.point_type.generator_point()
         # one scalar multiplication per distinct key not seen before (sk -> pk is deterministic; a small per-class memo
@@ -448,7 +429,7 @@ class RingVRF(VRF):
         sk_bytes = [bytes(sk) for sk in secret_keys]
         tag_of = {sk: tag(sk) for sk in dict.fromkeys(sk_bytes)}     # one hash per distinct key of THIS call (a local, not kept)
         tags = [tag_of[sk] for sk in sk_bytes]
-        # prove_batch may run on several threads at once (DOTRING_PROVE_PARTS, application lanes): lookups, the clear() at the size
+        # prove_batch may run on several threads at once (application lanes): lookups, the clear() at the size
         # cap and the update all happen under one lock, and the comparison below uses this call's own snapshot
         with _PK_MEMO_LOCK:
             memo = cls.__dict__.get("_pk_memo")
@@ -474,20 +455,12 @@ class RingVRF(VRF):
             if root is not None and computed.encode() != root.encode():
                 raise ValueError("ring_root does not match ring")
             root = computed
-        if pipeline is None:
-            pipeline = int(os.environ.get("DOTRING_PROVE_PIPELINE", "1"))
-        pipeline = max(1, min(pipeline, count))
-        if pipeline == 1 and device_prover.supported(ring.params) and os.environ.get("DOTRING_NATIVE_HOST", "1") != "0":
+        if device_prover.supported(ring.params) and os.environ.get("DOTRING_NATIVE_HOST", "1") != "0":
             return cls._prove_batch_native(alphas, additional_data, secret_keys, producer_keys, ring, root, salts)
+        # Python orchestration over the same kernels (custom PCS / domain layouts, DOTRING_NATIVE_HOST=0)
         if device_prover.supported(ring.params):
-            for slot in range(pipeline):
-                device_prover.get_device_prover(ring, slot)                    # per-ring tables, built outside the pipeline
-        salts_ = salts or [b""] * count
-        cuts = [count * i // pipeline for i in range(pipeline + 1)]
-        parts = run_pipelined(
-            cls._prove_gen(alphas[lo:hi], additional_data[lo:hi], secret_keys[lo:hi], producer_keys[lo:hi], ring, root, salts_[lo:hi], slot)
-            for slot, (lo, hi) in enumerate(zip(cuts, cuts[1:])))
-        return [proof for part in parts for proof in part]
+            device_prover.get_device_prover(ring, 0)                       # per-ring tables
+        return drive(cls._prove_gen(alphas, additional_data, secret_keys, producer_keys, ring, root, salts or [b""] * count, 0))
 
     @classmethod
     def _prove_batch_native(cls, alphas, additional_data, secret_keys, producer_keys, ring, root, salts) -> list:
@@ -525,24 +498,10 @@ class RingVRF(VRF):
                 if aux is None:
                     _native.wipe_thread_buffer("prove_aux")
 
-        # Opt-in (DOTRING_PROVE_PARTS=2; default 1 = one call): large batches as two halves from two threads — while one half is in
-        # its store-bound sort or its latency-bound bucket reduction / affine conversion, the other half's accumulate kernel fills
-        # the machine.  Measured +0.8 % on the bench (+3 % without per-kernel timers: 94.9 -> 92 ms per 1024 proofs), while every
-        # kernel's own duration roughly doubles — per-launch roofline figures are only meaningful with one call at a time.
         count = len(alphas)
-        parts = max(1, int(os.environ.get("DOTRING_PROVE_PARTS", "1")))
-        spans = []
-        for lo in range(0, count, device_prover.MAX_DEVICE_BATCH * parts):
-            hi = min(count, lo + device_prover.MAX_DEVICE_BATCH * parts)
-            k = parts if hi - lo >= 512 else 1
-            spans.append([(lo + (hi - lo) * j // k, lo + (hi - lo) * (j + 1) // k) for j in range(k)])
         out = []
-        for group in spans:
-            futures = [_helper_pool().submit(prove_span, a, b) for a, b in group[1:]]
-            first = prove_span(*group[0])
-            out.extend(first)
-            for f in futures:
-                out.extend(f.result())
+        for lo in range(0, count, device_prover.MAX_DEVICE_BATCH):
+            out.extend(prove_span(lo, min(count, lo + device_prover.MAX_DEVICE_BATCH)))
         return out
 
     @classmethod

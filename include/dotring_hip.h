@@ -149,21 +149,13 @@ DR_API int dr_srs_precompute(dr_ctx *ctx, dr_srs *srs, int window_bits);
 /* Shape of the table dr_srs_precompute built (all zero: none) and the tiling `batch` MSMs of n points over it would take.  An SRS
  * small enough (256 * count * 128 bytes within DOTRING_SRS_BIT_ROWS_MB, default 512: 201 MB for 6145 points) gets a row for EVERY bit,
  * table[s][i] = 2^s * base[i]; batches of hundreds of MSMs then recode every scalar in width-w non-adjacent form (w chosen per call from
- * n and batch; DOTRING_SRS_NAF_BITS forces window_bits + that, -1 = never; DOTRING_SRS_TILING=rows keeps the window rows): 256 / (w + 1) odd digits per scalar on average, each one a
+ * n and batch; DOTRING_SRS_TILING=rows keeps the window rows): 256 / (w + 1) odd digits per scalar on average, each one a
  * point of the row of its bit position added to one of 2^(w-2) odd-multiple buckets — against 256 / window_bits additions over the
  * window rows.  Results are unchanged.
  *   info[0] window_bits, info[1] rows of the table (W or 256), info[2] digit rows (windows / slots) per scalar for this (n, batch),
  *   info[3] width w of the per-call tiling (0 = the window rows), info[4] tiling: 0 = window rows, 2 = width-w non-adjacent
  *   form, info[5] expected non-zero digits per scalar x 1000 */
 DR_API int dr_srs_table_info(const dr_srs *srs, size_t n, size_t batch, int info[6]);
-/* Comb table on top of the window table (window_bits <= 14): comb[i][w][d-1] = d * 2^(start_w) * base[i] for every
- * digit magnitude d <= 2^(window_bits-1) — count * W * 2^(window_bits-1) * 128 bytes (one cache line per entry: 35 GB for
- * the shipped SRS at 12 bits; MI355X has 288 GB).  Batched MSMs (>= 32 scalar vectors) over this SRS then skip bucket
- * sorting and bucket reduction altogether: each MSM is the sum of its n*W selected entries.  DR_ERR_NOMEM when it does
- * not fit (the window table keeps working).  Results are unchanged.  Measured on MI355X: the looked-up entries come
- * from HBM instead of L2 / Infinity Cache and the additions run at 4.4-4.6 G/s instead of 5.3 G/s, which costs more
- * than the sort and reduction it saves — opt-in (DOTRING_SRS_COMB=1 in the Python layer). */
-DR_API int dr_srs_precompute_comb(dr_ctx *ctx, dr_srs *srs);
 /* copy `count` bases starting at `offset` back to the host as BE x||y records */
 DR_API int dr_srs_download(dr_ctx *ctx, const dr_srs *srs, size_t offset, size_t count, uint8_t *out_be_xy);
 DR_API void dr_srs_destroy(dr_srs *srs);

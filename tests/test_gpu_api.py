@@ -322,12 +322,11 @@ def test_tuning_knobs_do_not_change_the_bytes(ctx):
     variants = [
         {},
         {"DOTRING_NATIVE_HOST": "0"},
-        {"DOTRING_PROVE_OVERLAP": "0", "DOTRING_CHAIN_WAVE": "0", "DOTRING_MSM_LEVELS": "0", "DOTRING_WITNESS_BY_PARTS": "0"},
-        {"DOTRING_SRS_WINDOW": "9", "DOTRING_PS_WINDOW": "8", "DOTRING_MSM_CHUNK": "8", "DOTRING_AFFINE_ON_HOST": "1", "DOTRING_HOST_THREADS": "3"},
-        {"DOTRING_SRS_WINDOW": "0", "DOTRING_NATIVE_HOST": "0", "DOTRING_PROVE_PIPELINE": "2"},
-        {"DOTRING_SRS_COMB": "1", "DOTRING_SRS_WINDOW": "9", "DOTRING_PS_COMB": "1", "DOTRING_PS_WINDOW": "8"},
-        {"DOTRING_BSN_GLV": "0", "DOTRING_MSM_LEVEL_LANES": "1", "DOTRING_HOST_POOL": "0", "DOTRING_MSM_GROUPS": "3"},
-        {"DOTRING_BSN_FIXED_BASE": "0", "DOTRING_BSN_PIPPENGER_FROM": "0", "DOTRING_MSM_SETSCAN": "0", "DOTRING_VERIFY_HOST_MAX": "0"},
+        {"DOTRING_SRS_WINDOW": "9", "DOTRING_PS_WINDOW": "8", "DOTRING_HOST_THREADS": "3", "DOTRING_WIPE": "0"},
+        {"DOTRING_SRS_WINDOW": "0", "DOTRING_NATIVE_HOST": "0"},
+        {"DOTRING_SRS_TILING": "rows", "DOTRING_SRS_BIT_ROWS_MB": "0", "DOTRING_MSM_GROUPS": "3", "DOTRING_KECCAK_GENERIC": "1"},
+        {"DOTRING_SRS_TILING": "rows", "DOTRING_VERIFY_HOST_MAX": "0", "DOTRING_MSM_WINDOW": "9", "DOTRING_TRACE": "1"},
+        {"DOTRING_VERIFY_HOST_MAX": "8", "DOTRING_SRS_WINDOW": "13", "DOTRING_PS_WINDOW": "12"},
     ]
     digests = []
     for extra in variants:
@@ -447,10 +446,12 @@ def test_rings_release_their_device_state(ctx):
     assert used[-1] - used[2] < 32 << 20, used
 
 
-def test_prove_batch_in_two_concurrent_halves_gives_the_same_proofs(ctx, monkeypatch):
-    """DOTRING_PROVE_PARTS=2: batches of 512+ proofs run as two halves on two threads (own context, stream and prover state
-    each); deterministic proofs must come out identical and in order, and the helper thread's context must be visible to the
-    profiling registry."""
+def test_prove_batch_from_two_threads_gives_the_same_proofs(ctx):
+    """The library is thread-compatible: two application threads proving halves of a batch over ONE ring at the same time
+    — each gets its own context, stream and per-ring prover state — must produce the proofs of one call, in order, and the helper
+    thread's context must be visible to the profiling registry."""
+    import threading
+
     import dot_ring_amd as d
     from dot_ring_amd import runtime
 
@@ -462,12 +463,19 @@ def test_prove_batch_in_two_concurrent_halves_gives_the_same_proofs(ctx, monkeyp
     root = d.RingRoot.from_ring(ring, params)
     n = 601
     al = [b"p%d" % i for i in range(n)]
-    args = (al, al, [sks[i % 16] for i in range(n)], [keys[i % 16] for i in range(n)], ring, root)
-    monkeypatch.setenv("DOTRING_PROVE_PARTS", "1")
-    one = [p.encode() for p in d.RingVRF[cv].prove_batch(*args)]
+    sk_of, pk_of = [sks[i % 16] for i in range(n)], [keys[i % 16] for i in range(n)]
+    one = [p.encode() for p in d.RingVRF[cv].prove_batch(al, al, sk_of, pk_of, ring, root)]
     before = len(runtime.contexts())
-    monkeypatch.setenv("DOTRING_PROVE_PARTS", "2")
-    two = [p.encode() for p in d.RingVRF[cv].prove_batch(*args)]
+    halves = [None, None]
+
+    def work(k, lo, hi):
+        halves[k] = [p.encode() for p in d.RingVRF[cv].prove_batch(al[lo:hi], al[lo:hi], sk_of[lo:hi], pk_of[lo:hi], ring, root)]
+
+    th = threading.Thread(target=work, args=(1, 300, n))
+    th.start()
+    work(0, 0, 300)
+    th.join()
+    two = halves[0] + halves[1]
     assert one == two
     assert len(runtime.contexts()) >= max(2, before)
     assert d.RingVRF[cv].batch_verify(d.RingVRF[cv].decode_batch(two), al, al, ring, root)

@@ -410,12 +410,12 @@ def test_g1_msm_many_bucket_sets_level_reduction(ctx, srs_bytes, bits, batch):
 
 
 @pytest.mark.parametrize("bits,n,batch", [(9, 700, 40), (12, 300, 70), (10, 64, 4100), (8, 1, 33)])
-def test_g1_msm_comb_table_matches_plain(ctx, srs_bytes, bits, n, batch):
-    """dr_srs_precompute_comb: batched MSMs as sums of looked-up multiples (k_g1_comb_msm) — identical results to the
-    bucket method, incl. zero vectors, scalars >= r, offsets into the SRS and every block shape (1..4 waves per MSM)."""
+def test_g1_msm_batched_over_table_matches_plain(ctx, srs_bytes, bits, n, batch):
+    """batches of MSMs over a fixed-base table (window rows below 256 vectors, the non-adjacent form over bit rows from there on) —
+    identical results to plain bases and the oracle, incl. zero vectors, scalars >= r and 2^255"""
     rng = random.Random(bits * 1000 + n)
     plain = ctx.srs_load(srs_bytes[: 96 * (n + 5)])
-    comb = ctx.srs_load(srs_bytes[: 96 * (n + 5)]).precompute(bits).precompute_comb()
+    comb = ctx.srs_load(srs_bytes[: 96 * (n + 5)]).precompute(bits)
     vecs = [b"".join(rng.randrange(coracle.FR_P).to_bytes(32, "little") for _ in range(n)) for _ in range(6)]
     vecs.append(bytes(32 * n))
     vecs.append(b"".join(v.to_bytes(32, "little") for v in ([1, coracle.FR_P - 1, (1 << 256) - 1, 2**255, coracle.FR_P] * n)[:n]))
