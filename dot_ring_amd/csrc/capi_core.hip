@@ -245,7 +245,7 @@ void dr_ctx_destroy(dr_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (Scratch* s : {&ctx->scalars, &ctx->digits, &ctx->counts, &ctx->offsets, &ctx->cursor, &ctx->tiles, &ctx->sorted,
                        &ctx->buckets, &ctx->partial, &ctx->winsum, &ctx->result, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->perm, &ctx->cells,
-                       &ctx->cell_off, &ctx->part_base, &ctx->heavy, &ctx->vfy_bases, &ctx->vfy_in, &ctx->vfy_std})
+                       &ctx->cell_off, &ctx->part_base, &ctx->heavy, &ctx->flag, &ctx->vfy_bases, &ctx->vfy_in, &ctx->vfy_std})
         s->release();
     for (auto& it : ctx->prof_pending) {
         (void)hipEventDestroy(it.second.first);
@@ -328,14 +328,14 @@ int te_scalar_mul_batch_dev(dr_ctx* ctx, int cv, const void* d_pts, const void* 
     constexpr long w2_from = 32768;
     if (drh::te_curve(cv) && drh::te_curve(cv)->glv && n < 16384) {
         // latency-bound launch: GLV on lane pairs, the scalars reduced and decomposed by the lanes themselves (k_bsn_scalar_mul_glv<true>)
-        TRY(ctx->io_b.reserve(4));
-        HIP_TRY(hipMemsetAsync(ctx->io_b.p, 0, 4, ctx->stream));
+        TRY(ctx->flag.reserve(64));              // (not io_b: internal callers pass the context's io buffers as operands)
+        HIP_TRY(hipMemsetAsync(ctx->flag.p, 0, 4, ctx->stream));
         TRY(launch(ctx, "k_bsn_scalar_mul", [&] {
             hipLaunchKernelGGL(dr::k_bsn_scalar_mul_glv<true>, dim3(div_up(2 * n, dr::BSN_BLOCK)), dim3(dr::BSN_BLOCK), 0, ctx->stream,
-                               (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t*)d_out, (uint32_t)n, ctx->io_b.as<uint32_t>());
+                               (const uint32_t*)d_pts, (const uint32_t*)d_scalars, (uint32_t*)d_out, (uint32_t)n, ctx->flag.as<uint32_t>());
         }));
         uint32_t bad = 0;
-        HIP_TRY(hipMemcpyAsync(&bad, ctx->io_b.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(&bad, ctx->flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->prof) TRY(prof_collect(ctx));
         if (bad) return fail(DR_ERR_DEVICE, "GLV decomposition out of range");

@@ -93,6 +93,7 @@ struct dr_ctx {
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
     // MSM workspaces
     Scratch scalars, digits, counts, offsets, cursor, tiles, sorted, buckets, partial, winsum, result, io_a, io_b, io_c, perm, cells, cell_off, part_base, heavy;
+    Scratch flag;                            // one word for kernels that report a condition (never an operand buffer of a caller)
     Scratch vfy_bases, vfy_in, vfy_std;      // dr_ringvrf_verify_batch: decompressed G1 points stay resident between its steps
     dr_ctx* aux = nullptr;                   // second stream for the latency-bound Bandersnatch side of the batch verifier
     dr_ctx* aux2 = nullptr;                  // third stream: the verifier's two G1 MSMs run side by side

@@ -138,57 +138,76 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     if (n >= (1ull << 31)) return fail(DR_ERR_INVALID, "MSM size must be below 2^31");
     const bool single = tbl != nullptr && tbl->table != nullptr;
     PhaseTrace tr_("msm_device");                 // DOTRING_TRACE=1: where the wall time of a call goes
-    MsmPlan pl = make_plan(n, g_force_c, !single && batch == 1 && n <= 32768);
-    if (single) {
-        // A table with a row per bit and hundreds of MSMs (the batched prover): one more bit per window, buckets for odd multiples only
-        // — as many buckets as before, a window less per scalar.  Needs the per-set LDS sort and the set-scan reduction (below).
-        const Tiling tl = tiling_for(*tbl, n, batch);
-        const bool odd = tl.mode != 0;
-        dr::WindowTable wo{};
-        if (odd) {                                       // slots of the non-adjacent form: positions [c j, c j + c) of k << shift
-            wo.W = tl.slots;
-            wo.cmax = tl.c;
-            const int shift = wo.W * tl.c - 256;          // (msm_recode.hip.h: for_each_wnaf_digit)
-            for (int j = 0; j < wo.W; j++) {
-                wo.start[j] = (uint8_t)(tl.c * j);
-                wo.row[j] = (uint8_t)(j ? tl.c * j - shift : 0);
-                wo.width[j] = (uint8_t)tl.c;
+    // The plan — tiling of the scalars, index groups, reduction chunks — and the two paths every later step depends on: the per-set
+    // LDS sort and the set-scan reduction.  The non-adjacent form over a bit-row table needs both; they are decided HERE, from one set
+    // of predicates, and a plan that would not get them falls back to the table's window rows before anything is launched.
+    MsmPlan pl;
+    uint32_t groups = 1;
+    size_t windows = 0, bsets = 0, per_set_scalars = 0, per_set_digits = 0;
+    bool lds_sort = false, setscan = false;
+    const auto make = [&](bool allow_naf) {
+        pl = make_plan(n, g_force_c, !single && batch == 1 && n <= 32768);
+        if (single) {
+            // a table with a row per bit and hundreds of MSMs (the batched prover): non-adjacent form, buckets for odd multiples (tiling_for)
+            const Tiling tl = allow_naf ? tiling_for(*tbl, n, batch) : Tiling{0, 0, 0, 0.0};
+            const bool odd = tl.mode != 0;
+            dr::WindowTable wo{};
+            if (odd) {                                       // slots of the non-adjacent form: positions [c j, c j + c) of k << shift
+                wo.W = tl.slots;
+                wo.cmax = tl.c;
+                const int shift = wo.W * tl.c - 256;          // (msm_recode.hip.h: for_each_wnaf_digit)
+                for (int j = 0; j < wo.W; j++) {
+                    wo.start[j] = (uint8_t)(tl.c * j);
+                    wo.row[j] = (uint8_t)(j ? tl.c * j - shift : 0);
+                    wo.width[j] = (uint8_t)tl.c;
+                }
+                wo.odd = 2;
             }
-            wo.odd = 2;
+            pl.wt = odd ? wo : tbl->wt;
+            pl.W = pl.wt.W;
+            pl.H = odd ? 1u << (pl.wt.cmax - 2) : 1u << (pl.wt.cmax - 1);
+            pl.L = std::min<uint32_t>(pl.H, 16u);
+            pl.T = pl.H / pl.L;
         }
-        pl.wt = odd ? wo : tbl->wt;
-        pl.W = pl.wt.W;
-        pl.H = odd ? 1u << (pl.wt.cmax - 2) : 1u << (pl.wt.cmax - 1);
-        pl.L = std::min<uint32_t>(pl.H, 16u);
-        pl.T = pl.H / pl.L;
+        // table mode: split the points of each MSM into index groups when one bucket set per MSM would leave lanes idle
+        groups = 1;
+        if (single) {
+            // 8 waves per SIMD: finer slices balance better than 4 (2^20 bases: accumulate 3.98 -> 3.6 ms); below 2^19 points half of that —
+            // every bucket is another lane-step of the reduction's chain, and the walk is short anyway (2^16 pairs over 16-bit windows:
+            // 8 groups 0.875 ms, 16 groups 1.03, 2 groups 0.96)
+            const size_t target_lanes = n >= ((size_t)1 << 19) ? 524288 : 262144;
+            while (groups < 64 && batch * groups * (size_t)pl.H < target_lanes && (size_t)n / (groups * 2) >= 64) groups *= 2;
+            static const int force_groups = std::getenv("DOTRING_MSM_GROUPS") ? std::atoi(std::getenv("DOTRING_MSM_GROUPS")) : 0;
+            if (force_groups > 0 && batch == 1 && (size_t)n / (size_t)force_groups >= 64) groups = (uint32_t)force_groups;
+        }
+        windows = batch * (size_t)pl.W;                   // digit rows
+        bsets = single ? batch * groups : windows;        // bucket sets
+        // few bucket sets of moderate size (a single MSM over a window table): the reduction is a latency chain of
+        // 2L additions + a log2(H)-bit double-and-add + the fold of H/L partial sums; L = 4 makes it ~40 % shorter
+        if (single && pl.L == 16 && pl.H >= 256 && pl.H <= 4096 && bsets * (size_t)(pl.H / 16) < l4_below()) {
+            pl.L = 4;
+            pl.T = pl.H / 4;
+        }
+        // (one huge MSM, 16 groups x 32768 buckets: L stays 16 — measured 0.90 ms for the chunk kernel against 1.15 at L = 8 and 1.00
+        //  at L = 4: every chunk pays a 15-bit double-and-add whatever its length)
+        // the same for a small MSM over plain bases (the verifier's 2- and 11-point folds): 41 -> 16 dependent additions
+        if (!single && pl.L == 16 && pl.H >= 16 && bsets * (size_t)(pl.H / 16) < ((size_t)1 << 12)) {
+            pl.L = 4;
+            pl.T = pl.H / 4;
+        }
+        per_set_scalars = single ? (n + groups - 1) / groups : n;
+        per_set_digits = single ? per_set_scalars * (size_t)pl.W : n;
+        // small bucket sets fed by a bounded number of digits (the batched prover): one workgroup sorts a set entirely in LDS
+        lds_sort = pl.H <= dr::SORT_MAX_H && bsets >= 64 && per_set_digits <= (1u << 20) && bsets * per_set_digits < (1ull << 32);
+        // many sets of <= 4096 buckets (every batched MSM of the prover): first level with 2 additions per bucket, then one workgroup
+        // per set scans and folds its <= 256 chunk results
+        setscan = pl.L == 16 && pl.T >= 8 && pl.T <= 256 && bsets >= 256;
+    };
+    make(true);
+    if (pl.wt.odd && !(lds_sort && setscan)) make(false);
+    if (single) {
         d_bases = tbl->table;
         if (((uint64_t)pl.wt.row[pl.W - 1] + pl.wt.cmax + 1) * tbl->stride >= (1ull << 31)) return fail(DR_ERR_INVALID, "window table too large");
-    }
-    // table mode: split the points of each MSM into index groups when one bucket set per MSM would leave lanes idle
-    uint32_t groups = 1;
-    if (single) {
-        // 8 waves per SIMD: finer slices balance better than 4 (2^20 bases: accumulate 3.98 -> 3.6 ms); below 2^19 points half of that —
-        // every bucket is another lane-step of the reduction's chain, and the walk is short anyway (2^16 pairs over 16-bit windows:
-        // 8 groups 0.875 ms, 16 groups 1.03, 2 groups 0.96)
-        const size_t target_lanes = n >= ((size_t)1 << 19) ? 524288 : 262144;
-        while (groups < 64 && batch * groups * (size_t)pl.H < target_lanes && (size_t)n / (groups * 2) >= 64) groups *= 2;
-        static const int force_groups = std::getenv("DOTRING_MSM_GROUPS") ? std::atoi(std::getenv("DOTRING_MSM_GROUPS")) : 0;
-        if (force_groups > 0 && batch == 1 && (size_t)n / (size_t)force_groups >= 64) groups = (uint32_t)force_groups;
-    }
-    const size_t windows = batch * (size_t)pl.W;                   // digit rows
-    const size_t bsets = single ? batch * groups : windows;        // bucket sets
-    // few bucket sets of moderate size (a single MSM over a window table): the reduction is a latency chain of
-    // 2L additions + a log2(H)-bit double-and-add + the fold of H/L partial sums; L = 4 makes it ~40 % shorter
-    if (single && pl.L == 16 && pl.H >= 256 && pl.H <= 4096 && bsets * (size_t)(pl.H / 16) < l4_below()) {
-        pl.L = 4;
-        pl.T = pl.H / 4;
-    }
-    // (one huge MSM, 16 groups x 32768 buckets: L stays 16 — measured 0.90 ms for the chunk kernel against 1.15 at L = 8 and 1.00
-    //  at L = 4: every chunk pays a 15-bit double-and-add whatever its length)
-    // the same for a small MSM over plain bases (the verifier's 2- and 11-point folds): 41 -> 16 dependent additions
-    if (!single && pl.L == 16 && pl.H >= 16 && bsets * (size_t)(pl.H / 16) < ((size_t)1 << 12)) {
-        pl.L = 4;
-        pl.T = pl.H / 4;
     }
     const size_t nbuckets = bsets * (size_t)pl.H;
     const size_t ndigits = windows * n;
@@ -215,9 +234,6 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     };
     // Sorting the digits by bucket.  Small bucket sets fed by a bounded number of digits (the batched prover) are
     // sorted by one workgroup each, entirely in LDS; a few huge sets (one 2^20-point MSM) use global atomics.
-    const size_t per_set_scalars = single ? (n + groups - 1) / groups : n;
-    const size_t per_set_digits = single ? per_set_scalars * (size_t)pl.W : n;
-    const bool lds_sort = pl.H <= dr::SORT_MAX_H && bsets >= 64 && per_set_digits <= (1u << 20) && bsets * per_set_digits < (1ull << 32);
     // a few huge sets over a window table (one 2^20-point MSM): two-pass partition sort (k_g1_part_scatter / k_g1_part_sort)
     uint32_t part_p = 1, part_shift = 0;
     {
@@ -370,10 +386,7 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     // many bucket sets (batched prover): level-wise reduction, 2 additions per entry and no scalar multiplications;
     // few sets (single MSMs): chunk sums + double-and-add, whose latency is one short chain
     const bool leveled = pl.L == 16 && pl.H >= 256 && bsets * (size_t)(pl.H / 16) >= ((size_t)1 << 18);
-    // many sets of <= 2048 buckets (every batched MSM of the prover): first level with 2 additions per bucket, then one workgroup
-    // per set scans and folds its <= 128 chunk results
-    const bool setscan = pl.L == 16 && pl.T >= 8 && pl.T <= 256 && bsets >= 256;
-    if (pl.wt.odd && !(setscan && lds_sort)) return fail(DR_ERR_DEVICE, "internal: non-adjacent form planned for a path that does not support it");
+    if (pl.wt.odd && !(setscan && lds_sort)) return fail(DR_ERR_DEVICE, "internal: non-adjacent form on a path that does not support it");   // (cannot happen: see the plan)
     // a single MSM over a wide window table (H >= 8192 buckets per index group): workgroup scan, (V, S) pairs to the host
     // buckets per lane of that scan: as few as keep the launch within one wave per SIMD (65536 lanes), at most 8
     uint32_t ws_per_lane = 1;

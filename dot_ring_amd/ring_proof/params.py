@@ -19,28 +19,29 @@ def _is_power_of_two(n: int) -> bool:
 
 
 def _sqrt_mod_prime(n: int, prime: int) -> int:
-    """Tonelli-Shanks with the reference's schedule (params.py:63) — the root it returns fixes omega for N = 4096."""
+    """The square root the reference's Tonelli-Shanks returns (params.py:63-105) — WHICH of the two roots matters: three square roots of
+    the shipped 2048-th root of unity fix omega for N = 4096, and with it the row order of the domain and every proof byte.
+    Closed form of that loop: with prime - 1 = q 2^s, c = z^q for the smallest non-residue z and n^q = c^e (e even for a square), it
+    returns n^((q+1)/2) c^((2^s - e)/2) — the root whose 2-power part has its logarithm below 2^(s-1); for e = 0 plainly n^((q+1)/2).
+    e is read bit by bit in the group of order 2^s (s = 32 for the BLS12-381 scalar field)."""
+    n %= prime
     if n == 0:
         return 0
-    if prime % 4 == 3:
+    s = ((prime - 1) & -(prime - 1)).bit_length() - 1
+    q = (prime - 1) >> s
+    if s == 1:
         return pow(n, (prime + 1) // 4, prime)
-    if pow(n, (prime - 1) // 2, prime) != 1:
+    z = next(v for v in range(2, prime) if pow(v, (prime - 1) // 2, prime) == prime - 1)
+    c, rest, e = pow(z, q, prime), pow(n, q, prime), 0
+    c_inv = pow(c, -1, prime)
+    for k in range(s):                        # bit k of e: (n^q c^-(bits below k))^(2^(s-1-k)) is -1 exactly when it is set
+        if pow(rest, 1 << (s - 1 - k), prime) != 1:
+            e |= 1 << k
+            rest = rest * pow(c_inv, 1 << k, prime) % prime
+    if e & 1:
         raise ValueError("No square root exists for provided value")
-    q, s = prime - 1, 0
-    while q % 2 == 0:
-        s, q = s + 1, q // 2
-    z = 2
-    while pow(z, (prime - 1) // 2, prime) != prime - 1:
-        z += 1
-    m, c, x, t = s, pow(z, q, prime), pow(n, (q + 1) // 2, prime), pow(n, q, prime)
-    while t != 1:
-        i, probe = 1, t * t % prime
-        while i < m and probe != 1:
-            probe = probe * probe % prime
-            i += 1
-        b = pow(c, 1 << (m - i - 1), prime)
-        x, t, c, m = x * b % prime, t * b * b % prime, b * b % prime, i
-    return x
+    root = pow(n, (q + 1) // 2, prime)
+    return root * pow(c, ((1 << s) - e) // 2, prime) % prime if e else root
 
 
 @lru_cache(maxsize=8)

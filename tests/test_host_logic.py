@@ -194,3 +194,34 @@ def test_from_ring_size_matches_spec_capacity(ring_size, domain_size, max_ring_s
     assert (params.domain_size, params.max_ring_size, params.max_effective_ring_size) == (domain_size, max_ring_size, max_ring_size)
     assert pow(params.omega, params.domain_size, params.prime) == 1 and pow(params.omega, params.domain_size // 2, params.prime) != 1
     assert params.required_srs_degree == max(params.domain_size - 1, params.radix_domain_size - params.domain_size)
+
+
+def test_sqrt_root_choice_matches_the_reference_schedule():
+    """RingProofParams extends the shipped 2048-th root of unity by repeated square roots for 4N > 2048 (params.py:108-115), and WHICH
+    root each step returns fixes omega for N = 4096.  The closed form in dot_ring_amd/ring_proof/params.py must return the root of the
+    reference's Tonelli-Shanks loop (restated in oracle/pyref/ring.py): the three extension steps, random squares, the error for
+    non-residues, and other primes (p = 3 mod 4, other 2-adicities) as plain square roots."""
+    import inspect
+    import random
+
+    from dot_ring_amd.ring_proof.params import ROOT_OF_UNITY_2048, _sqrt_mod_prime
+    from oracle.pyref import ring as oring
+
+    P = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    ref = oring._sqrt_mod_prime
+    ref_call = (lambda v: ref(v, P)) if len(inspect.signature(ref).parameters) == 2 else ref
+    root = ROOT_OF_UNITY_2048
+    for _ in range(3):
+        nxt = _sqrt_mod_prime(root, P)
+        assert nxt == ref_call(root) and nxt * nxt % P == root
+        root = nxt
+    rng = random.Random(11)
+    for _ in range(200):
+        sq = pow(rng.randrange(1, P), 2, P)
+        assert _sqrt_mod_prime(sq, P) == ref_call(sq)
+    with pytest.raises(ValueError, match="No square root"):
+        _sqrt_mod_prime(5, P)                                   # 5 is the non-residue of this field
+    assert _sqrt_mod_prime(0, P) == 0
+    for pr in (13, 17, 97, 193, 257, 7681, 12289, 65537, 1000003):
+        for v in range(1, min(pr, 300)):
+            assert pow(_sqrt_mod_prime(v * v % pr, pr), 2, pr) == v * v % pr
