@@ -46,6 +46,14 @@ for path in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"
             k = short(row["Kernel_Name"])
             sums[k][row["Counter_Name"]] += float(row["Counter_Value"])
             launches[k][row["Counter_Name"]] += 1
+# the clock the chip held under the bucket walk in the --pmc pass: GRBM_GUI_ACTIVE counts cycles of all 8 XCDs
+clock_cycles = clock_ns = 0.0
+for path in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] == "GRBM_GUI_ACTIVE" and short(row["Kernel_Name"]).endswith("k_g1_accumulate") and int(row["Grid_Size"]) >= 2000000:
+                clock_cycles += float(row["Counter_Value"]) / 8.0
+                clock_ns += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
 avg = {k: {c: sums[k][c] / launches[k][c] for c in sorted(sums[k])} for k in sums}
 for k in avg:
     avg[k]["launches_per_pass"] = max(launches[k].values())
@@ -65,6 +73,10 @@ if acc and "FETCH_SIZE" in acc and "WRITE_SIZE" in acc:
             "WRITE_SIZE_KB": acc["WRITE_SIZE"],
         },
     }
+    if clock_ns:
+        traffic["_clock_ghz"] = round(clock_cycles / clock_ns, 4)
+        traffic["_clock_source"] = (f"GRBM_GUI_ACTIVE / 8 XCDs / launch duration over the dense k_g1_accumulate launches of the rocprofv3 --pmc pass of "
+                                    f"tools/profile_round.sh {tag} (the profiled run; bench.py itself is not under the profiler)")
     with open("profiles/hbm_traffic.json", "w") as f:
         json.dump(traffic, f, indent=1)
 print("wrote profiles for", tag, "; kernels with counters:", len(avg))
