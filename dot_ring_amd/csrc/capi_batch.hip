@@ -561,8 +561,8 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
     }
     tr_.mark("decode");
 
-    // ---- 3. Pedersen part: the helper thread may go on (te_xy is complete)
-    open_gate(1);
+    // ---- 3. (the Pedersen helper may go on only once the two host passes below have their slices of the worker pool: its challenge hashing
+    //          queued first would be drained first — the pool serves the oldest job — and the critical path would wait behind it)
 
     // ---- 4. ring proofs: transcript replay + verifier scalar pass per proof, random linear combination of all claims
     drh::RingVerifierDomain dm;
@@ -671,7 +671,8 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         for (int k = 0; k < 3; k++) mp.mul(r[0], cl.nus[k], fp + 4 * k);
         mp.mul(r[0], cl.agg_zeta, v); mp.mul(r[1], cl.l_zw, w); mp.add(v, w, fp + 12);
       }
-    });
+    }, 1);
+    open_gate(1);                // Pedersen part: te_xy has been complete since the decode; its hashing and MSM run beside the G1 folds and the pairing
     for (size_t i = 0; i < B; i++) if (bad[i]) return DR_OK;
     tr_.mark("transcripts");
     {

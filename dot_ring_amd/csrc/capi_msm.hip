@@ -610,7 +610,7 @@ int msm_batch_results_to_bytes(dr_ctx* ctx, size_t batch, uint8_t* out_be_xy, in
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->prof) TRY(prof_collect(ctx));
         g1_dev_to_host(res.data(), res.size());
-        drh::parallel_for(batch, [&](size_t b) { g1_result_to_bytes(res[b], out_be_xy + 96 * b, is_inf ? is_inf + b : nullptr); });
+        drh::parallel_for(batch, [&](size_t b) { g1_result_to_bytes(res[b], out_be_xy + 96 * b, is_inf ? is_inf + b : nullptr); }, 1);    // an inversion each
         return DR_OK;
     }
     TRY(ctx->io_c.reserve(batch * 96));

@@ -133,10 +133,12 @@ inline WorkerPool* worker_pool() {
 // f(i) for i in [0, n).  Short loops stay on the calling thread.  An exception thrown by f on a worker (std::bad_alloc from a
 // staging buffer) is carried to the calling thread and rethrown there, where the C entry points' try / catch turn it into a
 // status code.
+// `grain`: the fewest items worth a thread of their own — 16 for the usual few-microsecond items; 1 where an item is itself a slice of work
+// (the batch verifier's claim scalars go in slices of 16 proofs around a shared inversion: 64 items that ran on FOUR threads until round 4)
 template <class F>
-void parallel_for(size_t n, F f) {
+void parallel_for(size_t n, F f, size_t grain = 16) {
     unsigned t = host_threads();
-    if (t > n / 16) t = (unsigned)(n / 16);
+    if (t > n / grain) t = (unsigned)(n / grain);
     if (t <= 1) {
         for (size_t i = 0; i < n; i++) f(i);
         return;
