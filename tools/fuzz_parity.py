@@ -140,7 +140,7 @@ report("g1 msm shapes", total, wrong, t0)
 # (window rows) and a sample against the oracle; scalars dense, sparse, short, repeated
 t0 = time.perf_counter()
 wrong = total = 0
-for table, n, batch in ((9, 50, 8192), (10, 333, 4096), (12, 2047, 1024), (13, 700, 512)):
+for table, n, batch in ((9, 50, 8192), (10, 333, 4096), (12, 2047, 1024), (13, 700, 1100)):
     if scale < 1 and n > 400:
         continue
     srs = ctx.srs_load(srs_be[: 96 * n]).precompute(table)
