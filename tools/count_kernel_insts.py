@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "dot_ring_amd", "csrc", "build")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 # kernel (substring of the mangled name) -> minimal number of v_mad_i64_i32 that makes a loop "the" loop
-KERNELS = {"k_g1_accumulateILb0EE": 2000, "k_te_msm_accumulateILi1E": 600}
+KERNELS = {"15k_g1_accumulateE": 2000, "k_te_msm_accumulateILi1E": 600}
 OUT = os.path.join(ROOT, "dot_ring_amd", "kernel_counts.json")
 
 _HEAD = re.compile(r"^([0-9a-f]+) <(\S+)>:")
