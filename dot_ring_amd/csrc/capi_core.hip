@@ -164,11 +164,17 @@ int dri::ctx_wipe_scratch(dr_ctx* ctx) {
     if (!wipe_enabled()) return DR_OK;
     TRY(use_ctx(ctx));
     hipError_t e = hipSuccess;
+    size_t total = 0;
     TRY(launch(ctx, "wipe", [&] {
         for (Scratch* s : ctx_scratch_list(ctx))
-            if (s->p && s->cap && e == hipSuccess) e = hipMemsetAsync(s->p, 0, s->cap, ctx->stream);
+            if (s->p && s->cap && e == hipSuccess) { e = hipMemsetAsync(s->p, 0, s->cap, ctx->stream); total += s->cap; }
     }));
     HIP_TRY(e);
+    if (std::getenv("DOTRING_TRACE")) {
+        std::fprintf(stderr, "[dotring] wipe of context scratch: %.1f MB |", (double)total / 1e6);
+        for (Scratch* s : ctx_scratch_list(ctx)) std::fprintf(stderr, " %.0f", (double)s->cap / 1e6);
+        std::fprintf(stderr, "\n");
+    }
     return DR_OK;
 }
 int dri::count_nonzero_words(dr_ctx* ctx, const void* d_buf, size_t bytes, uint64_t* total) {

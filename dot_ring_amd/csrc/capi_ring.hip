@@ -508,11 +508,17 @@ int dr_ring_prover_wipe(dr_ring_prover* p) {
     if (!wipe_enabled()) return DR_OK;
     TRY(use_ctx(p->ctx));
     hipError_t e = hipSuccess;
+    size_t total = 0;
     TRY(launch(p->ctx, "wipe", [&] {
         for (Scratch* s : prover_batch_state(p))
-            if (s->p && s->cap && e == hipSuccess) e = hipMemsetAsync(s->p, 0, s->cap, p->ctx->stream);
+            if (s->p && s->cap && e == hipSuccess) { e = hipMemsetAsync(s->p, 0, s->cap, p->ctx->stream); total += s->cap; }
     }));
     HIP_TRY(e);
+    if (std::getenv("DOTRING_TRACE")) {
+        std::fprintf(stderr, "[dotring] wipe of prover state: %.1f MB |", (double)total / 1e6);
+        for (Scratch* s : prover_batch_state(p)) std::fprintf(stderr, " %.0f", (double)s->cap / 1e6);
+        std::fprintf(stderr, "\n");
+    }
     p->fwd_pending = p->quot2_pending = false;
     return ctx_wipe_scratch(p->ctx);
 }
