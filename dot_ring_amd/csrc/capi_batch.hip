@@ -137,7 +137,7 @@ struct PedersenBatch {
             }
         });
         // device copies of x, b, k, k_b (scalar uploads of the fixed-base and variable-base launches) do not outlive the call either
-        return ctx_wipe_scratch(actx);
+        return ctx_wipe_scratch(actx, true);
     }
 };
 
@@ -155,6 +155,7 @@ int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_
         if (alpha_off[i + 1] < alpha_off[i] || ad_off[i + 1] < ad_off[i] || (salt_off && salt_off[i + 1] < salt_off[i]))
             return fail(DR_ERR_INVALID, "offsets must be non-decreasing");
     dr_ctx* ctx = ring_prover_ctx(p);
+    TRY(use_ctx(ctx));
     const size_t B = batch;
     PhaseTrace tr_("prove_batch");
 
@@ -373,7 +374,10 @@ int pedersen_verify_core(dr_ctx* actx, const drh::VrfSuite& su, size_t B, const 
 int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_ring_verifier_key* vk, size_t batch, const uint8_t* proofs,
                                      const uint8_t* inputs, const uint64_t* in_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts,
                                      const uint64_t* salt_off, const uint8_t seed32[32], int* ok) {
-    TRY(use_ctx(ctx));
+    // (not use_ctx: a prover that ran on this context may have left the zeroing of its buffers on the wipe stream; the decoding phase
+    //  below works in verifier-owned buffers and runs beside it, the MSM phase — the first to touch the context's scratch — joins it)
+    if (!ctx) return fail(DR_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
     if (!vk || !proofs || !in_off || !ad_off || !seed32 || !ok || !vk->fs_prefix) return fail(DR_ERR_INVALID, "null argument");
     *ok = 0;
     if (batch == 0) { *ok = 1; return DR_OK; }
@@ -498,21 +502,21 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
             }
         }
     } else {
-        TRY(ctx->io_a.reserve(n_te * 32));
-        TRY(ctx->io_b.reserve(n_te * 64));
-        TRY(ctx->io_c.reserve(n_te * 4 + n_g1 * 4));
+        Scratch &te_in = ctx->vfy_te_in, &te_out = ctx->vfy_te_out, &vflags = ctx->vfy_flags;
+        TRY(te_in.reserve(n_te * 32));
+        TRY(te_out.reserve(n_te * 64));
+        TRY(vflags.reserve(n_te * 4 + n_g1 * 4));
         hipStream_t st = ctx->stream;
-        // the third stream (G1 decompression, below) writes its verdicts into this context's io_c: it starts behind whatever this stream
-        // still has to do with its scratch — a prover that ran on this context leaves the wipe of its buffers in the stream
-        // (capi_core.hip: ctx_wipe_scratch) — but not behind the decoding kernel launched next
+        // the third stream (G1 decompression, below) writes its verdicts behind this stream's: it starts when this stream is done with
+        // whatever an earlier call left in it, but not behind the decoding kernel launched next
         hipEvent_t scratch_ready;
         HIP_TRY(hipEventCreateWithFlags(&scratch_ready, hipEventDisableTiming));
         struct EventGuard { hipEvent_t e; ~EventGuard() { (void)hipEventDestroy(e); } } scratch_ready_guard{scratch_ready};
         HIP_TRY(hipEventRecord(scratch_ready, st));
-        HIP_TRY(hipMemcpyAsync(ctx->io_a.p, te_enc.data(), n_te * 32, hipMemcpyHostToDevice, st));
-        uint32_t* d_ok = ctx->io_c.as<uint32_t>();
+        HIP_TRY(hipMemcpyAsync(te_in.p, te_enc.data(), n_te * 32, hipMemcpyHostToDevice, st));
+        uint32_t* d_ok = vflags.as<uint32_t>();
         TRY(launch(ctx, "k_bsn_decode_points", [&] {
-            launch_decode_points(ctx, st, su.cv->id, false, ctx->io_a.as<uint32_t>(), ctx->io_b.as<uint32_t>(), d_ok, n_te);
+            launch_decode_points(ctx, st, su.cv->id, false, te_in.as<uint32_t>(), te_out.as<uint32_t>(), d_ok, n_te);
         }));
         std::vector<uint32_t> flags(n_te + n_g1);
         // G1: bases buffer = 7B decompressed points followed by C_px, C_py, C_s and G1[0]
@@ -533,7 +537,7 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         // only now the copy back of the decoded Bandersnatch points: into pageable memory it blocks this thread until the decoding
         // kernel is done, and issued before the G1 launch (as it was until round 3) it kept the two decoders from running side by
         // side — 1.06 + 0.96 ms in a row instead of 1.06
-        HIP_TRY(hipMemcpyAsync(te_xy.data(), ctx->io_b.p, n_te * 64, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(te_xy.data(), te_out.p, n_te * 64, hipMemcpyDeviceToHost, st));
         {
             hipEvent_t done;
             HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
@@ -715,6 +719,7 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         put(lhs_pt, 0);
         put(rhs_pt, 1);
     } else {
+        TRY(use_ctx(ctx));           // from here on the context's scratch is used: behind a pending wipe of it
         TRY(ctx->scalars.reserve(n_g1 * 32));
         // the two MSMs are independent and each is a short latency chain (sort, accumulate, reduce, fold): the rhs runs on
         // a third stream from a helper thread while this thread does the lhs

@@ -10,7 +10,7 @@ thread_local std::string g_err;
 int use_ctx(dr_ctx* ctx) {
     if (!ctx) return fail(DR_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
-    return DR_OK;
+    return ctx_join_wipe(ctx);
 }
 
 int prof_collect(dr_ctx* ctx) {
@@ -160,14 +160,37 @@ bool dri::wipe_enabled() {
     static const bool on = std::getenv("DOTRING_WIPE") == nullptr || std::atoi(std::getenv("DOTRING_WIPE")) != 0;
     return on;
 }
-int dri::ctx_wipe_scratch(dr_ctx* ctx) {
-    if (!wipe_enabled()) return DR_OK;
-    TRY(use_ctx(ctx));
+int dri::ctx_join_wipe(dr_ctx* ctx) {
+    if (!ctx->wipe_pending) return DR_OK;
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->wipe_done, 0));
+    ctx->wipe_pending = false;
+    return DR_OK;
+}
+int dri::ctx_wipe_begin(dr_ctx* ctx, bool in_stream, hipStream_t* out) {
+    TRY(use_ctx(ctx));                       // (an earlier wipe still pending: this stream waits for it first, so the two stay in order)
+    if (in_stream || ctx->prof) { *out = ctx->stream; return DR_OK; }
+    if (!ctx->wipe_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->wipe_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->wipe_from, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->wipe_done, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(ctx->wipe_from, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->wipe_stream, ctx->wipe_from, 0));
+    *out = ctx->wipe_stream;
+    return DR_OK;
+}
+int dri::ctx_wipe_end(dr_ctx* ctx, hipStream_t wipe_st) {
+    if (wipe_st == ctx->stream) return DR_OK;
+    HIP_TRY(hipEventRecord(ctx->wipe_done, wipe_st));
+    ctx->wipe_pending = true;
+    return DR_OK;
+}
+int dri::ctx_wipe_enqueue_scratch(dr_ctx* ctx, hipStream_t wst) {
     hipError_t e = hipSuccess;
     size_t total = 0;
     TRY(launch(ctx, "wipe", [&] {
         for (Scratch* s : ctx_scratch_list(ctx))
-            if (s->p && s->cap && e == hipSuccess) { e = hipMemsetAsync(s->p, 0, s->cap, ctx->stream); total += s->cap; }
+            if (s->p && s->cap && e == hipSuccess) { e = hipMemsetAsync(s->p, 0, s->cap, wst); total += s->cap; }
     }));
     HIP_TRY(e);
     if (std::getenv("DOTRING_TRACE")) {
@@ -176,6 +199,13 @@ int dri::ctx_wipe_scratch(dr_ctx* ctx) {
         std::fprintf(stderr, "\n");
     }
     return DR_OK;
+}
+int dri::ctx_wipe_scratch(dr_ctx* ctx, bool in_stream) {
+    if (!wipe_enabled()) return DR_OK;
+    hipStream_t wst = nullptr;
+    TRY(ctx_wipe_begin(ctx, in_stream, &wst));
+    TRY(ctx_wipe_enqueue_scratch(ctx, wst));
+    return ctx_wipe_end(ctx, wst);
 }
 int dri::count_nonzero_words(dr_ctx* ctx, const void* d_buf, size_t bytes, uint64_t* total) {
     if (!d_buf || bytes < 4) return DR_OK;
@@ -249,9 +279,16 @@ void dr_ctx_destroy(dr_ctx* ctx) {
     if (ctx->aux2) { dr_ctx_destroy(ctx->aux2); ctx->aux2 = nullptr; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->wipe_stream) {
+        (void)hipStreamSynchronize(ctx->wipe_stream);
+        (void)hipStreamDestroy(ctx->wipe_stream);
+        (void)hipEventDestroy(ctx->wipe_from);
+        (void)hipEventDestroy(ctx->wipe_done);
+    }
     for (Scratch* s : {&ctx->scalars, &ctx->digits, &ctx->counts, &ctx->offsets, &ctx->cursor, &ctx->tiles, &ctx->sorted,
                        &ctx->buckets, &ctx->partial, &ctx->winsum, &ctx->result, &ctx->io_a, &ctx->io_b, &ctx->io_c, &ctx->perm, &ctx->cells,
-                       &ctx->cell_off, &ctx->part_base, &ctx->heavy, &ctx->flag, &ctx->vfy_bases, &ctx->vfy_in, &ctx->vfy_std})
+                       &ctx->cell_off, &ctx->part_base, &ctx->heavy, &ctx->flag, &ctx->vfy_bases, &ctx->vfy_in, &ctx->vfy_std, &ctx->vfy_te_in,
+                       &ctx->vfy_te_out, &ctx->vfy_flags})
         s->release();
     for (auto& it : ctx->prof_pending) {
         (void)hipEventDestroy(it.second.first);

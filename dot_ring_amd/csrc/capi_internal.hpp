@@ -95,6 +95,12 @@ struct dr_ctx {
     Scratch scalars, digits, counts, offsets, cursor, tiles, sorted, buckets, partial, winsum, result, io_a, io_b, io_c, perm, cells, cell_off, part_base, heavy;
     Scratch flag;                            // one word for kernels that report a condition (never an operand buffer of a caller)
     Scratch vfy_bases, vfy_in, vfy_std;      // dr_ringvrf_verify_batch: decompressed G1 points stay resident between its steps
+    Scratch vfy_te_in, vfy_te_out, vfy_flags;   // ... and its Bandersnatch decoding (public data: none of the six is ever wiped)
+    // The zeroing of secret-derived buffers runs on a stream of its own, behind the work that used them (ctx_wipe_begin / _end); whoever
+    // touches the context next waits for it on the device (use_ctx -> ctx_join_wipe), the caller that enqueued it never does.
+    hipStream_t wipe_stream = nullptr;
+    hipEvent_t wipe_from = nullptr, wipe_done = nullptr;
+    bool wipe_pending = false;
     dr_ctx* aux = nullptr;                   // second stream for the latency-bound Bandersnatch side of the batch verifier
     dr_ctx* aux2 = nullptr;                  // third stream: the verifier's two G1 MSMs run side by side
     std::vector<dr_ctx*> helpers;            // further streams working for this context (a prover's Pedersen stream): profiling only
@@ -133,7 +139,15 @@ int prof_collect(dr_ctx* ctx);
 // sorted entries, buckets and partial sums — all of them functions of the scalars), stream-ordered behind the work already enqueued;
 // the caller does not wait.  DOTRING_WIPE=0 turns every wipe of the library off (the A/B of its cost).
 bool wipe_enabled();
-int ctx_wipe_scratch(dr_ctx* ctx);
+// `in_stream`: the memsets go into the context's own stream (helper contexts whose next user is another thread's plain launch);
+// otherwise onto the wipe stream.  With the per-kernel timers on they always go in-stream, so that the "wipe" timer holds them.
+int ctx_wipe_scratch(dr_ctx* ctx, bool in_stream = false);
+// the stream a wipe's memsets go to (ordered behind everything enqueued on ctx->stream so far); ctx_wipe_end marks them enqueued
+int ctx_wipe_begin(dr_ctx* ctx, bool in_stream, hipStream_t* out);
+int ctx_wipe_end(dr_ctx* ctx, hipStream_t wipe_st);
+int ctx_wipe_enqueue_scratch(dr_ctx* ctx, hipStream_t wipe_st);     // the memsets of ctx_wipe_scratch, between a begin and an end
+// make ctx->stream wait (on the device) for a wipe enqueued earlier; nothing to do when there is none
+int ctx_join_wipe(dr_ctx* ctx);
 // non-zero 32-bit words in the context's scratch buffers (the test of the wipe)
 int ctx_scratch_residue(dr_ctx* ctx, uint64_t* words);
 int count_nonzero_words(dr_ctx* ctx, const void* d_buf, size_t bytes, uint64_t* total);   // adds to *total
