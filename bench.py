@@ -65,13 +65,14 @@ def _madd_instructions():
     try:
         with open(os.path.join(ROOT, "dot_ring_amd", "kernel_counts.json")) as f:
             rec = json.load(f)["k_g1_accumulate"]
-        return int(rec["loop_instructions"]), rec["source"]
+        return int(rec["loop_instructions"]), int(rec.get("loop_valu_instructions", rec["loop_instructions"])), rec["source"]
     except Exception:
-        return MADD_INSTRUCTIONS_LITERAL, "literal in bench.py (dot_ring_amd/kernel_counts.json missing)"
+        return MADD_INSTRUCTIONS_LITERAL, MADD_INSTRUCTIONS_LITERAL, "literal in bench.py (dot_ring_amd/kernel_counts.json missing)"
 
 
-MADD_INSTRUCTIONS, MADD_SOURCE = _madd_instructions()
-VALU_PEAK_GADD_S = 1024 * 2.4e9 / 4.2 * 64 / MADD_INSTRUCTIONS / 1e9
+# all wave-instructions of the loop, and the VALU ones among them: the issue-rate ceiling is a VALU ceiling and is priced with the latter
+MADD_INSTRUCTIONS, MADD_VALU_INSTRUCTIONS, MADD_SOURCE = _madd_instructions()
+VALU_PEAK_GADD_S = 1024 * 2.4e9 / 4.2 * 64 / MADD_VALU_INSTRUCTIONS / 1e9
 # the same bucket walk in isolation (tools/ubench_limbs.hip: 2048 chained additions per lane over the prover's 13 MB table,
 # profiles/r02_ubench_limbs_fused.txt): an empirical ceiling for the kernel's inner loop on this chip
 MEASURED_CHAIN_GADD_S = 7.56
@@ -439,8 +440,11 @@ def ring_roofline(w: "RingWorkload", steps: int, barrier=lambda: None):
     # dense (base, scalar) pairs per proof: quotient 3N+1, two opening quotients 3N + (N-1)  (SURVEY 3.3); the four witness columns
     # (4N) are committed by summation by parts: 4N scalars are read, only ~1.1k bases gathered, so they are priced at the 32 B scalar
     pairs_per_proof, scalar_only_per_proof = 7 * n_dom, 4 * n_dom
-    tinfo = w.pcs._srs().device().table_info(3 * n_dom + 1, batch)
-    dense_adds = float(batch) * pairs_per_proof * tinfo["digits_per_scalar"] * steps
+    # digits per scalar of each dense call as the library plans it: the quotient (batch vectors of 3N + 1 terms) and the two opening
+    # quotients (ONE call of 2 * batch vectors of 3N terms; the N - 1 terms of the second are followed by zeros, which have no digits)
+    dev_srs = w.pcs._srs().device()
+    tinfo, tinfo_open = dev_srs.table_info(3 * n_dom + 1, batch), dev_srs.table_info(3 * n_dom, 2 * batch)
+    dense_adds = float(batch) * steps * ((3 * n_dom + 1) * tinfo["digits_per_scalar"] + (4 * n_dom - 1) * tinfo_open["digits_per_scalar"])
     avg_acc_s = (acc_ms / max(1, acc_launches)) / 1e3
     alg_bytes_launch = (ALG_BYTES_PER_PAIR * batch * pairs_per_proof + 32.0 * batch * scalar_only_per_proof) * steps / max(1, acc_launches)
     achieved = alg_bytes_launch / avg_acc_s / 1e9 if avg_acc_s > 0 else 0.0
@@ -451,8 +455,10 @@ def ring_roofline(w: "RingWorkload", steps: int, barrier=lambda: None):
             "timers": "HIP events per launch, in a second pass of the same steps (the timed region runs without them); "
                       f"that pass took {elapsed_prof / steps * 1e3:.2f} ms per step",
             "valu": {"achieved_gadd_s": gadd, "peak_gadd_s": VALU_PEAK_GADD_S, "frac": gadd / VALU_PEAK_GADD_S if gadd else None,
-                     "instructions_per_addition": MADD_INSTRUCTIONS, "table": tinfo, "additions_per_pair": tinfo["digits_per_scalar"],
-                     "note": "dense bucket additions only (7N pairs x non-zero digits per proof); by-parts and verify-side additions not counted"}}
+                     "instructions_per_addition": MADD_INSTRUCTIONS, "valu_instructions_per_addition": MADD_VALU_INSTRUCTIONS,
+                     "table": tinfo, "table_openings": tinfo_open, "additions_per_pair": tinfo["digits_per_scalar"],
+                     "note": "dense bucket additions only (7N pairs x non-zero digits per proof, per call shape); by-parts and verify-side additions "
+                             "not counted; the ceilings are VALU issue rates over the loop's VALU instructions"}}
     return roof, kernel_ms
 
 
@@ -763,9 +769,9 @@ def main() -> int:
                   # (16 lanes per cycle) — not at the 4.2 cycles of the v_mad_i64_i32 micro-benchmark; the static instruction count holds
                   # ~150 cold instructions (the exact zero test of the exceptional cases) that a round of the loop does not execute, so a
                   # fraction slightly above 1 means "at the issue rate", not faster than it
-                  "peak_gadd_s_at_measured_clock": 1024 * clock_ghz * 1e9 / 4.0 * 64 / MADD_INSTRUCTIONS / 1e9, "measured_clock_ghz": clock_ghz,
+                  "peak_gadd_s_at_measured_clock": 1024 * clock_ghz * 1e9 / 4.0 * 64 / MADD_VALU_INSTRUCTIONS / 1e9, "measured_clock_ghz": clock_ghz,
                   "measured_clock_source": clock_source,
-                  "frac_at_measured_clock": v["achieved_gadd_s"] / (1024 * clock_ghz * 1e9 / 4.0 * 64 / MADD_INSTRUCTIONS / 1e9) if v["achieved_gadd_s"] else None,
+                  "frac_at_measured_clock": v["achieved_gadd_s"] / (1024 * clock_ghz * 1e9 / 4.0 * 64 / MADD_VALU_INSTRUCTIONS / 1e9) if v["achieved_gadd_s"] else None,
                   "instructions_source": MADD_SOURCE, "isolated_chain_gadd_s": MEASURED_CHAIN_GADD_S,
                   "isolated_chain_source": "profiles/r02_ubench_limbs_fused.txt (tools/ubench_limbs.hip on another box; not re-measured in this run)"})
         # per-proof unique traffic (11N scalars + 14 NTT passes' data + 784 B out), 3.17 KB per
