@@ -409,3 +409,38 @@ def test_prove_batch_leaves_no_secret_state_in_hbm():
     assert ctx.scratch_residue() == 0
     d.TinyVRF[cv].prove_batch(als, sks[:n], ads)
     assert ctx.scratch_residue() == 0
+
+
+@pytest.mark.gpu
+def test_calls_that_follow_a_batch_wait_for_the_zeroing_of_its_scratch():
+    """prove_batch leaves the zeroing of its buffers on the context's wipe stream and returns (capi_core.hip: ctx_wipe_begin / _end).  Whatever
+    uses the context next is ordered behind it on the device: a commitment computed right after a batch — its digit rows, sorted entries and
+    buckets live in the scratch being zeroed — equals the one computed before, the batch verifier (which joins the wipe only before its G1
+    folds) accepts the proofs, and a batch proved while the previous batch's wipe may still be running gives the same bytes."""
+    import random
+
+    import dot_ring_amd as d
+
+    cv = d.Bandersnatch
+    sks = [(1700 + i).to_bytes(32, "little") for i in range(48)]
+    keys = [cv.public_key_from_secret(sk) for sk in sks]
+    params = d.RingProofParams.from_ring_size(48, test_vectors=True)
+    ring = d.Ring(keys, params)
+    root = d.RingRoot.from_ring(ring, params)
+    vrf = d.RingVRF[cv]
+    n = 32
+    als, ads = [b"order-%d" % i for i in range(n)], [b"ad-%d" % i for i in range(n)]
+    rng = random.Random(404)
+    coeffs = [rng.randrange(d.KZG.scalar_modulus) for _ in range(3001)]
+    want_commit = d.KZG.commit(coeffs)
+    want_batch = d.KZG.commit_batch([coeffs[:1500], coeffs[1500:3000]])
+    first = None
+    for round_ in range(4):
+        proofs = vrf.prove_batch(als, ads, sks[:n], keys[:n], ring, root)
+        if round_ % 2 == 0:
+            assert d.KZG.commit(coeffs) == want_commit                       # straight into the scratch the wipe is zeroing
+            assert d.KZG.commit_batch([coeffs[:1500], coeffs[1500:3000]]) == want_batch
+        assert vrf.batch_verify(proofs, als, ads, ring, root)
+        enc = [p.encode() for p in proofs]
+        first = first or enc
+        assert enc == first
