@@ -145,7 +145,9 @@ void parallel_for(size_t n, F f, size_t grain = 16) {
     }
     if (WorkerPool* pool = worker_pool()) {
         const std::function<void(size_t)> fn = [&f](size_t i) { f(i); };
-        pool->run(n, t, fn);
+        // four chunks per thread, taken on demand: a worker that wakes late or loses its core to another tenant of the host holds up a
+        // quarter of a share, not a whole one (the phases between the GPU calls are 0.1 - 0.5 ms long; one late thread used to double them)
+        pool->run(n, 4 * t, fn);
         return;
     }
     std::vector<std::thread> pool;
