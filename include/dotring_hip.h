@@ -262,7 +262,8 @@ DR_API int dr_ring_prove_openings(dr_ring_prover *p, size_t batch, const uint8_t
 /* Secrets do not stay in HBM.  dr_ring_prove_openings — the last phase of a batch — ends by zeroing the prover's per-batch state
  * (blinding factors, hidden rows, the witness columns with their bit column, every polynomial derived from them) and the MSM scratch
  * of its context; the batch entry points (dr_ringvrf_prove_batch, dr_pedersen_prove_batch, dr_ietf_prove_batch) also zero the device
- * copies of secret scalars and nonces.  Stream-ordered memsets that the call does not wait for.  dr_ring_prover_wipe does the same on
+ * copies of secret scalars and nonces.  The memsets are ordered behind the batch's last kernel on a stream of their own; the call does not
+ * wait for them, and whatever uses the context next is ordered behind them on the device.  dr_ring_prover_wipe does the same on
  * request; dr_ring_prover_residue counts the non-zero 32-bit words left in those buffers (0 after a wipe; a test hook).
  * DOTRING_WIPE=0 disables the wipes (to measure their cost). */
 DR_API int dr_ring_prover_wipe(dr_ring_prover *p);
