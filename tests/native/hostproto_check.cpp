@@ -3,7 +3,10 @@
 // around a batched inversion — on pseudo-random inputs, incl. zeta on the special points (1, w^(n-4): zero denominators) and in the
 // domain (refused).  Prints "ok <cases>" or the first difference.  Plain g++, no GPU.
 #include <cstdio>
+#include <atomic>
 #include <cstring>
+#include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "hostproto.hpp"
@@ -114,6 +117,38 @@ int main() {
             if (std::memcmp(&want, &got, sizeof want)) { printf("ring_verifier_terms differs (%zu)\n", k); return 1; }
         }
         cases += n;
+    }
+    // 4. parallel_for (the worker pool every host phase of the batch calls goes through): every index exactly once for any size and grain,
+    //    also with two threads posting jobs at the same time; an exception thrown by an item reaches the caller
+    {
+        const size_t sizes[] = {0, 1, 15, 16, 17, 63, 64, 65, 256, 1000, 1024, 4099};
+        const size_t grains[] = {1, 16, 100};
+        for (size_t n : sizes)
+            for (size_t g : grains) {
+                std::vector<std::atomic<int>> hits(n);
+                for (auto& h : hits) h.store(0);
+                parallel_for(n, [&](size_t i) { hits[i].fetch_add(1); }, g);
+                for (size_t i = 0; i < n; i++)
+                    if (hits[i].load() != 1) { printf("parallel_for: index %zu of %zu (grain %zu) visited %d times\n", i, n, g, hits[i].load()); return 1; }
+                cases++;
+            }
+        std::vector<std::atomic<int>> a(5000), b(3000);
+        for (auto& h : a) h.store(0);
+        for (auto& h : b) h.store(0);
+        std::thread other([&] { for (int r = 0; r < 20; r++) parallel_for(b.size(), [&](size_t i) { b[i].fetch_add(1); }); });
+        for (int r = 0; r < 20; r++) parallel_for(a.size(), [&](size_t i) { a[i].fetch_add(1); });
+        other.join();
+        for (auto& h : a) if (h.load() != 20) { printf("parallel_for: concurrent jobs lost or repeated an item\n"); return 1; }
+        for (auto& h : b) if (h.load() != 20) { printf("parallel_for: concurrent jobs lost or repeated an item\n"); return 1; }
+        bool thrown = false;
+        try {
+            parallel_for(2048, [&](size_t i) { if (i == 1234) throw std::runtime_error("item 1234"); });
+        } catch (const std::runtime_error& e) { thrown = std::strcmp(e.what(), "item 1234") == 0; }
+        if (!thrown) { printf("parallel_for: the exception of an item did not reach the caller\n"); return 1; }
+        std::atomic<size_t> after{0};
+        parallel_for(512, [&](size_t) { after.fetch_add(1); });           // the pool still works after a failed job
+        if (after.load() != 512) { printf("parallel_for: pool unusable after an exception\n"); return 1; }
+        cases += 3;
     }
     printf("ok %zu\n", cases);
     return 0;

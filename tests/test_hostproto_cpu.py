@@ -1,4 +1,5 @@
-"""Host arithmetic of the batch verifier (dot_ring_amd/csrc/hostproto.hpp), compiled with plain g++: the two routines that were split
+"""Host arithmetic of the batch verifier and the worker pool (dot_ring_amd/csrc/hostproto.hpp), compiled with plain g++: parallel_for visits
+every index exactly once for any size and grain, also from two posting threads, and carries an item's exception to the caller; the two routines that were split
 around their field inversion so that sixteen proofs share one (te_add_affine, ring_verifier_terms) must give what the unsplit
 routines give, batch_inv must equal single inversions and keep zeros, and an evaluation point inside the domain must be refused by
 the first half already (tests/native/hostproto_check.cpp)."""
