@@ -142,59 +142,65 @@ DR_DEV void ntt_butterfly(Fs& u, Fs& v, const Fs& w, bool trivial, bool carry_u)
 // columns of a strided-pass tile: 1024 / rows, at least 64 (host and device agree through this one function)
 __host__ __device__ inline int ntt_strided_col_bits(int row_bits) { return row_bits >= 4 ? 6 : 10 - row_bits; }
 
-// Pass A: stages 1..S (S = min(k, NTT_LOG_TILE)) on tile `blockIdx.x` of transform `blockIdx.y`.
+// Pass A: stages 1..S (S = min(k, LOG_TILE)) on tile `blockIdx.x` of transform `blockIdx.y`.  Two instances: 2^10 elements per tile
+// (36 KB of LDS, 256 lanes) and 2^11 (72 KB, 512 lanes) — the second one for k = 11, the prover's domain at ring 1024, whose 16
+// transforms per proof then take ONE pass over HBM instead of a ten-stage pass plus a one-stage strided pass (round 4: NTT kernels
+// 3.08 -> 2.95 ms per 1024 proofs; with 256 lanes per transform 3.1, with 1024 lanes 3.4 — the eleventh stage costs the local pass
+// twice a normal stage: 1024 distinct twiddle records per workgroup).
 // src is read at bit-reversed positions, dst written contiguously (src == dst is allowed only when S == k, where one workgroup
 // owns the whole transform and the formats have the same element size or the whole tile is loaded before anything is stored).
-__global__ __launch_bounds__(NTT_BLOCK) void k_ntt_local(NttSource in, uint32_t* dst,
+template <int LOG_TILE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_ntt_local(NttSource in, uint32_t* dst,
                                                          const uint32_t* __restrict__ tw, int k, int S, int final_pass, int fmt_out,
                                                          int has_factor, FsArg out_factor, int pad) {
-    __shared__ int32_t tile[L29 * NTT_TILE];
+    constexpr int TILE = 1 << LOG_TILE;
+    __shared__ int32_t tile[L29 * TILE];
     const size_t n = (size_t)1 << k;
     const int tsize = 1 << S;
     const size_t xform = blockIdx.y, tbase = (size_t)blockIdx.x * tsize;
     const size_t n_src = n >> pad;
     uint32_t* out = dst + xform * n * (final_pass && fmt_out == NTT_FMT_STD8 ? 8 : L29);
     if (pad == 0) {
-        for (int i = threadIdx.x; i < tsize; i += NTT_BLOCK) {
+        for (int i = threadIdx.x; i < tsize; i += BLOCK) {
             size_t pos = tbase + i;
             size_t rev = (size_t)(__brevll((unsigned long long)pos) >> (64 - k));
-            lds_put9(tile, i, ntt_load(in, xform, rev, n_src));
+            lds_put9<TILE>(tile, i, ntt_load(in, xform, rev, n_src));
         }
     } else {
         // the input is a polynomial of n / 2^pad coefficients, zero-padded to n: in bit-reversed order only every 2^pad-th
         // position is non-zero (the low `pad` bits of a position are the top bits of its source index), and the first `pad`
         // stages — butterflies with a zero lower half and twiddles that never multiply anything but zero — just copy that
         // value over its group.  So: load n / 2^pad values, replicate, start at stage pad + 1 (no padded copy in HBM either).
-        for (int i = threadIdx.x; i < (tsize >> pad); i += NTT_BLOCK) {
+        for (int i = threadIdx.x; i < (tsize >> pad); i += BLOCK) {
             size_t grp = (tbase >> pad) + i;
             size_t rev = (size_t)(__brevll((unsigned long long)grp) >> (64 - (k - pad)));
             const Fs v = ntt_load(in, xform, rev, n_src);
-            for (int c = 0; c < (1 << pad); c++) lds_put9(tile, (i << pad) + c, v);
+            for (int c = 0; c < (1 << pad); c++) lds_put9<TILE>(tile, (i << pad) + c, v);
         }
     }
     __syncthreads();
     for (int s = 1 + pad; s <= S; s++) {
         const int half = 1 << (s - 1);
         const bool cu = ((s - pad) & 1) != 0;       // the first stage run here and every second one after it carry both operands
-        for (int t = threadIdx.x; t < tsize / 2; t += NTT_BLOCK) {
+        for (int t = threadIdx.x; t < tsize / 2; t += BLOCK) {
             int j = t & (half - 1);
             int base = (t >> (s - 1)) << s;
-            Fs u = lds_get9(tile, base + j), v = lds_get9(tile, base + j + half);
+            Fs u = lds_get9<TILE>(tile, base + j), v = lds_get9<TILE>(tile, base + j + half);
             Fs w = Fs::zero();
             if (s > 1) w = tw_load(tw + ((size_t)j << (k - s)) * NTT_TW_WORDS);   // stage 1: every twiddle is w^0 = 1 (wave-uniform: no product at all)
             ntt_butterfly(u, v, w, s == 1, cu);
-            lds_put9(tile, base + j, u);
-            lds_put9(tile, base + j + half, v);
+            lds_put9<TILE>(tile, base + j, u);
+            lds_put9<TILE>(tile, base + j + half, v);
         }
         __syncthreads();
     }
     const Fs f = from_arg(out_factor);
     if (final_pass && fmt_out == NTT_FMT_STD8) {
-        for (int i = threadIdx.x; i < tsize; i += NTT_BLOCK) ntt_store_std8(out, tbase + i, lds_get9(tile, i), f);
+        for (int i = threadIdx.x; i < tsize; i += BLOCK) ntt_store_std8(out, tbase + i, lds_get9<TILE>(tile, i), f);
         return;
     }
-    for (int i = threadIdx.x; i < tsize; i += NTT_BLOCK) {
-        const Fs v = lds_get9(tile, i);
+    for (int i = threadIdx.x; i < tsize; i += BLOCK) {
+        const Fs v = lds_get9<TILE>(tile, i);
         fs_store9(out + (tbase + i) * L29, final_pass ? ntt_final_fs9(v, has_factor, f) : v);
     }
 }
@@ -315,11 +321,17 @@ int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp,
     const int has_factor = (fmt_out == NTT_FMT_STD8 || scale_mont) ? 1 : 0;
     const FsArg fa = fmt_out == NTT_FMT_STD8 ? fs_arg_std(scale_mont ? *scale_mont : drh::Fr::one())
                                              : fs_arg_mont(scale_mont ? *scale_mont : drh::Fr::one());
-    const int S = (int)std::min<unsigned>(k, NTT_LOG_TILE);
+    const bool wide = k == NTT_LOG_TILE + 1;                           // one workgroup of 512 lanes owns a whole 2048-point transform
+    const int S = wide ? (int)k : (int)std::min<unsigned>(k, NTT_LOG_TILE);
     NttSource src{d_src ? d_src : d_data, d_in_scale, d_special, fmt_in, src_div ? src_div : 1u};
     if ((int)k == S) {
         int rc = launch("k_ntt_local", [&] {
-            hipLaunchKernelGGL(k_ntt_local, dim3(1, (unsigned)batch), dim3(NTT_BLOCK), 0, st, src, d_data, d_tw, (int)k, S, 1, fmt_out, has_factor, fa, pad);
+            if (wide)
+                hipLaunchKernelGGL((k_ntt_local<NTT_LOG_TILE + 1, 2 * NTT_BLOCK>), dim3(1, (unsigned)batch), dim3(2 * NTT_BLOCK), 0, st, src, d_data, d_tw, (int)k, S, 1,
+                                   fmt_out, has_factor, fa, pad);
+            else
+                hipLaunchKernelGGL((k_ntt_local<NTT_LOG_TILE, NTT_BLOCK>), dim3(1, (unsigned)batch), dim3(NTT_BLOCK), 0, st, src, d_data, d_tw, (int)k, S, 1, fmt_out,
+                                   has_factor, fa, pad);
         });
         if (rc != DR_OK) return rc;
         return sync();
@@ -332,7 +344,8 @@ int ntt_run(hipStream_t st, Launch&& launch, TwiddleCache& cache, ScratchT& tmp,
         d_mid = reinterpret_cast<uint32_t*>(tmp.p);
     }
     int rc = launch("k_ntt_local", [&] {
-        hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> S), (unsigned)batch), dim3(NTT_BLOCK), 0, st, src, d_mid, d_tw, (int)k, S, 0, fmt_out, has_factor, fa, pad);
+        hipLaunchKernelGGL((k_ntt_local<NTT_LOG_TILE, NTT_BLOCK>), dim3((unsigned)(n >> S), (unsigned)batch), dim3(NTT_BLOCK), 0, st, src, d_mid, d_tw, (int)k, S, 0, fmt_out,
+                           has_factor, fa, pad);
     });
     if (rc != DR_OK) return rc;
     for (int lo = S; lo < (int)k; lo += NTT_MAX_ROW_BITS) {
