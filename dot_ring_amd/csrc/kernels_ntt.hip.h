@@ -182,12 +182,15 @@ __global__ __launch_bounds__(BLOCK) void k_ntt_local(NttSource in, uint32_t* dst
     for (int s = 1 + pad; s <= S; s++) {
         const int half = 1 << (s - 1);
         const bool cu = ((s - pad) & 1) != 0;       // the first stage run here and every second one after it carry both operands
+        // while half <= BLOCK every butterfly of a lane has the same j (BLOCK is a multiple of half): one twiddle load per stage and lane
+        const bool one_tw = half <= BLOCK;
+        Fs w = Fs::zero();
+        if (s > 1 && one_tw) w = tw_load(tw + ((size_t)(threadIdx.x & (half - 1)) << (k - s)) * NTT_TW_WORDS);
         for (int t = threadIdx.x; t < tsize / 2; t += BLOCK) {
             int j = t & (half - 1);
             int base = (t >> (s - 1)) << s;
             Fs u = lds_get9<TILE>(tile, base + j), v = lds_get9<TILE>(tile, base + j + half);
-            Fs w = Fs::zero();
-            if (s > 1) w = tw_load(tw + ((size_t)j << (k - s)) * NTT_TW_WORDS);   // stage 1: every twiddle is w^0 = 1 (wave-uniform: no product at all)
+            if (s > 1 && !one_tw) w = tw_load(tw + ((size_t)j << (k - s)) * NTT_TW_WORDS);   // stage 1: every twiddle is w^0 = 1 (wave-uniform: no product at all)
             ntt_butterfly(u, v, w, s == 1, cu);
             lds_put9<TILE>(tile, base + j, u);
             lds_put9<TILE>(tile, base + j + half, v);
