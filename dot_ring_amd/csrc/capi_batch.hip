@@ -396,9 +396,25 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
     PhaseTrace tr_("verify_batch");
     // ---- 1. canonical scalars; gather encoded points
     std::vector<uint8_t> te_enc(B * 4 * 32), g1_enc(B * 7 * 48);
+    // verifier randomness: two non-zero coefficients per proof (kzg.py:84-108) — they depend on the seed alone, and they are the only scalars of
+    // the rhs fold (r1, r2 on the two opening proofs): drawn here, so that that fold can start as soon as the points are decoded
+    std::vector<uint8_t> rhs_sc(2 * B * 32);
     std::atomic<bool> canonical{true};
     drh::parallel_for(B, [&](size_t i) {
         const uint8_t* pr = proofs + 784 * i;
+        for (int k = 0; k < 2; k++) {
+            drh::Shake256 sh;
+            sh.update(seed32, 32);
+            uint8_t ctr[9] = {0};
+            for (int j = 0; j < 8; j++) ctr[j] = (uint8_t)((uint64_t)(2 * i + k) >> (8 * j));
+            sh.update(ctr, 8);
+            uint8_t raw[48];
+            sh.digest(raw, 48);
+            uint64_t r[4];
+            mp.reduce_bytes(raw, 48, true, r);
+            if (mp.is_zero(r)) mp.set_u64(1, r);
+            drh::store_le32(r, rhs_sc.data() + 64 * i + 32 * k);
+        }
         std::memcpy(te_enc.data() + 128 * i, pr, 128);
         uint64_t v[4];
         bool ok_i = true;
@@ -565,6 +581,43 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
     }
     tr_.mark("decode");
 
+    // ---- 3a. the rhs fold — r1, r2 on the two opening proofs of every proof, zero scalars (no digits, no cost) on everything else — needs
+    // nothing from the transcripts: it starts now, on the third stream from a helper thread, and runs under the two host passes below;
+    // the thread then takes the Miller loop of its pair (-rhs, G2[1]) as well, so that after the lhs fold only one loop, one product in
+    // Fq12 and the final exponentiation are left (the two loops' product is what the joint loop of dr_pairing_check computes).
+    std::vector<uint8_t> rhs_full(n_g1 * 32, 0);
+    for (size_t i = 0; i < B; i++) std::memcpy(rhs_full.data() + 224 * i + 160, rhs_sc.data() + 64 * i, 64);
+    uint8_t pair_g1[2 * 96];
+    int pair_inf[2] = {0, 0};
+    drh::Fq12 f_rhs = drh::Fq12::one();
+    int rhs_rc = DR_OK;
+    std::string rhs_err;
+    std::thread rhs_thread;
+    struct RhsJoiner {               // (declared after everything the thread touches: joined before any of it goes away)
+        std::thread& t;
+        ~RhsJoiner() { if (t.joinable()) t.join(); }
+    } rhs_joiner{rhs_thread};
+    if (!small) {
+        if (!ctx->aux2) TRY(ctx_create_role(ctx->device, 2, &ctx->aux2));
+        dr_ctx* bctx = ctx->aux2;
+        bctx->prof = ctx->prof;
+        rhs_thread = std::thread([&, bctx] {
+            run_guarded(rhs_rc, rhs_err, [&]() -> int {
+                TRY(use_ctx(bctx));
+                TRY(bctx->scalars.reserve(n_g1 * 32));
+                HIP_TRY(hipMemcpyAsync(bctx->scalars.p, rhs_full.data(), n_g1 * 32, hipMemcpyHostToDevice, bctx->stream));
+                TRY(msm_to_bytes(bctx, g1_bases.as<uint32_t>(), bctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1 + 96, pair_inf + 1));
+                // (a vanishing rhs can only come from r1 = r2 = 0 or infinity openings: its pair then contributes 1 and the equation demands lhs = O)
+                if (!pair_inf[1]) {                                              // e(lhs, G2[0]) * e(-rhs, G2[1]) == 1
+                    drh::Fq y;
+                    if (!drh::Fq::load_be(y, pair_g1 + 144)) return fail(DR_ERR_DEVICE, "MSM result out of range");
+                    y.neg().store_be(pair_g1 + 144);
+                }
+                return pairing_miller(pair_g1 + 96, vk->g2 + 192, 1, f_rhs);
+            });
+        });
+    }
+
     // ---- 3. (the Pedersen helper may go on only once the two host passes below have their slices of the worker pool: its challenge hashing
     //          queued first would be drained first — the pool serves the oldest job — and the critical path would wait behind it)
 
@@ -573,7 +626,7 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
     dm.init(vk->log2n, vk->omega_n, vk->seed_xy);
     drh::FsTranscript4 base;
     base.sh.update_same(vk->fs_prefix, vk->fs_prefix_len);
-    std::vector<uint8_t> lhs_sc(n_g1 * 32), rhs_sc(2 * B * 32);
+    std::vector<uint8_t> lhs_sc(n_g1 * 32);
     std::vector<uint64_t> fixed_part(B * 16);           // per proof: r1*nu0, r1*nu1, r1*nu2, r1*agg + r2*l_zw
     std::vector<int> bad(B, 0);
     auto be_rec = [&](size_t idx, uint8_t out[96]) {     // device LE limbs -> serialize() form
@@ -647,19 +700,8 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         drh::te_add_affine_finish(ta[k], den[2 * k], result_seed);          // seed + blinded public key
         drh::RingClaimScalars cl;
         drh::ring_verifier_terms_finish(*su.cv, dm, al, nus, zeta, pl + 192, pl + 464, result_seed, rt[k], den[2 * k + 1], cl);
-        // verifier randomness: two non-zero coefficients per proof
-        uint64_t r[2][4];
-        for (int k = 0; k < 2; k++) {
-            drh::Shake256 sh;
-            sh.update(seed32, 32);
-            uint8_t ctr[9] = {0};
-            for (int j = 0; j < 8; j++) ctr[j] = (uint8_t)((uint64_t)(2 * i + k) >> (8 * j));
-            sh.update(ctr, 8);
-            uint8_t raw[48];
-            sh.digest(raw, 48);
-            mp.reduce_bytes(raw, 48, true, r[k]);
-            if (mp.is_zero(r[k])) mp.set_u64(1, r[k]);
-        }
+        uint64_t r[2][4];                                                    // this proof's verifier randomness (drawn in pass 1)
+        for (int k = 0; k < 2; k++) drh::load_le32(rhs_sc.data() + 64 * i + 32 * k, r[k]);
         uint64_t v[4], w[4];
         uint8_t* L = lhs_sc.data() + 224 * i;
         mp.mul(r[0], cl.nus[3], v); drh::store_le32(v, L);                                                      // C_b
@@ -669,8 +711,6 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         mp.mul(r[0], cl.nus[7], v); drh::store_le32(v, L + 128);                                                 // C_q
         mp.mul(r[0], cl.zeta, v); drh::store_le32(v, L + 160);                                                   // Phi_zeta
         mp.mul(r[1], cl.zeta_omega, v); drh::store_le32(v, L + 192);                                             // Phi_zeta_omega
-        drh::store_le32(r[0], rhs_sc.data() + 64 * i);
-        drh::store_le32(r[1], rhs_sc.data() + 64 * i + 32);
         uint64_t* fp = &fixed_part[16 * i];
         for (int k = 0; k < 3; k++) mp.mul(r[0], cl.nus[k], fp + 4 * k);
         mp.mul(r[0], cl.agg_zeta, v); mp.mul(r[1], cl.l_zw, w); mp.add(v, w, fp + 12);
@@ -686,26 +726,15 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         mp.neg(acc[3], acc[3]);                                                   // - sum_v on G1[0]
         for (int k = 0; k < 4; k++) drh::store_le32(acc[k], lhs_sc.data() + 224 * B + 32 * k);
     }
-    // two MSMs over the decompressed bases (already resident): lhs over all 7B+4 points, rhs with zero scalars on
-    // everything but the 2B opening proofs (zero digits cost nothing).  Two single MSMs rather than a batch of two:
-    // the final 255-doubling window combination of a single MSM runs on the host (0.2 ms), a batch leaves it to one
-    // GPU lane per MSM (4 ms).
-    std::vector<uint8_t> rhs_full(n_g1 * 32, 0);
-    for (size_t i = 0; i < B; i++) std::memcpy(rhs_full.data() + 224 * i + 160, rhs_sc.data() + 64 * i, 64);
-    uint8_t pair_g1[2 * 96];
-    int pair_inf[2] = {0, 0};
+    // two MSMs over the decompressed bases (already resident): lhs over all 7B+4 points here, rhs (started above) over the 2B opening
+    // proofs.  Two single MSMs rather than a batch of two: the final 255-doubling window combination of a single MSM runs on the host
+    // (0.2 ms), a batch leaves it to one GPU lane per MSM (4 ms).
     if (small) {
         // both folds on the host: the rhs (2B live terms) on a helper thread, the lhs split over two more
         drh::G1 rhs_pt = drh::G1::inf();
-        int rhs_rc = DR_OK;
-        std::string rhs_err;
-        std::thread rhs_thread([&] {
+        rhs_thread = std::thread([&] {
             run_guarded(rhs_rc, rhs_err, [&]() -> int { rhs_pt = drh::g1_msm_small(host_bases.data(), rhs_full.data(), n_g1, 1); return DR_OK; });
         });
-        struct RhsJoiner {
-            std::thread& t;
-            ~RhsJoiner() { if (t.joinable()) t.join(); }
-        } rhs_joiner{rhs_thread};
         drh::G1 lhs_pt = drh::g1_msm_small(host_bases.data(), lhs_sc.data(), n_g1, 2);
         rhs_thread.join();
         if (rhs_rc != DR_OK) return fail(rhs_rc, rhs_err);
@@ -721,40 +750,26 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
     } else {
         TRY(use_ctx(ctx));           // from here on the context's scratch is used: behind a pending wipe of it
         TRY(ctx->scalars.reserve(n_g1 * 32));
-        // the two MSMs are independent and each is a short latency chain (sort, accumulate, reduce, fold): the rhs runs on
-        // a third stream from a helper thread while this thread does the lhs
-        if (!ctx->aux2) TRY(ctx_create_role(ctx->device, 2, &ctx->aux2));
-        dr_ctx* bctx = ctx->aux2;
-        bctx->prof = ctx->prof;
-        int rhs_rc = DR_OK;
-        std::string rhs_err;
-        std::thread rhs_thread([&] {
-            run_guarded(rhs_rc, rhs_err, [&]() -> int {
-                TRY(use_ctx(bctx));
-                TRY(bctx->scalars.reserve(n_g1 * 32));
-                HIP_TRY(hipMemcpyAsync(bctx->scalars.p, rhs_full.data(), n_g1 * 32, hipMemcpyHostToDevice, bctx->stream));
-                return msm_to_bytes(bctx, g1_bases.as<uint32_t>(), bctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1 + 96, pair_inf + 1);
-            });
-        });
-        struct RhsJoiner {
-            std::thread& t;
-            ~RhsJoiner() { if (t.joinable()) t.join(); }
-        } rhs_joiner{rhs_thread};
         HIP_TRY(hipMemcpyAsync(ctx->scalars.p, lhs_sc.data(), n_g1 * 32, hipMemcpyHostToDevice, st));
         TRY(msm_to_bytes(ctx, g1_bases.as<uint32_t>(), ctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1, pair_inf));
         rhs_thread.join();
         if (rhs_rc != DR_OK) return fail(rhs_rc, rhs_err.empty() ? "rhs MSM failed" : rhs_err);
     }
     tr_.mark("g1 msms");
-    const int inf_r = pair_inf[1];
-    // (a vanishing rhs can only come from r1 = r2 = 0 or infinity openings: the pairing equation then demands lhs = O)
-    if (!inf_r) {                                                                 // e(lhs, G2[0]) * e(-rhs, G2[1]) == 1
-        drh::Fq y;
-        if (!drh::Fq::load_be(y, pair_g1 + 144)) return fail(DR_ERR_DEVICE, "MSM result out of range");
-        y.neg().store_be(pair_g1 + 144);
-    }
     int pok = 0;
-    TRY(dr_pairing_check(pair_g1, vk->g2, 2, &pok));
+    if (small) {
+        // (a vanishing rhs can only come from r1 = r2 = 0 or infinity openings: the pairing equation then demands lhs = O)
+        if (!pair_inf[1]) {                                                       // e(lhs, G2[0]) * e(-rhs, G2[1]) == 1
+            drh::Fq y;
+            if (!drh::Fq::load_be(y, pair_g1 + 144)) return fail(DR_ERR_DEVICE, "MSM result out of range");
+            y.neg().store_be(pair_g1 + 144);
+        }
+        TRY(dr_pairing_check(pair_g1, vk->g2, 2, &pok));
+    } else {
+        drh::Fq12 f_lhs;
+        TRY(pairing_miller(pair_g1, vk->g2, 1, f_lhs));
+        pok = pairing_product_is_one(f_lhs * f_rhs) ? 1 : 0;
+    }
     tr_.mark("pairing");
     side.join();
     tr_.mark("pedersen join");

@@ -148,6 +148,11 @@ int ctx_wipe_end(dr_ctx* ctx, hipStream_t wipe_st);
 int ctx_wipe_enqueue_scratch(dr_ctx* ctx, hipStream_t wipe_st);     // the memsets of ctx_wipe_scratch, between a begin and an end
 // make ctx->stream wait (on the device) for a wipe enqueued earlier; nothing to do when there is none
 int ctx_join_wipe(dr_ctx* ctx);
+// the two halves of dr_pairing_check (capi_msm.hip), for callers that have their pairs at different times: the product of the Miller
+// loops of n (G1, G2) pairs (encodings as dr_pairing_check takes them; pairs with an infinite member contribute 1), and the final
+// exponentiation's verdict on a product of such values
+int pairing_miller(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, drh::Fq12& f);
+bool pairing_product_is_one(const drh::Fq12& f);
 // non-zero 32-bit words in the context's scratch buffers (the test of the wipe)
 int ctx_scratch_residue(dr_ctx* ctx, uint64_t* words);
 int count_nonzero_words(dr_ctx* ctx, const void* d_buf, size_t bytes, uint64_t* total);   // adds to *total

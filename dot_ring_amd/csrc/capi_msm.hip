@@ -1136,6 +1136,9 @@ int miller_product(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, drh:
 }
 }  // namespace
 
+int dri::pairing_miller(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, drh::Fq12& f) { return miller_product(g1_be_xy, g2_be, n, f); }
+bool dri::pairing_product_is_one(const drh::Fq12& f) { return drh::final_exponentiation_check(f) == drh::Fq12::one(); }
+
 int dr_pairing_check(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, int* ok) {
     if (!ok || (n && (!g1_be_xy || !g2_be))) return fail(DR_ERR_INVALID, "null buffer");
     drh::Fq12 f;
