@@ -10,7 +10,7 @@ one() {
 import json,sys
 d=json.loads(sys.stdin.read())
 k=d['gpu_kernel_ms_per_step']
-names=('k_ntt_local','k_ntt_strided','k_ring_constraints','k_ring_quotient','k_ring_eval','k_ring_linpoly','k_ring_aggpoly','k_syndiv')
+names=('k_ntt_local','k_ntt_strided','k_ring_constraints','k_ring_quotient','k_ring_eval','k_ring_linpoly','k_ring_aggpoly','k_syndiv','k_g1_sort_sets')
 print('$2', round(d['value']), round(d['ms_per_step'],2), round(d['prove_only_proofs_per_s']), d['parity_ok'], 'acc', k.get('k_g1_accumulate'), 'k6-k8', round(sum(k.get(n,0) for n in names),2), [k.get(n) for n in names], 'kernel sum', round(sum(k.values()),2))" >> "$out"
 }
 for i in $(seq $reps); do one ab_old old; one . new; done
