@@ -590,6 +590,7 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
     uint8_t pair_g1[2 * 96];
     int pair_inf[2] = {0, 0};
     drh::Fq12 f_rhs = drh::Fq12::one();
+    drh::G1 rhs_pt = drh::G1::inf();             // (the host path's rhs fold, one or two proofs)
     int rhs_rc = DR_OK;
     std::string rhs_err;
     std::thread rhs_thread;
@@ -731,7 +732,6 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
     // (0.2 ms), a batch leaves it to one GPU lane per MSM (4 ms).
     if (small) {
         // both folds on the host: the rhs (2B live terms) on a helper thread, the lhs split over two more
-        drh::G1 rhs_pt = drh::G1::inf();
         rhs_thread = std::thread([&] {
             run_guarded(rhs_rc, rhs_err, [&]() -> int { rhs_pt = drh::g1_msm_small(host_bases.data(), rhs_full.data(), n_g1, 1); return DR_OK; });
         });
