@@ -498,15 +498,9 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
             else for (int q = 0; q < 48; q++) { le[q] = be[47 - q]; le[48 + q] = be[95 - q]; }
             good[j] = 1;
         };
-        {   // a thread per few points: 4B + 7B decodings of 35 - 80 us each
-            const size_t total = n_te + 7 * B;
-            const unsigned nt = (unsigned)std::min<size_t>(std::min<size_t>(total, drh::host_threads()), 8);
-            std::vector<std::thread> pool;
-            for (unsigned k = 1; k < nt; k++)
-                pool.emplace_back([&, k] { for (size_t j = k; j < total; j += nt) decode_one(j); });
-            for (size_t j = 0; j < total; j += nt) decode_one(j);
-            for (auto& th : pool) th.join();
-        }
+        // 4B + 7B decodings of 35 - 80 us each, one per item of the worker pool (its threads are already there: starting seven of our
+        // own cost more than a decoding)
+        drh::parallel_for(n_te + 7 * B, decode_one, 1);
         for (int g : good) if (!g) return DR_OK;                     // malformed / invalid point: ok = 0
         host_bases.resize(n_g1);
         for (size_t k = 0; k < 7 * B; k++) {
