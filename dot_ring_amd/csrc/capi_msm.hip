@@ -400,7 +400,11 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     if (plain_one) ws_per_lane = std::min<uint32_t>(8u, std::max<uint32_t>(1u, pl.H / 1024u));
     else while (ws_per_lane < 8 && bsets * (size_t)pl.H > (size_t)65536 * ws_per_lane) ws_per_lane *= 2;
     const uint32_t ws_span = dr::WS_BLOCK * ws_per_lane;
-    const bool wgscan = (plain_one || (!setscan && !leveled && single && batch == 1 && pl.H >= 8192)) && pl.H % ws_span == 0;
+    // ... and a handful of MSMs over a window table whose launch does not fill the chip (RingVRF.prove of ONE proof: 1, 2 and 4 commitments,
+    // up to 32 index groups of 512 .. 2048 buckets each): the chunk kernel's chain there was 8 additions + an 11-bit double-and-add +
+    // the fold, ~0.65 ms per call; the scan is 19 additions deep
+    const bool few_table = single && batch <= 8 && !setscan && !leveled && pl.H >= 256 && !pl.wt.odd && bsets * (size_t)pl.H <= ((size_t)1 << 19);
+    const bool wgscan = (plain_one || few_table || (!setscan && !leveled && single && batch == 1 && pl.H >= 8192)) && pl.H % ws_span == 0;
     const size_t wg_per_set = pl.H / ws_span, wg_count = bsets * wg_per_set;
     if (setscan) {
         const size_t cnt = bsets * pl.T;
@@ -525,6 +529,22 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
         if (drh::WorkerPool* pool = bsets > 1 ? drh::worker_pool() : nullptr) pool->run(bsets, (unsigned)std::min<size_t>(bsets, drh::host_threads()), one_set);
         else for (size_t set = 0; set < bsets; set++) one_set(set);
         drh::G1 acc = drh::G1::inf();
+        if (single && batch > 1) {
+            // a few MSMs over the table: each is the sum of its index groups' sets; the batched contract wants them in ctx->result
+            for (size_t b = 0; b < batch; b++) {
+                drh::G1 v = drh::G1::inf();
+                for (uint32_t g = 0; g < groups; g++) v = drh::g1_add(v, set_sum[b * groups + g]);
+                results[b] = v;
+            }
+            TRY(ctx->result.reserve(batch * 192));
+            std::vector<drh::G1> up(results);
+            g1_host_to_dev(up.data(), up.size());
+            HIP_TRY(hipMemcpyAsync(ctx->result.p, up.data(), batch * 192, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            tr_.mark("host_fold");
+            if (ctx->prof) TRY(prof_collect(ctx));
+            return DR_OK;
+        }
         if (single) {
             for (size_t set = 0; set < bsets; set++) acc = drh::g1_add(acc, set_sum[set]);      // the bucket-set sums ARE the MSM value
         } else {
