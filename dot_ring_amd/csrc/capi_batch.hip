@@ -221,7 +221,7 @@ int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_
         }
         fs[g].absorb_labeled("committed_cols", in, 4 * 96);
         fs[g].challenges("constraints_aggregation", 7, out);
-    });
+    }, 4);        // (an item is four proofs' sponges, 10 - 20 us: worth a thread from four items on)
     tr_.mark("fs1");
     TRY(dr_ring_prove_quotient(p, B, alphas7.data(), cq.data(), cq_inf.data()));
     tr_.mark("quotient");
@@ -237,7 +237,7 @@ int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_
         }
         fs[g].absorb_labeled("quotient", in, 96);
         fs[g].challenges("evaluation_point", 1, out);
-    });
+    }, 4);        // (an item is four proofs' sponges, 10 - 20 us: worth a thread from four items on)
     tr_.mark("fs2");
     TRY(dr_ring_prove_evals(p, B, zetas.data(), evals.data()));
     tr_.mark("evals");
@@ -253,7 +253,7 @@ int ringvrf_prove_batch_impl(dr_ring_prover* p, const dr_vrf_suite* suite, size_
         fs[g].absorb_labeled("register_evaluations", in, 224);
         fs[g].absorb_labeled("shifted_linearization_evaluation", in2, 32);
         fs[g].challenges("kzg_aggregation", 8, out);
-    });
+    }, 4);        // (an item is four proofs' sponges, 10 - 20 us: worth a thread from four items on)
     tr_.mark("fs3");
     TRY(dr_ring_prove_openings(p, B, nus.data(), opens.data(), open_inf.data()));
     wipe_guard.armed = false;        // (the openings phase ended with the wipe)
@@ -684,7 +684,7 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         t.absorb_labeled("register_evaluations", in, 224);
         t.absorb_labeled("shifted_linearization_evaluation", in2, 32);
         t.challenges("kzg_aggregation", 8, out);
-    });
+    }, 4);        // (an item is four proofs' sponges, 10 - 20 us: worth a thread from four items on)
     tr_.mark("replay");
     // Every proof needs two field inversions (seed + relation in affine form; the Lagrange / vanishing denominators at zeta) — at 7 us
     // each they were two thirds of this pass.  Sixteen proofs share ONE (Montgomery's trick, drh::batch_inv): both halves of the

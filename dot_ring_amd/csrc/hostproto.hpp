@@ -32,6 +32,8 @@ inline unsigned host_threads() {
         const char* e = std::getenv("DOTRING_HOST_THREADS");
         unsigned n = e ? (unsigned)std::atoi(e) : 0;
         if (n == 0) {
+            // 16, not more: 24 - 48 threads gave +0.7 % proofs/s on a GPU box whose 256-thread host was lightly loaded (load average 18 - 26)
+            // and -1 % on one under load (52) — the other tenants' load is not ours to choose (DOTRING_HOST_THREADS overrides)
             n = std::thread::hardware_concurrency();
             if (n == 0) n = 1;
             if (n > 16) n = 16;
