@@ -429,6 +429,53 @@ def test_g1_msm_batched_over_table_matches_plain(ctx, srs_bytes, bits, n, batch)
     comb.close()
 
 
+@pytest.mark.parametrize("bits,n", [(9, 513), (10, 2048), (12, 6145)])
+def test_g1_msm_a_few_over_a_table_take_the_workgroup_scan(ctx, srs_bytes, bits, n):
+    """1 .. 9 MSMs over a window table in one call — RingVRF.prove of ONE proof commits 4, 1 and 2 polynomials this way; up to eight take the
+    workgroup-scan reduction with a host fold per index group, nine the chunk kernels: every result equals the oracle's, incl. a zero
+    vector, an all-equal vector, scalars >= r and a vector whose scalars are +-1 (most buckets empty)."""
+    rng = random.Random(bits * 7 + n)
+    srs = ctx.srs_load(srs_bytes[: 96 * n]).precompute(bits)
+    vecs = [b"".join(rng.randrange(coracle.FR_P).to_bytes(32, "little") for _ in range(n)) for _ in range(5)]
+    vecs.append(bytes(32 * n))
+    vecs.append((0x1234567890ABCDEF1234567890ABCDEF).to_bytes(32, "little") * n)
+    vecs.append(b"".join(v.to_bytes(32, "little") for v in ([1, coracle.FR_P - 1, (1 << 256) - 1, 2**255, coracle.FR_P] * n)[:n]))
+    vecs.append(b"".join((1 if rng.random() < 0.5 else coracle.FR_P - 1).to_bytes(32, "little") for _ in range(n)))
+    want = [_oracle_msm_be(srs_bytes, v, n) for v in vecs]
+    for batch in (1, 2, 3, 5, 8, 9):
+        ks = b"".join(vecs[(batch + i) % len(vecs)] for i in range(batch))
+        got = ctx.g1_msm_batch(srs, ks, n)
+        assert got == [want[(batch + i) % len(vecs)] for i in range(batch)], batch
+    srs.close()
+
+
+@pytest.mark.parametrize("n", [300, 1000, 3000, 7172, 20000, 50000])
+def test_g1_msm_one_plain_call_takes_the_workgroup_scan(ctx, n):
+    """one MSM over plain bases (no table): the window width follows the size (256 .. 4096 buckets per window), every window is reduced by
+    a few workgroup scans and folded on the host — the closed form [sum k_i (1 + i)] G over synthetic bases, a prefix against the
+    oracle's Pippenger, and degenerate vectors (all equal, r - 1 everywhere, zero)."""
+    import bench
+
+    srs = ctx.srs_synthetic(bench.G1_BE, n, first=1)
+    vals, raw = bench.seeded_scalars(n, b"plain%d" % n)
+    le_g = bench.be_to_le_points(bench.G1_BE)
+
+    def closed(values):
+        e = sum(k * (1 + i) for i, k in enumerate(values)) % coracle.FR_P
+        if e == 0:
+            return None
+        w = bytes(coracle.g1_msm_raw(le_g, e.to_bytes(32, "little"), 1))
+        return w[:48][::-1] + w[48:][::-1]
+
+    assert ctx.g1_msm(srs, raw) == closed(vals)
+    m = min(n, 2000)
+    cpu = bytes(coracle.g1_msm_raw(bench.be_to_le_points(srs.download(0, m)), raw[: 32 * m], m))
+    assert ctx.g1_msm(srs, raw[: 32 * m]) == cpu[:48][::-1] + cpu[48:][::-1]
+    for values in ([0x0F0E0D0C0B0A09080706050403020100] * n, [coracle.FR_P - 1] * n, [0] * n):
+        assert ctx.g1_msm(srs, b"".join(v.to_bytes(32, "little") for v in values)) == closed(values)
+    srs.close()
+
+
 @pytest.mark.parametrize("bits", [7, 12, 16])
 def test_g1_msm_fixed_base_table_matches_plain(ctx, srs_bytes, bits):
     """dr_srs_precompute: one bucket set per MSM over the window table — identical results, single and batched."""
