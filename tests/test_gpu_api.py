@@ -209,10 +209,11 @@ def test_ring_zk_rows_are_random_without_test_vectors(ctx, golden_dir):
     assert p1.verify(b"x", b"y", ring, root) and p2.verify(b"x", b"y", ring, root)
 
 
-def test_native_batch_verify_rejects_what_the_python_path_rejects(ctx, monkeypatch):
-    """dr_ringvrf_verify_batch (decoding on the GPU, transcripts on worker threads) against the per-object Python path
-    on good and tampered proofs: wrong input / ad, flipped bits in every section of the 784 bytes, non-canonical and
-    off-subgroup points, bad G1 flag bits, proofs of another ring."""
+@pytest.mark.parametrize("n", [6, 12])
+def test_native_batch_verify_rejects_what_the_python_path_rejects(ctx, monkeypatch, n):
+    """dr_ringvrf_verify_batch against the per-object Python path on good and tampered proofs: wrong input / ad, flipped bits in every
+    section of the 784 bytes, non-canonical and off-subgroup points, bad G1 flag bits, proofs of another ring — six proofs (decoding
+    and G1 folds on the host: up to DOTRING_VERIFY_HOST_MAX = 8) and twelve (decoding and folds on the GPU)."""
     import dot_ring_amd as d
     from dot_ring_amd.vrf.ring_vrf import RingVRF
 
@@ -222,7 +223,6 @@ def test_native_batch_verify_rejects_what_the_python_path_rejects(ctx, monkeypat
     keys = [cv.public_key_from_secret(sk) for sk in sks]
     ring = d.Ring(keys)
     root = d.RingRoot.from_ring(ring)
-    n = 6
     als = [b"in%d" % i for i in range(n)]
     ads = [b"ad%d" % (i % 2) for i in range(n)]
     proofs = vrf.prove_batch(als, ads, sks[:n], keys[:n], ring, root)
@@ -326,7 +326,7 @@ def test_tuning_knobs_do_not_change_the_bytes(ctx):
         {"DOTRING_SRS_WINDOW": "0", "DOTRING_NATIVE_HOST": "0"},
         {"DOTRING_SRS_TILING": "rows", "DOTRING_SRS_BIT_ROWS_MB": "0", "DOTRING_MSM_GROUPS": "3", "DOTRING_KECCAK_GENERIC": "1"},
         {"DOTRING_SRS_TILING": "rows", "DOTRING_VERIFY_HOST_MAX": "0", "DOTRING_MSM_WINDOW": "9", "DOTRING_TRACE": "1"},
-        {"DOTRING_VERIFY_HOST_MAX": "8", "DOTRING_SRS_WINDOW": "13", "DOTRING_PS_WINDOW": "12"},
+        {"DOTRING_VERIFY_HOST_MAX": "2", "DOTRING_SRS_WINDOW": "13", "DOTRING_PS_WINDOW": "12"},
     ]
     digests = []
     for extra in variants:
