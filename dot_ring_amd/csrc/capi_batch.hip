@@ -475,10 +475,11 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         std::function<void()> give_up;
         ~Joiner() { give_up(); if (t.joinable()) t.join(); }
     } joiner{side, [&] { open_gate(0); }};
-    // Up to eight proofs: every launch chain below would be pure latency (0.7 - 2 ms each), so the points are decoded and the two
+    // Up to six proofs: every launch chain below would be pure latency (0.7 - 2 ms each), so the points are decoded and the two
     // G1 folds done on the host (hostsmall.hpp: ~80 us per point on the worker pool, ~0.4 ms per fold); the Pedersen side keeps its
-    // stream.  Measured at the end of round 4: 1.6 ms for two proofs + 0.13 ms per further one against a flat 2.9 ms through the kernels.
-    static const size_t host_max = std::getenv("DOTRING_VERIFY_HOST_MAX") ? (size_t)std::atol(std::getenv("DOTRING_VERIFY_HOST_MAX")) : 8;
+    // stream.  Measured at the end of round 4: 1.6 ms for two proofs + 0.13 - 0.2 ms per further one (the host's load decides) against a flat 2.9 ms
+    // through the kernels: eight proofs are a draw on a loaded host.
+    static const size_t host_max = std::getenv("DOTRING_VERIFY_HOST_MAX") ? (size_t)std::atol(std::getenv("DOTRING_VERIFY_HOST_MAX")) : 6;
     const bool small = B <= host_max;
     Scratch &g1_bases = ctx->vfy_bases, &g1_in = ctx->vfy_in, &g1_std = ctx->vfy_std;
     std::vector<uint8_t> g1_le(7 * B * 96);

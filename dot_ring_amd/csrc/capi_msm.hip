@@ -400,10 +400,10 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     if (plain_one) ws_per_lane = std::min<uint32_t>(8u, std::max<uint32_t>(1u, pl.H / 1024u));
     else while (ws_per_lane < 8 && bsets * (size_t)pl.H > (size_t)65536 * ws_per_lane) ws_per_lane *= 2;
     const uint32_t ws_span = dr::WS_BLOCK * ws_per_lane;
-    // ... and a handful of MSMs over a window table whose launch does not fill the chip (RingVRF.prove of ONE proof: 1, 2 and 4 commitments,
-    // up to 32 index groups of 512 .. 2048 buckets each): the chunk kernel's chain there was 8 additions + an 11-bit double-and-add +
+    // ... and up to 32 MSMs over a window table whose launch does not fill the chip (RingVRF.prove of ONE proof: 1, 2 and 4 commitments,
+    // up to 32 index groups of 512 .. 2048 buckets each; prove_batch of 8 / 16 / 32 proofs: 6.7 -> 6.5, 6.95 -> 6.4, 8.1 -> 7.6 ms): the chunk kernel's chain there was 8 additions + an 11-bit double-and-add +
     // the fold, ~0.65 ms per call; the scan is 19 additions deep
-    const bool few_table = single && batch <= 8 && !setscan && !leveled && pl.H >= 256 && !pl.wt.odd && bsets * (size_t)pl.H <= ((size_t)1 << 19);
+    const bool few_table = single && batch <= 32 && !setscan && !leveled && pl.H >= 256 && !pl.wt.odd && bsets * (size_t)pl.H <= ((size_t)1 << 19);
     const bool wgscan = (plain_one || few_table || (!setscan && !leveled && single && batch == 1 && pl.H >= 8192)) && pl.H % ws_span == 0;
     const size_t wg_per_set = pl.H / ws_span, wg_count = bsets * wg_per_set;
     if (setscan) {

@@ -431,8 +431,8 @@ def test_g1_msm_batched_over_table_matches_plain(ctx, srs_bytes, bits, n, batch)
 
 @pytest.mark.parametrize("bits,n", [(9, 513), (10, 2048), (12, 6145)])
 def test_g1_msm_a_few_over_a_table_take_the_workgroup_scan(ctx, srs_bytes, bits, n):
-    """1 .. 9 MSMs over a window table in one call — RingVRF.prove of ONE proof commits 4, 1 and 2 polynomials this way; up to eight take the
-    workgroup-scan reduction with a host fold per index group, nine the chunk kernels: every result equals the oracle's, incl. a zero
+    """1 .. 33 MSMs over a window table in one call — RingVRF.prove of ONE proof commits 4, 1 and 2 polynomials this way; up to 32 take the
+    workgroup-scan reduction with a host fold per index group, 33 the chunk kernels: every result equals the oracle's, incl. a zero
     vector, an all-equal vector, scalars >= r and a vector whose scalars are +-1 (most buckets empty)."""
     rng = random.Random(bits * 7 + n)
     srs = ctx.srs_load(srs_bytes[: 96 * n]).precompute(bits)
@@ -442,7 +442,7 @@ def test_g1_msm_a_few_over_a_table_take_the_workgroup_scan(ctx, srs_bytes, bits,
     vecs.append(b"".join(v.to_bytes(32, "little") for v in ([1, coracle.FR_P - 1, (1 << 256) - 1, 2**255, coracle.FR_P] * n)[:n]))
     vecs.append(b"".join((1 if rng.random() < 0.5 else coracle.FR_P - 1).to_bytes(32, "little") for _ in range(n)))
     want = [_oracle_msm_be(srs_bytes, v, n) for v in vecs]
-    for batch in (1, 2, 3, 5, 8, 9):
+    for batch in (1, 2, 3, 5, 8, 9, 20, 32, 33):
         ks = b"".join(vecs[(batch + i) % len(vecs)] for i in range(batch))
         got = ctx.g1_msm_batch(srs, ks, n)
         assert got == [want[(batch + i) % len(vecs)] for i in range(batch)], batch
