@@ -928,7 +928,11 @@ __global__ __launch_bounds__(256) void k_size_pick(const uint32_t* __restrict__ 
         __syncthreads();
     }
     if (c == 0) {
-        const unsigned long long want = tot[0] / 265000ull;
+        // ... and never below twice the launch's mean list (+ 16): a launch of ~262 k buckets — the plan's target for a batch of 64 .. 512
+        // proofs over window rows — has total / 265 k = its MEAN length, and half of its lists went through the 16-lane kernel with its
+        // four-addition shuffle tree (batch 128: the walk at 3.3 G additions/s)
+        const unsigned long long mean2 = nbuckets ? 2ull * tot[0] / (unsigned long long)nbuckets + 16ull : 0ull;
+        const unsigned long long share = tot[0] / 265000ull, want = share > mean2 ? share : mean2;
         // (never below 64: the 16-lane kernel ends with four dependent full additions, ~0.1 ms — as long as one lane needs for ~6 entries more —
         //  and a small launch, a single 2^16-point MSM, is a latency chain that would only get longer)
         const uint32_t L = want < 64ull ? 64u : want > (unsigned long long)G1_LONG_BUCKET ? G1_LONG_BUCKET : (uint32_t)want;
