@@ -92,7 +92,9 @@ MsmPlan make_plan(size_t n, int force_c, bool latency_bound = false) {
 
 // fewer first-level chunks than this over all sets of a table MSM: chunks of 4 buckets instead of 16 (shorter dependent chains for
 // launches that do not fill the chip)
-static constexpr size_t l4_below() { return (size_t)1 << 17; }
+// (2^15 since the end of round 4 — 256 sets of 2048 buckets: same-box sweeps of prove_batch at 256 / 384 / 512 proofs gave 20.7 / 28.4 / 32.9 ms with
+//  2^17, 20.2 / 27.1 / 31.8 with 2^16, 19.6 / 26.6 / 31.6 with 2^15; 1024 proofs the same)
+static constexpr size_t l4_below() { return (size_t)1 << 15; }
 
 // DOTRING_SRS_TILING=rows: batched MSMs keep the window rows of a bit-row table (default: the non-adjacent form below)
 static bool naf_tiling_on() {
