@@ -113,7 +113,7 @@ static bool naf_tiling_on() {
 // shares the bits at the top evenly, so the fullest bucket holds ~4x the average list and stays in the one-lane walk.
 // Needs the per-set LDS sort and the set-scan reduction (hundreds of sets; with fewer the L = 4 latency reduction of msm_device
 // applies); w <= 13: the staged sort's u16 digit rows hold 11 bucket bits + 4 offset bits + sign.  Among the widths that qualify the
-// cheapest wins: n x digits bucket additions + ~5.2 addition-equivalents per bucket of the reduction (measured: level 1 + set scan
+// cheapest wins: n x digits bucket additions + ~1.5 addition-equivalents per bucket of the reduction (measured: level 1 + set scan
 // per bucket against the walk's time per entry): w = 13 for the 3N = 6144-point vectors of domain 2048 and the 12288 of domain 4096.
 Tiling tiling_for(const MsmTable& t, size_t n, size_t batch) {
     Tiling none{0, 0, 0, 0.0};
@@ -129,7 +129,10 @@ Tiling tiling_for(const MsmTable& t, size_t n, size_t batch) {
         if ((n + 64) * slots > ((size_t)1 << 20) || batch * (n + 64) * slots >= (1ull << 32)) continue;
         const double digits = 256.0 / (w + 1) + 0.55;        // (+ the evenly shared digits at the top and the end effects: 18.8 measured at w = 13)
         if (t.naf_delta < 0 && (double)n * digits / (double)H > 160.0) continue;      // the fullest lists (~4x) stay near the one-lane limit
-        const double cost = (double)n * digits + 5.2 * (double)H;
+        // (1.5 addition-equivalents per bucket: with the widths 12 and 13 both admitted at ring 256 — 3N = 3072 terms, 1024 proofs — the
+        //  narrower one saved 0.15 ms of reduction per step and cost 1.15 ms of walk; the 5.2 of the first fit priced the reduction at its
+        //  issue rate, which launches of this size do not reach)
+        const double cost = (double)n * digits + 1.5 * (double)H;
         if (!best.mode || cost < best_cost) { best = Tiling{2, w, (int)slots, digits}; best_cost = cost; }
     }
     return best;
