@@ -61,6 +61,96 @@ inline bool te_decode_checked(const TeCurveHost& cv, const uint8_t enc[32], uint
     return true;
 }
 
+// ---- Elligator 2 and one scalar multiplication on the host, for the head of a prover call of a few dozen proofs: the two kernels
+// (k_bsn_encode_to_curve, k_bsn_scalar_mul_glv) are dependent chains of ~1.2 ms whatever the batch; one x86 core does both in ~0.06 ms per input.
+// The map follows ell2_prepare / ell2_finish of kernels_bsn.hip.h step by step (te_curve.py:48-95: RFC 9380 6.7.1 with Z = 5 on the
+// Montgomery model, then the birational map), so the two give the same point for every input, exceptional cases included.
+struct Ell2ConstsHost {
+    Fr d, neg_a, aob, inv_b2, mont_b, five;
+};
+inline const Ell2ConstsHost& ell2_consts_bandersnatch() {
+    static const Ell2ConstsHost c = [] {
+        Ell2ConstsHost k;
+        uint8_t d_le[32];
+        store_le32(te_curve(0)->d, d_le);
+        (void)Fr::load_le(k.d, d_le);
+        k.five = Fr::from_u64(5);
+        k.neg_a = k.five;
+        const Fr a = k.five.neg(), inv_den = (a - k.d).inv();
+        const Fr mont_a = (a + k.d).dbl() * inv_den;
+        k.mont_b = Fr::from_u64(4) * inv_den;
+        k.aob = mont_a * k.mont_b.inv();
+        k.inv_b2 = k.mont_b.sqr().inv();
+        return k;
+    }();
+    return c;
+}
+// one Elligator map: u (Montgomery form) and 1 / (1 + 5 u^2) -> a point in extended coordinates
+inline TeExt ell2_map_host(const Ell2ConstsHost& k, const Fr& u, const Fr& tv1, const Fr& inv_den) {
+    const Fr one = Fr::one();
+    const Fr x1 = (k.aob * inv_den).neg();
+    const Fr gx1 = ((x1 + k.aob) * x1 + k.inv_b2) * x1;
+    Fr y;
+    const bool e2 = fr_sqrt(y, gx1);                       // sqrt(g(x1)), or sqrt(Z g(x1)) when g(x1) is not a square
+    Fr x = x1;
+    if (!e2) {
+        Fr r;
+        (void)fr_sqrt(r, k.five * gx1);                    // Z g(x1) is a square when g(x1) is not
+        x = x1.neg() - k.aob;
+        y = tv1.is_zero() ? Fr::zero() : u * r;            // sqrt(Z u^2 g(x1))
+    }
+    const bool odd = (y.from_mont().l[0] & 1u) != 0;
+    if (e2 != odd) y = y.neg();                            // e2 XOR sgn0(y) -> negate
+    const Fr s = x * k.mont_b, t = y * k.mont_b;
+    const Fr sp1 = s + one, Z = sp1 * t;
+    if (Z.is_zero()) return {Fr::zero(), one, one, Fr::zero()};
+    const Fr X = s * sp1, Y = (s - one) * t;
+    return {X * Z, Y * Z, Z.sqr(), X * Y};
+}
+// encode_to_curve of Bandersnatch from the two field elements of hash_to_field (32-byte little-endian each): map both, add, clear the
+// cofactor 4; affine x || y out
+inline bool te_encode_to_curve_host(const uint8_t u2[64], uint8_t out_xy[64]) {
+    const Ell2ConstsHost& k = ell2_consts_bandersnatch();
+    const Fr one = Fr::one();
+    Fr u[2], tv1[2], den[2];
+    for (int h = 0; h < 2; h++) {
+        if (!Fr::load_le(u[h], u2 + 32 * h)) return false;
+        tv1[h] = k.five * u[h].sqr();
+        if ((tv1[h] + one).is_zero()) tv1[h] = Fr::zero();
+        den[h] = tv1[h] + one;
+    }
+    const Fr both = (den[0] * den[1]).inv();               // never zero (tv1 = -1 was mapped to 0)
+    const TeExt q0 = ell2_map_host(k, u[0], tv1[0], both * den[1]), q1 = ell2_map_host(k, u[1], tv1[1], both * den[0]);
+    TeExt r = te_ext_add(q0, q1, k.d, k.neg_a);
+    r = te_ext_add(r, r, k.d, k.neg_a);
+    r = te_ext_add(r, r, k.d, k.neg_a);
+    const Fr zi = r.z.inv();
+    (r.x * zi).store_le(out_xy);
+    (r.y * zi).store_le(out_xy + 32);
+    return true;
+}
+// k * P on Bandersnatch, P affine x || y, k a 256-bit little-endian scalar (plain double-and-add: ~0.12 ms); affine out
+inline bool te_scalar_mul_host(const uint8_t p_xy[64], const uint8_t k_le[32], uint8_t out_xy[64]) {
+    const Ell2ConstsHost& c = ell2_consts_bandersnatch();
+    const Fr one = Fr::one();
+    Fr x, y;
+    if (!Fr::load_le(x, p_xy) || !Fr::load_le(y, p_xy + 32)) return false;
+    const TeExt P{x, y, one, x * y};
+    TeExt acc{Fr::zero(), one, one, Fr::zero()};
+    bool started = false;
+    for (int i = 255; i >= 0; i--) {
+        if (started) acc = te_ext_add(acc, acc, c.d, c.neg_a);
+        if ((k_le[i >> 3] >> (i & 7)) & 1) {
+            acc = started ? te_ext_add(acc, P, c.d, c.neg_a) : P;
+            started = true;
+        }
+    }
+    const Fr zi = acc.z.inv();
+    (acc.x * zi).store_le(out_xy);
+    (acc.y * zi).store_le(out_xy + 32);
+    return true;
+}
+
 struct G1AffineHost {
     Fq x, y;
     bool inf;

@@ -327,6 +327,7 @@ def test_tuning_knobs_do_not_change_the_bytes(ctx):
         {"DOTRING_SRS_TILING": "rows", "DOTRING_SRS_BIT_ROWS_MB": "0", "DOTRING_MSM_GROUPS": "3", "DOTRING_KECCAK_GENERIC": "1"},
         {"DOTRING_SRS_TILING": "rows", "DOTRING_VERIFY_HOST_MAX": "0", "DOTRING_MSM_WINDOW": "9", "DOTRING_TRACE": "1"},
         {"DOTRING_VERIFY_HOST_MAX": "2", "DOTRING_SRS_WINDOW": "13", "DOTRING_PS_WINDOW": "12"},
+        {"DOTRING_HEAD_HOST_MAX": "0"},           # Elligator 2 and x * I of the five proofs through the kernels (default: on the host up to 64 proofs)
     ]
     digests = []
     for extra in variants:
