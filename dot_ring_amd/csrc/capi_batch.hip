@@ -475,11 +475,11 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
         std::function<void()> give_up;
         ~Joiner() { give_up(); if (t.joinable()) t.join(); }
     } joiner{side, [&] { open_gate(0); }};
-    // Up to six proofs: every launch chain below would be pure latency (0.7 - 2 ms each), so the points are decoded and the two
+    // Up to eight proofs: every launch chain below would be pure latency (0.7 - 2 ms each), so the points are decoded and the two
     // G1 folds done on the host (hostsmall.hpp: ~80 us per point on the worker pool, ~0.4 ms per fold); the Pedersen side keeps its
-    // stream.  Measured at the end of round 4: 1.6 ms for two proofs + 0.13 - 0.2 ms per further one (the host's load decides) against a flat 2.9 ms
-    // through the kernels: eight proofs are a draw on a loaded host.
-    static const size_t host_max = std::getenv("DOTRING_VERIFY_HOST_MAX") ? (size_t)std::atol(std::getenv("DOTRING_VERIFY_HOST_MAX")) : 6;
+    // stream.  Measured at the end of round 4: 1.2 ms for one proof + 0.13 - 0.2 ms per further one (the host's load decides) against a flat 2.9 ms
+    // through the kernels.
+    static const size_t host_max = std::getenv("DOTRING_VERIFY_HOST_MAX") ? (size_t)std::atol(std::getenv("DOTRING_VERIFY_HOST_MAX")) : 8;
     const bool small = B <= host_max;
     Scratch &g1_bases = ctx->vfy_bases, &g1_in = ctx->vfy_in, &g1_std = ctx->vfy_std;
     std::vector<uint8_t> g1_le(7 * B * 96);
@@ -745,23 +745,22 @@ int ringvrf_verify_batch_impl(dr_ctx* ctx, const dr_vrf_suite* suite, const dr_r
     // proofs.  Two single MSMs rather than a batch of two: the final 255-doubling window combination of a single MSM runs on the host
     // (0.2 ms), a batch leaves it to one GPU lane per MSM (4 ms).
     if (small) {
-        // the lhs fold on the host, split over two threads (the rhs has been running since the decode)
-        const drh::G1 lhs_pt = drh::g1_msm_small(host_bases.data(), lhs_sc.data(), n_g1, 2);
+        // the lhs fold on the host, three or four points per worker thread (the rhs has been running since the decode)
+        const drh::G1 lhs_pt = drh::g1_msm_small(host_bases.data(), lhs_sc.data(), n_g1, (unsigned)std::min<size_t>(8, std::max<size_t>(2, n_g1 / 3)));
         g1_pair_operand(lhs_pt, false, pair_g1, pair_inf);
-        rhs_thread.join();
-        if (rhs_rc != DR_OK) return fail(rhs_rc, rhs_err.empty() ? "rhs fold failed" : rhs_err);
     } else {
         TRY(use_ctx(ctx));           // from here on the context's scratch is used: behind a pending wipe of it
         TRY(ctx->scalars.reserve(n_g1 * 32));
         HIP_TRY(hipMemcpyAsync(ctx->scalars.p, lhs_sc.data(), n_g1 * 32, hipMemcpyHostToDevice, st));
         TRY(msm_to_bytes(ctx, g1_bases.as<uint32_t>(), ctx->scalars.as<uint32_t>(), n_g1, 1, pair_g1, pair_inf));
-        rhs_thread.join();
-        if (rhs_rc != DR_OK) return fail(rhs_rc, rhs_err.empty() ? "rhs MSM failed" : rhs_err);
     }
     tr_.mark("g1 msms");
-    // e(lhs, G2[0]) * e(-rhs, G2[1]) == 1: the second loop came with the rhs fold
+    // e(lhs, G2[0]) * e(-rhs, G2[1]) == 1: the second loop comes with the rhs fold — joined only now: with one proof that thread (fold +
+    // loop, ~0.45 ms from the decode on) ends after this one's lhs fold, and this loop needs nothing from it
     drh::Fq12 f_lhs;
     TRY(pairing_miller(pair_g1, vk->g2, 1, f_lhs));
+    rhs_thread.join();
+    if (rhs_rc != DR_OK) return fail(rhs_rc, rhs_err.empty() ? "rhs fold failed" : rhs_err);
     const int pok = pairing_product_is_one(f_lhs * f_rhs) ? 1 : 0;
     tr_.mark("pairing");
     side.join();

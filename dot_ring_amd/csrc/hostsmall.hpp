@@ -1,6 +1,6 @@
 // Host-side versions of three GPU steps for SINGLE proofs (and pairs): a kernel launch chain costs 0.7 - 2 ms of latency
 // whatever the batch size, while one x86 core decodes a point in ~80 us and folds an 11-point G1 MSM in ~0.6 ms.  The batch
-// verifier uses these up to DOTRING_VERIFY_HOST_MAX proofs (default 6) so that RingVRF.verify of one proof is not slower than
+// verifier uses these up to DOTRING_VERIFY_HOST_MAX proofs (default 8) so that RingVRF.verify of one proof is not slower than
 // the reference's CPU verifier (3.99 ms, docs/BENCHMARK.md:73); every larger batch takes the kernels.
 //   te_decode_checked   dec_point (dot_ring/curve/point.py:150-214, vrf/codec.py:39-45, curve/curve.py:56-67): decompress,
 //                       then non-identity member of the prime-order subgroup — same verdicts as k_bsn_decode_points
@@ -181,10 +181,7 @@ inline G1 g1_msm_small(const G1AffineHost* pts, const uint8_t* scalars, size_t n
     if (threads <= 1 || n < 6) return part(0, n);
     if (threads > n) threads = (unsigned)n;
     std::vector<G1> res(threads);
-    std::vector<std::thread> pool;
-    for (unsigned k = 1; k < threads; k++) pool.emplace_back([&, k] { res[k] = part(n * k / threads, n * (k + 1) / threads); });
-    res[0] = part(0, n / threads);
-    for (auto& th : pool) th.join();
+    parallel_for(threads, [&](size_t k) { res[k] = part(n * k / threads, n * (k + 1) / threads); }, 1);      // (the worker pool: no thread is started here)
     G1 acc = res[0];
     for (unsigned k = 1; k < threads; k++) acc = g1_add(acc, res[k]);
     return acc;

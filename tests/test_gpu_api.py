@@ -213,7 +213,7 @@ def test_ring_zk_rows_are_random_without_test_vectors(ctx, golden_dir):
 def test_native_batch_verify_rejects_what_the_python_path_rejects(ctx, monkeypatch, n):
     """dr_ringvrf_verify_batch against the per-object Python path on good and tampered proofs: wrong input / ad, flipped bits in every
     section of the 784 bytes, non-canonical and off-subgroup points, bad G1 flag bits, proofs of another ring — six proofs (decoding
-    and G1 folds on the host: up to DOTRING_VERIFY_HOST_MAX = 6) and twelve (decoding and folds on the GPU)."""
+    and G1 folds on the host: up to DOTRING_VERIFY_HOST_MAX = 8) and twelve (decoding and folds on the GPU)."""
     import dot_ring_amd as d
     from dot_ring_amd.vrf.ring_vrf import RingVRF
 
