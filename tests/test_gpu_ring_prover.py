@@ -444,3 +444,31 @@ def test_calls_that_follow_a_batch_wait_for_the_zeroing_of_its_scratch():
         enc = [p.encode() for p in proofs]
         first = first or enc
         assert enc == first
+
+
+@pytest.mark.gpu
+def test_prover_head_on_the_host_and_through_the_kernels_give_the_same_proofs():
+    """Elligator 2 and x * I of the prover's head run on the host up to DOTRING_HEAD_HOST_MAX = 64 proofs (hostsmall.hpp) and through
+    k_bsn_encode_to_curve / k_bsn_scalar_mul_glv above: 70 deterministic proofs in one call (kernels) equal the same proofs made 35 at a
+    time (host), byte for byte, inputs of lengths 0 .. 69 included; the first and the last also equal the oracle's."""
+    import dot_ring_amd as d
+    from oracle.pyref import ring as oring
+
+    cv = d.Bandersnatch
+    sks = [(2600 + i).to_bytes(32, "little") for i in range(72)]
+    keys = [cv.public_key_from_secret(sk) for sk in sks]
+    params = d.RingProofParams.from_ring_size(72, test_vectors=True)
+    ring = d.Ring(keys, params)
+    root = d.RingRoot.from_ring(ring, params)
+    vrf = d.RingVRF[cv]
+    n = 70
+    als = [bytes([i]) * i for i in range(n)]
+    ads = [b"ad-%d" % (i % 3) for i in range(n)]
+    whole = [p.encode() for p in vrf.prove_batch(als, ads, sks[:n], keys[:n], ring, root)]
+    halves = [p.encode() for lo in (0, 35) for p in vrf.prove_batch(als[lo : lo + 35], ads[lo : lo + 35], sks[lo : lo + 35], keys[lo : lo + 35], ring, root)]
+    assert whole == halves
+    assert vrf.batch_verify([vrf.decode(b) for b in whole], als, ads, ring, root)
+    o_ring = oring.Ring(keys, oring.Params.from_ring_size(72, test_vectors=True))
+    o_root = oring.RingRoot(o_ring)
+    for i in (0, n - 1):
+        assert oring.ring_vrf_prove(o_ring, o_root, als[i], ads[i], sks[i]).hex() == whole[i].hex()
