@@ -20,11 +20,14 @@ Secondary measurements in the same JSON line (rank 0, one GPU):
   other_ring_sizes   the metric's other ring sizes: 256 (N = 1024) and 3000 (N = 4096, known-tau SRS: BASELINE configs[4]'s shape)
   distinct_signers   the headline workload with 1024 different signing keys instead of one
   single_call_ms     latency of one RingVRF.prove / one RingVRF.verify (the reference's own benchmark shape, docs/BENCHMARK.md:63-73)
+                     and of one Tiny / Thin / Pedersen prove and verify (docs/BENCHMARK.md:20-47), the reference's numbers beside them
+  host_threads       the headline step with 4 and 2 host worker threads (what a rank gets when N ranks share a host), phase times by name
   pipelined_prove_verify  the headline's work with batch_verify of batch k on a helper thread beside prove_batch of batch k + 1
   batch_sweep        the headline's step at 512 and 2048 proofs per call
 With N ranks (one per GPU) every rank proves and verifies its own 1024 proofs — independent units, no collective.  N > 1 adds
-  config5            BASELINE configs[4] at its per-GPU shape: ring 3839 (the largest ring of domain 4096, known-tau SRS),
-                     1024 proofs per rank, prove + verify, parity subset against the oracle on rank 0
+  config5            BASELINE configs[4] through the library call: ONE batch of 1024 x N proofs over ring 3839 (the largest ring of
+                     domain 4096, known-tau SRS) sharded by parallel.prove_batch_sharded / batch_verify_sharded, the gather of the
+                     784-byte proofs inside the timed region and timed on its own; parity: proofs of different shards vs the oracle
   g1_msm_sharded     one MSM over bases sharded across the ranks with an RCCL all-gather of the partial points
                      (dot_ring_amd/parallel.py, dr_comm_*), `rccl_ranks` = ncclCommCount
 No PyTorch anywhere: a launcher only has to export RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
@@ -175,10 +178,43 @@ def single_msm_table_bits(log2n: int) -> int:
     return int(os.environ.get("DOTRING_BENCH_MSM_TABLE", "0")) or (20 if log2n >= 20 else 18 if log2n >= 18 else 16)
 
 
+SRS_FILE = os.path.join(ROOT, "dot_ring_amd", "data", "bls12-381-srs-2-11-uncompressed-zcash.bin")
+
+
+def survey_msm_bases(ctx, n: int):
+    """SURVEY 8(d) config 3's bases: the real SRS (the shipped 2^11 file's 6145 G1 points, /root/reference/dot_ring/ring_proof/pcs/
+    srs.py:42-90) followed by [t^i] G1 for i >= 6145, t a fixed public test scalar (dr_srs_powers generates them on the GPU).
+    Returns (Srs in HBM, real prefix as BE records, t)."""
+    with open(SRS_FILE, "rb") as f:
+        blob = f.read()
+    m = min(n, int.from_bytes(blob[:8], "little"))
+    real = blob[8 : 8 + 96 * m]
+    t = int.from_bytes(hashlib.sha256(b"bench-known-tau").digest(), "little") % FR
+    powers = ctx.srs_powers(G1_BE, t, n)
+    tail = powers.download(m, n - m) if n > m else b""
+    powers.close()
+    return ctx.srs_load(real + tail), real, t
+
+
+def survey_msm_expected(real_be: bytes, t: int, vals, raw: bytes):
+    """The whole MSM over survey_msm_bases' points from its structure: sum_{i < m} k_i S_i (oracle Pippenger over the m real SRS points)
+    + [sum_{i >= m} k_i t^i] G1 — ONE oracle MSM of m + 1 terms that accounts for every one of the n pairs.  BE x||y."""
+    from oracle import coracle
+
+    m = len(real_be) // 96
+    acc, tp = 0, pow(t, m, FR)
+    for k in vals[m:]:
+        acc = (acc + k * tp) % FR
+        tp = tp * t % FR
+    bases = be_to_le_points(real_be + G1_BE)
+    want = bytes(coracle.g1_msm_raw(bases, raw[: 32 * m] + acc.to_bytes(32, "little"), m + 1))
+    return want[:48][::-1] + want[48:][::-1]
+
+
 def g1_msm_measurement(ctx, log2n: int, steps: int, cpu_sample_log2: int, do_cpu: bool):
-    """BASELINE configs[2]: G1 MSM at 2^log2n synthetic bases. Returns a dict (rank-local)."""
+    """BASELINE configs[2] on SURVEY 8(d)'s inputs: G1 MSM over 2^log2n bases = real SRS prefix + [t^i] G1. Returns a dict (rank-local)."""
     n = 1 << log2n
-    srs = ctx.srs_synthetic(G1_BE, n, first=1)
+    srs, real_be, t = survey_msm_bases(ctx, n)
     # fixed-base window table in HBM (W * n * 128 B = 1.7 GB at 2^20 with 20-bit windows): one bucket set per MSM
     table_bits = single_msm_table_bits(log2n)
     srs.precompute(table_bits)
@@ -200,8 +236,8 @@ def g1_msm_measurement(ctx, log2n: int, steps: int, cpu_sample_log2: int, do_cpu
     kern = {k: round(ctx.prof_get(k)[0] / max(1, min(steps, 5)), 3) for k in MSM_KERNELS if ctx.prof_get(k)[1]}
     total_kernel_ms = sum(kern.values())
     out = {"pairs": n, "table_window_bits": table_bits,
-           "inputs": "bases (1 + i) G1 (dr_srs_synthetic: the closed form [sum k_i (1 + i)] G1 checks all 2^log2n terms) instead of SURVEY 8(d)'s "
-                     "SRS prefix + [t^i] G1; scalars uniform in [0, r) from SHAKE256('g1msm' || tag) as 8(d) fixes them",
+           "inputs": f"SURVEY 8(d) config 3: the shipped SRS's {len(real_be) // 96} G1 points followed by [t^i] G1 (dr_srs_powers, t public); "
+                     "scalars uniform in [0, r) from SHAKE256('g1msm' || tag)",
            "scalar_muls_per_s": n * steps / elapsed, "ms_per_msm": elapsed / steps * 1e3,
            "k_g1_accumulate_avg_ms": acc_ms / max(1, acc_n), "kernel_ms_per_msm": kern,
            "non_accumulate_share": 1.0 - kern.get("k_g1_accumulate", 0.0) / (elapsed / steps * 1e3) if elapsed else None,
@@ -210,10 +246,8 @@ def g1_msm_measurement(ctx, log2n: int, steps: int, cpu_sample_log2: int, do_cpu
     if do_cpu:
         from oracle import coracle
 
-        expect = sum(k * (1 + i) for i, k in enumerate(vals)) % FR
-        want = coracle.g1_unpack1(bytes(coracle.g1_msm_raw(be_to_le_points(G1_BE), expect.to_bytes(32, "little"), 1)))
-        got = None if result is None else (int.from_bytes(result[:48], "big"), int.from_bytes(result[48:], "big"))
-        out["parity_closed_form"] = got == want
+        # every pair accounted for: oracle Pippenger over the real prefix + the closed form of the [t^i] G1 tail
+        out["parity_closed_form"] = result == survey_msm_expected(real_be, t, vals, raw)
         if cpu_sample_log2 > 0:
             m = min(n, 1 << cpu_sample_log2)
             bases = be_to_le_points(srs.download(0, m))
@@ -381,29 +415,38 @@ class RingWorkload:
         barrier()
         return time.perf_counter() - t0, all_ok
 
-    def parity(self, m: int, time_it: bool = False):
-        """m deterministic proofs (test_vectors=True) byte-compared with the CPU oracle; returns (ok, cpu proofs, cpu seconds)"""
-        from oracle.pyref import bandersnatch as obsn
-        from oracle.pyref import ring as oring
-
+    def deterministic_ring(self):
+        """(ring, root) of the same keys in test-vector mode (hidden rows zero: proofs are a function of their inputs)"""
         d = self.d
         tv_params = d.RingProofParams.from_ring_size(self.ring_size, test_vectors=True, pcs=self.pcs)
         tv_ring = d.Ring(self.keys, tv_params)
-        tv_root = d.RingRoot.from_ring(tv_ring, tv_params)
-        # the WHOLE batch in deterministic mode, so that the m proofs compared below come through the same code path as the timed
-        # batches (from a few hundred MSMs on, the KZG commitments recode their scalars in non-adjacent form over the bit-row SRS table)
-        nb = len(self.alphas)
-        gpu_all = self.vrf.prove_batch(self.alphas, self.ads, self.sks[:nb], self.pks[:nb], tv_ring, tv_root)
-        gpu_proofs = gpu_all[:m]
+        return tv_ring, d.RingRoot.from_ring(tv_ring, tv_params)
+
+    def oracle_ring(self):
+        """(ring, root) of the CPU oracle for these keys, test-vector mode, over the same SRS"""
+        from oracle.pyref import bandersnatch as obsn
+        from oracle.pyref import ring as oring
+
         o_srs = None
         if self.big:
             from oracle.pyref import kzg as okzg
 
             o_srs = okzg.SRS.from_tau(self.tau, 3 * 4096 + 1)
             o_srs.g2_raw = list(self.pcs.srs.g2_raw)
-        o_params = oring.Params.from_ring_size(self.ring_size, test_vectors=True, suite=obsn.SHA512, srs=o_srs)
-        o_ring = oring.Ring(self.keys, o_params)
-        o_root = oring.RingRoot(o_ring)
+        o_ring = oring.Ring(self.keys, oring.Params.from_ring_size(self.ring_size, test_vectors=True, suite=obsn.SHA512, srs=o_srs))
+        return o_ring, oring.RingRoot(o_ring)
+
+    def parity(self, m: int, time_it: bool = False):
+        """m deterministic proofs (test_vectors=True) byte-compared with the CPU oracle; returns (ok, cpu proofs, cpu seconds)"""
+        from oracle.pyref import ring as oring
+
+        tv_ring, tv_root = self.deterministic_ring()
+        # the WHOLE batch in deterministic mode, so that the m proofs compared below come through the same code path as the timed
+        # batches (from a few hundred MSMs on, the KZG commitments recode their scalars in non-adjacent form over the bit-row SRS table)
+        nb = len(self.alphas)
+        gpu_all = self.vrf.prove_batch(self.alphas, self.ads, self.sks[:nb], self.pks[:nb], tv_ring, tv_root)
+        gpu_proofs = gpu_all[:m]
+        o_ring, o_root = self.oracle_ring()
         ok = o_root.encode() == tv_root.encode() == self.root.encode()
         t1 = time.perf_counter()
         cpu_proofs = [oring.ring_vrf_prove(o_ring, o_root, self.alphas[i], self.ads[i], self.sks[i]) for i in range(m)]
@@ -541,6 +584,139 @@ def ring_size_leg(d, ring_size: int, batch: int, steps: int, parity_proofs: int,
         out["roofline"] = roof
         out["g1_msm_batched"] = msm_batched
     del w
+    return out
+
+
+def config5_sharded_leg(d, ring_size: int, batch_per_rank: int, steps: int, parity_proofs: int, comm, barrier):
+    """BASELINE configs[4] as the library call: ONE batch of batch_per_rank x world proofs over a ring of domain 4096, the same
+    arguments on every rank; parallel.prove_batch_sharded gives rank g its slice and gathers the 784-byte proofs to EVERY rank,
+    parallel.batch_verify_sharded verifies the slices and ANDs the verdicts.  The gather is inside the timed region; its own time
+    (payload phase, after the 9-byte status header has absorbed the wait for the slowest rank) is reported beside it, also for the
+    gather-to-rank-0 form.  Parity (rank 0): deterministic proofs from DIFFERENT shards against the CPU oracle."""
+    from dot_ring_amd import parallel
+
+    rank, world = comm.rank, comm.world
+    total = batch_per_rank * world
+    w = RingWorkload(d, ring_size, total)                          # the same whole batch on every rank
+    vrf = w.vrf
+    args = (w.alphas, w.ads, w.sks, w.pks, w.ring, w.root)
+
+    def step(dst):
+        t = time.perf_counter()
+        proofs = parallel.prove_batch_sharded(comm, vrf, *args, dst=dst)
+        ex = dict(parallel.last_exchange)
+        t1 = time.perf_counter()
+        ok = parallel.batch_verify_sharded(comm, vrf, proofs, w.alphas, w.ads, w.ring, w.root)
+        return ok, t1 - t, time.perf_counter() - t1, ex
+
+    step(None)                                                     # warm-up: prover tables, verifier key, the sockets' buffers
+    barrier()
+    t0 = time.perf_counter()
+    all_ok, prove_s, verify_s, gather_s = True, 0.0, 0.0, 0.0
+    for _ in range(steps):
+        ok, tp, tv, ex = step(None)
+        all_ok, prove_s, verify_s, gather_s = all_ok and ok, prove_s + tp, verify_s + tv, gather_s + ex["payload_s"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # the other form of the gather: all proofs to rank 0 only (batch_verify_sharded then starts with a broadcast from there)
+    ok0, tp0, tv0, ex0 = step(0)
+    stats = [struct.unpack("<dddddB", b) for b in comm.all_gather(struct.pack("<dddddB", elapsed, prove_s, verify_s, gather_s, ex0["payload_s"],
+                                                                               1 if all_ok and ok0 else 0))]
+    elapsed = max(s_[0] for s_ in stats)
+    # parity: deterministic mode through the same sharded call; rank 0 compares proofs of different shards with the oracle
+    parity_ok, checked = True, []
+    if parity_proofs:
+        tv_ring, tv_root = w.deterministic_ring()
+        tv = parallel.prove_batch_sharded(comm, vrf, w.alphas, w.ads, w.sks, w.pks, tv_ring, tv_root, dst=0)
+        if rank == 0:
+            from oracle.pyref import ring as oring
+
+            o_ring, o_root = w.oracle_ring()
+            checked = sorted({0, parallel.shard_range(total, world - 1, world)[0], total - 1})      # first shard, first and last proof of the last shard
+            parity_ok = o_root.encode() == tv_root.encode() and len(tv) == total
+            for i in checked:
+                parity_ok = parity_ok and tv[i].encode() == oring.ring_vrf_prove(o_ring, o_root, w.alphas[i], w.ads[i], w.sks[i])
+        verdict = parallel.batch_verify_sharded(comm, vrf, tv, w.alphas, w.ads, tv_ring, tv_root)
+        parity_ok = parity_ok and verdict
+    return {"config": f"BASELINE configs[4]: RingVRF[Bandersnatch] ring {ring_size} (domain {w.ring.params.domain_size}, known-tau SRS), ONE batch of "
+                      f"{total} proofs sharded over {world} ranks by parallel.prove_batch_sharded / batch_verify_sharded",
+            "ring_size": ring_size, "domain_size": w.ring.params.domain_size, "batch_total": total, "batch_per_rank": batch_per_rank, "ranks": world,
+            "steps": steps, "proofs_per_s": total * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
+            "ms_per_step_by_rank": [s_[0] / steps * 1e3 for s_ in stats],
+            "prove_sharded_ms": max(s_[1] for s_ in stats) / steps * 1e3, "verify_sharded_ms": max(s_[2] for s_ in stats) / steps * 1e3,
+            "gather": {"bytes": 784 * total, "communicator": type(comm).__name__, "inside_timed_region": True,
+                       "to_every_rank_ms": max(s_[3] for s_ in stats) / steps * 1e3, "to_rank0_only_ms": stats[0][4] * 1e3},
+            "parity_ok": bool(parity_ok and all(s_[5] for s_ in stats)), "parity_proof_indices": checked,
+            "srs": "known-tau, 12289 points" if w.big else "shipped 2^11 file"}
+
+
+def host_threads_sweep(args, counts=(4, 2)):
+    """The headline step with fewer host worker threads (DOTRING_HOST_THREADS; the N-rank launcher gives each rank cores // N of them):
+    one child process per setting — the pool is sized once per process — running this script's timed region only, with the library's
+    phase trace on (DOTRING_TRACE) so that the host phases of the verifier show by name.  Children run one after the other while this
+    process is idle; they share its GPU."""
+    import re
+    import subprocess
+
+    out = {}
+    for t in counts:
+        env = dict(os.environ)
+        env.update({"DOTRING_HOST_THREADS": str(t), "DOTRING_TRACE": "1"})
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1", "--ring-size", str(args.ring_size),
+               "--batch", str(args.batch), "--cpu-proofs", "0", "--msm-log2n", "0", "--extras", "0"]
+        try:
+            proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+            phases = {}
+            for what in ("prove_batch", "verify_batch"):
+                rows = [ln for ln in proc.stderr.splitlines() if ln.startswith(f"[dotring] {what} ")][-3:]   # the timed steps
+                acc = {}
+                for ln in rows:
+                    for name, ms in re.findall(r" ([A-Za-z0-9+*_ ]+?)=([0-9.]+)", ln.split("|", 1)[1] if "|" in ln else ""):
+                        acc[name.strip()] = acc.get(name.strip(), 0.0) + float(ms) / len(rows)
+                    m_ = re.search(r"total=([0-9.]+)", ln)
+                    if m_:
+                        acc["total"] = acc.get("total", 0.0) + float(m_.group(1)) / len(rows)
+                phases[what] = {k: round(v, 3) for k, v in acc.items()}
+            out[str(t)] = {"proofs_per_s": line["value"], "ms_per_step": line["ms_per_step"],
+                           "prove_only_proofs_per_s": line["prove_only_proofs_per_s"], "verify_only_proofs_per_s": line["verify_only_proofs_per_s"],
+                           "phase_ms": phases}
+        except Exception as exc:          # noqa: BLE001 — a sweep point that cannot run is reported, not fatal
+            out[str(t)] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
+
+
+def small_vrf_single_call_leg(d, reps: int = 20):
+    """Latency of ONE prove and ONE verify of the three small schemes (BASELINE configs[0]'s shape; the reference publishes them in
+    docs/BENCHMARK.md:20-21,33-34,46-47 for one M1 Max core): fresh inputs per call, minimum and median over `reps`."""
+    cv = d.Bandersnatch
+    pk, sk = cv.secret_from_seed(_seed("signer", 0, 0))
+    ref = {"TinyVRF": (2.21, 1.97, "docs/BENCHMARK.md:20-21"), "ThinVRF": (2.21, 1.99, "docs/BENCHMARK.md:33-34"),
+           "PedersenVRF": (2.40, 1.74, "docs/BENCHMARK.md:46-47")}
+    out, all_ok = {}, True
+    for name, (ref_p, ref_v, src) in ref.items():
+        vrf = getattr(d, name)[cv]
+        tp, tv, ok = [], [], True
+        for i in range(reps + 2):
+            al = b"single-call-input" + i.to_bytes(4, "little")
+            t = time.perf_counter()
+            pr = vrf.prove(al, sk, b"ad")
+            tp.append(time.perf_counter() - t)
+            pr = vrf.decode(pr.encode())
+            t = time.perf_counter()
+            good = pr.verify(al, b"ad") if name == "PedersenVRF" else pr.verify(pk, al, b"ad")
+            tv.append(time.perf_counter() - t)
+            bad = pr.verify(al + b"x", b"ad") if name == "PedersenVRF" else pr.verify(pk, al + b"x", b"ad")
+            ok = ok and good and not bad
+        tp, tv = sorted(tp[2:]), sorted(tv[2:])
+        out[name] = {"prove_ms_min": tp[0] * 1e3, "prove_ms_median": tp[len(tp) // 2] * 1e3, "verify_ms_min": tv[0] * 1e3,
+                     "verify_ms_median": tv[len(tv) // 2] * 1e3, "reference_ms_min": {"prove": ref_p, "verify": ref_v, "source": src + " (M1 Max, one core)"},
+                     "verified": bool(ok)}
+        all_ok = all_ok and ok
+    out["verified"] = bool(all_ok)
+    out["reps"] = reps
     return out
 
 
@@ -718,6 +894,10 @@ def main() -> int:
 
     # ---- the same steps again with the per-kernel timers on (every context of this process: prove_batch's helper threads too)
     roof, kernel_ms = ring_roofline(w, args.steps, barrier)
+    if ctl is not None:
+        # every rank measured its own GPU: the line carries rank 0's roofline in full and the others' figures beside it
+        rec = struct.pack("<dddd", roof["frac"], roof["achieved"], roof["avg_kernel_ms"], roof["valu"]["frac"] or 0.0)
+        roof["by_rank"] = [dict(zip(("frac", "achieved", "avg_kernel_ms", "valu_frac"), struct.unpack("<dddd", b))) for b in ctl.all_gather(rec)]
 
     rc = 0
     line = None
@@ -729,16 +909,17 @@ def main() -> int:
         parity_ok = all_ok
         cpu = cpu_all = None
         if args.cpu_proofs > 0:
-            m = args.cpu_proofs if world == 1 else min(2, args.cpu_proofs)     # N > 1: parity check only, no CPU timing
+            # (N > 1 as well: rank 0 times the CPU port after the timed region while the other ranks wait at the next exchange)
+            m = args.cpu_proofs
             ok, cpu_proofs, cpu_s = w.parity(m)
             parity_ok = parity_ok and ok
-            cpu = None if world > 1 else {
+            cpu = {
                 "value": m / cpu_s, "unit": "proofs/s", "cores": 1, "kind": "port", "work": "prove only",
                 "sample": f"{m} proofs of the same workload through oracle/ (Python orchestration + oracle/c kernels for NTT and G1 "
                           f"Pippenger), {cpu_s:.1f} s.  PROVE ONLY — the GPU figure is prove + verify; the reference's verify adds 0.7 % "
                           f"to its prove time (3.99 ms vs 534.57 ms, docs/BENCHMARK.md:72-73)"}
             # the same port on all host cores: one oracle process per core, released together
-            if world == 1 and not w.big and args.cpu_workers != 0:
+            if not w.big and args.cpu_workers != 0:
                 cpu_all = cpu_baseline_all_cores(w.keys, args.ring_size, w.signer_sk, max(2, m // 4), args.cpu_workers, cpu_proofs)
 
         total = batch * world * args.steps
@@ -778,7 +959,7 @@ def main() -> int:
         # domain point = 6.5 MB per proof at N = 2048, over the whole job
         roof["whole_proof"] = {"algorithmic_bytes_per_proof": 3174 * n_dom, "achieved": 3174 * n_dom * value / 1e9, "unit": "GB/s",
                                "frac": 3174 * n_dom * value / 1e9 / (HBM_PEAK_GBS * world)}
-        g1 = bsn = others = distinct = single = pipelined = sweep = msm_batched = None
+        g1 = bsn = others = distinct = single = pipelined = sweep = msm_batched = threads_sweep = None
         if world == 1 and args.extras:
             # the second half of BASELINE's metric at this ring size: the batched G1 MSM of `batch` 3N-term commitments
             msm_batched = g1_msm_batched_leg(ctx, w.pcs, n_dom, batch, 3, VALU_PEAK_GADD_S)
@@ -795,6 +976,9 @@ def main() -> int:
             parity_ok = parity_ok and bsn["parity_ok"]
             single = single_call_leg(w)
             parity_ok = parity_ok and single["verified"]
+            single["small_vrfs"] = small_vrf_single_call_leg(d)
+            parity_ok = parity_ok and single["small_vrfs"]["verified"]
+            threads_sweep = host_threads_sweep(args)
             pipelined = pipelined_leg(w, max(3, args.steps))
             parity_ok = parity_ok and pipelined["all_verified"]
             if args.ring_size == 1024 and batch == 1024:
@@ -855,6 +1039,8 @@ def main() -> int:
             "single_call_ms": single,
             "pipelined_prove_verify": pipelined,
             "batch_sweep": sweep,
+            "host_threads": {"this_run": int(os.environ.get("DOTRING_HOST_THREADS", "0")) or min(16, len(os.sched_getaffinity(0))),
+                             "sweep": threads_sweep} ,
             "ring_root_s": w.ring_root_s,
             "setup_s": setup_s,
         }
@@ -869,13 +1055,12 @@ def main() -> int:
     # of taking the measured headline with it — and the process then exits NON-ZERO (3 = error, 4 = stalled).
     hung = False
     if ctl is not None and args.extras:
-        leg5 = ring_size_leg(d, 3839, batch, max(1, min(args.steps, 5)), 2 if args.cpu_proofs > 0 else 0, rank, ctl, barrier)
+        leg5 = config5_sharded_leg(d, 3839, batch, max(1, min(args.steps, 5)), 2 if args.cpu_proofs > 0 else 0, ctl, barrier)
         if line is not None:
             leg5["rccl_ranks"] = None
-            leg5["collective"] = "none: proofs are sharded per rank (its one exchange step is the base-sharded MSM, g1_msm_sharded)" + (
+            leg5["collective"] = ("the gather of 784 B x B proofs over the launcher's TCP star (no exchange while the GPUs work; RCCL serves the "
+                                  "base-sharded MSM, g1_msm_sharded)") + (
                 "; every rank on ONE GPU (DOTRING_BENCH_SHARE_GPU rehearsal)" if share_mode in ("1", "rccl") else "")
-            leg5["config"] = (f"BASELINE configs[4]: RingVRF[Bandersnatch] prove_batch + batch_verify, ring 3839 (domain 4096), {batch} proofs per "
-                              f"rank = {batch * world} proofs per step on {world} GPUs; its sharded MSM: g1_msm_sharded")
             line["config5"] = leg5
             if not leg5["parity_ok"]:
                 print("bench.py: PARITY FAILURE — config5 leg", file=sys.stderr)

@@ -232,7 +232,9 @@ int msm_device(dr_ctx* ctx, const uint32_t* d_bases, const uint32_t* d_scalars, 
     TRY(ctx->buckets.reserve(nbuckets * 192));
     TRY(ctx->partial.reserve((bsets * pl.T + bsets * (pl.T / 256 + 1)) * 192));
     TRY(ctx->winsum.reserve(bsets * 192));
-    TRY(ctx->heavy.reserve((ndigits / 1024 + ndigits / 4096 + 64) * 192));          // segment sums of lists >= 1024 entries (segments >= 1024)
+    // segment sums of lists >= 1024 entries: sum_i ceil(len_i / seg) <= total / seg + n_heavy.  Up to 1024 heavy lists: seg >= 1024, so
+    // total / 1024 + 1024; more of them: seg = 4096 and n_heavy <= total / 1024, so total / 4096 + total / 1024 (heavy_segment_size)
+    TRY(ctx->heavy.reserve((ndigits / 1024 + ndigits / 4096 + dr::G1_HEAVY_SLOTS / 2 + 64) * 192));
     hipStream_t st = ctx->stream;
     auto exclusive_scan = [&](const uint32_t* in, uint32_t* out, size_t count) {
         const unsigned nt = div_up(count, dr::SCAN_TILE);

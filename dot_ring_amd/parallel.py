@@ -6,6 +6,11 @@ each rank reduces its shard of (base, scalar) pairs to one G1 point, the points 
 latency-bound on xGMI, nowhere near the per-link bandwidth) and every rank folds them with the group law.  Point addition
 is not an RCCL reduction op, so this is an all-gather followed by a local fold, not an all-reduce.
 
+`prove_batch_sharded` / `batch_verify_sharded` are the library form of the first way (BASELINE configs[4]): every rank calls them
+with the SAME whole batch, rank g proves (verifies) proofs [g B / G, (g + 1) B / G) on its GPU, and the 784-byte proofs are
+gathered — to every rank or to one — so that the caller holds all B of them, in order (the reference's process-sharded bench
+hands its index ranges out and takes every result back the same way, tests/benchmark/bench_ring_proof.py:168-182).
+
 Communicators (same small interface: rank, world, all_gather(bytes) -> list[bytes], barrier(), close()):
 
 * `RcclComm`   — the product path: ncclAllGather through the C ABI (`dr_comm_*`, dot_ring_amd/csrc/capi_comm.hip).  The
@@ -119,7 +124,26 @@ class SocketComm:
 
     def broadcast(self, data: bytes | None, nbytes: int) -> bytes:
         """`data` of rank 0 to everyone (all ranks pass the length)."""
-        return self.all_gather(data if self.rank == 0 else bytes(nbytes))[0]
+        if self.world == 1:
+            return bytes(data)
+        if self.rank == 0:
+            for r in range(1, self.world):
+                self._peers[r].sendall(data)
+            return bytes(data)
+        return _recv_exact(self._up, nbytes)
+
+    def gather(self, mine: bytes, sizes: list) -> list | None:
+        """Every rank's bytes (rank r sends sizes[r] of them; all ranks pass the same sizes) to rank 0: the list there, None
+        elsewhere.  One hop per rank — half the bytes of all_gather on this star, and nothing travels back."""
+        if self.world == 1:
+            return [bytes(mine)]
+        if len(mine) != sizes[self.rank]:
+            raise ValueError("gather: this rank's payload does not have the announced size")
+        if self.rank == 0:
+            return [bytes(mine)] + [_recv_exact(self._peers[r], sizes[r]) for r in range(1, self.world)]
+        if mine:
+            self._up.sendall(mine)
+        return None
 
     def barrier(self) -> None:
         self.all_gather(b"\0")
@@ -280,3 +304,102 @@ def g1_msm_sharded(ctx, comm, srs_shard, d_scalars, n_local: int, offset: int = 
         return comm.g1_msm_sharded_dev(srs_shard, d_scalars, n_local, offset)
     part = ctx.g1_msm_dev(srs_shard, d_scalars, n_local, offset) if n_local else None
     return combine_partials(part, comm)
+
+
+# ------------------------------------------------------------------------------------------------ proof-sharded batches
+class DotRingShardError(_native.DotRingHipError):
+    """a shard of a sharded call failed on some rank (the message names the rank and carries its error)"""
+
+
+_HDR = struct.Struct("<BQ")          # status (0 ok, 1 failed), payload bytes
+# what the last exchange of this process moved and how long its payload phase took (benchmarks read it; the header all_gather before
+# it absorbs the wait for the slowest rank, so `payload_s` is transfer time, not straggling)
+last_exchange = {"what": None, "payload_bytes": 0, "payload_s": 0.0, "header_s": 0.0}
+
+
+def _exchange(comm, what: str, mine: bytes, failed: str | None, dst: int | None):
+    """The variable-size gather every sharded call ends with.  First a 9-byte header per rank (status + size) travels by
+    all_gather, so that a rank whose shard failed is seen by all of them BEFORE anyone waits for its payload — every rank then
+    raises the first failing rank's error (ValueError for the reference's argument errors, DotRingShardError otherwise).  Then
+    the payloads: to every rank (dst None) or to rank `dst` only.  Returns the payload per rank, or None off `dst`."""
+    t0 = time.perf_counter()
+    hdrs = [_HDR.unpack(h) for h in comm.all_gather(_HDR.pack(1 if failed else 0, 0 if failed else len(mine)))]
+    t1 = time.perf_counter()
+    bad = [r for r, (st, _) in enumerate(hdrs) if st]
+    if bad:
+        texts = comm.all_gather((failed or "").encode()[:400].ljust(400))
+        text = texts[bad[0]].decode(errors="replace").strip()
+        kind = ValueError if text.startswith("ValueError:") else DotRingShardError
+        raise kind(f"sharded {what} failed on rank {bad[0]}: {text}")
+    sizes = [n for _, n in hdrs]
+    if dst == 0 and hasattr(comm, "gather"):
+        parts = comm.gather(mine, sizes)
+    else:
+        width = max(sizes)
+        parts = comm.all_gather(bytes(mine).ljust(width, b"\0")) if width else [b""] * comm.world
+        parts = None if dst is not None and comm.rank != dst else [part[:n] for part, n in zip(parts, sizes)]
+    last_exchange.update(what=what, payload_bytes=sum(sizes), payload_s=time.perf_counter() - t1, header_s=t1 - t0)
+    return parts
+
+
+def prove_batch_sharded(comm, vrf, alphas, additional_data, secret_keys, producer_keys, ring, ring_root=None, salts=None,
+                        dst: int | None = None):
+    """RingVRF.prove_batch of ONE batch over the ranks of `comm` (one process per GPU): every rank passes the same arguments,
+    rank g proves proofs [g B / G, (g + 1) B / G) on its own GPU, the encoded proofs (784 bytes each) are gathered, and the
+    result is the list of all B proofs in order — element i equals vrf.prove(alphas[i], ...) — on every rank (`dst` None), or
+    on rank `dst` only (None elsewhere: half the traffic).  Ragged splits and empty shards (B < G) are fine.  No collective
+    runs while the GPUs work; the one exchange is this gather (B x 784 bytes, 6.4 MB at 8192 proofs).
+
+    `vrf` is the bound scheme, e.g. dot_ring_amd.RingVRF[Bandersnatch].  If any rank's shard raises, EVERY rank raises
+    instead of waiting for proofs that never come.  Mirrors the process-sharded driver of the reference's bench
+    (tests/benchmark/bench_ring_proof.py:168-182: index ranges out, all results back) over dot_ring/vrf/ring/vrf.py:185-209."""
+    count = len(alphas)
+    if not (len(additional_data) == len(secret_keys) == len(producer_keys) == count) or (salts is not None and len(salts) != count):
+        raise ValueError("batch arguments must have equal lengths")
+    lo, hi = shard_range(count, comm.rank, comm.world)
+    blob, failed = b"", None
+    if hi > lo:
+        try:
+            mine = vrf.prove_batch(alphas[lo:hi], additional_data[lo:hi], secret_keys[lo:hi], producer_keys[lo:hi], ring, ring_root,
+                                   None if salts is None else salts[lo:hi])
+            blob = vrf.encode_batch(mine)
+        except Exception as exc:                                   # noqa: BLE001 — reported to every rank, raised by _exchange
+            failed = f"{type(exc).__name__}: {exc}"
+    parts = _exchange(comm, "prove_batch", blob, failed, dst)
+    if parts is None:
+        return None
+    for r, part in enumerate(parts):
+        a, b = shard_range(count, r, comm.world)
+        if len(part) != 784 * (b - a):
+            raise DotRingShardError(f"rank {r} sent {len(part)} bytes for {b - a} proofs")
+    return vrf._from_encoded(b"".join(parts), count)
+
+
+def batch_verify_sharded(comm, vrf, proofs, inputs, additional_data, ring, ring_root) -> bool:
+    """RingVRF.batch_verify of ONE batch over the ranks of `comm`: every rank passes the same inputs; rank g verifies proofs
+    [g B / G, (g + 1) B / G) — its own random linear combination, its own pairing equation — and the verdicts are AND-ed
+    (one byte per rank).  `proofs` may be None on every rank but 0 (prove_batch_sharded(dst=0) left them there): rank 0 then
+    broadcasts the encoded batch first.  True on every rank iff every proof verifies (dot_ring/vrf/ring/vrf.py:239-283)."""
+    count = len(inputs)
+    if len(additional_data) != count or (proofs is not None and len(proofs) != count):
+        raise ValueError("batch arguments must have equal lengths")
+    have = comm.all_gather(bytes([0 if proofs is None else 1]))
+    lo, hi = shard_range(count, comm.rank, comm.world)
+    if all(h[0] for h in have):
+        mine = proofs[lo:hi]
+    else:
+        if not have[0][0]:
+            raise ValueError("batch_verify_sharded: rank 0 must hold the proofs when another rank does not")
+        whole = vrf.encode_batch(proofs) if comm.rank == 0 else None
+        if hasattr(comm, "broadcast"):
+            whole = comm.broadcast(whole, 784 * count)
+        else:
+            whole = comm.all_gather(whole if comm.rank == 0 else bytes(784 * count))[0]
+        mine = vrf._from_encoded(whole[784 * lo : 784 * hi], hi - lo)
+    ok, failed = True, None
+    if hi > lo:
+        try:
+            ok = bool(vrf.batch_verify(mine, inputs[lo:hi], additional_data[lo:hi], ring, ring_root))
+        except Exception as exc:                                   # noqa: BLE001
+            ok, failed = False, f"{type(exc).__name__}: {exc}"
+    return all(p[0] for p in _exchange(comm, "batch_verify", bytes([1 if ok else 0]), failed, None))

@@ -242,22 +242,47 @@ class RingVRF(VRF):
             out.append(p)
         return out
 
+    @classmethod
+    def _from_encoded(cls, blob: bytes, count: int) -> list:
+        """`count` proofs that arrived ENCODED in one byte string (the gather of a sharded prove_batch, a block of proofs off the
+        wire): every object only points into the shared string.  encode() and batch_verify never decode them; the first read of a
+        field decodes that proof (decode(): every point validated) and fills all fields."""
+        if len(blob) != 784 * count:
+            raise ValueError(f"expected {count} proofs of 784 bytes, got {len(blob)} bytes")
+        new = object.__new__
+        out = []
+        for i in range(count):
+            p = new(cls)
+            p.__dict__["_batch"] = (blob, None, i, None)
+            out.append(p)
+        return out
+
     @staticmethod
     def _unbatch(d) -> None:
         b = d.pop("_batch", None)
         if b is not None:
             raw_blob, aux_blob, i, blind = b
+            d["_raw"] = raw_blob[784 * i : 784 * i + 784]
+            if aux_blob is None:                      # encoded only: fields come from decode() when first read
+                d["_lazy"] = True
+                return
             ab = _native.RINGVRF_AUX_BYTES
             aux = aux_blob[ab * i : ab * i + ab]
             if blind is not None:
                 aux = aux[:256] + blind + aux[288:]
-            d["_raw"], d["_aux"] = raw_blob[784 * i : 784 * i + 784], aux
+            d["_aux"] = aux
 
     def __getattr__(self, name):
         d = self.__dict__
-        if name not in RingVRF._FIELDS or ("_aux" not in d and "_batch" not in d):
+        if name not in RingVRF._FIELDS or ("_aux" not in d and "_batch" not in d and "_lazy" not in d):
             raise AttributeError(name)
         RingVRF._unbatch(d)
+        if d.pop("_lazy", False):
+            decoded = type(self).decode(d["_raw"])
+            for nm in RingVRF._FIELDS:
+                d[nm] = decoded.__dict__[nm]
+            d["_snapshot"] = self._field_state()
+            return d[name]
         raw, aux = d["_raw"], d.pop("_aux")
         cv = self.cv
         pt = lambda i: cv.point_type._trusted(int.from_bytes(aux[64 * i : 64 * i + 32], "little"), int.from_bytes(aux[64 * i + 32 : 64 * i + 64], "little"))
@@ -277,7 +302,7 @@ class RingVRF(VRF):
 
     def __setattr__(self, name, value):
         d = self.__dict__
-        if name in RingVRF._FIELDS and ("_aux" in d or "_batch" in d):
+        if name in RingVRF._FIELDS and ("_aux" in d or "_batch" in d or "_lazy" in d):
             self.__getattr__(name)          # fill every field from the auxiliary record first: the lazy fill must not undo this write
         object.__setattr__(self, name, value)
 
@@ -306,7 +331,7 @@ class RingVRF(VRF):
         RingVRF._unbatch(d)
         raw = d.get("_raw")
         if raw is not None:
-            if "_aux" in d or d.get("_snapshot") == self._field_state():       # fields never read, or read and unchanged
+            if "_aux" in d or "_lazy" in d or d.get("_snapshot") == self._field_state():       # fields never read, or read and unchanged
                 return raw
             d.pop("_raw", None)                                                # mutated in place: the stored bytes are stale
         pcs = RingProofParams(cv=self.cv).pcs
@@ -564,6 +589,31 @@ class RingVRF(VRF):
         return _native.vrf_suite(sp.suite_id, sp.xof, le(gen[0]) + le(gen[1]), le(bb[0]) + le(bb[1]), sp.curve_id)
 
     @classmethod
+    def _shared_encoding(cls, proofs):
+        """The encoded bytes of `proofs` without touching them one by one, when they are untouched consecutive proofs of ONE native
+        batch (prove_batch's output, a gathered shard, a slice of either): a slice of the shared string; None otherwise."""
+        count = len(proofs)
+        first = proofs[0].__dict__.get("_batch") if count and type(proofs[0]) is cls else None
+        if first is None:
+            return None
+        blob, i0 = first[0], first[2]
+        if 784 * (i0 + count) > len(blob):
+            return None
+        for i, p in enumerate(proofs):
+            if type(p) is not cls:
+                return None
+            b = p.__dict__.get("_batch")
+            if b is None or b[0] is not blob or b[2] != i0 + i:
+                return None
+        return blob if i0 == 0 and len(blob) == 784 * count else blob[784 * i0 : 784 * (i0 + count)]
+
+    @classmethod
+    def encode_batch(cls, proofs) -> bytes:
+        """b"".join(p.encode() for p in proofs); for the untouched output of one prove_batch call that is the string they share."""
+        shared = cls._shared_encoding(proofs) if proofs else b""
+        return shared if shared is not None else b"".join(p.encode() for p in proofs)
+
+    @classmethod
     def _batch_verify_native(cls, proofs, inputs, additional_data, ring: Ring, ring_root: RingRoot) -> bool:
         """dr_ringvrf_verify_batch over the encoded proofs: point decoding/validation on the GPU, transcripts on the
         library's worker threads, one Bandersnatch MSM + two G1 MSMs + one pairing equation for the whole batch."""
@@ -583,13 +633,8 @@ class RingVRF(VRF):
         count = len(proofs)
         if not (count == len(inputs) == len(additional_data)):
             return False
-        # the untouched output of ONE prove_batch call, in order: its encoded bytes already lie in one string
-        joined = None
-        first = proofs[0].__dict__.get("_batch") if count and type(proofs[0]) is cls else None
-        if first is not None and first[2] == 0 and len(first[0]) == 784 * count:
-            blob = first[0]
-            if all(type(p) is cls and (b := p.__dict__.get("_batch")) is not None and b[0] is blob and b[2] == i for i, p in enumerate(proofs)):
-                joined = blob
+        # the untouched output of ONE prove_batch call (or a run of it), in order: its encoded bytes already lie in one string
+        joined = cls._shared_encoding(proofs)
         blobs = None
         if joined is None:
             try:

@@ -1,6 +1,7 @@
 """GPU: bench.py for N > 1 started as ONE bare command: the process spawns its two ranks itself, both share
 the test box's single GPU (DOTRING_BENCH_SHARE_GPU=1: device 0 for every rank, TCP all-gather since RCCL refuses two ranks per
-device), the line carries n_gpus = 2, the config5 leg (ring 3839, domain 4096) with oracle parity and the base-sharded MSM legs;
+device), the line carries n_gpus = 2, a CPU baseline and per-rank rooflines, the config5 leg (ONE batch over ring 3839 / domain 4096 sharded by
+parallel.prove_batch_sharded, gathered, verified, proofs of both shards against the oracle) and the base-sharded MSM legs;
 and a collective that cannot come up still prints the line but exits non-zero."""
 import json
 import os
@@ -29,9 +30,14 @@ def test_bare_command_two_ranks_sharing_the_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["parity_ok"] and line["metric"] == "ringvrf_proofs_per_sec"
     assert line["value"] > 0 and line["config"]["ring_size"] == 1024 and line["config"]["batch_per_gpu"] == 256
+    # an N > 1 line is complete: the CPU port timed in the same run (rank 0), a roofline for every rank
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] == 1
+    assert len(line["roofline"]["by_rank"]) == 2 and all(r["frac"] > 0 for r in line["roofline"]["by_rank"])
+    # BASELINE configs[4] through the library call: ONE batch of 512 proofs sharded over the two ranks, gathered and verified
     c5 = line["config5"]
-    assert (c5["ring_size"], c5["domain_size"], c5["max_ring_size"], c5["ranks"]) == (3839, 4096, 3839, 2)
-    assert c5["parity_ok"] and c5["parity_proofs"] == 2 and c5["proofs_per_s"] > 0
+    assert (c5["ring_size"], c5["domain_size"], c5["ranks"], c5["batch_total"], c5["batch_per_rank"]) == (3839, 4096, 2, 512, 256)
+    assert c5["parity_ok"] and c5["parity_proof_indices"] == [0, 256, 511] and c5["proofs_per_s"] > 0
+    assert c5["gather"]["bytes"] == 784 * 512 and c5["gather"]["inside_timed_region"] and c5["gather"]["to_every_rank_ms"] > 0
     legs = line["g1_msm_sharded"]
     assert [leg["scaling"] for leg in legs] == ["strong", "weak"]
     assert all(leg["parity_closed_form_all_ranks"] and leg["ranks"] == 2 and leg["collective"] == "SocketComm" for leg in legs)

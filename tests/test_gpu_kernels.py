@@ -294,6 +294,27 @@ def test_g1_msm_synthetic_bases_closed_form(ctx, log2n, table):
     srs.close()
 
 
+@pytest.mark.parametrize("log2n,table", [(16, 16), (20, 20), (13, 0)])
+def test_g1_msm_on_the_surveys_config3_bases(ctx, log2n, table):
+    """BASELINE configs[2] on SURVEY 8(d)'s inputs: bases = the real SRS (6145 points of the shipped file) followed by [t^i] G1.  The
+    expected value accounts for all 2^log2n pairs: oracle Pippenger over the real prefix + [sum_{i >= 6145} k_i t^i] G1; the tables
+    are bench.py's (16-bit windows at 2^16, 20-bit at 2^20), and 2^13 runs over plain bases."""
+    import bench
+
+    n = 1 << log2n
+    srs, real_be, t = bench.survey_msm_bases(ctx, n)
+    assert srs.download(0, 2) == real_be[:192] and srs.download(6144, 1) == real_be[96 * 6144 :]
+    one = srs.download(6145, 2)                       # [t^6145] G1, [t^6146] G1: the oracle's scalar multiplications
+    for j in range(2):
+        w = coracle.g1_msm_raw(bench.be_to_le_points(bench.G1_BE), pow(t, 6145 + j, coracle.FR_P).to_bytes(32, "little"), 1)
+        assert one[96 * j : 96 * j + 96] == bytes(w)[:48][::-1] + bytes(w)[48:][::-1]
+    if table:
+        srs.precompute(table)
+    vals, raw = bench.seeded_scalars(n, b"\0\0\0\0")
+    assert ctx.g1_msm(srs, raw) == bench.survey_msm_expected(real_be, t, vals, raw)
+    srs.close()
+
+
 def test_fr29_field_arithmetic_against_big_integers(ctx):
     """the unsaturated Fr of the twisted Edwards kernels (csrc/fr29.hip.h: 9 signed limbs of 29 bits, lazy reduction) through
     dr_fr_ops_selftest: products, squarings, sums, differences, inverses (division steps), a product of two lazy operands,
@@ -357,6 +378,29 @@ def test_g1_msm_partition_sort_skewed_and_ragged(ctx):
             raw = b"".join(k.to_bytes(32, "little") for k in col)
             assert ctx.g1_msm(srs, raw) == _closed_form_be(col), (bits, name)
         srs.close()
+
+
+@pytest.mark.parametrize("table", [0, 13])
+def test_g1_msm_many_heavy_lists_one_entry_over_a_segment(ctx, table):
+    """51 distinct scalars, each 1025 times: ~1000 bucket lists of 1025 entries, one over the 1024-entry segment, so every list is
+    cut in two and the segment sums number twice the heavy lists (the bound ctx->heavy is reserved for: total / seg + n_heavy);
+    closed form [sum k_i (1 + i)] G, then the same call again (the scratch neighbours of `heavy` must have survived)"""
+    import bench
+
+    rng = random.Random(1025)
+    distinct = [rng.randrange(coracle.FR_P) for _ in range(51)]
+    col = [distinct[i % 51] for i in range(51 * 1025)]
+    n = len(col)
+    srs = ctx.srs_synthetic(bench.G1_BE, n, first=1)
+    if table:
+        srs.precompute(table)
+    raw = b"".join(k.to_bytes(32, "little") for k in col)
+    want = _closed_form_be(col)
+    assert ctx.g1_msm(srs, raw) == want
+    assert ctx.g1_msm(srs, raw) == want
+    vals, raw2 = bench.seeded_scalars(n, b"after-heavy")
+    assert ctx.g1_msm(srs, raw2) == _closed_form_be(vals)
+    srs.close()
 
 
 def test_g1_msm_degenerate_scalars_at_full_size_within_twice_the_random_time(ctx):
