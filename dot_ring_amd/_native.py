@@ -114,6 +114,8 @@ _PROTOTYPES.update({
                                          POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), POINTER(c_int)]),
     "dr_ietf_prove_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_int, c_size_t, c_char_p, POINTER(ctypes.c_uint64), c_char_p,
                                     POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p, c_char_p, c_char_p]),
+    "dr_ietf_verify_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_int, c_size_t, c_char_p, c_char_p, c_char_p, POINTER(ctypes.c_uint64),
+                                     c_char_p, POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p]),
     "dr_host_hash": (c_int, [c_int, c_char_p, c_size_t, c_char_p, c_size_t]),
     "dr_hash_to_field_batch": (c_int, [POINTER(VrfSuiteStruct), c_char_p, POINTER(ctypes.c_uint64), c_size_t, c_char_p]),
     "dr_ringvrf_prove_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_size_t, c_char_p, POINTER(ctypes.c_uint64), c_char_p,
@@ -613,6 +615,20 @@ class Context:
         _check(lib().dr_ietf_prove_batch(self.handle, byref(suite), 1 if thin else 0, batch, a_blob, a_off, d_blob, d_off, s_blob, s_off,
                                          secret_scalars, out, aux))
         return out.raw[: plen * batch], aux.raw[: 128 * batch]
+
+    def ietf_verify_batch(self, suite: "VrfSuiteStruct", thin: bool, proofs: bytes, public_keys: bytes, inputs, ads, salts) -> bytes:
+        """dr_ietf_verify_batch over encoded Tiny (80-byte) / Thin (96-byte) proofs: one verdict byte per proof — 1 verifies, 0 does
+        not, 2 invalid public key, 3 malformed proof."""
+        batch, plen = len(inputs), 96 if thin else 80
+        if len(proofs) != plen * batch or len(public_keys) != 32 * batch:
+            raise ValueError(f"proofs must be {plen} bytes and public keys 32 bytes each")
+        i_blob, i_off = _ragged(inputs)
+        d_blob, d_off = _ragged(ads)
+        s_blob, s_off = (None, None) if not salts or not any(salts) else _ragged(salts)
+        verdict = ctypes.create_string_buffer(max(1, batch))
+        _check(lib().dr_ietf_verify_batch(self.handle, byref(suite), 1 if thin else 0, batch, proofs, public_keys, i_blob, i_off, d_blob, d_off,
+                                          s_blob, s_off, verdict))
+        return verdict.raw[:batch]
 
     def pedersen_verify_batch(self, suite: "VrfSuiteStruct", proofs: bytes, inputs, ads, salts) -> bool:
         batch = len(inputs)

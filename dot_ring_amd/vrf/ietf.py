@@ -91,6 +91,31 @@ class IetfVRF(VRF):
         return cls.prove_batch([alpha], [secret_key], [additional_data], [salt])[0]
 
     # ---- verifying (single proof; the relation is checked by the subclass)
+    @classmethod
+    def _suite_struct(cls):
+        sp = cls.cv.curve.params
+        le = lambda v: int(v).to_bytes(32, "little")
+        gen = sp.generator
+        bb = sp.auxiliary_points.blinding_base or gen
+        return _native.vrf_suite(sp.suite_id, sp.xof, le(gen[0]) + le(gen[1]), le(bb[0]) + le(bb[1]), sp.curve_id)
+
+    @classmethod
+    def _small_host_serves(cls) -> bool:
+        """one proof of an Elligator suite of Bandersnatch: the library checks it on a host core (dr_ietf_verify_batch, ~0.6 ms)
+        instead of three kernel launch chains.  DOTRING_SMALL_HOST_MAX=0 / DOTRING_NATIVE_HOST=0 keep the kernels."""
+        sp = cls.cv.curve.params
+        return (sp.curve_id == _native.CURVE_BANDERSNATCH and sp.e2c != "tai" and os.environ.get("DOTRING_NATIVE_HOST", "1") != "0"
+                and os.environ.get("DOTRING_SMALL_HOST_MAX", "64") != "0")
+
+    def _verify_small(self, public_key: bytes, input: bytes, additional_data: bytes, salt: bytes) -> bool:
+        if len(public_key) != 32:
+            raise ValueError("Invalid public key")
+        verdict = runtime.context().ietf_verify_batch(self._suite_struct(), self.THIN, self.encode(), bytes(public_key), [bytes(input)],
+                                                      [bytes(additional_data)], [bytes(salt)])[0]
+        if verdict == 2:
+            raise ValueError("Invalid public key")
+        return verdict == 1
+
     def _verifier_view(self, public_key: bytes, input: bytes, additional_data: bytes, salt: bytes):
         """(transcript, merged io) of the statement this proof is about."""
         cv = self.cv

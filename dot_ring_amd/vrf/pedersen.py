@@ -155,6 +155,16 @@ class PedersenVRF(VRF):
 
     def verify(self, input: bytes, additional_data: bytes, salt: bytes = b"") -> bool:
         cv = self.cv
+        sp = cv.curve.params
+        if (sp.curve_id == _native.CURVE_BANDERSNATCH and sp.e2c != "tai" and sp.auxiliary_points.blinding_base
+                and os.environ.get("DOTRING_NATIVE_HOST", "1") != "0" and os.environ.get("DOTRING_SMALL_HOST_MAX", "64") != "0"):
+            # one proof: the library checks both relations on a host core (dr_pedersen_verify_batch with B = 1, csrc/hostsigma.hpp) — two
+            # kernel launch chains otherwise
+            try:
+                blob = self.encode()
+            except (AttributeError, TypeError, ValueError, OverflowError):
+                return False
+            return runtime.context().pedersen_verify_batch(self._suite_struct(), blob, [bytes(input)], [bytes(additional_data)], [bytes(salt)])
         _, merged, c = self._challenge(input, additional_data, salt)
         # the two checks  s*I - c*O == O_k  and  s*G + s_b*B - c*Y_bar == R  as ONE launch of two 3-term groups
         gen = cv.point_type.generator_point()

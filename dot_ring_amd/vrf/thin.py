@@ -37,6 +37,8 @@ class ThinVRF(IetfVRF):
         return cls(gamma, r, dec_scalar(cv, proof_bytes[2 * pl :]))
 
     def verify(self, public_key: bytes, input: bytes, additional_data: bytes, salt: bytes = b"") -> bool:
+        if self._small_host_serves():
+            return self._verify_small(public_key, input, additional_data, salt)
         transcript, merged = self._verifier_view(public_key, input, additional_data, salt)
         c = challenge(self.cv, [self.r], transcript)
         return self.cv.point_type.msm([merged.input, merged.output], [self.s, -c]) == self.r

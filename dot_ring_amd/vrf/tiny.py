@@ -39,6 +39,8 @@ class TinyVRF(IetfVRF):
         return cls(gamma, dec_scalar_mod(cv, proof_bytes[pl : pl + CHALLENGE_LEN]), dec_scalar(cv, proof_bytes[pl + CHALLENGE_LEN :]))
 
     def verify(self, public_key: bytes, input: bytes, additional_data: bytes, salt: bytes = b"") -> bool:
+        if self._small_host_serves():
+            return self._verify_small(public_key, input, additional_data, salt)
         transcript, merged = self._verifier_view(public_key, input, additional_data, salt)
         r = self.cv.point_type.msm([merged.input, merged.output], [self.s, -self.c])
         return self.c == challenge(self.cv, [r], transcript)

@@ -347,6 +347,20 @@ DR_API int dr_ietf_prove_batch(dr_ctx *ctx, const dr_vrf_suite *suite, int thin,
                                const uint64_t *alpha_off, const uint8_t *ads, const uint64_t *ad_off, const uint8_t *salts,
                                const uint64_t *salt_off, const uint8_t *secret_scalars, uint8_t *out_proofs, uint8_t *out_aux);
 
+/* TinyVRF.verify / ThinVRF.verify (dot_ring/vrf/ietf/tiny.py:72-88, thin.py:96-118) for `batch` ENCODED proofs (80 bytes O || c || s, or
+ * 96 bytes O || R || s with thin = 1), proof i under the compressed public key public_keys[32 i ..]: verdict[i] = 1 verifies, 0 does
+ * not, 2 the public key does not decode to a prime-order point, 3 the proof is malformed (a point that does not decode, a scalar >= n)
+ * — the cases the reference raises ValueError for.  Each proof is checked on its own, one per worker thread, on HOST cores: this is the
+ * single-proof entry point (one proof: ~0.6 ms against three kernel launch chains); the relation of MANY Thin proofs at once is
+ * ThinVRF.batch_verify's one MSM on the GPU (dr_te_msm).  Elligator suites of Bandersnatch only.
+ *
+ * Small calls in general: up to DOTRING_SMALL_HOST_MAX proofs (default 64; 0 = never) dr_ietf_prove_batch, dr_pedersen_prove_batch and
+ * dr_pedersen_verify_batch run the same protocol on host cores too (csrc/hostsigma.hpp) — secret scalars on fixed-schedule
+ * multiplications — and give the same bytes and verdicts as the kernels. */
+DR_API int dr_ietf_verify_batch(dr_ctx *ctx, const dr_vrf_suite *suite, int thin, size_t batch, const uint8_t *proofs,
+                                const uint8_t *public_keys /* batch*32 */, const uint8_t *inputs, const uint64_t *in_off, const uint8_t *ads,
+                                const uint64_t *ad_off, const uint8_t *salts, const uint64_t *salt_off, uint8_t *verdict /* batch */);
+
 /* What a verifier knows about one ring (RingRoot + RingProofParams + SRS verifier part). */
 typedef struct dr_ring_verifier_key {
     unsigned log2n;                      /* domain size N = 2^log2n */

@@ -328,6 +328,7 @@ def test_tuning_knobs_do_not_change_the_bytes(ctx):
         {"DOTRING_SRS_TILING": "rows", "DOTRING_VERIFY_HOST_MAX": "0", "DOTRING_MSM_WINDOW": "9", "DOTRING_TRACE": "1"},
         {"DOTRING_VERIFY_HOST_MAX": "2", "DOTRING_SRS_WINDOW": "13", "DOTRING_PS_WINDOW": "12"},
         {"DOTRING_HEAD_HOST_MAX": "0"},           # Elligator 2 and x * I of the five proofs through the kernels (default: on the host up to 64 proofs)
+        {"DOTRING_SMALL_HOST_MAX": "0", "DOTRING_HEAD_HOST_MAX": "0"},      # ... and key derivation, point decoding, the Pedersen proofs: no small call on host cores
     ]
     digests = []
     for extra in variants:
@@ -338,6 +339,29 @@ def test_tuning_knobs_do_not_change_the_bytes(ctx):
         assert out.returncode == 0, (extra, out.stderr[-2000:])
         digests.append([ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
     assert len(set(digests)) == 1, list(zip(variants, digests))
+
+
+def test_small_vrf_vectors_through_the_kernels_too(ctx):
+    """Calls of up to DOTRING_SMALL_HOST_MAX proofs (default 64) run the Tiny / Thin / Pedersen protocols, and dec_point of a few points,
+    on host cores (csrc/hostsigma.hpp) — so the vector tests above exercise that route.  The same vector tests (all Tiny, Thin and
+    Pedersen KATs of both directories, key generation and hash-to-curve KATs, the batch-verify and negative cases) once more in ONE
+    child test run with the host routes off: DOTRING_SMALL_HOST_MAX=0, DOTRING_HEAD_HOST_MAX=0, DOTRING_VERIFY_HOST_MAX=0 — every
+    proof through the kernels."""
+    import os
+    import subprocess
+    import sys
+
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("DOTRING_")}
+    env.update({"DOTRING_SMALL_HOST_MAX": "0", "DOTRING_HEAD_HOST_MAX": "0", "DOTRING_VERIFY_HOST_MAX": "0"})
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                          os.path.join(root_dir, "tests", "test_gpu_api.py"), os.path.join(root_dir, "tests", "test_gpu_reference_cases.py"),
+                          "-k", "tiny_vrf_vectors or thin_vrf_vectors or pedersen_vrf_vectors or keygen_and_h2c or batch_verify_apis or "
+                                "proof_to_hash or native_orchestration"],
+                         cwd=root_dir, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    passed = [ln for ln in out.stdout.splitlines() if " passed" in ln]
+    assert passed and int(passed[-1].split(" passed")[0].split()[-1]) >= 25, out.stdout[-500:]
 
 
 @pytest.mark.parametrize("suite", ["sha512", "shake128", "jubjub"])
