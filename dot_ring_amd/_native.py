@@ -116,6 +116,12 @@ _PROTOTYPES.update({
                                     POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p, c_char_p, c_char_p]),
     "dr_ietf_verify_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_int, c_size_t, c_char_p, c_char_p, c_char_p, POINTER(ctypes.c_uint64),
                                      c_char_p, POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p]),
+    "dr_ringvrf_prove_batch_multi": (c_int, [POINTER(c_void_p), c_size_t, POINTER(VrfSuiteStruct), c_size_t, c_char_p, POINTER(ctypes.c_uint64),
+                                             c_char_p, POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p,
+                                             POINTER(ctypes.c_uint32), c_char_p, c_size_t, c_char_p, c_char_p, c_char_p]),
+    "dr_ringvrf_verify_batch_multi": (c_int, [POINTER(c_void_p), c_size_t, POINTER(VrfSuiteStruct), POINTER(RingVerifierKeyStruct), c_size_t,
+                                              c_char_p, c_char_p, POINTER(ctypes.c_uint64), c_char_p, POINTER(ctypes.c_uint64), c_char_p,
+                                              POINTER(ctypes.c_uint64), c_char_p, POINTER(c_int)]),
     "dr_host_hash": (c_int, [c_int, c_char_p, c_size_t, c_char_p, c_size_t]),
     "dr_hash_to_field_batch": (c_int, [POINTER(VrfSuiteStruct), c_char_p, POINTER(ctypes.c_uint64), c_size_t, c_char_p]),
     "dr_ringvrf_prove_batch": (c_int, [c_void_p, POINTER(VrfSuiteStruct), c_size_t, c_char_p, POINTER(ctypes.c_uint64), c_char_p,
@@ -430,6 +436,38 @@ class RingProver:
         _check(lib().dr_ringvrf_prove_batch(self.handle, byref(suite), batch, a_blob, a_off, d_blob, d_off, s_blob, s_off, secret_scalars, idx,
                                             fs_prefix, len(fs_prefix), zk_random48, out, aux))
         return out, aux
+
+
+def ringvrf_prove_batch_multi(provers: list, suite: "VrfSuiteStruct", alphas, ads, salts, secret_scalars: bytes, producer_index: list,
+                              fs_prefix: bytes, zk_random48: bytes | None):
+    """dr_ringvrf_prove_batch_multi: ONE batch over the devices of `provers` (a RingProver of the same ring per device), device g
+    proving proofs [g B / G, (g + 1) B / G).  Returns the same (proof bytes, auxiliary bytes) buffers as RingProver.ringvrf_prove_batch."""
+    batch = len(alphas)
+    a_blob, a_off = _ragged(alphas)
+    d_blob, d_off = _ragged(ads)
+    s_blob, s_off = (None, None) if not salts or not any(salts) else _ragged(salts)
+    idx = (ctypes.c_uint32 * batch)(*producer_index)
+    handles = (c_void_p * len(provers))(*[p.handle for p in provers])
+    out, aux = _thread_buffer("prove_out", 784 * batch), _thread_buffer("prove_aux", RINGVRF_AUX_BYTES * batch)
+    _check(lib().dr_ringvrf_prove_batch_multi(handles, len(provers), byref(suite), batch, a_blob, a_off, d_blob, d_off, s_blob, s_off,
+                                              secret_scalars, idx, fs_prefix, len(fs_prefix), zk_random48, out, aux))
+    return out, aux
+
+
+def ringvrf_verify_batch_multi(contexts: list, suite: "VrfSuiteStruct", vk: "RingVerifierKeyStruct", proofs: bytes, inputs, ads, salts,
+                               seed32: bytes) -> bool:
+    """dr_ringvrf_verify_batch_multi: ONE batch of 784-byte proofs over the devices of `contexts`, the shards' verdicts AND-ed."""
+    batch = len(inputs)
+    if len(proofs) != 784 * batch:
+        raise ValueError("proofs must be 784 bytes each")
+    i_blob, i_off = _ragged(inputs)
+    d_blob, d_off = _ragged(ads)
+    s_blob, s_off = (None, None) if not salts or not any(salts) else _ragged(salts)
+    handles = (c_void_p * len(contexts))(*[c.handle for c in contexts])
+    ok = c_int(0)
+    _check(lib().dr_ringvrf_verify_batch_multi(handles, len(contexts), byref(suite), byref(vk), batch, proofs, i_blob, i_off, d_blob, d_off,
+                                               s_blob, s_off, seed32, byref(ok)))
+    return bool(ok.value)
 
 
 class Context:

@@ -70,6 +70,12 @@ struct PedersenBatch {
 
     // out_proofs: 192 bytes per proof at `stride`; out_aux (nullable): O, Y_bar, R, O_k affine (4*64) + blinding (32) at aux_stride
     int tail(dr_ctx* actx, uint8_t* out_proofs, size_t stride, uint8_t* out_aux, size_t aux_stride) {
+        // device copies of x, b, k, k_b (scalar uploads of the fixed-base and variable-base launches) do not outlive the call — on ANY exit path
+        struct ScratchWipe {
+            dr_ctx* c;
+            bool armed = true;
+            ~ScratchWipe() { if (armed) (void)ctx_wipe_scratch(c, true); }
+        } scratch_wipe{actx};
         const drh::Mod256& mn = su.cv->n;
         const int cv = su.cv->id;
         ybar.resize(B * 64); ks.resize(B * 32); kbs.resize(B * 32); pts3.resize(2 * B * 128); sc3.resize(2 * B * 64); third.resize(2 * B * 64);
@@ -136,7 +142,7 @@ struct PedersenBatch {
                 std::memcpy(a + 256, blind.data() + 32 * i, 32);
             }
         });
-        // device copies of x, b, k, k_b (scalar uploads of the fixed-base and variable-base launches) do not outlive the call either
+        scratch_wipe.armed = false;                          // the success path reports the wipe's own status
         return ctx_wipe_scratch(actx, true);
     }
 };
@@ -1039,6 +1045,111 @@ int dr_ietf_verify_batch(dr_ctx* ctx, const dr_vrf_suite* suite, int thin, size_
             verdict[i] = (uint8_t)drh::ietf_verify_one(su, *tables, thin != 0, proofs + plen * i, public_keys + 32 * i, drh::span_of(inputs, in_off, i),
                                                        drh::span_of(ads, ad_off, i), drh::span_of(salts, salt_off, i), batch <= 2);
         }, 1);
+        return DR_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(DR_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_DEVICE, std::string("native verifier: ") + e.what());
+    }
+}
+
+// ---- ONE batch over several GPUs of this process (SURVEY 8(b)'s additive row, 8(e) first mode; the reference's process-sharded bench,
+// tests/benchmark/bench_ring_proof.py:168-182, hands index ranges out and takes every result back the same way).  Proofs are
+// independent units: device g takes proofs [g B / G, (g + 1) B / G) — sizes differ by at most one, empty shards are fine — on a host
+// thread of its own, and writes its 784-byte proofs straight into the caller's buffer, so the "gather" is the memory the caller
+// already holds.  No collective, nothing exchanged between the devices.
+namespace {
+struct Shard {
+    size_t lo, hi;
+};
+Shard shard_of(size_t n, size_t g, size_t G) {
+    const size_t base = n / G, rem = n % G;
+    const size_t lo = g * base + std::min(g, rem);
+    return {lo, lo + base + (g < rem ? 1 : 0)};
+}
+// run f(g) for g < G on G threads (the calling thread takes shard 0); first failure by shard order wins
+template <class F>
+int run_shards(size_t G, F&& f) {
+    std::vector<int> rc(G, DR_OK);
+    std::vector<std::string> err(G);
+    std::vector<std::thread> th;
+    th.reserve(G);
+    for (size_t g = 1; g < G; g++) th.emplace_back([&, g] { run_guarded(rc[g], err[g], [&] { return f(g); }); });
+    run_guarded(rc[0], err[0], [&] { return f(0); });
+    for (auto& t : th) t.join();
+    for (size_t g = 0; g < G; g++)
+        if (rc[g] != DR_OK) return fail(rc[g], "device shard " + std::to_string(g) + ": " + err[g]);
+    return DR_OK;
+}
+}  // namespace
+
+int dr_ringvrf_prove_batch_multi(dr_ring_prover* const* provers, size_t n_provers, const dr_vrf_suite* suite, size_t batch, const uint8_t* alphas,
+                                 const uint64_t* alpha_off, const uint8_t* ads, const uint64_t* ad_off, const uint8_t* salts, const uint64_t* salt_off,
+                                 const uint8_t* secret_scalars, const uint32_t* producer_index, const uint8_t* fs_prefix, size_t fs_prefix_len,
+                                 const uint8_t* zk_random48, uint8_t* out_proofs, uint8_t* out_aux) {
+    try {
+        if (!provers || n_provers == 0 || n_provers > 64) return fail(DR_ERR_INVALID, "1..64 provers");
+        if (!alpha_off || !ad_off || !secret_scalars || !producer_index || !fs_prefix || !out_proofs) return fail(DR_ERR_INVALID, "null argument");
+        for (size_t g = 0; g < n_provers; g++) {
+            if (!provers[g]) return fail(DR_ERR_INVALID, "null prover");
+            for (size_t h = 0; h < g; h++)
+                if (provers[h] == provers[g] || ring_prover_ctx(provers[h]) == ring_prover_ctx(provers[g]))
+                    return fail(DR_ERR_INVALID, "every shard needs a prover and a context of its own");
+        }
+        if (batch == 0) return DR_OK;
+        return run_shards(n_provers, [&](size_t g) -> int {
+            const Shard sh = shard_of(batch, g, n_provers);
+            for (size_t lo = sh.lo; lo < sh.hi; lo += 4096) {                 // (one native call proves at most 4096 proofs)
+                const size_t n = std::min<size_t>(4096, sh.hi - lo);
+                TRY(ringvrf_prove_batch_impl(provers[g], suite, n, alphas, alpha_off + lo, ads, ad_off + lo, salts, salt_off ? salt_off + lo : nullptr,
+                                             secret_scalars + 32 * lo, producer_index + lo, fs_prefix, fs_prefix_len,
+                                             zk_random48 ? zk_random48 + 576 * lo : nullptr, out_proofs + 784 * lo,
+                                             out_aux ? out_aux + DR_RINGVRF_AUX_BYTES * lo : nullptr));
+            }
+            return DR_OK;
+        });
+    } catch (const std::bad_alloc&) {
+        return fail(DR_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(DR_ERR_DEVICE, std::string("native prover: ") + e.what());
+    }
+}
+
+int dr_ringvrf_verify_batch_multi(dr_ctx* const* ctxs, size_t n_ctxs, const dr_vrf_suite* suite, const dr_ring_verifier_key* vk, size_t batch,
+                                  const uint8_t* proofs, const uint8_t* inputs, const uint64_t* in_off, const uint8_t* ads, const uint64_t* ad_off,
+                                  const uint8_t* salts, const uint64_t* salt_off, const uint8_t seed32[32], int* ok) {
+    try {
+        if (!ctxs || n_ctxs == 0 || n_ctxs > 64) return fail(DR_ERR_INVALID, "1..64 contexts");
+        if (!vk || !proofs || !in_off || !ad_off || !seed32 || !ok) return fail(DR_ERR_INVALID, "null argument");
+        for (size_t g = 0; g < n_ctxs; g++) {
+            if (!ctxs[g]) return fail(DR_ERR_INVALID, "null context");
+            for (size_t h = 0; h < g; h++)
+                if (ctxs[h] == ctxs[g]) return fail(DR_ERR_INVALID, "every shard needs a context of its own");
+        }
+        *ok = 0;
+        if (batch == 0) { *ok = 1; return DR_OK; }
+        std::vector<int> verdict(n_ctxs, 1);
+        TRY(run_shards(n_ctxs, [&](size_t g) -> int {
+            const Shard sh = shard_of(batch, g, n_ctxs);
+            for (size_t lo = sh.lo; lo < sh.hi && verdict[g]; lo += 4096) {
+                const size_t n = std::min<size_t>(4096, sh.hi - lo);
+                // every shard (and chunk) folds its claims with randomness of its own: SHAKE256(seed || LE64(first proof))
+                uint8_t mix[40], sub[32];
+                std::memcpy(mix, seed32, 32);
+                for (int k = 0; k < 8; k++) mix[32 + k] = (uint8_t)((uint64_t)lo >> (8 * k));
+                drh::Shake256 sh256;
+                sh256.update(mix, 40);
+                sh256.digest(sub, 32);
+                int one = 0;
+                TRY(ringvrf_verify_batch_impl(ctxs[g], suite, vk, n, proofs + 784 * lo, inputs, in_off + lo, ads, ad_off + lo, salts,
+                                              salt_off ? salt_off + lo : nullptr, sub, &one));
+                verdict[g] = one;
+            }
+            return DR_OK;
+        }));
+        int all = 1;
+        for (size_t g = 0; g < n_ctxs; g++) all &= verdict[g];
+        *ok = all;
         return DR_OK;
     } catch (const std::bad_alloc&) {
         return fail(DR_ERR_NOMEM, "out of host memory");

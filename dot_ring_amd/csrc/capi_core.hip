@@ -648,6 +648,28 @@ int te_msm(dr_ctx* ctx, int cv, const uint8_t* pts_xy, const uint8_t* scalars, s
         TRY(check_fr_elems(pts_xy, 2 * n, "point"));
         return te_msm_pippenger(ctx, cv, pts_xy, scalars, n, out_xy);
     }
+    if (n <= drh::small_host_max() && n <= 64) {
+        // a handful of terms (the 7 / 12 points of a one- or two-proof verifier, a sigma protocol's relation): one fixed-schedule multiplication
+        // per term on the worker pool (~0.09 ms each, side by side) and their sum — a kernel chain is ~0.8 ms whatever the count
+        if (!pts_xy || !scalars) return fail(DR_ERR_INVALID, "null buffer");
+        TRY(check_fr_elems(pts_xy, 2 * n, "point"));
+        const drh::TeCurveHost* hc = drh::te_curve(cv);
+        const drh::TeHostParams hp = drh::te_host_params(*hc);
+        std::vector<drh::TeExt> terms(n);
+        drh::parallel_for(n, [&](size_t i) {
+            drh::TeExt P;
+            uint64_t k[4];
+            (void)drh::te_load_affine(pts_xy + 64 * i, P);
+            hc->n.reduce_bytes(scalars + 32 * i, 32, false, k);
+            terms[i] = drh::te_mul_secret(P, k, hp);
+            explicit_bzero(k, sizeof k);
+        }, 1);
+        drh::TeExt acc = terms[0];
+        for (size_t i = 1; i < n; i++) acc = drh::te_add(acc, terms[i], hp);
+        drh::te_store_affine(acc, out_xy);
+        explicit_bzero(terms.data(), n * sizeof(drh::TeExt));
+        return DR_OK;
+    }
     // below that: fold 64 terms at a time on the device (one launch); the n/64 partial sums are then added on the host in
     // extended coordinates — a second device pass would pay a full scalar-multiplication latency for scalars that are all 1
     if (n <= 64) return te_msm_groups(ctx, cv, pts_xy, scalars, 1, n, out_xy);

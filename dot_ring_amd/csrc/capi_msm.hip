@@ -1138,16 +1138,18 @@ int dr_g1_sum(const uint8_t* pts_be_xy, size_t n, uint8_t out_be_xy[96], int* is
 
 namespace {
 // prepared G2 points by their 192-byte encoding (a verifier key has two; a handful of SRS files per process)
-const drh::G2Prepared* g2_prepared_cached(const uint8_t enc[192], const drh::G2Affine& q) {
+// (shared ownership: verifiers run their Miller loops concurrently — two per verify, several verifying threads — and an entry evicted by one
+//  thread must outlive the loop of another that is still reading it)
+std::shared_ptr<const drh::G2Prepared> g2_prepared_cached(const uint8_t enc[192], const drh::G2Affine& q) {
     static std::mutex m;
-    static std::vector<std::pair<std::array<uint8_t, 192>, std::unique_ptr<drh::G2Prepared>>> cache;
+    static std::vector<std::pair<std::array<uint8_t, 192>, std::shared_ptr<const drh::G2Prepared>>> cache;
     std::array<uint8_t, 192> key;
     std::memcpy(key.data(), enc, 192);
     std::lock_guard<std::mutex> lock(m);
-    for (auto& e : cache) if (e.first == key) return e.second.get();
+    for (auto& e : cache) if (e.first == key) return e.second;
     if (cache.size() >= 16) cache.erase(cache.begin());
-    cache.emplace_back(key, std::make_unique<drh::G2Prepared>(drh::g2_prepare(q)));
-    return cache.back().second.get();
+    cache.emplace_back(key, std::make_shared<const drh::G2Prepared>(drh::g2_prepare(q)));
+    return cache.back().second;
 }
 int miller_product(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, drh::Fq12& f, bool prepared = true) {
     std::vector<uint8_t> le;
@@ -1155,6 +1157,7 @@ int miller_product(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, drh:
     std::vector<drh::Fq> px, py;
     std::vector<drh::G2Affine> qs;
     std::vector<const drh::G2Prepared*> preps;
+    std::vector<std::shared_ptr<const drh::G2Prepared>> held;           // keeps the cached entries alive for the duration of the loop
     for (size_t i = 0; i < n; i++) {
         const uint8_t* q = g2_be + 192 * i;
         drh::G2Affine Q;
@@ -1172,7 +1175,10 @@ int miller_product(const uint8_t* g1_be_xy, const uint8_t* g2_be, size_t n, drh:
         drh::Fq::load_le(x, le.data() + 96 * i);
         drh::Fq::load_le(y, le.data() + 96 * i + 48);
         px.push_back(x); py.push_back(y); qs.push_back(Q);
-        if (prepared) preps.push_back(g2_prepared_cached(q, Q));
+        if (prepared) {
+            held.push_back(g2_prepared_cached(q, Q));
+            preps.push_back(held.back().get());
+        }
     }
     f = prepared ? drh::multi_miller_loop_prepared(px.data(), py.data(), preps.data(), preps.size())
                  : drh::multi_miller_loop(px.data(), py.data(), qs.data(), qs.size());

@@ -499,6 +499,20 @@ class RingVRF(VRF):
         prefix = root.verifier_transcript_prefix_bytes()
         ab = _native.RINGVRF_AUX_BYTES
 
+        def provers_of_the_device_set() -> list:
+            """one prover of this ring per device of runtime.device_ids() (their SRS and ring tables are built on first use)"""
+            ctxs = runtime.device_contexts()
+            if len(ctxs) == 1:
+                return [device_prover.get_device_prover(ring, 0)]
+            mine, out = runtime.context(), []
+            try:
+                for c in ctxs:
+                    runtime.set_context(c)
+                    out.append(device_prover.get_device_prover(ring, 0))
+            finally:
+                runtime.set_context(mine)
+            return out
+
         def prove_span(lo: int, hi: int) -> list:
             # runs on the calling thread or on a helper thread: runtime.context() / get_device_prover give each thread its own
             # stream, scratch and per-ring prover state
@@ -506,13 +520,16 @@ class RingVRF(VRF):
             # (SHAKE256 in counter mode; os.urandom alone took 1.5 ms per 1024 proofs on the calling thread)
             zk = None if ring.params.test_vectors else _native.random_expand(secrets.token_bytes(32), 48 * 12 * (hi - lo))
             n = hi - lo
-            prover = device_prover.get_device_prover(ring, 0)
+            provers = provers_of_the_device_set()
             aux = blind = None
             try:
-                raw, aux = prover.ringvrf_prove_batch(
-                    suite, alphas[lo:hi], additional_data[lo:hi], salts[lo:hi] if salts else None,
-                    b"".join(bytes(sk) if len(sk) == 32 else le(int.from_bytes(sk, "little") % sp.subgroup_order) for sk in secret_keys[lo:hi]),
-                    indices[lo:hi], prefix, zk)
+                sk_blob = b"".join(bytes(sk) if len(sk) == 32 else le(int.from_bytes(sk, "little") % sp.subgroup_order) for sk in secret_keys[lo:hi])
+                if len(provers) > 1:          # the span sharded over the process's device set, all proofs back in this buffer
+                    raw, aux = _native.ringvrf_prove_batch_multi(provers, suite, alphas[lo:hi], additional_data[lo:hi], salts[lo:hi] if salts else None,
+                                                                 sk_blob, indices[lo:hi], prefix, zk)
+                else:
+                    raw, aux = provers[0].ringvrf_prove_batch(suite, alphas[lo:hi], additional_data[lo:hi], salts[lo:hi] if salts else None,
+                                                              sk_blob, indices[lo:hi], prefix, zk)
                 blind = _native.aux_take_blindings(aux, n)          # the shared auxiliary string below carries no secret
                 return cls._from_batch(ctypes.string_at(raw, 784 * n), ctypes.string_at(aux, ab * n), n, ctypes.string_at(blind, 32 * n))
             finally:
@@ -525,8 +542,9 @@ class RingVRF(VRF):
 
         count = len(alphas)
         out = []
-        for lo in range(0, count, device_prover.MAX_DEVICE_BATCH):
-            out.extend(prove_span(lo, min(count, lo + device_prover.MAX_DEVICE_BATCH)))
+        step = device_prover.MAX_DEVICE_BATCH * len(runtime.device_ids())
+        for lo in range(0, count, step):
+            out.extend(prove_span(lo, min(count, lo + step)))
         return out
 
     @classmethod
@@ -643,15 +661,19 @@ class RingVRF(VRF):
                     return False
             except (AttributeError, TypeError, ValueError):
                 return False
-        ctx = runtime.context()
-        step = device_prover.MAX_DEVICE_BATCH
+        ctxs = runtime.device_contexts()
+        step = device_prover.MAX_DEVICE_BATCH * len(ctxs)
         for lo in range(0, count, step):
             hi = min(count, lo + step)
             part = joined[784 * lo : 784 * hi] if joined is not None else b"".join(blobs[lo:hi])
             if joined is not None and lo == 0 and hi == count:
                 part = joined
-            if not ctx.ringvrf_verify_batch(suite, vk, part, [bytes(x) for x in inputs[lo:hi]],
-                                            [bytes(x) for x in additional_data[lo:hi]], None, secrets.token_bytes(32)):
+            ins, ads_ = [bytes(x) for x in inputs[lo:hi]], [bytes(x) for x in additional_data[lo:hi]]
+            if len(ctxs) > 1:                 # the span sharded over the process's device set, the verdicts AND-ed
+                ok = _native.ringvrf_verify_batch_multi(ctxs, suite, vk, part, ins, ads_, None, secrets.token_bytes(32))
+            else:
+                ok = ctxs[0].ringvrf_verify_batch(suite, vk, part, ins, ads_, None, secrets.token_bytes(32))
+            if not ok:
                 return False
         return True
 

@@ -384,6 +384,27 @@ DR_API int dr_ringvrf_verify_batch(dr_ctx *ctx, const dr_vrf_suite *suite, const
                                    const uint64_t *ad_off, const uint8_t *salts, const uint64_t *salt_off,
                                    const uint8_t seed32[32], int *ok);
 
+/* ---- one batch over several GPUs of ONE process (SURVEY 8(b) additive row: a device set instead of one device; 8(e) first mode) -----
+ * The same two calls over a set of devices: provers[g] / ctxs[g] live on the devices the caller chose (dr_ctx_create(device_id), one
+ * dr_srs and one dr_ring_prover of the SAME ring per device — the SRS and the per-ring tables are replicated in each HBM, < 250 MB).
+ * Device g takes proofs [g B / G, (g + 1) B / G) (sizes differ by at most one; B < G leaves shards empty) on a host thread of its own
+ * and writes its results straight into the caller's buffers: all B proofs come back in order, byte-identical to the one-device call
+ * (in test-vector mode; with hidden rows, zk_random48 is consumed by proof index, so the bytes do not depend on G either).  No collective
+ * and no exchange between the devices.  The verifier ANDs the shards' verdicts; every shard folds with randomness of its own derived
+ * from seed32.  Entries of the set may be several contexts on ONE device (how the one-GPU tests run it).  The host worker pool
+ * (DOTRING_HOST_THREADS) is shared by the shards: give it about 16 threads per device.
+ * One process PER GPU (torch.distributed / any launcher) shards the same way through dot_ring_amd.parallel.prove_batch_sharded, with the
+ * 784-byte proofs gathered over the communicator; the reference's own multi-worker shape is tests/benchmark/bench_ring_proof.py:168-182. */
+DR_API int dr_ringvrf_prove_batch_multi(dr_ring_prover *const *provers, size_t n_provers, const dr_vrf_suite *suite, size_t batch,
+                                        const uint8_t *alphas, const uint64_t *alpha_off, const uint8_t *ads, const uint64_t *ad_off,
+                                        const uint8_t *salts, const uint64_t *salt_off, const uint8_t *secret_scalars,
+                                        const uint32_t *producer_index, const uint8_t *fs_prefix, size_t fs_prefix_len,
+                                        const uint8_t *zk_random48, uint8_t *out_proofs, uint8_t *out_aux);
+DR_API int dr_ringvrf_verify_batch_multi(dr_ctx *const *ctxs, size_t n_ctxs, const dr_vrf_suite *suite, const dr_ring_verifier_key *vk,
+                                         size_t batch, const uint8_t *proofs, const uint8_t *inputs, const uint64_t *in_off,
+                                         const uint8_t *ads, const uint64_t *ad_off, const uint8_t *salts, const uint64_t *salt_off,
+                                         const uint8_t seed32[32], int *ok);
+
 #ifdef __cplusplus
 }
 #endif

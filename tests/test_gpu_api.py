@@ -360,8 +360,17 @@ def test_small_vrf_vectors_through_the_kernels_too(ctx):
                                 "proof_to_hash or native_orchestration"],
                          cwd=root_dir, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    passed = [ln for ln in out.stdout.splitlines() if " passed" in ln]
-    assert passed and int(passed[-1].split(" passed")[0].split()[-1]) >= 25, out.stdout[-500:]
+    # what this test is for: every named vector test ran (and, rc 0, passed) with the host routes off — checked by name from the
+    # child's own collection, not by a count (a first version asserted a guessed count and was then lowered to fit: removed)
+    listed = subprocess.run([sys.executable, "-m", "pytest", "--collect-only", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                             os.path.join(root_dir, "tests", "test_gpu_api.py"), os.path.join(root_dir, "tests", "test_gpu_reference_cases.py"),
+                             "-k", "tiny_vrf_vectors or thin_vrf_vectors or pedersen_vrf_vectors or keygen_and_h2c or batch_verify_apis or "
+                                   "proof_to_hash or native_orchestration"],
+                            cwd=root_dir, env=env, capture_output=True, text=True, timeout=300).stdout
+    for name in ("test_tiny_vrf_vectors", "test_thin_vrf_vectors", "test_pedersen_vrf_vectors", "test_keygen_and_h2c_kats",
+                 "test_batch_verify_apis_and_negative_cases", "test_native_orchestration_equals_python_orchestration"):
+        assert name in listed, f"{name} was not part of the kernels-only run"
+    assert " failed" not in out.stdout and " error" not in out.stdout, out.stdout[-500:]
 
 
 @pytest.mark.parametrize("suite", ["sha512", "shake128", "jubjub"])
